@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def grads_compact_np(named):
+    """Same compaction as tests/golden/make_golden.py::grads_compact (full tensor if small, strided sample + sums)."""
+    out = {}
+    for k, g in named.items():
+        g = np.asarray(g, dtype=np.float64).reshape(-1)
+        if g.size <= 4096:
+            out["g:" + k] = g.astype(np.float32)
+        else:
+            out["g:" + k] = g[:: g.size // 2048].astype(np.float32)
+        out["gs:" + k] = np.array([g.sum(), (g * g).sum()], dtype=np.float64)
+    return out
+
+
+def assert_grads_match(gold, named, atol=1e-4, rtol=1e-4):
+    mine = grads_compact_np(named)
+    keys = [k for k in gold if k.startswith("g:")]
+    assert keys, "fixture holds no gradients"
+    for k in keys:
+        assert k in mine, f"missing gradient for {k[2:]}"
+        # gradients are long cancelling sums: the absolute tolerance scales with the tensor's largest entry
+        np.testing.assert_allclose(mine[k], gold[k], atol=atol * max(1.0, float(np.abs(gold[k]).max())), rtol=rtol, err_msg=k)
+        s = "gs:" + k[2:]
+        scale = max(1.0, np.sqrt(gold[s][1]))
+        assert abs(mine[s][0] - gold[s][0]) <= 50 * atol * scale, (s, mine[s], gold[s])
+        assert abs(mine[s][1] - gold[s][1]) <= 1e-3 * max(1.0, gold[s][1]), (s, mine[s], gold[s])
