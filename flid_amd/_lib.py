@@ -1,0 +1,75 @@
+"""ctypes binding of libflid_tg.so (include/flid_tg.h).  There is NO fallback: if the HIP library is missing or a call
+fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libflid_tg.so")
+
+c_i64, c_i32, c_f32, c_void = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+
+class AttnDesc(C.Structure):
+    """struct tg_attn_desc"""
+    _fields_ = [("d_feat", c_void), ("feat_ld", c_i64), ("d_feat_idx", c_void),
+                ("d_edge", c_void), ("edge_ld", c_i64), ("d_edge_idx", c_void),
+                ("d_nbr", c_void), ("d_dt", c_void), ("d_te_w", c_void), ("d_te_b", c_void),
+                ("m", c_i64), ("k", C.c_int), ("heads", C.c_int), ("dn", C.c_int), ("de", C.c_int), ("dt_dim", C.c_int),
+                ("scale", c_f32), ("dropout_p", c_f32), ("seed", C.c_uint64)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/flid_tg.h
+SIGNATURES = {
+    "tg_last_error": (C.c_char_p, []),
+    "tg_version": (C.c_int, []),
+    "tg_graph_create": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, C.POINTER(c_void)]),
+    "tg_graph_destroy": (None, [c_void]),
+    "tg_graph_num_rows": (c_i64, [c_void]),
+    "tg_graph_num_entries": (c_i64, [c_void]),
+    "tg_graph_export": (C.c_int, [c_void, c_void, c_void, c_void, c_void]),
+    "tg_sample_recent": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "tg_first_hop_window": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void]),
+    "tg_time_encode": (C.c_int, [c_void, c_i64, c_void, c_void, C.c_int, C.c_int, c_void, c_void]),
+    "tg_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void]),
+    "tg_attn_bwd_parts": (C.c_int, [c_i64]),
+    "tg_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_void, c_void]),
+    "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
+                              c_void, C.c_int, C.c_int, c_void]),
+    "tg_gather_rows": (C.c_int, [c_void, c_i64, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
+    "tg_scatter_add_rows": (C.c_int, [c_void, c_i64, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
+    "tg_add_layernorm_fwd": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "tg_rowop_parts": (C.c_int, [c_i64]),
+    "tg_add_layernorm_bwd": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "tg_colsum": (C.c_int, [c_void, c_i64, c_i64, C.c_int, c_void, C.c_int, c_void]),
+    "tg_relu_bwd_inplace": (C.c_int, [c_void, c_void, c_i64, c_void]),
+}
+
+_lib = None
+
+
+class TgError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the CDLL with typed entry points.  Raises if the HIP extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TgError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"or `make -C flid_amd/csrc`.  flid_amd has no CPU fallback.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)      # AttributeError if the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().tg_last_error().decode("utf-8", "replace")
+        if rc == -1 and ("greater than 0" in msg or "greater than 1" in msg):
+            raise AssertionError(msg.split("invalid argument: ", 1)[-1])       # reference raises AssertionError there
+        raise TgError(f"{what or 'libflid_tg'} failed (rc={rc}): {msg}")

@@ -1,0 +1,402 @@
+// Gather-fused single-query temporal attention (forward + backward), one wavefront per attention instance.
+//
+// replaces: models/modules.py:167-245 (MultiHeadAttention.forward, neighbor side) and the gathers that feed it,
+//           models/TGAT.py:110-129 / models/MemoryModel.py:679-700.
+//
+// The query has length 1, so with u_h = Wk_h^T q_h (computed by the dense kernels)
+//     score_{h,n} = scale * u_h . z_n            z_n = [feat[feat_idx_n] | edge[edge_idx_n] | cos(dt_n * w + b)]
+//     agg_h       = sum_n dropout(softmax_n(score))_{h,n} * z_n          (ctx_h = Wv_h agg_h, dense kernel)
+// is algebraically the reference's attention; each neighbor row is streamed from HBM exactly once per pass
+// (online softmax: running max / denominator, no second pass, no LDS).  Lanes own columns of z: a row of
+// dk floats is read as 16-byte chunks, lane l owning chunks l, l+64, ...  (688-B table rows -> 43 chunks).
+#include <math.h>
+
+#include "tg_common.h"
+
+namespace {
+
+using tg::kWave;
+
+template <int VEC> struct Chunk;
+template <> struct Chunk<4> { using T = float4; };
+template <> struct Chunk<1> { using T = float; };
+
+template <int VEC>
+__device__ __forceinline__ void load_chunk(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void store_chunk(float* __restrict__ p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else *p = v[0];
+}
+
+struct Seg { int kind; int col; };   // kind 0 node feature, 1 edge feature, 2 time encoding, 3 none
+
+__device__ __forceinline__ Seg classify(int col, int dn, int de, int dk) {
+    if (col >= dk) return {3, 0};
+    if (col < dn) return {0, col};
+    if (col < dn + de) return {1, col - dn};
+    return {2, col - dn - de};
+}
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+__host__ __device__ inline int64_t attn_grid(int64_t m) {
+    int64_t b = (m + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    return b < 1 ? 1 : (b > tg::kMaxGridBlocks ? tg::kMaxGridBlocks : b);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int VEC, int CPL, int H>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_attn_desc a, const float* __restrict__ u,
+                                                                         float* __restrict__ agg, float* __restrict__ prob) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int dk = a.dn + a.de + a.dt_dim;
+    const int k = a.k;
+
+    Seg seg[CPL];
+    float tw[CPL][VEC], tb[CPL][VEC];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        seg[i] = classify((lane + kWave * i) * VEC, a.dn, a.de, dk);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            tw[i][e] = seg[i].kind == 2 ? a.d_te_w[seg[i].col + e] : 0.f;
+            tb[i][e] = seg[i].kind == 2 ? a.d_te_b[seg[i].col + e] : 0.f;
+        }
+    }
+
+    for (int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; row < a.m; row += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        float uh[H][CPL][VEC], acc[H][CPL][VEC];
+        float mx[H], den[H], keep_score[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            mx[h] = -INFINITY; den[h] = 0.f; keep_score[h] = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                if (seg[i].kind != 3) load_chunk<VEC>(u + (row * H + h) * dk + (lane + kWave * i) * VEC, uh[h][i]);
+                else { for (int e = 0; e < VEC; ++e) uh[h][i][e] = 0.f; }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[h][i][e] = 0.f;
+            }
+        }
+        for (int s0 = 0; s0 < k; s0 += kWave) {
+            // lane s holds the metadata of slot s0+s: one coalesced read per array, broadcast per slot below
+            const int sl = s0 + lane;
+            const int64_t mo = row * k + sl;
+            const int my_f = sl < k ? a.d_feat_idx[mo] : 0;
+            const int my_e = sl < k ? a.d_edge_idx[mo] : 0;
+            const int my_n = sl < k ? a.d_nbr[mo] : 0;
+            const float my_dt = sl < k ? a.d_dt[mo] : 0.f;
+            const int cnt = (k - s0) < kWave ? (k - s0) : kWave;
+            for (int s = 0; s < cnt; ++s) {
+                const int64_t fi = __builtin_amdgcn_readlane(my_f, s);
+                const int64_t ei = __builtin_amdgcn_readlane(my_e, s);
+                const int nb = __builtin_amdgcn_readlane(my_n, s);
+                const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), s));
+                float z[CPL][VEC];
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    if (seg[i].kind == 0) load_chunk<VEC>(a.d_feat + fi * a.feat_ld + seg[i].col, z[i]);
+                    else if (seg[i].kind == 1) load_chunk<VEC>(a.d_edge + ei * a.edge_ld + seg[i].col, z[i]);
+                    else if (seg[i].kind == 2) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) z[i][e] = cosf(fmaf(dt, tw[i][e], tb[i][e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) z[i][e] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) p = fmaf(uh[h][i][e], z[i][e], p);
+                    float sc = tg::wave_sum(p) * a.scale;
+                    if (nb == 0) sc = -1e10f;                                    // modules.py:221
+                    if (lane == s) keep_score[h] = sc;
+                    const float mnew = fmaxf(mx[h], sc);
+                    const float corr = expf(mx[h] - mnew);
+                    const float pe = expf(sc - mnew);
+                    den[h] = den[h] * corr + pe;
+                    const float wgt = pe * tg::dropout_keep_scale(a.seed, row, h, s0 + s, a.dropout_p);
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[h][i][e] = fmaf(wgt, z[i][e], acc[h][i][e] * corr);
+                    mx[h] = mnew;
+                }
+            }
+            // probabilities of this slot tile need the final max/denominator: only exact when k <= 64 (one tile);
+            // for longer rows they are fixed up after the loop from the saved raw scores.
+            if (k <= kWave) {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+                    if (lane < k) prob[(row * H + h) * k + lane] = expf(keep_score[h] - mx[h]) / den[h];
+            } else {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+                    if (sl < k) prob[(row * H + h) * k + sl] = keep_score[h];   // raw score for now
+            }
+        }
+        if (k > kWave) {
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+                for (int sl = lane; sl < k; sl += kWave) {
+                    const int64_t o = (row * H + h) * k + sl;
+                    prob[o] = expf(prob[o] - mx[h]) / den[h];
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float inv = 1.f / den[h];
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                if (seg[i].kind == 3) continue;
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = acc[h][i][e] * inv;
+                store_chunk<VEC>(agg + (row * H + h) * dk + (lane + kWave * i) * VEC, o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// d score_{h,n} = a'_{h,n} (dagg_h . z_n) - a_{h,n} (dagg_h . agg_h)      a' = dropped/scaled prob, a = softmax prob
+// masked slots get no score gradient (masked_fill), but still pass d z through a'.
+template <int VEC, int CPL, int H>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_attn_desc a, const float* __restrict__ u,
+        const float* __restrict__ agg, const float* __restrict__ prob, const float* __restrict__ dagg,
+        float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld, float* __restrict__ dte_part) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int dk = a.dn + a.de + a.dt_dim;
+    const int k = a.k;
+    extern __shared__ float red[];   // WAVES_PER_BLOCK * 2 * dt_dim
+
+    Seg seg[CPL];
+    float tw[CPL][VEC], tb[CPL][VEC], gw[CPL][VEC], gb[CPL][VEC];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        seg[i] = classify((lane + kWave * i) * VEC, a.dn, a.de, dk);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            tw[i][e] = seg[i].kind == 2 ? a.d_te_w[seg[i].col + e] : 0.f;
+            tb[i][e] = seg[i].kind == 2 ? a.d_te_b[seg[i].col + e] : 0.f;
+            gw[i][e] = 0.f; gb[i][e] = 0.f;
+        }
+    }
+
+    for (int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; row < a.m; row += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        float uh[H][CPL][VEC], dg[H][CPL][VEC], dacc[H][CPL][VEC];
+        float cterm[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                float ag[VEC];
+                if (seg[i].kind != 3) {
+                    const int64_t o = (row * H + h) * dk + (lane + kWave * i) * VEC;
+                    load_chunk<VEC>(u + o, uh[h][i]);
+                    load_chunk<VEC>(dagg + o, dg[h][i]);
+                    load_chunk<VEC>(agg + o, ag);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { uh[h][i][e] = 0.f; dg[h][i][e] = 0.f; ag[e] = 0.f; }
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { p = fmaf(dg[h][i][e], ag[e], p); dacc[h][i][e] = 0.f; }
+            }
+            cterm[h] = tg::wave_sum(p);
+        }
+        for (int s0 = 0; s0 < k; s0 += kWave) {
+            const int sl = s0 + lane;
+            const int64_t mo = row * k + sl;
+            const int my_f = sl < k ? a.d_feat_idx[mo] : 0;
+            const int my_e = sl < k ? a.d_edge_idx[mo] : 0;
+            const int my_n = sl < k ? a.d_nbr[mo] : 0;
+            const float my_dt = sl < k ? a.d_dt[mo] : 0.f;
+            float my_p[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) my_p[h] = sl < k ? prob[(row * H + h) * k + sl] : 0.f;
+            const int cnt = (k - s0) < kWave ? (k - s0) : kWave;
+            for (int s = 0; s < cnt; ++s) {
+                const int64_t fi = __builtin_amdgcn_readlane(my_f, s);
+                const int64_t ei = __builtin_amdgcn_readlane(my_e, s);
+                const int nb = __builtin_amdgcn_readlane(my_n, s);
+                const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), s));
+                float z[CPL][VEC], sn[CPL][VEC], dz[CPL][VEC];
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { sn[i][e] = 0.f; dz[i][e] = 0.f; }
+                    if (seg[i].kind == 0) load_chunk<VEC>(a.d_feat + fi * a.feat_ld + seg[i].col, z[i]);
+                    else if (seg[i].kind == 1) load_chunk<VEC>(a.d_edge + ei * a.edge_ld + seg[i].col, z[i]);
+                    else if (seg[i].kind == 2) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float arg = fmaf(dt, tw[i][e], tb[i][e]);
+                            sincosf(arg, &sn[i][e], &z[i][e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) z[i][e] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) p = fmaf(dg[h][i][e], z[i][e], p);
+                    const float da = tg::wave_sum(p);
+                    const float pr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_p[h]), s));
+                    const float pd = pr * tg::dropout_keep_scale(a.seed, row, h, s0 + s, a.dropout_p);
+                    const float dsc = nb == 0 ? 0.f : (pd * da - pr * cterm[h]) * a.scale;
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            dacc[h][i][e] = fmaf(dsc, z[i][e], dacc[h][i][e]);
+                            dz[i][e] = fmaf(pd, dg[h][i][e], fmaf(dsc, uh[h][i][e], dz[i][e]));
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    if (seg[i].kind == 0 && dfeat) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) atomicAdd(dfeat + fi * dfeat_ld + seg[i].col + e, dz[i][e]);
+                    } else if (seg[i].kind == 2) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float dph = -sn[i][e] * dz[i][e];
+                            gw[i][e] = fmaf(dt, dph, gw[i][e]);
+                            gb[i][e] += dph;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int i = 0; i < CPL; ++i)
+                if (seg[i].kind != 3) store_chunk<VEC>(du + (row * H + h) * dk + (lane + kWave * i) * VEC, dacc[h][i]);
+    }
+
+    // block partial of (dw | db): waves -> LDS -> one slab row per workgroup (no atomics, deterministic)
+    const int T = a.dt_dim;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+        if (seg[i].kind == 2)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                red[wave * 2 * T + seg[i].col + e] = gw[i][e];
+                red[wave * 2 * T + T + seg[i].col + e] = gb[i][e];
+            }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * T; j += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += red[w * 2 * T + j];
+        dte_part[(int64_t)blockIdx.x * 2 * T + j] = s;
+    }
+}
+
+template <int VEC, int CPL>
+int launch_fwd(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s) {
+    const dim3 grid((unsigned)attn_grid(a.m)), block(WAVES_PER_BLOCK * kWave);
+    switch (a.heads) {
+        case 1: attn_fwd_kernel<VEC, CPL, 1><<<grid, block, 0, s>>>(a, u, agg, prob); break;
+        case 2: attn_fwd_kernel<VEC, CPL, 2><<<grid, block, 0, s>>>(a, u, agg, prob); break;
+        case 4: attn_fwd_kernel<VEC, CPL, 4><<<grid, block, 0, s>>>(a, u, agg, prob); break;
+        default: tg::set_error("tg_attn: heads must be 1, 2 or 4"); return TG_EINVAL;
+    }
+    return tg::launch_status("attn_fwd_kernel");
+}
+
+template <int VEC, int CPL>
+int launch_bwd(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
+               float* dfeat, int64_t dfeat_ld, float* dte, hipStream_t s) {
+    const dim3 grid((unsigned)attn_grid(a.m)), block(WAVES_PER_BLOCK * kWave);
+    const size_t lds = sizeof(float) * WAVES_PER_BLOCK * 2 * a.dt_dim;
+    switch (a.heads) {
+        case 1: attn_bwd_kernel<VEC, CPL, 1><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte); break;
+        case 2: attn_bwd_kernel<VEC, CPL, 2><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte); break;
+        case 4: attn_bwd_kernel<VEC, CPL, 4><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte); break;
+        default: tg::set_error("tg_attn: heads must be 1, 2 or 4"); return TG_EINVAL;
+    }
+    return tg::launch_status("attn_bwd_kernel");
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_desc(const tg_attn_desc* a) {
+    TG_REQUIRE(a, "tg_attn: null descriptor");
+    TG_REQUIRE(a->d_feat && a->d_feat_idx && a->d_edge && a->d_edge_idx && a->d_nbr && a->d_dt && a->d_te_w && a->d_te_b,
+               "tg_attn: null pointer in descriptor");
+    TG_REQUIRE(a->m >= 0 && a->k > 0 && a->dn > 0 && a->de >= 0 && a->dt_dim > 0, "tg_attn: sizes");
+    TG_REQUIRE(a->dn + a->de + a->dt_dim <= 1024, "tg_attn: key dimension > 1024 unsupported");
+    TG_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "tg_attn: dropout_p");
+    return TG_OK;
+}
+
+bool vec4_ok(const tg_attn_desc* a, const void* p0, const void* p1, const void* p2, const void* p3, const void* p4) {
+    return a->dn % 4 == 0 && a->de % 4 == 0 && a->dt_dim % 4 == 0 && a->feat_ld % 4 == 0 && a->edge_ld % 4 == 0 &&
+           aligned16(a->d_feat) && aligned16(a->d_edge) && aligned16(p0) && aligned16(p1) && aligned16(p2) &&
+           aligned16(p3) && aligned16(p4);
+}
+
+}  // namespace
+
+extern "C" int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg, float* d_prob, void* stream) {
+    if (int rc = check_desc(a)) return rc;
+    TG_REQUIRE(d_u && d_agg && d_prob, "tg_attn_fwd: null pointer");
+    if (a->m == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int dk = a->dn + a->de + a->dt_dim;
+    if (vec4_ok(a, d_u, d_agg, nullptr, nullptr, nullptr)) {
+        const int c = (dk / 4 + 63) / 64;
+        if (c <= 1) return launch_fwd<4, 1>(*a, d_u, d_agg, d_prob, s);
+        if (c <= 2) return launch_fwd<4, 2>(*a, d_u, d_agg, d_prob, s);
+        return launch_fwd<4, 4>(*a, d_u, d_agg, d_prob, s);
+    }
+    const int c = (dk + 63) / 64;
+    if (c <= 1) return launch_fwd<1, 1>(*a, d_u, d_agg, d_prob, s);
+    TG_REQUIRE(c <= 8, "tg_attn_fwd: unaligned rows wider than 512 floats unsupported");
+    return launch_fwd<1, 8>(*a, d_u, d_agg, d_prob, s);
+}
+
+extern "C" int tg_attn_bwd_parts(int64_t m) { return (int)attn_grid(m); }
+
+extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
+                           const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, float* d_dte_part,
+                           void* stream) {
+    if (int rc = check_desc(a)) return rc;
+    TG_REQUIRE(d_u && d_agg && d_prob && d_dagg && d_du && d_dte_part, "tg_attn_bwd: null pointer");
+    if (a->m == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int dk = a->dn + a->de + a->dt_dim;
+    if (vec4_ok(a, d_u, d_agg, d_dagg, d_du, nullptr)) {
+        const int c = (dk / 4 + 63) / 64;
+        if (c <= 1) return launch_bwd<4, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
+        if (c <= 2) return launch_bwd<4, 2>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
+        return launch_bwd<4, 4>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
+    }
+    const int c = (dk + 63) / 64;
+    if (c <= 1) return launch_bwd<1, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
+    TG_REQUIRE(c <= 8, "tg_attn_bwd: unaligned rows wider than 512 floats unsupported");
+    return launch_bwd<1, 8>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
+}

@@ -1,0 +1,202 @@
+// Temporal adjacency (device CSR) + neighbor lookups.
+//   tg_graph_create      <- utils/utils.py:283-302, :96-103   (reference: python lists of tuples, per-node sorted())
+//   tg_sample_recent     <- utils/utils.py:130-147, :149-214 ('recent' branch :200-209)
+//   tg_first_hop_window  <- utils/utils.py:254-273 + models/DyGFormer.py:196-245
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "tg_common.h"
+
+namespace tg {
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+}  // namespace tg
+
+struct tg_graph {
+    int64_t num_rows = 0;
+    int64_t num_entries = 0;
+    int64_t* d_row_ptr = nullptr;
+    tg::Incidence* d_inc = nullptr;
+};
+
+extern "C" const char* tg_last_error(void) { return tg::g_err.c_str(); }
+extern "C" int tg_version(void) { return 1; }
+
+extern "C" int tg_graph_create(const int64_t* h_src, const int64_t* h_dst, const int64_t* h_eid, const double* h_t,
+                               int64_t num_edges, int64_t num_rows, tg_graph** out) {
+    TG_REQUIRE(out && num_edges >= 0 && num_rows > 0, "tg_graph_create: sizes");
+    TG_REQUIRE(num_edges == 0 || (h_src && h_dst && h_eid && h_t), "tg_graph_create: null arrays");
+    TG_REQUIRE(2 * num_edges < (int64_t)INT32_MAX * 2, "tg_graph_create: too many incidences");
+    // counting sort by owner keeps stream order inside a row; then a stable per-row sort by time.
+    std::vector<int64_t> row_ptr(num_rows + 1, 0);
+    for (int64_t i = 0; i < num_edges; ++i) {
+        int64_t s = h_src[i], d = h_dst[i];
+        TG_REQUIRE(s >= 0 && s < num_rows && d >= 0 && d < num_rows, "tg_graph_create: node id out of range");
+        TG_REQUIRE(h_eid[i] >= 0 && h_eid[i] <= INT32_MAX, "tg_graph_create: edge id out of range");
+        row_ptr[s + 1]++;
+        row_ptr[d + 1]++;
+    }
+    for (int64_t r = 0; r < num_rows; ++r) row_ptr[r + 1] += row_ptr[r];
+    std::vector<tg::Incidence> inc(2 * num_edges);
+    {
+        std::vector<int64_t> cur(row_ptr.begin(), row_ptr.end() - 1);
+        for (int64_t i = 0; i < num_edges; ++i) {   // source endpoint first, as the reference appends (:299-300)
+            inc[cur[h_src[i]]++] = tg::Incidence{(int32_t)h_dst[i], (int32_t)h_eid[i], h_t[i]};
+            inc[cur[h_dst[i]]++] = tg::Incidence{(int32_t)h_src[i], (int32_t)h_eid[i], h_t[i]};
+        }
+    }
+    bool chronological = true;
+    for (int64_t i = 1; i < num_edges && chronological; ++i) chronological = h_t[i - 1] <= h_t[i];
+    if (!chronological) {
+        for (int64_t r = 0; r < num_rows; ++r)
+            std::stable_sort(inc.begin() + row_ptr[r], inc.begin() + row_ptr[r + 1],
+                             [](const tg::Incidence& a, const tg::Incidence& b) { return a.t < b.t; });
+    }
+    tg_graph* g = new tg_graph();
+    g->num_rows = num_rows;
+    g->num_entries = 2 * num_edges;
+    TG_HIP_CHECK(hipMalloc(&g->d_row_ptr, sizeof(int64_t) * (num_rows + 1)));
+    TG_HIP_CHECK(hipMalloc(&g->d_inc, sizeof(tg::Incidence) * std::max<int64_t>(1, g->num_entries)));
+    TG_HIP_CHECK(hipMemcpy(g->d_row_ptr, row_ptr.data(), sizeof(int64_t) * (num_rows + 1), hipMemcpyHostToDevice));
+    if (g->num_entries)
+        TG_HIP_CHECK(hipMemcpy(g->d_inc, inc.data(), sizeof(tg::Incidence) * g->num_entries, hipMemcpyHostToDevice));
+    *out = g;
+    return TG_OK;
+}
+
+extern "C" void tg_graph_destroy(tg_graph* g) {
+    if (!g) return;
+    (void)hipFree(g->d_row_ptr);
+    (void)hipFree(g->d_inc);
+    delete g;
+}
+extern "C" int64_t tg_graph_num_rows(const tg_graph* g) { return g ? g->num_rows : -1; }
+extern "C" int64_t tg_graph_num_entries(const tg_graph* g) { return g ? g->num_entries : -1; }
+
+extern "C" int tg_graph_export(const tg_graph* g, int64_t* h_row_ptr, int32_t* h_nbr, int32_t* h_eid, double* h_t) {
+    TG_REQUIRE(g && h_row_ptr && h_nbr && h_eid && h_t, "tg_graph_export: null");
+    std::vector<tg::Incidence> inc(g->num_entries);
+    TG_HIP_CHECK(hipMemcpy(h_row_ptr, g->d_row_ptr, sizeof(int64_t) * (g->num_rows + 1), hipMemcpyDeviceToHost));
+    if (g->num_entries)
+        TG_HIP_CHECK(hipMemcpy(inc.data(), g->d_inc, sizeof(tg::Incidence) * g->num_entries, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < g->num_entries; ++i) { h_nbr[i] = inc[i].nbr; h_eid[i] = inc[i].eid; h_t[i] = inc[i].t; }
+    return TG_OK;
+}
+
+namespace {
+
+// number of incidences of `row` with t strictly below `when` (numpy searchsorted side='left')
+__device__ __forceinline__ int64_t history_end(const tg::Incidence* __restrict__ inc, int64_t lo, int64_t hi, double when) {
+    int64_t a = lo, b = hi;
+    while (a < b) {
+        int64_t mid = (a + b) >> 1;
+        if (inc[mid].t < when) a = mid + 1; else b = mid;
+    }
+    return a - lo;
+}
+
+// One query per (k-lane group): lane 0 of the group searches, then the group's lanes copy one slot each.
+template <int GROUP>
+__global__ void __launch_bounds__(256) sample_recent_kernel(const int64_t* __restrict__ row_ptr,
+        const tg::Incidence* __restrict__ inc, int64_t num_rows, const int32_t* __restrict__ ids,
+        const double* __restrict__ t64, const float* __restrict__ t32, int64_t n, int k,
+        int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid, float* __restrict__ o_t, float* __restrict__ o_dt,
+        int32_t* __restrict__ status) {
+    const int lane = threadIdx.x % GROUP;
+    const int64_t groups_per_block = blockDim.x / GROUP;
+    for (int64_t q = blockIdx.x * groups_per_block + threadIdx.x / GROUP; q < n; q += (int64_t)gridDim.x * groups_per_block) {
+        const int32_t v = ids[q];
+        // hop >= 2 queries arrive as float32 and are promoted exactly (numpy semantics of utils.py:141)
+        const double when = t64 ? t64[q] : (double)t32[q];
+        int64_t cnt = 0, lo = 0;
+        if (v < 0 || v >= num_rows) {
+            if (lane == 0 && status) atomicExch(status, 1);
+        } else {
+            lo = row_ptr[v];
+            if (lane == 0) cnt = history_end(inc, lo, row_ptr[v + 1], when);
+            cnt = __shfl(cnt, 0, GROUP);
+        }
+        const int64_t take = cnt < k ? cnt : k;
+        const int64_t first = lo + cnt - take;   // newest `take`, oldest first
+        for (int s = lane; s < k; s += GROUP) {
+            const int64_t j = s - (k - take);
+            int32_t nb = 0, ed = 0;
+            float tt = 0.f;
+            if (j >= 0) {
+                const tg::Incidence e = inc[first + j];
+                nb = e.nbr; ed = e.eid; tt = (float)e.t;
+            }
+            const int64_t o = q * k + s;
+            o_nbr[o] = nb; o_eid[o] = ed; o_t[o] = tt;
+            if (o_dt) o_dt[o] = t64 ? (float)(when - (double)tt) : (t32[q] - tt);   // TGAT.py:120-125 dtype rules
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) first_hop_window_kernel(const int64_t* __restrict__ row_ptr,
+        const tg::Incidence* __restrict__ inc, int64_t num_rows, const int32_t* __restrict__ ids,
+        const double* __restrict__ t64, int64_t n, int max_len, int width,
+        int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid, float* __restrict__ o_t, int32_t* __restrict__ o_len) {
+    constexpr int GROUP = 32;
+    const int lane = threadIdx.x % GROUP;
+    const int64_t gpb = blockDim.x / GROUP;
+    for (int64_t q = blockIdx.x * gpb + threadIdx.x / GROUP; q < n; q += (int64_t)gridDim.x * gpb) {
+        const int32_t v = ids[q];
+        const double when = t64[q];
+        int64_t cnt = 0, lo = 0;
+        if (v >= 0 && v < num_rows) {
+            lo = row_ptr[v];
+            if (lane == 0) cnt = history_end(inc, lo, row_ptr[v + 1], when);
+            cnt = __shfl(cnt, 0, GROUP);
+        }
+        const int64_t keep = cnt < (max_len - 1) ? cnt : (max_len - 1);
+        const int64_t first = lo + cnt - keep;
+        for (int s = lane; s < width; s += GROUP) {
+            int32_t nb = 0, ed = 0;
+            float tt = 0.f;
+            if (s == 0) { nb = v; tt = (float)when; }                       // DyGFormer.py:235-237
+            else if (s <= keep) { const tg::Incidence e = inc[first + s - 1]; nb = e.nbr; ed = e.eid; tt = (float)e.t; }
+            const int64_t o = q * width + s;
+            o_nbr[o] = nb; o_eid[o] = ed; o_t[o] = tt;
+        }
+        if (lane == 0) o_len[q] = (int32_t)(keep + 1);
+    }
+}
+
+inline int grid_for(int64_t work_items, int64_t per_block) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, 8 * tg::kMaxGridBlocks));
+}
+
+}  // namespace
+
+extern "C" int tg_sample_recent(const tg_graph* g, const int32_t* d_ids, const double* d_times64, const float* d_times32,
+                                int64_t n, int k, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, float* d_out_dt,
+                                int32_t* d_status, void* stream) {
+    TG_REQUIRE(g && d_ids && d_out_nbr && d_out_eid && d_out_t, "tg_sample_recent: null pointer");
+    TG_REQUIRE((d_times64 != nullptr) != (d_times32 != nullptr), "tg_sample_recent: pass exactly one of times64/times32");
+    TG_REQUIRE(k > 0, "Number of sampled neighbors for each node should be greater than 0!");
+    TG_REQUIRE(n >= 0, "tg_sample_recent: n");
+    if (n == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (k <= 8)
+        sample_recent_kernel<8><<<grid_for(n, 256 / 8), 256, 0, s>>>(g->d_row_ptr, g->d_inc, g->num_rows, d_ids, d_times64,
+            d_times32, n, k, d_out_nbr, d_out_eid, d_out_t, d_out_dt, d_status);
+    else
+        sample_recent_kernel<32><<<grid_for(n, 256 / 32), 256, 0, s>>>(g->d_row_ptr, g->d_inc, g->num_rows, d_ids, d_times64,
+            d_times32, n, k, d_out_nbr, d_out_eid, d_out_t, d_out_dt, d_status);
+    return tg::launch_status("sample_recent_kernel");
+}
+
+extern "C" int tg_first_hop_window(const tg_graph* g, const int32_t* d_ids, const double* d_times64, int64_t n, int max_len,
+                                   int width, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, int32_t* d_out_len,
+                                   void* stream) {
+    TG_REQUIRE(g && d_ids && d_times64 && d_out_nbr && d_out_eid && d_out_t && d_out_len, "tg_first_hop_window: null pointer");
+    TG_REQUIRE(max_len - 1 > 0, "Maximal number of neighbors for each node should be greater than 1!");
+    TG_REQUIRE(width >= max_len || width >= 1, "tg_first_hop_window: width");
+    if (n == 0) return TG_OK;
+    first_hop_window_kernel<<<grid_for(n, 8), 256, 0, (hipStream_t)stream>>>(g->d_row_ptr, g->d_inc, g->num_rows, d_ids,
+        d_times64, n, max_len, width, d_out_nbr, d_out_eid, d_out_t, d_out_len);
+    return tg::launch_status("first_hop_window_kernel");
+}

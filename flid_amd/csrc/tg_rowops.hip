@@ -1,0 +1,251 @@
+// Row-wise helpers around the dense kernels: gathers, fused add+LayerNorm (fwd/bwd), column sums, ReLU mask,
+// time encoding.  All HBM-bound, 16-byte accesses where the shape allows.
+//   tg_gather_rows        <- models/TGAT.py:87            node_raw_features[ids]
+//   tg_add_layernorm_*    <- models/modules.py:238        layer_norm(output + residual), eps 1e-5
+//   tg_time_encode        <- models/modules.py:28-40      cos(w t + b)
+#include <math.h>
+
+#include "tg_common.h"
+
+namespace {
+
+using tg::kWave;
+constexpr int ROW_WAVES = 4;
+
+__host__ __device__ inline int64_t row_grid(int64_t n) {
+    int64_t b = (n + ROW_WAVES - 1) / ROW_WAVES;
+    return b < 1 ? 1 : (b > tg::kMaxGridBlocks ? tg::kMaxGridBlocks : b);
+}
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ table, int64_t tld,
+        const int32_t* __restrict__ idx, int64_t n, int cols, float* __restrict__ out, int64_t old, int vec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
+        const float* src = table + (int64_t)idx[r] * tld;
+        float* dst = out + r * old;
+        if (vec) {
+            for (int c = lane * 4; c < cols; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+        } else {
+            for (int c = lane; c < cols; c += 64) dst[c] = src[c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float* __restrict__ src, int64_t sld,
+        const int32_t* __restrict__ idx, int64_t n, int cols, float* __restrict__ table, int64_t tld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
+        float* dst = table + (int64_t)idx[r] * tld;
+        const float* s = src + r * sld;
+        for (int c = lane; c < cols; c += 64) atomicAdd(dst + c, s[c]);
+    }
+}
+
+// y = LN(a + b): one wave per row, the row lives in registers (cols <= 64 * MAXC)
+template <int MAXC>
+__global__ void __launch_bounds__(256) add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+        int cols, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+        float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
+        float x[MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            x[i] = c < cols ? a[r * cols + c] + b[r * cols + c] : 0.f;
+            s += x[i];
+        }
+        const float mu = tg::wave_sum(s) / cols;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const float d = c < cols ? x[i] - mu : 0.f;
+            v = fmaf(d, d, v);
+        }
+        const float rs = rsqrtf(tg::wave_sum(v) / cols + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) y[r * cols + c] = (x[i] - mu) * rs * gamma[c] + beta[c];
+        }
+        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; per-workgroup partials of dgamma / dbeta
+template <int MAXC>
+__global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+        const float* __restrict__ dy, int64_t n, int cols, const float* __restrict__ gamma, const float* __restrict__ mean,
+        const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ float red[];   // ROW_WAVES * 2 * cols
+    float dgam[MAXC], dbet[MAXC], gm[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        dgam[i] = 0.f; dbet[i] = 0.f;
+        const int c = lane + 64 * i;
+        gm[i] = c < cols ? gamma[c] : 0.f;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
+        const float mu = mean[r], rs = rstd[r];
+        float xh[MAXC], g[MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = c < cols;
+            const float d = ok ? dy[r * cols + c] : 0.f;
+            xh[i] = ok ? (a[r * cols + c] + b[r * cols + c] - mu) * rs : 0.f;
+            g[i] = d * gm[i];
+            s1 += g[i];
+            s2 = fmaf(g[i], xh[i], s2);
+            dgam[i] = fmaf(d, xh[i], dgam[i]);
+            dbet[i] += d;
+        }
+        const float m1 = tg::wave_sum(s1) / cols, m2 = tg::wave_sum(s2) / cols;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) dx[r * cols + c] = rs * (g[i] - m1 - xh[i] * m2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cols) { red[wave * 2 * cols + c] = dgam[i]; red[wave * 2 * cols + cols + c] = dbet[i]; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * cols; j += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < ROW_WAVES; ++w) s += red[w * 2 * cols + j];
+        part[(int64_t)blockIdx.x * 2 * cols + j] = s;
+    }
+}
+
+// column sums: grid.x blocks over column groups of 64, grid.y row slices; second pass folds the slices.
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int cols,
+                                                             float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < cols)
+        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < n; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int slices, int cols,
+                                                           float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < slices; ++i) s += part[(int64_t)i * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ void __launch_bounds__(256) relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        if (!(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+__global__ void __launch_bounds__(256) time_encode_kernel(const float* __restrict__ t, int64_t n, const float* __restrict__ w,
+        const float* __restrict__ b, int dim, int fused, float* __restrict__ out) {
+    const int64_t total = n * dim;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dim;
+        const int j = (int)(i - r * dim);
+        const float tv = t[r];
+        float arg;
+        if (fused) arg = fmaf(tv, w[j], b[j]);
+        else arg = __fadd_rn(__fmul_rn(tv, w[j]), b[j]);   // keep the two roundings (no contraction)
+        out[i] = cosf(arg);
+    }
+}
+
+float* g_colsum_ws = nullptr;
+size_t g_colsum_ws_floats = 0;
+
+}  // namespace
+
+extern "C" int tg_rowop_parts(int64_t n) { return (int)row_grid(n); }
+
+extern "C" int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols, float* d_out,
+                              int64_t out_ld, void* stream) {
+    TG_REQUIRE(d_table && d_idx && d_out && cols > 0 && n >= 0, "tg_gather_rows: arguments");
+    if (n == 0) return TG_OK;
+    const int vec = cols % 4 == 0 && table_ld % 4 == 0 && out_ld % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(d_table) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
+    gather_rows_kernel<<<(unsigned)row_grid(n), 256, 0, (hipStream_t)stream>>>(d_table, table_ld, d_idx, n, cols, d_out, out_ld, vec);
+    return tg::launch_status("gather_rows_kernel");
+}
+
+extern "C" int tg_scatter_add_rows(const float* d_src, int64_t src_ld, const int32_t* d_idx, int64_t n, int cols,
+                                   float* d_table, int64_t table_ld, void* stream) {
+    TG_REQUIRE(d_src && d_idx && d_table && cols > 0 && n >= 0, "tg_scatter_add_rows: arguments");
+    if (n == 0) return TG_OK;
+    scatter_add_rows_kernel<<<(unsigned)row_grid(n), 256, 0, (hipStream_t)stream>>>(d_src, src_ld, d_idx, n, cols, d_table, table_ld);
+    return tg::launch_status("scatter_add_rows_kernel");
+}
+
+extern "C" int tg_add_layernorm_fwd(const float* d_a, const float* d_b, int64_t n, int cols, const float* d_gamma,
+                                    const float* d_beta, float* d_y, float* d_mean, float* d_rstd, void* stream) {
+    TG_REQUIRE(d_a && d_b && d_gamma && d_beta && d_y && d_mean && d_rstd, "tg_add_layernorm_fwd: null pointer");
+    TG_REQUIRE(cols > 0 && cols <= 1024, "tg_add_layernorm_fwd: cols must be in 1..1024");
+    if (n == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = (unsigned)row_grid(n);
+    if (cols <= 64) add_ln_fwd_kernel<1><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
+    else if (cols <= 320) add_ln_fwd_kernel<5><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
+    else add_ln_fwd_kernel<16><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
+    return tg::launch_status("add_ln_fwd_kernel");
+}
+
+extern "C" int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const float* d_dy, int64_t n, int cols,
+                                    const float* d_gamma, const float* d_mean, const float* d_rstd, float* d_dx,
+                                    float* d_dgb_part, void* stream) {
+    TG_REQUIRE(d_a && d_b && d_dy && d_gamma && d_mean && d_rstd && d_dx && d_dgb_part, "tg_add_layernorm_bwd: null pointer");
+    TG_REQUIRE(cols > 0 && cols <= 1024, "tg_add_layernorm_bwd: cols must be in 1..1024");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = (unsigned)row_grid(n);
+    const size_t lds = sizeof(float) * ROW_WAVES * 2 * cols;
+    if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
+    else if (cols <= 320) add_ln_bwd_kernel<5><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
+    else add_ln_bwd_kernel<16><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
+    return tg::launch_status("add_ln_bwd_kernel");
+}
+
+extern "C" int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, float* d_out, int accumulate, void* stream) {
+    TG_REQUIRE(d_x && d_out && cols > 0 && n >= 0 && ld >= cols, "tg_colsum: arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int slices = (int)std::min<int64_t>(256, std::max<int64_t>(1, n / 64));
+    const size_t need = (size_t)slices * cols;
+    if (need > g_colsum_ws_floats) {   // grows rarely; never inside a captured region after warm-up
+        if (g_colsum_ws) (void)hipFree(g_colsum_ws);
+        g_colsum_ws_floats = std::max<size_t>(need, 256 * 1024);
+        TG_HIP_CHECK(hipMalloc(&g_colsum_ws, g_colsum_ws_floats * sizeof(float)));
+    }
+    colsum_partial_kernel<<<dim3((cols + 63) / 64, slices), 256, 0, s>>>(d_x, ld, n, cols, g_colsum_ws);
+    colsum_final_kernel<<<(cols + 255) / 256, 256, 0, s>>>(g_colsum_ws, slices, cols, d_out, accumulate);
+    return tg::launch_status("colsum kernels");
+}
+
+extern "C" int tg_relu_bwd_inplace(float* d_dy, const float* d_y, int64_t numel, void* stream) {
+    TG_REQUIRE(d_dy && d_y && numel >= 0, "tg_relu_bwd_inplace: arguments");
+    if (numel == 0) return TG_OK;
+    const int64_t blocks = std::min<int64_t>((numel + 255) / 256, tg::kMaxGridBlocks);
+    relu_bwd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_dy, d_y, numel);
+    return tg::launch_status("relu_bwd_kernel");
+}
+
+extern "C" int tg_time_encode(const float* d_t, int64_t n, const float* d_w, const float* d_b, int dim, int fused_fma,
+                              float* d_out, void* stream) {
+    TG_REQUIRE(d_t && d_w && d_b && d_out && dim > 0 && n >= 0, "tg_time_encode: arguments");
+    if (n == 0) return TG_OK;
+    const int64_t blocks = std::min<int64_t>((n * dim + 255) / 256, tg::kMaxGridBlocks);
+    time_encode_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_t, n, d_w, d_b, dim, fused_fma, d_out);
+    return tg::launch_status("time_encode_kernel");
+}

@@ -1,0 +1,271 @@
+"""Device engine for the recursive temporal-attention embedding (TGAT, and TGN's GraphAttentionEmbedding).
+
+replaces: models/TGAT.py:68-144 compute_node_temporal_embeddings and models/MemoryModel.py:632-715, including the
+sampler calls (utils/utils.py:149-214) and every gather / cat / Linear / softmax / LayerNorm under them.
+
+Frontier layout.  With n roots and k neighbors, all nodes touched by an L-layer embedding are kept in ONE row space:
+rows [0, n) are the roots, and the j-th sampled neighbor of row r is row  n + r*k + j.  So
+  * the sampler output arrays S_*[r, j] (r < R_1) are at the same time the ids / query times of the deeper rows,
+  * layer l computes H^l for the first R_l = n (1 + k + ... + k^(L-l)) rows from H^(l-1) of the first R_(l-1) rows,
+  * the neighbor features of layer l >= 2 are rows of the previous layer's output (feat_idx = n + r*k + j) and, for
+    layer 1, rows of the node table itself (feat_idx = neighbor id) -- the deepest frontier is never materialised.
+Every FLOP and gathered byte runs in libflid_tg.so (ops.py); torch supplies memory, the stream and autograd plumbing.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .graph import TemporalGraph
+
+LAYER_PARAMS = ("query_projection.weight", "key_projection.weight", "value_projection.weight", "layer_norm.weight",
+                "layer_norm.bias", "residual_fc.weight", "residual_fc.bias")
+MERGE_PARAMS = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
+
+
+@dataclass
+class _LayerCtx:
+    R: int
+    own: torch.Tensor = None
+    raw: torch.Tensor = None
+    q: torch.Tensor = None
+    u: torch.Tensor = None
+    attn: ops.AttnArgs = None
+    agg: torch.Tensor = None
+    prob: torch.Tensor = None
+    ctxv: torch.Tensor = None
+    res: torch.Tensor = None
+    drop: Optional[torch.Tensor] = None
+    x: torch.Tensor = None
+    mean: torch.Tensor = None
+    rstd: torch.Tensor = None
+    y: torch.Tensor = None
+    f1: torch.Tensor = None
+
+
+@dataclass
+class _Ctx:
+    n: int
+    k: int
+    ids_all: torch.Tensor = None
+    cosb: torch.Tensor = None
+    layers: List[_LayerCtx] = field(default_factory=list)
+    table: torch.Tensor = None
+    table_grad: bool = False
+
+
+def frontier_rows(n: int, k: int, depth: int) -> int:
+    """n (1 + k + ... + k^depth)"""
+    return n * sum(k ** d for d in range(depth + 1))
+
+
+def sample_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torch.Tensor, k: int, num_layers: int):
+    """All sampler lookups of one embedding call: level 0 with float64 query times, deeper levels with the float32
+    neighbor times fed straight back (models/TGAT.py:110-111).  Returns S_nbr, S_eid, S_t, S_dt of shape (R_1, k)."""
+    n = ids_dev.numel()
+    dev = ids_dev.device
+    R1 = frontier_rows(n, k, num_layers - 1)
+    S = (torch.empty((R1, k), dtype=torch.int32, device=dev), torch.empty((R1, k), dtype=torch.int32, device=dev),
+         torch.empty((R1, k), dtype=torch.float32, device=dev), torch.empty((R1, k), dtype=torch.float32, device=dev))
+    graph.sample_recent(ids_dev, times_dev, k, out=tuple(t[0:n] for t in S))
+    off, cnt = 0, n
+    for _ in range(1, num_layers):
+        q_ids = S[0][off:off + cnt].reshape(-1)
+        q_t = S[2][off:off + cnt].reshape(-1)
+        lo = off + cnt
+        graph.sample_recent(q_ids, q_t, k, out=tuple(t[lo:lo + cnt * k] for t in S))
+        off, cnt = lo, cnt * k
+    return S
+
+
+class _EmbedFn(torch.autograd.Function):
+    """One autograd node for the whole L-layer embedding.  Inputs after the fixed ones: te_w, te_b, then per layer the
+    7 attention + 4 merge parameters, then (optionally) the layer-0 base table when it carries gradient (TGN)."""
+
+    @staticmethod
+    def forward(ctx, cfg, S, ids_dev, table, te_w, te_b, *layer_params):
+        n, k, L, H = cfg["n"], cfg["k"], cfg["num_layers"], cfg["num_heads"]
+        edge = cfg["edge_table"]
+        p_drop, training = cfg["dropout"], cfg["training"]
+        dev = ids_dev.device
+        Dn, T = table.shape[1], te_w.numel()
+        Dq = Dn + T
+        hd = Dq // H
+        S_nbr, S_eid, S_t, S_dt = S
+        st = _Ctx(n=n, k=k)
+        st.table = table
+        st.table_grad = cfg["table_grad"]
+        ids_all = torch.cat([ids_dev, S_nbr.reshape(-1)])
+        st.ids_all = ids_all
+        te_w_flat = te_w.reshape(-1)
+        # time encoding of a zero interval: cos(b) (models/TGAT.py:84-85); one row, shared by every query
+        cosb = ops.time_encode(torch.zeros(1, device=dev), te_w_flat, te_b).reshape(-1)
+        st.cosb = cosb
+        H_prev = None
+        for l in range(1, L + 1):
+            Wq, Wk, Wv, ln_g, ln_b, Wr, br, W1, b1, W2, b2 = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
+            R = frontier_rows(n, k, L - l)
+            lc = _LayerCtx(R=R)
+            lc.raw = ops.gather_rows(table, ids_all[:R])
+            lc.own = lc.raw if l == 1 else H_prev[:R]
+            # q = [own | cos(b)] Wq^T : the constant half folds into a bias row
+            qbias = torch.empty((1, Dq), device=dev)
+            ops.gemm(cosb.view(1, T), Wq[:, Dn:], qbias, tb=True)
+            lc.q = torch.empty((R, Dq), device=dev)
+            ops.gemm(lc.own, Wq[:, :Dn], lc.q, tb=True, bias=qbias.view(-1))
+            # u_h = Wk_h^T q_h : the query carried into key space (score = u . z)
+            Dk = Wk.shape[1]
+            lc.u = torch.empty((R, H, Dk), device=dev)
+            for h in range(H):
+                ops.gemm(lc.q[:, h * hd:(h + 1) * hd], Wk[h * hd:(h + 1) * hd], lc.u[:, h, :])
+            if l == 1:
+                feat, feat_idx = table, S_nbr[:R].reshape(-1)
+            else:
+                feat, feat_idx = H_prev, torch.arange(n, n + R * k, dtype=torch.int32, device=dev)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p_drop > 0) else 0
+            lc.attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
+                                   te_w_flat, te_b, k, H, hd ** -0.5, p_drop if training else 0.0, seed)
+            lc.agg, lc.prob = ops.attn_fwd(lc.attn, lc.u)
+            lc.ctxv = torch.empty((R, Dq), device=dev)
+            for h in range(H):
+                ops.gemm(lc.agg[:, h, :], Wv[h * hd:(h + 1) * hd], lc.ctxv[:, h * hd:(h + 1) * hd], tb=True)
+            lc.res = torch.empty((R, Dq), device=dev)
+            ops.gemm(lc.ctxv, Wr, lc.res, tb=True, bias=br)
+            if training and p_drop > 0:                                     # modules.py:235
+                lc.drop = (torch.rand_like(lc.res) >= p_drop).to(torch.float32) / (1.0 - p_drop)
+                lc.res = lc.res * lc.drop
+            lc.x = torch.cat([lc.own, cosb.view(1, T).expand(R, T)], dim=1)
+            lc.y, lc.mean, lc.rstd = ops.add_layernorm_fwd(lc.res, lc.x, ln_g, ln_b)
+            lc.f1 = torch.empty((R, W1.shape[0]), device=dev)
+            ops.gemm(lc.y, W1[:, :Dq], lc.f1, tb=True, bias=b1)
+            ops.gemm(lc.raw, W1[:, Dq:], lc.f1, tb=True, accumulate=True, relu=True)
+            H_cur = torch.empty((R, W2.shape[0]), device=dev)
+            ops.gemm(lc.f1, W2, H_cur, tb=True, bias=b2)
+            st.layers.append(lc)
+            H_prev = H_cur
+        ctx.st = st
+        ctx.cfg = cfg
+        ctx.save_for_backward(te_w, te_b, *layer_params)
+        return H_prev
+
+    @staticmethod
+    def backward(ctx, dH):
+        st, cfg = ctx.st, ctx.cfg
+        te_w, te_b, *layer_params = ctx.saved_tensors
+        n, k, L, H = st.n, st.k, cfg["num_layers"], cfg["num_heads"]
+        dev = dH.device
+        Dn, T = st.table.shape[1], te_w.numel()
+        Dq = Dn + T
+        hd = Dq // H
+        grads = [None] * len(layer_params)
+        d_tew = torch.zeros(T, device=dev)
+        d_teb = torch.zeros(T, device=dev)
+        d_cosb = torch.zeros(T, device=dev)
+        d_table = torch.zeros_like(st.table) if st.table_grad else None
+        dH = dH.contiguous()
+        for l in range(L, 0, -1):
+            lc = st.layers[l - 1]
+            R = lc.R
+            Wq, Wk, Wv, ln_g, ln_b, Wr, br, W1, b1, W2, b2 = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
+            Dk = Wk.shape[1]
+            need_own = l >= 2 or st.table_grad
+            dHl = dH[:R]
+            # merge layer
+            dW2 = torch.empty_like(W2)
+            ops.gemm(dHl, lc.f1, dW2, ta=True)
+            db2 = ops.colsum(dHl)
+            df1 = torch.empty_like(lc.f1)
+            ops.gemm(dHl, W2, df1)
+            ops.relu_bwd_(df1, lc.f1)
+            dW1 = torch.empty_like(W1)
+            ops.gemm(df1, lc.y, dW1[:, :Dq], ta=True)
+            ops.gemm(df1, lc.raw, dW1[:, Dq:], ta=True)
+            db1 = ops.colsum(df1)
+            dy = torch.empty((R, Dq), device=dev)
+            ops.gemm(df1, W1[:, :Dq], dy)
+            d_rawrows = None
+            if st.table_grad:
+                d_rawrows = torch.empty((R, Dn), device=dev)
+                ops.gemm(df1, W1[:, Dq:], d_rawrows)
+            # residual + layer norm
+            dsum, dg, dbeta = ops.add_layernorm_bwd(lc.res, lc.x, dy, ln_g, lc.mean, lc.rstd)
+            d_cosb += ops.colsum(dsum[:, Dn:])
+            dres = dsum * lc.drop if lc.drop is not None else dsum
+            dWr = torch.empty_like(Wr)
+            ops.gemm(dres, lc.ctxv, dWr, ta=True)
+            dbr = ops.colsum(dres)
+            dctx = torch.empty((R, Dq), device=dev)
+            ops.gemm(dres, Wr, dctx)
+            # value path
+            dagg = torch.empty((R, H, Dk), device=dev)
+            dWv = torch.empty_like(Wv)
+            for h in range(H):
+                ops.gemm(dctx[:, h * hd:(h + 1) * hd], Wv[h * hd:(h + 1) * hd], dagg[:, h, :])
+                ops.gemm(dctx[:, h * hd:(h + 1) * hd], lc.agg[:, h, :], dWv[h * hd:(h + 1) * hd], ta=True)
+            # fused attention backward: re-streams the neighbor rows once
+            if l >= 2:
+                R_prev = frontier_rows(n, k, L - l + 1)
+                dH_prev = torch.zeros((R_prev, Dn), device=dev)
+                dfeat = dH_prev
+            else:
+                dH_prev = None
+                dfeat = d_table
+            du, dw_part, db_part = ops.attn_bwd(lc.attn, lc.u, lc.agg, lc.prob, dagg, dfeat)
+            d_tew += dw_part
+            d_teb += db_part
+            # key / query path
+            dq = torch.empty((R, Dq), device=dev)
+            dWk = torch.empty_like(Wk)
+            for h in range(H):
+                ops.gemm(du[:, h, :], Wk[h * hd:(h + 1) * hd], dq[:, h * hd:(h + 1) * hd], tb=True)
+                ops.gemm(lc.q[:, h * hd:(h + 1) * hd], du[:, h, :], dWk[h * hd:(h + 1) * hd], ta=True)
+            dWq = torch.empty_like(Wq)
+            ops.gemm(dq, lc.own, dWq[:, :Dn], ta=True)
+            dq_sum = ops.colsum(dq)
+            dWq[:, Dn:] = torch.outer(dq_sum, st.cosb)
+            tmp = torch.empty((1, T), device=dev)
+            ops.gemm(dq_sum.view(1, Dq), Wq[:, Dn:], tmp)
+            d_cosb += tmp.view(-1)
+            if need_own:
+                d_own = torch.empty((R, Dn), device=dev)
+                ops.gemm(dq, Wq[:, :Dn], d_own)
+                d_own += dsum[:, :Dn]
+                if l >= 2:
+                    dH_prev[:R] += d_own
+                    if st.table_grad:
+                        ops.scatter_add_rows(d_rawrows, st.ids_all[:R], d_table)
+                else:
+                    d_own += d_rawrows
+                    ops.scatter_add_rows(d_own, st.ids_all[:R], d_table)
+            grads[(l - 1) * 11:(l - 1) * 11 + 11] = [dWq, dWk, dWv, dg, dbeta, dWr, dbr, dW1, db1, dW2, db2]
+            dH = dH_prev
+        # d cos(b) -> d b  (t = 0, so no weight gradient from the zero-interval encoding)
+        sinb = torch.sin(te_b)
+        d_teb -= sinb * d_cosb
+        ctx.st = None
+        return (None, None, None, d_table, d_tew.view_as(te_w), d_teb, *grads)
+
+
+def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, te_w, te_b, layer_params, ids: np.ndarray,
+          times: np.ndarray, k: int, num_layers: int, num_heads: int, dropout: float, training: bool,
+          table_requires_grad: bool = False):
+    """H^L for `ids` at `times` (host numpy in, device tensor out, autograd-connected to the parameters)."""
+    dev = table.device
+    ids = np.asarray(ids)
+    if len(ids) and (int(ids.max()) >= graph.num_rows or int(ids.min()) < 0):
+        raise IndexError("list index out of range")                      # what utils/utils.py:141 raises
+    assert k > 0, 'Number of sampled neighbors for each node should be greater than 0!'
+    n = len(ids)
+    ids_dev = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(dev)
+    tt = np.asarray(times)
+    times_dev = torch.from_numpy(np.ascontiguousarray(tt, dtype=np.float32 if tt.dtype == np.float32 else np.float64)).to(dev)
+    if n == 0:
+        return torch.zeros((0, table.shape[1]), device=dev)
+    if num_layers == 0:
+        return ops.gather_rows(table, ids_dev)
+    S = sample_frontier(graph, ids_dev, times_dev, k, num_layers)
+    cfg = dict(n=n, k=k, num_layers=num_layers, num_heads=num_heads, dropout=float(dropout), training=bool(training),
+               edge_table=edge_table, table_grad=bool(table_requires_grad))
+    return _EmbedFn.apply(cfg, S, ids_dev, table, te_w, te_b, *layer_params)

@@ -1,0 +1,84 @@
+"""TemporalGraph: device-resident time-sorted adjacency (tg_graph) + typed lookups.
+
+replaces the storage half of utils/utils.py:71-110 (python lists of per-node numpy arrays)."""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+from .ops import _p, _stream
+
+
+class TemporalGraph:
+    def __init__(self, src: np.ndarray, dst: np.ndarray, eid: np.ndarray, t: np.ndarray, num_rows: Optional[int] = None):
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.ascontiguousarray(dst, dtype=np.int64)
+        eid = np.ascontiguousarray(eid, dtype=np.int64)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        if not (len(src) == len(dst) == len(eid) == len(t)):
+            raise ValueError("src/dst/eid/t must have equal length")
+        if num_rows is None:
+            num_rows = int(max(src.max(), dst.max())) + 1 if len(src) else 1        # utils/utils.py:293-297
+        self.num_rows = int(num_rows)
+        self.num_edges = len(src)
+        h = C.c_void_p()
+        check(lib().tg_graph_create(src.ctypes.data, dst.ctypes.data, eid.ctypes.data, t.ctypes.data, len(src),
+                                    self.num_rows, C.byref(h)), "tg_graph_create")
+        self._h = h
+        self._host = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().tg_graph_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def host_csr(self):
+        """(row_ptr i64, nbr i32, eid i32, t f64) copied back once; used by the numpy-facing sampler strategies."""
+        if self._host is None:
+            n = lib().tg_graph_num_entries(self._h)
+            rp = np.empty(self.num_rows + 1, dtype=np.int64)
+            nb = np.empty(n, dtype=np.int32)
+            ei = np.empty(n, dtype=np.int32)
+            tt = np.empty(n, dtype=np.float64)
+            check(lib().tg_graph_export(self._h, rp.ctypes.data, nb.ctypes.data, ei.ctypes.data, tt.ctypes.data), "tg_graph_export")
+            self._host = (rp, nb, ei, tt)
+        return self._host
+
+    # ---- device lookups ---------------------------------------------------------------------------
+    def sample_recent(self, ids: torch.Tensor, times: torch.Tensor, k: int, out=None, want_dt=True):
+        """ids int32 (n,), times float64 or float32 (n,) on the device.  Returns (nbr i32, eid i32, t f32, dt f32|None),
+        each (n, k).  `out` may carry four preallocated row-slices to fill in place."""
+        n = ids.numel()
+        dev = ids.device
+        if out is None:
+            out = (torch.empty((n, k), dtype=torch.int32, device=dev), torch.empty((n, k), dtype=torch.int32, device=dev),
+                   torch.empty((n, k), dtype=torch.float32, device=dev),
+                   torch.empty((n, k), dtype=torch.float32, device=dev) if want_dt else None)
+        t64 = times if times.dtype == torch.float64 else None
+        t32 = times if times.dtype == torch.float32 else None
+        if t64 is None and t32 is None:
+            raise ValueError("times must be float64 or float32")
+        assert ids.dtype == torch.int32 and ids.is_contiguous() and times.is_contiguous()
+        check(lib().tg_sample_recent(self._h, _p(ids), _p(t64), _p(t32), n, int(k), _p(out[0]), _p(out[1]), _p(out[2]),
+                                     _p(out[3]), C.c_void_p(0), _stream()), "tg_sample_recent")
+        return out
+
+    def first_hop_window(self, ids: torch.Tensor, times: torch.Tensor, max_len: int, width: int):
+        n = ids.numel()
+        dev = ids.device
+        nbr = torch.empty((n, width), dtype=torch.int32, device=dev)
+        eid = torch.empty((n, width), dtype=torch.int32, device=dev)
+        tt = torch.empty((n, width), dtype=torch.float32, device=dev)
+        ln = torch.empty(n, dtype=torch.int32, device=dev)
+        check(lib().tg_first_hop_window(self._h, _p(ids), _p(times), n, int(max_len), int(width), _p(nbr), _p(eid), _p(tt),
+                                        _p(ln), _stream()), "tg_first_hop_window")
+        return nbr, eid, tt, ln

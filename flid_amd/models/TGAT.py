@@ -1,0 +1,69 @@
+"""TGAT backbone -- drop-in for the reference class (models/TGAT.py): same constructor, methods, parameter names.
+
+compute_src_dst_node_temporal_embeddings() takes host numpy (int64 ids, float64 times) and returns two device fp32
+tensors connected by autograd to this module's parameters; the work in between runs in libflid_tg.so."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import engine
+from ..utils.utils import NeighborSampler
+from .modules import MergeLayer, MultiHeadAttention, TimeEncoder
+
+
+class TGAT(nn.Module):
+
+    def __init__(self, node_raw_features: np.ndarray, edge_raw_features: np.ndarray, neighbor_sampler: NeighborSampler,
+                 time_feat_dim: int, num_layers: int = 2, num_heads: int = 2, dropout: float = 0.1, device: str = 'cpu'):
+        super().__init__()
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("flid_amd.TGAT runs on a ROCm device only (device='cuda' / 'cuda:N'); there is no CPU path")
+        # plain tensors, not parameters/buffers: not in state_dict, no grad (reference TGAT.py:26-29)
+        self.node_raw_features = torch.from_numpy(node_raw_features.astype(np.float32)).to(device).contiguous()
+        self.edge_raw_features = torch.from_numpy(edge_raw_features.astype(np.float32)).to(device).contiguous()
+        self.neighbor_sampler = neighbor_sampler
+        self.node_feat_dim = self.node_raw_features.shape[1]
+        self.edge_feat_dim = self.edge_raw_features.shape[1]
+        self.time_feat_dim = time_feat_dim
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.time_encoder = TimeEncoder(time_dim=time_feat_dim)
+        self.temporal_conv_layers = nn.ModuleList([
+            MultiHeadAttention(node_feat_dim=self.node_feat_dim, edge_feat_dim=self.edge_feat_dim, time_feat_dim=self.time_feat_dim,
+                               num_heads=self.num_heads, dropout=self.dropout) for _ in range(num_layers)])
+        self.merge_layers = nn.ModuleList([
+            MergeLayer(input_dim1=self.node_feat_dim + self.time_feat_dim, input_dim2=self.node_feat_dim,
+                       hidden_dim=self.node_feat_dim, output_dim=self.node_feat_dim) for _ in range(num_layers)])
+
+    def _layer_params(self):
+        out = []
+        for conv, merge in zip(self.temporal_conv_layers, self.merge_layers):
+            out += conv.fused_params() + [merge.fc1.weight, merge.fc1.bias, merge.fc2.weight, merge.fc2.bias]
+        return out
+
+    def compute_src_dst_node_temporal_embeddings(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray,
+                                                 node_interact_times: np.ndarray, num_neighbors: int = 20):
+        # both sides share one device pass: rows are independent (reference computes them one after the other, :61-65)
+        nsrc = len(src_node_ids)
+        ids = np.concatenate([src_node_ids, dst_node_ids])
+        times = np.concatenate([node_interact_times, node_interact_times])
+        emb = self.compute_node_temporal_embeddings(ids, times, self.num_layers, num_neighbors)
+        return emb[:nsrc], emb[nsrc:]
+
+    def compute_node_temporal_embeddings(self, node_ids: np.ndarray, node_interact_times: np.ndarray,
+                                         current_layer_num: int, num_neighbors: int = 20):
+        assert current_layer_num >= 0
+        if self.neighbor_sampler.sample_neighbor_strategy != "recent":
+            raise NotImplementedError("the device path samples 'recent' neighbors (the FLiD default, load_configs.py:115); "
+                                      "uniform / time_interval_aware are host-RNG strategies")
+        params = self._layer_params()[:11 * current_layer_num]
+        return engine.embed(self.neighbor_sampler.graph, self.node_raw_features, self.edge_raw_features,
+                            self.time_encoder.w.weight, self.time_encoder.w.bias, params, node_ids, node_interact_times,
+                            num_neighbors, current_layer_num, self.num_heads, self.dropout, self.training)
+
+    def set_neighbor_sampler(self, neighbor_sampler: NeighborSampler):
+        self.neighbor_sampler = neighbor_sampler
+        if self.neighbor_sampler.sample_neighbor_strategy in ['uniform', 'time_interval_aware']:
+            assert self.neighbor_sampler.seed is not None
+            self.neighbor_sampler.reset_random_state()

@@ -1,0 +1,150 @@
+"""Torch-tensor front ends of the C ABI.  torch supplies device memory and the stream; every FLOP and every gathered byte
+goes through libflid_tg.so."""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import AttnDesc, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, dtype, name):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a device tensor (flid_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _rowmajor_ld(t: torch.Tensor, name):
+    """(rows, cols) view with unit column stride -> leading dimension"""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: need a 2-D tensor with contiguous columns, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, ta=False, tb=False, bias=None, relu=False, accumulate=False,
+         alpha=1.0):
+    """out[M,N] = alpha * op(a) @ op(b) (+bias) (+out) (relu).  a: (M,K) or (K,M) if ta; b: (K,N) or (N,K) if tb."""
+    _chk(a, torch.float32, "a"); _chk(b, torch.float32, "b"); _chk(out, torch.float32, "out")
+    M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
+    if K != Kb or out.shape[0] != M or out.shape[1] != N:
+        raise ValueError(f"gemm: shape mismatch op(a)=({M},{K}) op(b)=({Kb},{N}) out={tuple(out.shape)}")
+    check(lib().tg_gemm_f32(int(ta), int(tb), M, N, K, float(alpha), _p(a), _rowmajor_ld(a, "a"), _p(b), _rowmajor_ld(b, "b"),
+                            _p(out), _rowmajor_ld(out, "out"), _p(bias), int(relu), int(accumulate), _stream()), "tg_gemm_f32")
+    return out
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None):
+    _chk(table, torch.float32, "table"); _chk(idx, torch.int32, "idx")
+    n, cols = idx.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((n, cols), dtype=torch.float32, device=table.device)
+    check(lib().tg_gather_rows(_p(table), _rowmajor_ld(table, "table"), _p(idx), n, cols, _p(out), _rowmajor_ld(out, "out"),
+                               _stream()), "tg_gather_rows")
+    return out
+
+
+def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, table: torch.Tensor):
+    _chk(src, torch.float32, "src"); _chk(idx, torch.int32, "idx"); _chk(table, torch.float32, "table")
+    check(lib().tg_scatter_add_rows(_p(src), _rowmajor_ld(src, "src"), _p(idx), idx.numel(), src.shape[1], _p(table),
+                                    _rowmajor_ld(table, "table"), _stream()), "tg_scatter_add_rows")
+    return table
+
+
+def add_layernorm_fwd(a, b, gamma, beta):
+    n, cols = a.shape
+    y = torch.empty_like(a)
+    mean = torch.empty(n, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(n, dtype=torch.float32, device=a.device)
+    assert a.is_contiguous() and b.is_contiguous()
+    check(lib().tg_add_layernorm_fwd(_p(a), _p(b), n, cols, _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _stream()),
+          "tg_add_layernorm_fwd")
+    return y, mean, rstd
+
+
+def add_layernorm_bwd(a, b, dy, gamma, mean, rstd):
+    """returns dx (n, cols) and (dgamma, dbeta)"""
+    n, cols = a.shape
+    assert a.is_contiguous() and b.is_contiguous() and dy.is_contiguous()
+    parts = lib().tg_rowop_parts(n)
+    dx = torch.empty_like(a)
+    part = torch.empty((parts, 2 * cols), dtype=torch.float32, device=a.device)
+    check(lib().tg_add_layernorm_bwd(_p(a), _p(b), _p(dy), n, cols, _p(gamma), _p(mean), _p(rstd), _p(dx), _p(part), _stream()),
+          "tg_add_layernorm_bwd")
+    dgb = colsum(part)
+    return dx, dgb[:cols], dgb[cols:]
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate=False):
+    _chk(x, torch.float32, "x")
+    n, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+        accumulate = False
+    check(lib().tg_colsum(_p(x), _rowmajor_ld(x, "x"), n, cols, _p(out), int(accumulate), _stream()), "tg_colsum")
+    return out
+
+
+def relu_bwd_(dy: torch.Tensor, y: torch.Tensor):
+    assert dy.is_contiguous() and y.is_contiguous() and dy.shape == y.shape
+    check(lib().tg_relu_bwd_inplace(_p(dy), _p(y), dy.numel(), _stream()), "tg_relu_bwd_inplace")
+    return dy
+
+
+def time_encode(t: torch.Tensor, w: torch.Tensor, b: torch.Tensor, fused_fma=True):
+    _chk(t, torch.float32, "t")
+    t = t.contiguous()
+    dim = w.numel()
+    out = torch.empty(tuple(t.shape) + (dim,), dtype=torch.float32, device=t.device)
+    check(lib().tg_time_encode(_p(t), t.numel(), _p(w), _p(b), dim, int(fused_fma), _p(out), _stream()), "tg_time_encode")
+    return out
+
+
+class AttnArgs:
+    """Keeps the tensors behind a tg_attn_desc alive and builds the C struct."""
+
+    def __init__(self, feat, feat_idx, edge, edge_idx, nbr, dt, te_w, te_b, k, heads, scale, dropout_p=0.0, seed=0):
+        _chk(feat, torch.float32, "feat"); _chk(edge, torch.float32, "edge")
+        for t, nm in ((feat_idx, "feat_idx"), (edge_idx, "edge_idx"), (nbr, "nbr")):
+            _chk(t, torch.int32, nm)
+            assert t.is_contiguous()
+        _chk(dt, torch.float32, "dt")
+        self.keep = (feat, feat_idx, edge, edge_idx, nbr, dt, te_w, te_b)
+        m = nbr.numel() // k
+        self.m, self.k, self.heads = m, k, heads
+        self.dn, self.de, self.dt_dim = feat.shape[1], edge.shape[1], te_w.numel()
+        self.dk = self.dn + self.de + self.dt_dim
+        self.desc = AttnDesc(_p(feat), _rowmajor_ld(feat, "feat"), _p(feat_idx), _p(edge), _rowmajor_ld(edge, "edge"), _p(edge_idx),
+                             _p(nbr), _p(dt), _p(te_w), _p(te_b), m, k, heads, self.dn, self.de, self.dt_dim,
+                             float(scale), float(dropout_p), int(seed))
+
+
+def attn_fwd(args: AttnArgs, u: torch.Tensor):
+    assert u.is_contiguous() and u.shape == (args.m, args.heads, args.dk)
+    agg = torch.empty_like(u)
+    prob = torch.empty((args.m, args.heads, args.k), dtype=torch.float32, device=u.device)
+    check(lib().tg_attn_fwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _stream()), "tg_attn_fwd")
+    return agg, prob
+
+
+def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] = None):
+    """returns du, (dw, db) of the time encoder; adds the neighbor-feature gradient into dfeat rows if given"""
+    assert dagg.is_contiguous() and dagg.shape == u.shape
+    du = torch.empty_like(u)
+    parts = lib().tg_attn_bwd_parts(args.m)
+    part = torch.empty((parts, 2 * args.dt_dim), dtype=torch.float32, device=u.device)
+    check(lib().tg_attn_bwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _p(dagg), _p(du), _p(dfeat),
+                            0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), _p(part), _stream()), "tg_attn_bwd")
+    dwb = colsum(part)
+    return du, dwb[:args.dt_dim], dwb[args.dt_dim:]

@@ -1,0 +1,132 @@
+/* flid_tg.h -- C ABI of the MI355X (gfx950) temporal-graph embedding engine.
+ *
+ * The reference (3205914485/FLiD) has no native layer: its hot path is Python/PyTorch
+ * (SURVEY.md 8b "Language / ABI").  These entry points are what a Python `ctypes`/cffi binding of that
+ * path binds instead of the reference's per-node Python loops and ATen op chains; each one cites the
+ * reference code it replaces (paths relative to the reference root).  Plain pointers and sizes only:
+ * no torch types.  All `const T* d_*` / `T* d_*` arguments are DEVICE pointers; `stream` is a hipStream_t
+ * passed as void*.  Every function returns 0 on success, a negative TG_E* code otherwise, and never
+ * synchronises the stream unless stated.
+ */
+#ifndef FLID_TG_H
+#define FLID_TG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_OK 0
+#define TG_EINVAL -1   /* bad argument / unsupported shape */
+#define TG_EHIP -2     /* a HIP runtime call failed; tg_last_error() has the text */
+#define TG_ENOMEM -3
+
+typedef struct tg_graph tg_graph; /* opaque: device CSR of time-sorted incidences */
+
+const char* tg_last_error(void);
+int tg_version(void);
+
+/* ---- temporal adjacency ---------------------------------------------------------------------------
+ * replaces utils/utils.py:283-302 get_neighbor_sampler + :73-110 NeighborSampler.__init__
+ * HOST arrays of length num_edges.  Every edge is filed under both endpoints; per node the incidences are
+ * stable-sorted by time (ties keep stream order).  num_rows = max node id + 1 (row 0 = padding node).
+ * Device layout: row_ptr int64[num_rows+1]; entries {int32 nbr, int32 eid, double t} (16 B, AoS). */
+int tg_graph_create(const int64_t* h_src, const int64_t* h_dst, const int64_t* h_eid, const double* h_t,
+                    int64_t num_edges, int64_t num_rows, tg_graph** out);
+void tg_graph_destroy(tg_graph* g);
+int64_t tg_graph_num_rows(const tg_graph* g);
+int64_t tg_graph_num_entries(const tg_graph* g);
+/* copy the CSR back to HOST arrays (row_ptr: num_rows+1; others: num_entries) -- for the numpy-facing
+ * sampler methods (uniform / time_interval_aware, get_all_first_hop_neighbors) and tests. */
+int tg_graph_export(const tg_graph* g, int64_t* h_row_ptr, int32_t* h_nbr, int32_t* h_eid, double* h_t);
+
+/* ---- neighbor sampling ----------------------------------------------------------------------------
+ * replaces utils/utils.py:130-147 find_neighbors_before + :149-214 get_historical_neighbors ('recent').
+ * For each of n queries (node id, time): the last k incidences strictly earlier than the query time,
+ * right-aligned; unused leading slots are (0, 0, 0.0f).  Query times are float64 (d_times64) or, for hop>=2
+ * exactly as the reference feeds them back (models/TGAT.py:110-111), float32 (d_times32); pass exactly one.
+ * d_out_dt = query_time - neighbor_time in float32 (models/TGAT.py:120-125), may be NULL.
+ * Outputs are (n, k) row-major.  A node id outside [0, num_rows) sets *d_status (int32, may be NULL) to 1
+ * (the reference raises IndexError there, utils/utils.py:141). */
+int tg_sample_recent(const tg_graph* g, const int32_t* d_ids, const double* d_times64, const float* d_times32,
+                     int64_t n, int k, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, float* d_out_dt,
+                     int32_t* d_status, void* stream);
+
+/* DyGFormer first-hop window: replaces utils/utils.py:254-273 get_all_first_hop_neighbors +
+ * models/DyGFormer.py:196-245 pad_sequences (cut to the newest max_len-1, self in slot 0, left-aligned).
+ * Outputs are (n, width) row-major with width = max_len rounded up to a patch multiple by the caller;
+ * d_out_len[i] = 1 + kept neighbors.  Slots beyond d_out_len are (0, 0, 0.0f). */
+int tg_first_hop_window(const tg_graph* g, const int32_t* d_ids, const double* d_times64, int64_t n, int max_len,
+                        int width, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, int32_t* d_out_len,
+                        void* stream);
+
+/* ---- time encoding --------------------------------------------------------------------------------
+ * replaces models/modules.py:28-40 TimeEncoder.forward: out[i, j] = cos(fma(t[i], w[j], b[j])).
+ * fused_fma=0 evaluates fl(fl(t*w)+b) instead (the reference's (B,1)-shaped call). */
+int tg_time_encode(const float* d_t, int64_t n, const float* d_w, const float* d_b, int dim, int fused_fma,
+                   float* d_out, void* stream);
+
+/* ---- single-query temporal attention, gather-fused ------------------------------------------------
+ * replaces the neighbor side of models/modules.py:167-245 MultiHeadAttention.forward together with the
+ * gathers of models/TGAT.py:110-129.  Exact reassociation: score = (Wk^T q) . z, ctx = Wv (sum a z), so the
+ * kernel streams each neighbor row z = [feat[feat_idx] | edge[edge_idx] | cos(dt*w+b)] once from HBM.
+ *   d_u    (m, heads, dk)  query projected into key space, dk = dn + de + dt_dim
+ *   d_agg  (m, heads, dk)  out: attention-weighted sum of z per head (after dropout)
+ *   d_prob (m, heads, k)   out: softmax probabilities BEFORE dropout (saved for backward)
+ * Masking: slots with nbr id 0 score -1e10 (modules.py:211-221); an all-padded row is uniform.
+ * Dropout (modules.py:224): keep = hash(seed, row, head, slot) >= p, scaled 1/(1-p); p = 0 disables. */
+typedef struct tg_attn_desc {
+    const float* d_feat;   int64_t feat_ld;   const int32_t* d_feat_idx; /* (m*k) rows of d_feat */
+    const float* d_edge;   int64_t edge_ld;   const int32_t* d_edge_idx; /* (m*k) rows of d_edge */
+    const int32_t* d_nbr;  /* (m*k) neighbor node ids, 0 = padding */
+    const float* d_dt;     /* (m*k) float32 time deltas */
+    const float* d_te_w;   const float* d_te_b;
+    int64_t m; int k; int heads; int dn; int de; int dt_dim;
+    float scale; float dropout_p; uint64_t seed;
+} tg_attn_desc;
+
+int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg, float* d_prob, void* stream);
+
+/* backward of tg_attn_fwd.  d_dagg (m,heads,dk) in; d_du (m,heads,dk) out.
+ * d_dfeat: if non-NULL, (rows of the feat source, ld dfeat_ld) gradient w.r.t. gathered feature rows, ADDED with
+ * float atomics (rows may repeat); must be zeroed by the caller.
+ * d_dte_part: (parts, 2*dt_dim) per-workgroup partial sums of (dw | db); *parts is returned by tg_attn_bwd_parts(). */
+int tg_attn_bwd_parts(int64_t m);
+int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
+                const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, float* d_dte_part,
+                void* stream);
+
+/* ---- dense fp32 (MFMA 32x32x2 f32, exact fp32) -----------------------------------------------------
+ * replaces the aten::mm / addmm calls behind nn.Linear in models/modules.py:54-69,152-163,235.
+ * C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ C if accumulate), then optional ReLU.
+ * op(A) = A if !ta (A is M x K, lda) else A^T (A is K x M, lda); op(B) likewise (B is K x N or N x K).
+ * All row-major. */
+int tg_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda,
+                const float* d_B, int64_t ldb, float* d_C, int64_t ldc, const float* d_bias, int relu, int accumulate,
+                void* stream);
+
+/* ---- row-wise helpers ------------------------------------------------------------------------------ */
+/* out[i, 0:cols] = table[idx[i], 0:cols]        (models/TGAT.py:87 node_raw_features[ids]) */
+int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols,
+                   float* d_out, int64_t out_ld, void* stream);
+/* table[idx[i], :] += src[i, :] with float atomics */
+int tg_scatter_add_rows(const float* d_src, int64_t src_ld, const int32_t* d_idx, int64_t n, int cols,
+                        float* d_table, int64_t table_ld, void* stream);
+/* y = LayerNorm(a + b) * gamma + beta, eps 1e-5 (modules.py:238).  Saves mean/rstd (n each) for backward. */
+int tg_add_layernorm_fwd(const float* d_a, const float* d_b, int64_t n, int cols, const float* d_gamma,
+                         const float* d_beta, float* d_y, float* d_mean, float* d_rstd, void* stream);
+/* dx = dLN(dy); d_dgb_part (parts, 2*cols) partial sums of (dgamma | dbeta); parts = tg_rowop_parts(n). */
+int tg_rowop_parts(int64_t n);
+int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const float* d_dy, int64_t n, int cols,
+                         const float* d_gamma, const float* d_mean, const float* d_rstd, float* d_dx,
+                         float* d_dgb_part, void* stream);
+/* out[j] (+)= sum_i x[i, j]   (bias gradients, partial-slab reduction) */
+int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, float* d_out, int accumulate, void* stream);
+/* dx = dy * (y > 0) in place on dy */
+int tg_relu_bwd_inplace(float* d_dy, const float* d_y, int64_t numel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLID_TG_H */

@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library loads and exports every symbol include/flid_tg.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+from flid_amd import _lib
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "flid_tg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 20
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"libflid_tg.so does not export {n}"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_binding_loads_and_reports_version():
+    assert _lib.lib().tg_version() >= 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    l = _lib.lib()
+    rc = l.tg_gemm_f32(0, 0, -1, 1, 1, 1.0, None, 1, None, 1, None, 1, None, 0, 0, None)
+    assert rc == -1 and b"negative" in l.tg_last_error()
+    with pytest.raises(_lib.TgError):
+        _lib.check(rc, "tg_gemm_f32")
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, "flid_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                if re.search(r"^\s*(from|import)\s+oracle|oracle/", open(os.path.join(root, f)).read(), flags=re.M):
+                    bad.append(f)
+    assert not bad, f"product files reference the oracle: {bad}"

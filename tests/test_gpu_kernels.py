@@ -1,0 +1,301 @@
+"""GPU: each HIP kernel of libflid_tg.so (through the C ABI) against the oracle / a plain fp32-fp64 PyTorch restatement."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import flid_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _graph(g):
+    from flid_amd.graph import TemporalGraph
+    return TemporalGraph(g["src"], g["dst"], g["eid"], g["t"], int(g["num_rows"]))
+
+
+def test_graph_build_matches_oracle_adjacency(dev):
+    g = load_golden("sampler")
+    adj = O.build_adjacency(g["src"], g["dst"], g["eid"], g["t"], int(g["num_rows"]))
+    rp, nb, ei, tt = _graph(g).host_csr()
+    assert np.array_equal(rp, adj.row_ptr) and np.array_equal(nb, adj.nbr) and np.array_equal(ei, adj.eid)
+    assert np.array_equal(tt, adj.t)
+
+
+def test_graph_build_unsorted_stream_is_stable(dev):
+    rs = np.random.RandomState(0)
+    n = 500
+    src, dst = rs.randint(1, 20, n), rs.randint(20, 30, n)
+    t = rs.randint(0, 40, n).astype(np.float64)          # many ties, not chronological
+    eid = np.arange(1, n + 1)
+    from flid_amd.graph import TemporalGraph
+    adj = O.build_adjacency(src, dst, eid, t, 30)
+    rp, nb, ei, tt = TemporalGraph(src, dst, eid, t, 30).host_csr()
+    assert np.array_equal(nb, adj.nbr) and np.array_equal(ei, adj.eid) and np.array_equal(tt, adj.t)
+
+
+@pytest.mark.parametrize("k", [1, 3, 20])
+def test_sample_recent_bit_exact_vs_golden(dev, k):
+    g = load_golden("sampler")
+    gr = _graph(g)
+    ids = torch.from_numpy(g["ids"].astype(np.int32)).to(dev)
+    nbr, eid, t32, dt = gr.sample_recent(ids, torch.from_numpy(g["qt64"]).to(dev), k)
+    assert np.array_equal(nbr.cpu().numpy(), g[f"k{k}_n"]) and np.array_equal(eid.cpu().numpy(), g[f"k{k}_e"])
+    assert np.array_equal(t32.cpu().numpy(), g[f"k{k}_t"])
+    assert np.array_equal(dt.cpu().numpy(), (g["qt64"][:, None] - g[f"k{k}_t"]).astype(np.float32))
+    # hop 2: float32 query times fed back (the fp32-rounded time can "see" the edge that led to it)
+    n2, e2, t2, dt2 = gr.sample_recent(nbr.reshape(-1), t32.reshape(-1), k)
+    assert np.array_equal(n2.cpu().numpy(), g[f"k{k}_n2"]) and np.array_equal(e2.cpu().numpy(), g[f"k{k}_e2"])
+    assert np.array_equal(t2.cpu().numpy(), g[f"k{k}_t2"])
+    assert np.array_equal(dt2.cpu().numpy(), g[f"k{k}_t"].reshape(-1, 1) - g[f"k{k}_t2"])
+
+
+def test_sampler_mirror_api(dev):
+    """the numpy-facing NeighborSampler: recent on the device, uniform / time_interval_aware via the host RNG stream"""
+    from flid_amd.utils.utils import get_neighbor_sampler
+
+    class D:
+        pass
+    g = load_golden("sampler")
+    d = D()
+    d.src_node_ids, d.dst_node_ids, d.edge_ids, d.node_interact_times = g["src"], g["dst"], g["eid"], g["t"]
+    s = get_neighbor_sampler(d, "recent", seed=0)
+    a, b, c = s.get_historical_neighbors(g["ids"], g["qt64"], 20)
+    assert a.dtype == np.longlong and c.dtype == np.float32
+    assert np.array_equal(a, g["k20_n"]) and np.array_equal(b, g["k20_e"]) and np.array_equal(c, g["k20_t"])
+    la, lb, lc = s.get_all_first_hop_neighbors(g["ids"], g["qt64"])
+    assert np.array_equal(np.concatenate(la), g["fh_n"]) and np.array_equal(np.concatenate(lc), g["fh_t"])
+    with pytest.raises(AssertionError):
+        s.get_historical_neighbors(g["ids"], g["qt64"], 0)
+    with pytest.raises(IndexError):
+        s.get_historical_neighbors(np.array([int(g["num_rows"]) + 5]), np.array([1.0]), 3)
+    for strat, tsf in (("uniform", 0.0), ("time_interval_aware", 1e-4)):
+        u = get_neighbor_sampler(d, strat, time_scaling_factor=tsf, seed=1)
+        for call in (0, 1):
+            a, b, c = u.get_historical_neighbors(g["ids"], g["qt64"], 5)
+            assert np.array_equal(a, g[f"{strat}{call}_n"]) and np.array_equal(c, g[f"{strat}{call}_t"])
+        u.reset_random_state()
+        assert np.array_equal(u.get_historical_neighbors(g["ids"], g["qt64"], 5)[0], g[f"{strat}R_n"])
+
+
+def test_sample_recent_large_random_vs_oracle(dev):
+    rs = np.random.RandomState(7)
+    E, N = 20000, 700
+    src, dst = rs.randint(1, 500, E), rs.randint(500, N, E)
+    t = np.sort(rs.uniform(0, 2.6e6, E)).round(3)
+    eid = np.arange(1, E + 1)
+    from flid_amd.graph import TemporalGraph
+    gr = TemporalGraph(src, dst, eid, t, N)
+    adj = O.build_adjacency(src, dst, eid, t, N)
+    ids = rs.randint(0, N, 3000)
+    qt = np.concatenate([rs.choice(t, 1500), rs.uniform(0, 2.7e6, 1500)])
+    a, b, c = O.sample_recent(adj, ids, qt, 20)
+    nbr, eid_, t32, _ = gr.sample_recent(torch.from_numpy(ids.astype(np.int32)).to(dev), torch.from_numpy(qt).to(dev), 20)
+    assert np.array_equal(nbr.cpu().numpy(), a) and np.array_equal(eid_.cpu().numpy(), b) and np.array_equal(t32.cpu().numpy(), c)
+
+
+def test_first_hop_window_vs_oracle(dev):
+    g = load_golden("dyg_p1")
+    gr = _graph(g)
+    max_len = int(g["dims"][7])
+    adj = O.build_adjacency(g["src"], g["dst"], g["eid"], g["t"], int(g["num_rows"]))
+    a, b, c = O.first_hop_all(adj, g["bs"], g["bt"])
+    pn, pe, pt = O.pad_first_hop(g["bs"], g["bt"], a, b, c, 1, max_len)
+    ids = torch.from_numpy(g["bs"].astype(np.int32)).to(dev)
+    nbr, eid, tt, ln = gr.first_hop_window(ids, torch.from_numpy(g["bt"]).to(dev), max_len, max_len)
+    w = pn.shape[1]
+    assert int(ln.max()) == w
+    assert np.array_equal(nbr.cpu().numpy()[:, :w], pn) and np.array_equal(eid.cpu().numpy()[:, :w], pe)
+    assert np.array_equal(tt.cpu().numpy()[:, :w], pt)
+    assert not nbr.cpu().numpy()[:, w:].any()
+
+
+def test_time_encode_vs_golden(dev):
+    from flid_amd import ops
+    g = load_golden("time_encoder")
+    grid = torch.from_numpy(g["grid"]).to(dev)
+    for tag in ("b0", "b1"):
+        w, b = torch.from_numpy(g[tag + "_w"]).to(dev).reshape(-1), torch.from_numpy(g[tag + "_b"]).to(dev)
+        got = ops.time_encode(grid, w, b, fused_fma=True).cpu().numpy()
+        # cosine of arguments up to 2.7e6 rad: 1 ulp of the fp32 argument is 0.25 rad, so elementwise agreement REQUIRES
+        # the same rounding of t*w+b as the reference's CPU kernel (fused for (B,K) calls, separate for (B,1) calls)
+        np.testing.assert_allclose(got, g[tag + "_bk"], atol=2e-6)
+        got1 = ops.time_encode(grid.reshape(-1, 1), w, b, fused_fma=False).cpu().numpy()
+        np.testing.assert_allclose(got1, g[tag + "_b1"], atol=2e-6)
+
+
+GEMM_SHAPES = [
+    # (ta, tb, M, N, K)
+    (0, 1, 300, 272, 172), (0, 0, 257, 444, 136), (0, 1, 1000, 136, 444), (0, 1, 129, 172, 444), (1, 0, 272, 444, 5000),
+    (0, 0, 513, 172, 172), (0, 1, 7, 12, 12), (0, 0, 7, 18, 6), (1, 0, 12, 18, 7), (0, 1, 1, 272, 100), (0, 1, 64, 888, 272),
+    (1, 0, 172, 172, 30000),
+]
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", GEMM_SHAPES)
+def test_gemm_vs_fp64(dev, ta, tb, M, N, K):
+    from flid_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    a = rs.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    b = rs.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    A, B = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    out = torch.full((M, N), 7.0, device=dev)
+    ops.gemm(A, B, out, ta=bool(ta), tb=bool(tb))
+    tol = 2e-6 * np.sqrt(K) * 4 + 1e-5
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=tol * max(1.0, np.abs(ref).max() / 10))
+    # bias + relu + accumulate epilogues (only where the contraction is not split)
+    if K < 2048:
+        out2 = torch.ones((M, N), device=dev)
+        ops.gemm(A, B, out2, ta=bool(ta), tb=bool(tb), bias=torch.from_numpy(bias).to(dev), relu=True, accumulate=True)
+        np.testing.assert_allclose(out2.cpu().numpy(), np.maximum(ref + bias + 1.0, 0), atol=tol * max(1.0, np.abs(ref).max() / 10))
+
+
+def test_gemm_strided_views(dev):
+    """column-sliced weights / per-head slices as the engine passes them (leading dimension != logical width)"""
+    from flid_amd import ops
+    rs = np.random.RandomState(3)
+    W1 = torch.from_numpy(rs.standard_normal((172, 444)).astype(np.float32)).to(dev)
+    y = torch.from_numpy(rs.standard_normal((300, 272)).astype(np.float32)).to(dev)
+    raw = torch.from_numpy(rs.standard_normal((300, 172)).astype(np.float32)).to(dev)
+    out = torch.empty((300, 172), device=dev)
+    ops.gemm(y, W1[:, :272], out, tb=True)
+    ops.gemm(raw, W1[:, 272:], out, tb=True, accumulate=True, relu=True)
+    ref = torch.relu(torch.cat([y, raw], 1).double().cpu() @ W1.double().cpu().T)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-4)
+    U = torch.zeros((300, 2, 444), device=dev)
+    Wk = torch.from_numpy(rs.standard_normal((272, 444)).astype(np.float32)).to(dev)
+    for h in range(2):
+        ops.gemm(y[:, h * 136:(h + 1) * 136], Wk[h * 136:(h + 1) * 136], U[:, h, :])
+    ref = torch.stack([y[:, h * 136:(h + 1) * 136].double().cpu() @ Wk[h * 136:(h + 1) * 136].double().cpu() for h in range(2)], 1)
+    np.testing.assert_allclose(U.cpu().numpy(), ref.numpy(), atol=2e-4)
+
+
+def _attn_reference(feat, fidx, edge, eidx, nbr, dt, w, b, u, scale, dagg=None):
+    """plain fp64 PyTorch restatement of the fused op (same math as modules.py:190-228 after the reassociation)"""
+    m, H, dk = u.shape
+    k = nbr.numel() // m
+    feat, edge, w, b, u = (t.double().cpu().requires_grad_(True) for t in (feat, edge, w, b, u))
+    tf = torch.cos(dt.double().cpu().reshape(m, k, 1) * w + b)
+    z = torch.cat([feat[fidx.cpu().long()].reshape(m, k, -1), edge[eidx.cpu().long()].reshape(m, k, -1), tf], dim=2)
+    sc = torch.einsum("mhd,mkd->mhk", u, z) * scale
+    sc = sc.masked_fill((nbr.cpu().reshape(m, 1, k) == 0), -1e10)
+    a = torch.softmax(sc, dim=-1)
+    agg = torch.einsum("mhk,mkd->mhd", a, z)
+    if dagg is None:
+        return agg, a
+    (agg * dagg.double().cpu()).sum().backward()
+    return agg, a, u.grad, feat.grad, w.grad, b.grad
+
+
+@pytest.mark.parametrize("dn,de,T,H,k,m", [(172, 172, 100, 2, 20, 37), (8, 8, 4, 2, 5, 9), (8, 6, 4, 2, 3, 11), (16, 12, 8, 4, 70, 5),
+                                          (172, 172, 100, 2, 20, 3000)])
+def test_attn_fwd_bwd_vs_fp64(dev, dn, de, T, H, k, m):
+    from flid_amd import ops
+    rs = np.random.RandomState(dn + k + m)
+    rows, erows = 50, 80
+    feat = torch.from_numpy(rs.standard_normal((rows, dn)).astype(np.float32)).to(dev)
+    edge = torch.from_numpy(rs.standard_normal((erows, de)).astype(np.float32)).to(dev)
+    nbr = rs.randint(1, rows, size=(m, k)).astype(np.int32)
+    nbr[0, :] = 0                                     # all padded -> uniform attention
+    nbr[1 % m, : k // 2] = 0                          # front padded
+    fidx = np.where(nbr == 0, 0, rs.randint(0, rows, size=(m, k))).astype(np.int32)
+    eidx = np.where(nbr == 0, 0, rs.randint(0, erows, size=(m, k))).astype(np.int32)
+    dt = np.where(nbr == 0, 5000.0, rs.uniform(0, 3e4, size=(m, k))).astype(np.float32)
+    w = torch.from_numpy((1.0 / 10 ** np.linspace(0, 9, T)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rs.uniform(-1, 1, T).astype(np.float32)).to(dev)
+    u = torch.from_numpy((rs.standard_normal((m, H, dn + de + T)) * 0.3).astype(np.float32)).to(dev)
+    dagg = torch.from_numpy(rs.standard_normal((m, H, dn + de + T)).astype(np.float32)).to(dev)
+    tn = lambda x: torch.from_numpy(x).to(dev)
+    scale = 0.11
+    args = ops.AttnArgs(feat, tn(fidx.reshape(-1)), edge, tn(eidx.reshape(-1)), tn(nbr.reshape(-1)), tn(dt.reshape(-1)), w, b, k, H, scale)
+    agg, prob = ops.attn_fwd(args, u)
+    r_agg, r_a, r_du, r_dfeat, r_dw, r_db = _attn_reference(feat, tn(fidx.reshape(-1)), edge, tn(eidx.reshape(-1)), tn(nbr.reshape(-1)),
+                                                           tn(dt), w, b, u, scale, dagg)
+    np.testing.assert_allclose(prob.cpu().numpy(), r_a.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(agg.cpu().numpy(), r_agg.detach().numpy(), atol=2e-5)
+    assert np.allclose(prob.cpu().numpy()[0], 1.0 / k)
+    dfeat = torch.zeros_like(feat)
+    du, dw, db = ops.attn_bwd(args, u, agg, prob, dagg, dfeat)
+    np.testing.assert_allclose(du.cpu().numpy(), r_du.numpy(), atol=5e-5)
+    np.testing.assert_allclose(dfeat.cpu().numpy(), r_dfeat.numpy(), atol=1e-4 * max(1, m / 100))
+    gscale = max(1.0, float(r_dw.abs().max()))
+    np.testing.assert_allclose(dw.cpu().numpy(), r_dw.numpy(), atol=2e-4 * gscale, rtol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), r_db.numpy(), atol=2e-4 * max(1.0, float(r_db.abs().max())), rtol=1e-3)
+
+
+def test_attn_dropout_is_reproducible_and_unbiased(dev):
+    from flid_amd import ops
+    rs = np.random.RandomState(1)
+    m, k, H, dn, de, T = 4000, 20, 2, 8, 8, 4
+    feat = torch.from_numpy(rs.standard_normal((64, dn)).astype(np.float32)).to(dev)
+    edge = torch.from_numpy(rs.standard_normal((64, de)).astype(np.float32)).to(dev)
+    idx = torch.from_numpy(rs.randint(1, 64, size=m * k).astype(np.int32)).to(dev)
+    dt = torch.from_numpy(rs.uniform(0, 100, m * k).astype(np.float32)).to(dev)
+    w = torch.ones(T, device=dev) * 0.01
+    b = torch.zeros(T, device=dev)
+    u = torch.from_numpy(rs.standard_normal((m, H, dn + de + T)).astype(np.float32)).to(dev) * 0.2
+    base, _ = ops.attn_fwd(ops.AttnArgs(feat, idx, edge, idx, idx, dt, w, b, k, H, 0.3), u)
+    a1, p1 = ops.attn_fwd(ops.AttnArgs(feat, idx, edge, idx, idx, dt, w, b, k, H, 0.3, 0.1, 1234), u)
+    a2, _ = ops.attn_fwd(ops.AttnArgs(feat, idx, edge, idx, idx, dt, w, b, k, H, 0.3, 0.1, 1234), u)
+    a3, _ = ops.attn_fwd(ops.AttnArgs(feat, idx, edge, idx, idx, dt, w, b, k, H, 0.3, 0.1, 99), u)
+    assert torch.equal(a1, a2) and not torch.equal(a1, a3)
+    # E[dropout(a)] = a: the mean over many rows matches the undropped aggregate
+    assert float((a1.mean(0) - base.mean(0)).abs().max()) < 0.02
+    # backward with the same seed regenerates the same mask: finite-difference check on one u entry
+    args = ops.AttnArgs(feat, idx, edge, idx, idx, dt, w, b, k, H, 0.3, 0.1, 1234)
+    dagg = torch.ones_like(u)
+    du, _, _ = ops.attn_bwd(args, u, a1, p1, dagg, None)
+    eps = 1e-2
+    u2 = u.clone(); u2[5, 1, 3] += eps
+    ap, _ = ops.attn_fwd(args, u2)
+    u2[5, 1, 3] -= 2 * eps
+    am, _ = ops.attn_fwd(args, u2)
+    fd = float((ap - am).sum() / (2 * eps))
+    assert abs(fd - float(du[5, 1, 3])) < 5e-3 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize("n,cols", [(50, 12), (1000, 272), (3, 200), (4097, 272)])
+def test_add_layernorm_fwd_bwd(dev, n, cols):
+    from flid_amd import ops
+    rs = np.random.RandomState(n)
+    a, b, dy = (torch.from_numpy(rs.standard_normal((n, cols)).astype(np.float32)) for _ in range(3))
+    g, be = torch.from_numpy(1 + 0.1 * rs.standard_normal(cols).astype(np.float32)), torch.from_numpy(rs.standard_normal(cols).astype(np.float32))
+    ad, bd, gd = a.double().requires_grad_(True), b.double(), g.double().requires_grad_(True)
+    bed = be.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(ad + bd, (cols,), gd, bed, 1e-5)
+    (ref * dy.double()).sum().backward()
+    y, mean, rstd = ops.add_layernorm_fwd(a.to(dev), b.to(dev), g.to(dev), be.to(dev))
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().numpy(), atol=2e-5)
+    dx, dg, dbeta = ops.add_layernorm_bwd(a.to(dev), b.to(dev), dy.to(dev), g.to(dev), mean, rstd)
+    np.testing.assert_allclose(dx.cpu().numpy(), ad.grad.numpy(), atol=5e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), gd.grad.numpy(), atol=1e-4 * max(1, n / 100))
+    np.testing.assert_allclose(dbeta.cpu().numpy(), bed.grad.numpy(), atol=1e-4 * max(1, n / 100))
+
+
+def test_rowops(dev):
+    from flid_amd import ops
+    rs = np.random.RandomState(0)
+    table = torch.from_numpy(rs.standard_normal((100, 172)).astype(np.float32)).to(dev)
+    idx = torch.from_numpy(rs.randint(0, 100, 5000).astype(np.int32)).to(dev)
+    out = ops.gather_rows(table, idx)
+    assert torch.equal(out, table[idx.long()])
+    t6 = torch.from_numpy(rs.standard_normal((100, 6)).astype(np.float32)).to(dev)
+    assert torch.equal(ops.gather_rows(t6, idx), t6[idx.long()])
+    x = torch.from_numpy(rs.standard_normal((5000, 172)).astype(np.float32)).to(dev)
+    np.testing.assert_allclose(ops.colsum(x).cpu().numpy(), x.double().sum(0).cpu().numpy(), atol=2e-3)
+    np.testing.assert_allclose(ops.colsum(x[:, 100:]).cpu().numpy(), x[:, 100:].double().sum(0).cpu().numpy(), atol=2e-3)
+    acc = torch.zeros((100, 172), device=dev)
+    ops.scatter_add_rows(x, idx, acc)
+    ref = torch.zeros((100, 172), dtype=torch.float64).index_add_(0, idx.cpu().long(), x.double().cpu())
+    np.testing.assert_allclose(acc.cpu().numpy(), ref.numpy(), atol=1e-3)
+    dy, y = x.clone(), torch.from_numpy(rs.standard_normal((5000, 172)).astype(np.float32)).to(dev)
+    ops.relu_bwd_(dy, y)
+    assert torch.equal(dy, x * (y > 0))

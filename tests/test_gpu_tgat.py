@@ -1,0 +1,120 @@
+"""GPU parity: flid_amd.models.TGAT (HIP engine behind the reference's class surface) against
+  (1) the golden vectors the reference itself produced, (2) the oracle on fresh seeded batches,
+  (3) size-independent properties at the BASELINE batch size."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, assert_grads_match
+from oracle import flid_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4     # north_star: embeddings within 1e-4 fp32 of the reference CPU path
+CASES = ["tgat_L1_K2", "tgat_L2_K2", "tgat_L2_K20", "tgat_L2_K20_full", "tgat_L1_K20_full_bias"]
+
+
+class _Data:
+    def __init__(self, g):
+        self.src_node_ids, self.dst_node_ids, self.edge_ids, self.node_interact_times = g["src"], g["dst"], g["eid"], g["t"]
+
+
+def _model(g, dropout=0.0):
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    dn, de, dt, layers, k = [int(v) for v in g["dims"]]
+    sampler = get_neighbor_sampler(_Data(g), "recent", seed=0)
+    m = TGAT(g["node_feat"], g["edge_feat"], sampler, time_feat_dim=dt, num_layers=layers, num_heads=2, dropout=dropout, device="cuda:0")
+    p = O.seeded_like(O.tgat_shapes(dn, de, dt, layers), int(g["seed"]), float(g["scale"]))
+    if not bool(g["bias_te"]):
+        p["time_encoder.w.bias"].zero_()
+    m.load_state_dict(p)              # strict: the state_dict key/shape contract of the reference
+    return m.to("cuda:0"), p, k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_tgat_matches_reference_golden(name):
+    g = load_golden(name)
+    m, p, k = _model(g)
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    m.train()
+    s, d = m.compute_src_dst_node_temporal_embeddings(src_node_ids=g["bs"], dst_node_ids=g["bd"], node_interact_times=g["bt"], num_neighbors=k)
+    assert s.is_cuda and s.dtype == torch.float32 and s.shape == (len(g["bs"]), g["node_feat"].shape[1])
+    np.testing.assert_allclose(s.detach().cpu().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), g["d_emb"], atol=TOL)
+    r = torch.from_numpy(g["r"]).cuda()
+    ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.cpu().numpy() for k_, v in m.named_parameters()}, atol=2e-4, rtol=1e-3)
+
+
+def test_tgat_fresh_batches_vs_oracle():
+    g = load_golden("tgat_L2_K20")
+    m, p, k = _model(g)
+    m.eval()
+    adj = O.build_adjacency(g["src"], g["dst"], g["eid"], g["t"], int(g["num_rows"]))
+    orc = O.TGATOracle(torch.from_numpy(g["node_feat"]), torch.from_numpy(g["edge_feat"]), adj, p, 2, 2)
+    rs = np.random.RandomState(9)
+    for bsz in (1, 17, 64):
+        pick = np.sort(rs.choice(len(g["eid"]), bsz, replace=False))
+        bs, bd, bt = g["src"][pick], g["dst"][pick], g["t"][pick]
+        with torch.no_grad():
+            s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, k)
+            os_, od_ = orc.src_dst(bs, bd, bt, k)
+        np.testing.assert_allclose(s.cpu().numpy(), os_.numpy(), atol=TOL)
+        np.testing.assert_allclose(d.cpu().numpy(), od_.numpy(), atol=TOL)
+    # empty batch and an id beyond the graph (reference: IndexError from the sampler)
+    s, d = m.compute_src_dst_node_temporal_embeddings(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0), k)
+    assert s.shape == (0, g["node_feat"].shape[1])
+    with pytest.raises(IndexError):
+        m.compute_src_dst_node_temporal_embeddings(np.array([10 ** 6]), np.array([1]), np.array([5.0]), k)
+
+
+def test_tgat_baseline_shape_properties():
+    """BASELINE config 2 shape (B=600, K=20, L=2, 172/172/100): row independence, batch-split invariance, determinism,
+    and a sampled subset against the oracle."""
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = wikipedia_like(num_edges=30000, seed=0)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    torch.manual_seed(0)
+    m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 100, 2, 2, 0.0, "cuda:0").to("cuda:0").eval()
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.dim() > 1 and prm.shape[1] > 1:
+                prm.copy_(torch.randn_like(prm) * 0.05)
+    sl = slice(20000, 20600)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    with torch.no_grad():
+        s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 20)
+        s2, d2 = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 20)
+        assert torch.equal(s, s2) and torch.equal(d, d2)                       # deterministic forward
+        sa, da = m.compute_src_dst_node_temporal_embeddings(bs[:250], bd[:250], bt[:250], 20)
+        sb, db = m.compute_src_dst_node_temporal_embeddings(bs[250:], bd[250:], bt[250:], 20)
+    np.testing.assert_allclose(torch.cat([sa, sb]).cpu().numpy(), s.cpu().numpy(), atol=1e-6)    # split invariance
+    np.testing.assert_allclose(torch.cat([da, db]).cpu().numpy(), d.cpu().numpy(), atol=1e-6)
+    assert torch.isfinite(s).all() and torch.isfinite(d).all()
+    # oracle on 24 of the 600 edges (the full batch takes the CPU path many seconds)
+    p = {k_: v.detach().cpu() for k_, v in m.state_dict().items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    orc = O.TGATOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 2, 2)
+    pick = np.arange(0, 600, 25)
+    with torch.no_grad():
+        os_, od_ = orc.src_dst(bs[pick], bd[pick], bt[pick], 20)
+    np.testing.assert_allclose(s.cpu().numpy()[pick], os_.numpy(), atol=TOL)
+    np.testing.assert_allclose(d.cpu().numpy()[pick], od_.numpy(), atol=TOL)
+
+
+def test_tgat_dropout_train_mode_statistics():
+    g = load_golden("tgat_L2_K20")
+    m, p, k = _model(g, dropout=0.1)
+    m.eval()
+    with torch.no_grad():
+        ref, _ = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+        again, _ = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+    assert torch.equal(ref, again)                      # eval mode: dropout off, deterministic
+    m.train()
+    with torch.no_grad():
+        a, _ = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+        b, _ = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+    assert not torch.equal(a, b)                        # train mode: stochastic
+    assert torch.isfinite(a).all()
