@@ -70,8 +70,8 @@ class TimeEncoder(nn.Module):
             self.w.bias.requires_grad = False
 
     def forward(self, timestamps: torch.Tensor):
-        # (batch, seq) -> (batch, seq, time_dim); seq == 1 reproduces the reference's unfused t*w then +b rounding
-        return _TimeEncodeFn.apply(timestamps.contiguous().float(), self.w.weight, self.w.bias, timestamps.shape[-1] != 1)
+        # (batch, seq) -> (batch, seq, time_dim); t*w+b is rounded once (fma), as the reference's CPU Linear(1,T) does
+        return _TimeEncodeFn.apply(timestamps.contiguous().float(), self.w.weight, self.w.bias, True)
 
 
 class MergeLayer(nn.Module):

@@ -167,7 +167,7 @@ def gold_attention():
 
 
 # ------------------------------------------------------------------------------------------------- TGAT
-def run_tgat(tag, dn, de, dt, layers, k, batch, seed, graph_seed, bias_te=True):
+def run_tgat(tag, dn, de, dt, layers, k, batch, seed, graph_seed, bias_te=True, scale=0.15):
     src, dst, eid, t, num_rows = toy_graph(graph_seed)
     rs = np.random.RandomState(seed)
     node_feat = rs.standard_normal((num_rows, dn)).astype(np.float32)
@@ -178,7 +178,7 @@ def run_tgat(tag, dn, de, dt, layers, k, batch, seed, graph_seed, bias_te=True):
     model = TGAT(node_feat, edge_feat, ns, time_feat_dim=dt, num_layers=layers, num_heads=2, dropout=0.0)
     shapes = {k_: tuple(v.shape) for k_, v in model.state_dict().items()}
     assert shapes == O.tgat_shapes(dn, de, dt, layers), "state_dict contract drifted"
-    params = O.seeded_like(shapes, seed=seed, scale=0.15)
+    params = O.seeded_like(shapes, seed=seed, scale=scale)
     if not bias_te:
         params["time_encoder.w.bias"].zero_()
     model.load_state_dict(params)
@@ -193,7 +193,7 @@ def run_tgat(tag, dn, de, dt, layers, k, batch, seed, graph_seed, bias_te=True):
     r = rs.standard_normal((2, batch, dn)).astype(np.float32)
     (s_emb * torch.from_numpy(r[0])).sum().add((d_emb * torch.from_numpy(r[1])).sum()).backward()
     save(tag, src=src, dst=dst, eid=eid, t=t, num_rows=np.int64(num_rows), node_feat=node_feat, edge_feat=edge_feat,
-         dims=np.array([dn, de, dt, layers, k]), seed=np.int64(seed), scale=np.float64(0.15), bias_te=np.bool_(bias_te),
+         dims=np.array([dn, de, dt, layers, k]), seed=np.int64(seed), scale=np.float64(scale), bias_te=np.bool_(bias_te),
          bs=bs, bd=bd, bt=bt, r=r, s_emb=s_emb.detach().numpy(), d_emb=d_emb.detach().numpy(),
          keys=np.array(sorted(shapes)), **grads_compact({k_: p.grad for k_, p in model.named_parameters()}))
 
@@ -342,8 +342,9 @@ if __name__ == "__main__":
     run_tgat("tgat_L1_K2", 8, 8, 4, 1, 2, 6, seed=41, graph_seed=4)
     run_tgat("tgat_L2_K2", 8, 8, 4, 2, 2, 6, seed=42, graph_seed=4)
     run_tgat("tgat_L2_K20", 8, 6, 4, 2, 20, 9, seed=43, graph_seed=5)
-    run_tgat("tgat_L2_K20_full", 172, 172, 100, 2, 20, 8, seed=44, graph_seed=6, bias_te=False)
-    run_tgat("tgat_L1_K20_full_bias", 172, 172, 100, 1, 20, 8, seed=45, graph_seed=6, bias_te=True)
+    # full BASELINE dims: weight scale ~ PyTorch default init (1/sqrt(fan_in)) so that |emb| = O(1), where "within 1e-4" is meant
+    run_tgat("tgat_L2_K20_full", 172, 172, 100, 2, 20, 8, seed=44, graph_seed=6, bias_te=False, scale=0.05)
+    run_tgat("tgat_L1_K20_full_bias", 172, 172, 100, 1, 20, 8, seed=45, graph_seed=6, bias_te=True, scale=0.05)
     gold_tgn()
     run_dyg("dyg_p1", 1, 8, seed=51, graph_seed=7)
     run_dyg("dyg_p2", 2, 9, seed=52, graph_seed=7)

@@ -124,10 +124,13 @@ def test_time_encode_vs_golden(dev):
         w, b = torch.from_numpy(g[tag + "_w"]).to(dev).reshape(-1), torch.from_numpy(g[tag + "_b"]).to(dev)
         got = ops.time_encode(grid, w, b, fused_fma=True).cpu().numpy()
         # cosine of arguments up to 2.7e6 rad: 1 ulp of the fp32 argument is 0.25 rad, so elementwise agreement REQUIRES
-        # the same rounding of t*w+b as the reference's CPU kernel (fused for (B,K) calls, separate for (B,1) calls)
+        # the same single rounding of t*w+b as the reference's CPU kernel (an FMA for both call shapes in torch 2.10)
         np.testing.assert_allclose(got, g[tag + "_bk"], atol=2e-6)
-        got1 = ops.time_encode(grid.reshape(-1, 1), w, b, fused_fma=False).cpu().numpy()
+        got1 = ops.time_encode(grid.reshape(-1, 1), w, b, fused_fma=True).cpu().numpy()
         np.testing.assert_allclose(got1, g[tag + "_b1"], atol=2e-6)
+        if tag == "b0":     # with b = 0 the unfused form agrees as well
+            got2 = ops.time_encode(grid.reshape(-1, 1), w, b, fused_fma=False).cpu().numpy()
+            np.testing.assert_allclose(got2, g[tag + "_b1"], atol=2e-6)
 
 
 GEMM_SHAPES = [
@@ -183,7 +186,11 @@ def _attn_reference(feat, fidx, edge, eidx, nbr, dt, w, b, u, scale, dagg=None):
     m, H, dk = u.shape
     k = nbr.numel() // m
     feat, edge, w, b, u = (t.double().cpu().requires_grad_(True) for t in (feat, edge, w, b, u))
-    tf = torch.cos(dt.double().cpu().reshape(m, k, 1) * w + b)
+    # the kernel (like the reference's fp32 Linear) rounds the phase dt*w+b ONCE to fp32 before the cosine; at phases of
+    # 1e4..1e6 rad that rounding (up to 0.1 rad) is the dominant term, so the restatement rounds the same way
+    arg = dt.double().cpu().reshape(m, k, 1) * w + b
+    arg = arg + (arg.float().double() - arg).detach()
+    tf = torch.cos(arg)
     z = torch.cat([feat[fidx.cpu().long()].reshape(m, k, -1), edge[eidx.cpu().long()].reshape(m, k, -1), tf], dim=2)
     sc = torch.einsum("mhd,mkd->mhk", u, z) * scale
     sc = sc.masked_fill((nbr.cpu().reshape(m, 1, k) == 0), -1e10)

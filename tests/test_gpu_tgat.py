@@ -49,6 +49,10 @@ def test_tgat_matches_reference_golden(name):
 def test_tgat_fresh_batches_vs_oracle():
     g = load_golden("tgat_L2_K20")
     m, p, k = _model(g)
+    # phases reach 2.6e6 rad here, where one fp32 ulp is 0.25 rad: with a non-zero bias the reference's own CPU result
+    # depends on whether MKL fuses t*w+b for that call size.  b = 0 (the reference's init, modules.py:22) is exact either way.
+    p["time_encoder.w.bias"].zero_()
+    m.load_state_dict({k_: v for k_, v in p.items()})
     m.eval()
     adj = O.build_adjacency(g["src"], g["dst"], g["eid"], g["t"], int(g["num_rows"]))
     orc = O.TGATOracle(torch.from_numpy(g["node_feat"]), torch.from_numpy(g["edge_feat"]), adj, p, 2, 2)
