@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: edges/sec through TGAT.compute_src_dst_node_temporal_embeddings fwd + bwd (+ Adam step)
+on the Wikipedia-shape synthetic graph (BASELINE.json configs[1]: batch 600, 20 temporal neighbors, 2 attention layers).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of 600 edges per GPU (weak scaling: rank r of N takes batch step*N + r of
+the chronological stream), a scalar loss on both outputs, backward to every backbone parameter, the RCCL gradient all-reduce
+when N > 1, and the Adam update.  Batch ids/times are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md chip table
+MFMA_F32_PEAK = 157.3e12     # FLOP/s dense f32-input MFMA
+BATCH, K, L, H, DN, DE, DT = 600, 20, 2, 2, 172, 172, 100
+
+
+def tgat_bytes_per_edge(k=K, layers=L, dn=DN, de=DE):
+    """de-duplicated minimum bytes per root, forward: node rows + edge rows + sampler + output row;
+    an edge has 2 roots; backward re-reads the gathered inputs once."""
+    node = sum(k ** l for l in range(layers + 1)) * 4 * dn
+    edge = sum(k ** l for l in range(1, layers + 1)) * 4 * de
+    samp = sum(k ** l for l in range(layers)) * (16 + 64 + 16 * k)
+    root = node + edge + samp + 4 * dn
+    return 2 * root * 2
+
+
+def attn_bytes_per_instance(k=K, heads=H, dn=DN, de=DE, dt=DT, backward=False):
+    """algorithmic HBM bytes of ONE attention instance in tg_attn_fwd / tg_attn_bwd: k neighbor rows (node + edge, fp32),
+    k x 16 B of slot metadata (feat idx, edge idx, nbr id, dt), u in + agg out (+ prob).  Backward: + dagg, agg in, du out."""
+    dk = dn + de + dt
+    rows = k * 4 * (dn + de) + k * 16
+    vec = heads * dk * 4
+    if not backward:
+        return rows + 2 * vec + heads * k * 4
+    return rows + 4 * vec + heads * k * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--roofline-kernel", default="attn_bwd", choices=["attn_fwd", "attn_bwd", "gemm"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-edges", type=int, default=150)
+    args = ap.parse_args()
+
+    from flid_amd import dist as fdist
+    from flid_amd import ops
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+
+    rank, world, local = fdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    data = wikipedia_like(seed=0)
+    n_train = int(0.7 * data.num_interactions)
+    sampler = get_neighbor_sampler(data.slice(0, n_train), "recent", seed=0)       # train graph, as EM_warmup.py:71-76
+    torch.manual_seed(0)
+    model = TGAT(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=DT, num_layers=L, num_heads=H,
+                 dropout=args.dropout, device=str(dev)).to(dev).train()
+    fdist.broadcast_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)                              # load_configs.py:119,123
+    reducer = fdist.GradAllReducer(model.parameters()) if world > 1 else None
+
+    total_steps = args.warmup + args.steps
+    n_batches = n_train // BATCH
+    first = n_batches // 2                                                           # mid-stream: histories are populated
+    assert first + total_steps * world <= n_batches, "not enough batches for this many steps"
+
+    def batch_slice(step):
+        b = first + step * world + rank
+        return slice(b * BATCH, (b + 1) * BATCH)
+
+    # inputs resident in HBM before the timed region
+    dev_batches = []
+    for s in range(total_steps):
+        sl = batch_slice(s)
+        dev_batches.append((torch.from_numpy(data.src_node_ids[sl].astype(np.int32)).to(dev),
+                            torch.from_numpy(data.dst_node_ids[sl].astype(np.int32)).to(dev),
+                            torch.from_numpy(data.node_interact_times[sl]).to(dev)))
+    rw = torch.randn(2, BATCH, DN, device=dev)
+
+    def step(s):
+        src, dst, t = dev_batches[s]
+        opt.zero_grad(set_to_none=True)
+        se, de_ = model.compute_src_dst_node_temporal_embeddings(src, dst, t, K)
+        loss = (se * rw[0]).mean() + (de_ * rw[1]).mean()
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce()
+        opt.step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s)
+    ops.KernelTimer.enable({args.roofline_kernel})
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        step(s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timed = ops.KernelTimer.collect()
+    ops.KernelTimer.disable()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # one extra UNTIMED instrumented step: where a step's device time goes, per kernel family
+    ops.KernelTimer.enable({"attn_fwd", "attn_bwd", "gemm"})
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    step(total_steps - 1)
+    fam = ops.KernelTimer.collect()
+    ops.KernelTimer.disable()
+    wall_instr = time.perf_counter() - w0
+    breakdown = {k_: round(sum(ms for ms, _ in v), 4) for k_, v in fam.items()}
+    if os.environ.get("FLID_BENCH_DUMP") and rank == 0:
+        for ms, (m, n, k) in fam.get("gemm", []):
+            print(f"gemm M={m} N={n} K={k} {ms*1e3:.1f} us  {2.0*m*n*k/ms/1e9:.1f} TFLOP/s", file=sys.stderr)
+        for nm in ("attn_fwd", "attn_bwd"):
+            for ms, m in fam.get(nm, []):
+                print(f"{nm} m={m} {ms*1e3:.1f} us", file=sys.stderr)
+    breakdown["step_wall_ms_instrumented"] = round(wall_instr * 1e3, 3)
+
+    edges = args.steps * BATCH * world
+    value = edges / elapsed
+    bpe = tgat_bytes_per_edge()
+
+    # roofline of the dominant kernel, HIP events on its launch stream over the timed region
+    recs = timed.get(args.roofline_kernel, [])
+    if args.roofline_kernel == "gemm":
+        flops = sum(2.0 * m * n * k for _, (m, n, k) in recs)
+        secs = sum(ms for ms, _ in recs) * 1e-3
+        roof = {"bound": "mfma", "kernel": "gemm_kernel (tg_gemm_f32, all shapes of a step)",
+                "achieved": round(flops / secs / 1e12, 3), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
+                "frac": round(flops / secs / MFMA_F32_PEAK, 4), "traffic": None, "launches": len(recs),
+                "avg_launch_ms": round(secs * 1e3 / max(1, len(recs)), 4)}
+    else:
+        bwd = args.roofline_kernel == "attn_bwd"
+        # the layer-1 launch (n(1+k) instances) dominates; price each launch by its own instance count
+        nbytes = sum(m * attn_bytes_per_instance(backward=bwd) for _, m in recs)
+        secs = sum(ms for ms, _ in recs) * 1e-3
+        big = [ms for ms, m in recs if m == 2 * BATCH * (1 + K)]
+        roof = {"bound": "hbm", "kernel": "attn_bwd_kernel<4,2,2>" if bwd else "attn_fwd_kernel<4,2,2>",
+                "achieved": round(nbytes / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(nbytes / secs / HBM_PEAK, 4), "traffic": None, "launches": len(recs),
+                "avg_launch_ms_layer1": round(sum(big) / max(1, len(big)), 4),
+                "bytes_per_launch_layer1": 2 * BATCH * (1 + K) * attn_bytes_per_instance(backward=bwd)}
+        tr = os.path.join(REPO, "profiles", "traffic_r01.json")
+        if os.path.exists(tr):
+            try:
+                roof["traffic"] = json.load(open(tr)).get(args.roofline_kernel)
+            except Exception:
+                pass
+
+    out = {
+        "metric": "edges/sec (temporal-embedding fwd+bwd), TGAT Wikipedia, 1/2/4/8 MI355X",
+        "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Wikipedia-shape synthetic (9227 nodes, 157474 edges, 172-d edge feats) + TGAT L=2 H=2 T=100, "
+                               "batch 600 edges/GPU, 20 recent neighbors, dropout %.2f, fwd+bwd+Adam" % args.dropout,
+                   "batch_per_gpu": BATCH, "global_batch": BATCH * world, "num_neighbors": K, "num_layers": L,
+                   "parallelism": f"dp{world}"},
+        "path_roofline": {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4),
+                          "edges_per_s_at_100pct": round(HBM_PEAK / bpe, 1)},
+        "roofline": roof,
+        "breakdown_ms": breakdown,
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(data, n_train, model, batch_slice(args.warmup), args.cpu_sample_edges)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(data, n_train, model, sl, sample_edges):
+    """The oracle (CPU restatement of the reference path, parity-pinned) timed on this box's host cores on the first
+    `sample_edges` edges of the first timed batch: same graph, same weights, fwd + bwd.  Baseline only."""
+    from oracle import flid_oracle as O
+    threads = torch.get_num_threads()
+    p = {k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in model.state_dict().items()}
+    adj = O.build_adjacency(data.src_node_ids[:n_train], data.dst_node_ids[:n_train], data.edge_ids[:n_train],
+                            data.node_interact_times[:n_train])
+    orc = O.TGATOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, L, H,
+                       dropout=0.1, training=True)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+
+    def run(nn):
+        s, d = orc.src_dst(bs[:nn], bd[:nn], bt[:nn], K)
+        (s.mean() + d.mean()).backward()
+    run(4)
+    t0 = time.perf_counter()
+    run(sample_edges)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_edges / dt, 2), "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_edges} edges of one 600-edge batch, fwd+bwd, oracle/flid_oracle.py on torch CPU ({threads} threads), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""Edge-batch data parallelism: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The reference has no distributed code; the temporal embedding shards naturally: every rank
+holds the graph, the feature tables and the weights, embeds its own slice of the edge batch, and the only exchange is one
+sum all-reduce of the ~1 M fp32 gradients (4 MB, latency-bound on 7 x 153 GB/s links) in a single flat bucket, weighted so
+that a mean-reduced loss equals its single-GPU value.  TGN additionally all-gathers its new raw messages (tgn_exchange)."""
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them).  Returns
+    (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """contiguous slice [lo, hi) of an n-edge batch owned by `rank` (sizes differ by at most one)"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradAllReducer:
+    """Flat-bucket gradient all-reduce.  `weight` = local_edges / global_edges makes the reduced gradient that of the
+    mean loss over the global batch (BCELoss / .mean() CE of the reference trainers)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = group
+        self.numel = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(self.numel, dtype=ref.dtype, device=ref.device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def reduce(self, weight: float = None):
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return
+        w = (1.0 / world) if weight is None else float(weight)
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        if w != 1.0:
+            self.flat.mul_(w)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def all_gather_rows(x: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    """concatenate per-rank row blocks of possibly different heights (used for the TGN raw-message exchange)"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return x
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[:x.shape[0]] = x
+    out = [torch.empty_like(pad) for _ in counts]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)

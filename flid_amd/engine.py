@@ -253,14 +253,19 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
           table_requires_grad: bool = False):
     """H^L for `ids` at `times` (host numpy in, device tensor out, autograd-connected to the parameters)."""
     dev = table.device
-    ids = np.asarray(ids)
-    if len(ids) and (int(ids.max()) >= graph.num_rows or int(ids.min()) < 0):
-        raise IndexError("list index out of range")                      # what utils/utils.py:141 raises
     assert k > 0, 'Number of sampled neighbors for each node should be greater than 0!'
-    n = len(ids)
-    ids_dev = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(dev)
-    tt = np.asarray(times)
-    times_dev = torch.from_numpy(np.ascontiguousarray(tt, dtype=np.float32 if tt.dtype == np.float32 else np.float64)).to(dev)
+    if torch.is_tensor(ids):
+        # already resident in HBM (int32 ids, float64/float32 times): the caller vouches for the id range
+        ids_dev, times_dev = ids.to(device=dev, dtype=torch.int32).contiguous(), times.to(dev).contiguous()
+        n = ids_dev.numel()
+    else:
+        ids = np.asarray(ids)
+        if len(ids) and (int(ids.max()) >= graph.num_rows or int(ids.min()) < 0):
+            raise IndexError("list index out of range")                      # what utils/utils.py:141 raises
+        n = len(ids)
+        ids_dev = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(dev)
+        tt = np.asarray(times)
+        times_dev = torch.from_numpy(np.ascontiguousarray(tt, dtype=np.float32 if tt.dtype == np.float32 else np.float64)).to(dev)
     if n == 0:
         return torch.zeros((0, table.shape[1]), device=dev)
     if num_layers == 0:

@@ -46,8 +46,12 @@ class TGAT(nn.Module):
                                                  node_interact_times: np.ndarray, num_neighbors: int = 20):
         # both sides share one device pass: rows are independent (reference computes them one after the other, :61-65)
         nsrc = len(src_node_ids)
-        ids = np.concatenate([src_node_ids, dst_node_ids])
-        times = np.concatenate([node_interact_times, node_interact_times])
+        if torch.is_tensor(src_node_ids):          # ids/times already in HBM (bench, fused trainers)
+            ids = torch.cat([src_node_ids, dst_node_ids])
+            times = torch.cat([node_interact_times, node_interact_times])
+        else:
+            ids = np.concatenate([src_node_ids, dst_node_ids])
+            times = np.concatenate([node_interact_times, node_interact_times])
         emb = self.compute_node_temporal_embeddings(ids, times, self.num_layers, num_neighbors)
         return emb[:nsrc], emb[nsrc:]
 

@@ -13,6 +13,49 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """HIP-event timing of selected kernel families ON THE STREAM THEY ARE LAUNCHED ON (bench.py roofline leg).
+    Usage: KernelTimer.enable({"attn_fwd", ...}); run; KernelTimer.collect() -> {name: [(ms, tag), ...]}."""
+    names = frozenset()
+    pending = []
+
+    @classmethod
+    def enable(cls, names):
+        cls.names, cls.pending = frozenset(names), []
+
+    @classmethod
+    def disable(cls):
+        cls.names = frozenset()
+
+    @classmethod
+    def collect(cls):
+        torch.cuda.synchronize()
+        out = {}
+        for name, tag, a, b in cls.pending:
+            out.setdefault(name, []).append((a.elapsed_time(b), tag))
+        cls.pending = []
+        return out
+
+
+class _timed:
+    def __init__(self, name, tag=None):
+        self.on = name in KernelTimer.names
+        self.name, self.tag = name, tag
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record()
+            KernelTimer.pending.append((self.name, self.tag, self.a, self.b))
+        return False
+
+
 def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
 
@@ -40,8 +83,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, ta=False, tb=False
     Kb, N = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
     if K != Kb or out.shape[0] != M or out.shape[1] != N:
         raise ValueError(f"gemm: shape mismatch op(a)=({M},{K}) op(b)=({Kb},{N}) out={tuple(out.shape)}")
-    check(lib().tg_gemm_f32(int(ta), int(tb), M, N, K, float(alpha), _p(a), _rowmajor_ld(a, "a"), _p(b), _rowmajor_ld(b, "b"),
-                            _p(out), _rowmajor_ld(out, "out"), _p(bias), int(relu), int(accumulate), _stream()), "tg_gemm_f32")
+    with _timed("gemm", (M, N, K)):
+        check(lib().tg_gemm_f32(int(ta), int(tb), M, N, K, float(alpha), _p(a), _rowmajor_ld(a, "a"), _p(b), _rowmajor_ld(b, "b"),
+                                _p(out), _rowmajor_ld(out, "out"), _p(bias), int(relu), int(accumulate), _stream()), "tg_gemm_f32")
     return out
 
 
@@ -134,7 +178,8 @@ def attn_fwd(args: AttnArgs, u: torch.Tensor):
     assert u.is_contiguous() and u.shape == (args.m, args.heads, args.dk)
     agg = torch.empty_like(u)
     prob = torch.empty((args.m, args.heads, args.k), dtype=torch.float32, device=u.device)
-    check(lib().tg_attn_fwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _stream()), "tg_attn_fwd")
+    with _timed("attn_fwd", args.m):
+        check(lib().tg_attn_fwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _stream()), "tg_attn_fwd")
     return agg, prob
 
 
@@ -144,7 +189,8 @@ def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] =
     du = torch.empty_like(u)
     parts = lib().tg_attn_bwd_parts(args.m)
     part = torch.empty((parts, 2 * args.dt_dim), dtype=torch.float32, device=u.device)
-    check(lib().tg_attn_bwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _p(dagg), _p(du), _p(dfeat),
-                            0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), _p(part), _stream()), "tg_attn_bwd")
+    with _timed("attn_bwd", args.m):
+        check(lib().tg_attn_bwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _p(dagg), _p(du), _p(dfeat),
+                                0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), _p(part), _stream()), "tg_attn_bwd")
     dwb = colsum(part)
     return du, dwb[:args.dt_dim], dwb[args.dt_dim:]
