@@ -53,6 +53,28 @@ __host__ __device__ inline int64_t attn_grid(int64_t m) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// Slots are processed RB at a time: all RB rows' loads are issued first (memory-level parallelism: RB x CPL 16-byte loads
+// per lane in flight), then the RB x H partial dot products are folded across the wave together.
+constexpr int RB = 5;
+
+template <int VEC, int CPL>
+__device__ __forceinline__ void load_row(const tg_attn_desc& a, const Seg (&seg)[CPL], const float (&tw)[CPL][VEC],
+                                         const float (&tb)[CPL][VEC], int64_t fi, int64_t ei, float dt, bool live,
+                                         float (&z)[CPL][VEC]) {
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        if (live && seg[i].kind == 0) load_chunk<VEC>(a.d_feat + fi * a.feat_ld + seg[i].col, z[i]);
+        else if (live && seg[i].kind == 1) load_chunk<VEC>(a.d_edge + ei * a.edge_ld + seg[i].col, z[i]);
+        else if (live && seg[i].kind == 2) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) z[i][e] = tg::cos_phase(fmaf(dt, tw[i][e], tb[i][e]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) z[i][e] = 0.f;
+        }
+    }
+}
+
 template <int VEC, int CPL, int H>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_attn_desc a, const float* __restrict__ u,
                                                                          float* __restrict__ agg, float* __restrict__ prob) {
@@ -96,56 +118,65 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
             const int my_n = sl < k ? a.d_nbr[mo] : 0;
             const float my_dt = sl < k ? a.d_dt[mo] : 0.f;
             const int cnt = (k - s0) < kWave ? (k - s0) : kWave;
-            for (int s = 0; s < cnt; ++s) {
-                const int64_t fi = __builtin_amdgcn_readlane(my_f, s);
-                const int64_t ei = __builtin_amdgcn_readlane(my_e, s);
-                const int nb = __builtin_amdgcn_readlane(my_n, s);
-                const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), s));
-                float z[CPL][VEC];
+            for (int sb = 0; sb < cnt; sb += RB) {
+                float z[RB][CPL][VEC];
+                int nb[RB];
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) {
-                    if (seg[i].kind == 0) load_chunk<VEC>(a.d_feat + fi * a.feat_ld + seg[i].col, z[i]);
-                    else if (seg[i].kind == 1) load_chunk<VEC>(a.d_edge + ei * a.edge_ld + seg[i].col, z[i]);
-                    else if (seg[i].kind == 2) {
+                for (int r = 0; r < RB; ++r) {
+                    const int s = sb + r;
+                    const bool live = s < cnt;
+                    const int ss = live ? s : 0;
+                    const int64_t fi = __builtin_amdgcn_readlane(my_f, ss);
+                    const int64_t ei = __builtin_amdgcn_readlane(my_e, ss);
+                    nb[r] = __builtin_amdgcn_readlane(my_n, ss);
+                    const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), ss));
+                    load_row<VEC, CPL>(a, seg, tw, tb, fi, ei, dt, live, z[r]);
+                }
+                float part[RB * H];
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) z[i][e] = cosf(fmaf(dt, tw[i][e], tb[i][e]));
-                    } else {
+                for (int r = 0; r < RB; ++r)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) z[i][e] = 0.f;
+                    for (int h = 0; h < H; ++h) {
+                        float p = 0.f;
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) p = fmaf(uh[h][i][e], z[r][i][e], p);
+                        part[r * H + h] = p;
+                    }
+                tg::wave_sum_n<RB * H>(part);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const int s = sb + r;
+                    if (s >= cnt) break;               // wave-uniform
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        float sc = part[r * H + h] * a.scale;
+                        if (nb[r] == 0) sc = -1e10f;                                    // modules.py:221
+                        if (lane == s) keep_score[h] = sc;
+                        const float mnew = fmaxf(mx[h], sc);
+                        const float corr = __expf(mx[h] - mnew);
+                        const float pe = __expf(sc - mnew);
+                        den[h] = den[h] * corr + pe;
+                        const float wgt = pe * tg::dropout_keep_scale(a.seed, row, h, s0 + s, a.dropout_p);
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) acc[h][i][e] = fmaf(wgt, z[r][i][e], acc[h][i][e] * corr);
+                        mx[h] = mnew;
                     }
                 }
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    float p = 0.f;
-#pragma unroll
-                    for (int i = 0; i < CPL; ++i)
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) p = fmaf(uh[h][i][e], z[i][e], p);
-                    float sc = tg::wave_sum(p) * a.scale;
-                    if (nb == 0) sc = -1e10f;                                    // modules.py:221
-                    if (lane == s) keep_score[h] = sc;
-                    const float mnew = fmaxf(mx[h], sc);
-                    const float corr = expf(mx[h] - mnew);
-                    const float pe = expf(sc - mnew);
-                    den[h] = den[h] * corr + pe;
-                    const float wgt = pe * tg::dropout_keep_scale(a.seed, row, h, s0 + s, a.dropout_p);
-#pragma unroll
-                    for (int i = 0; i < CPL; ++i)
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc[h][i][e] = fmaf(wgt, z[i][e], acc[h][i][e] * corr);
-                    mx[h] = mnew;
-                }
             }
-            // probabilities of this slot tile need the final max/denominator: only exact when k <= 64 (one tile);
-            // for longer rows they are fixed up after the loop from the saved raw scores.
+            // probabilities need the final max/denominator: exact here when k <= 64 (one tile); for longer rows the raw
+            // scores are parked in `prob` and normalised after the loop.
             if (k <= kWave) {
 #pragma unroll
                 for (int h = 0; h < H; ++h)
-                    if (lane < k) prob[(row * H + h) * k + lane] = expf(keep_score[h] - mx[h]) / den[h];
+                    if (lane < k) prob[(row * H + h) * k + lane] = __expf(keep_score[h] - mx[h]) / den[h];
             } else {
 #pragma unroll
                 for (int h = 0; h < H; ++h)
-                    if (sl < k) prob[(row * H + h) * k + sl] = keep_score[h];   // raw score for now
+                    if (sl < k) prob[(row * H + h) * k + sl] = keep_score[h];
             }
         }
         if (k > kWave) {
@@ -153,7 +184,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
             for (int h = 0; h < H; ++h)
                 for (int sl = lane; sl < k; sl += kWave) {
                     const int64_t o = (row * H + h) * k + sl;
-                    prob[o] = expf(prob[o] - mx[h]) / den[h];
+                    prob[o] = __expf(prob[o] - mx[h]) / den[h];
                 }
         }
 #pragma unroll
@@ -174,6 +205,8 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
 // ------------------------------------------------------------------------------------------------ backward
 // d score_{h,n} = a'_{h,n} (dagg_h . z_n) - a_{h,n} (dagg_h . agg_h)      a' = dropped/scaled prob, a = softmax prob
 // masked slots get no score gradient (masked_fill), but still pass d z through a'.
+constexpr int RBB = 4;
+
 template <int VEC, int CPL, int H>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_attn_desc a, const float* __restrict__ u,
         const float* __restrict__ agg, const float* __restrict__ prob, const float* __restrict__ dagg,
@@ -218,8 +251,9 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) { p = fmaf(dg[h][i][e], ag[e], p); dacc[h][i][e] = 0.f; }
             }
-            cterm[h] = tg::wave_sum(p);
+            cterm[h] = p;
         }
+        tg::wave_sum_n<H>(cterm);
         for (int s0 = 0; s0 < k; s0 += kWave) {
             const int sl = s0 + lane;
             const int64_t mo = row * k + sl;
@@ -231,59 +265,72 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
 #pragma unroll
             for (int h = 0; h < H; ++h) my_p[h] = sl < k ? prob[(row * H + h) * k + sl] : 0.f;
             const int cnt = (k - s0) < kWave ? (k - s0) : kWave;
-            for (int s = 0; s < cnt; ++s) {
-                const int64_t fi = __builtin_amdgcn_readlane(my_f, s);
-                const int64_t ei = __builtin_amdgcn_readlane(my_e, s);
-                const int nb = __builtin_amdgcn_readlane(my_n, s);
-                const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), s));
-                float z[CPL][VEC], sn[CPL][VEC], dz[CPL][VEC];
+            for (int sb = 0; sb < cnt; sb += RBB) {
+                float z[RBB][CPL][VEC];
+                int nb[RBB];
+                int64_t fis[RBB];
+                float dts[RBB];
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) {
+                for (int r = 0; r < RBB; ++r) {
+                    const int s = sb + r;
+                    const bool live = s < cnt;
+                    const int ss = live ? s : 0;
+                    fis[r] = __builtin_amdgcn_readlane(my_f, ss);
+                    const int64_t ei = __builtin_amdgcn_readlane(my_e, ss);
+                    nb[r] = __builtin_amdgcn_readlane(my_n, ss);
+                    dts[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), ss));
+                    load_row<VEC, CPL>(a, seg, tw, tb, fis[r], ei, dts[r], live, z[r]);
+                }
+                float part[RBB * H];
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) { sn[i][e] = 0.f; dz[i][e] = 0.f; }
-                    if (seg[i].kind == 0) load_chunk<VEC>(a.d_feat + fi * a.feat_ld + seg[i].col, z[i]);
-                    else if (seg[i].kind == 1) load_chunk<VEC>(a.d_edge + ei * a.edge_ld + seg[i].col, z[i]);
-                    else if (seg[i].kind == 2) {
+                for (int r = 0; r < RBB; ++r)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const float arg = fmaf(dt, tw[i][e], tb[i][e]);
-                            sincosf(arg, &sn[i][e], &z[i][e]);
-                        }
-                    } else {
+                    for (int h = 0; h < H; ++h) {
+                        float p = 0.f;
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) z[i][e] = 0.f;
+                        for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) p = fmaf(dg[h][i][e], z[r][i][e], p);
+                        part[r * H + h] = p;
                     }
-                }
+                tg::wave_sum_n<RBB * H>(part);
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    float p = 0.f;
-#pragma unroll
-                    for (int i = 0; i < CPL; ++i)
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) p = fmaf(dg[h][i][e], z[i][e], p);
-                    const float da = tg::wave_sum(p);
-                    const float pr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_p[h]), s));
-                    const float pd = pr * tg::dropout_keep_scale(a.seed, row, h, s0 + s, a.dropout_p);
-                    const float dsc = nb == 0 ? 0.f : (pd * da - pr * cterm[h]) * a.scale;
+                for (int r = 0; r < RBB; ++r) {
+                    const int s = sb + r;
+                    if (s >= cnt) break;               // wave-uniform
+                    float dz[CPL][VEC];
 #pragma unroll
                     for (int i = 0; i < CPL; ++i)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            dacc[h][i][e] = fmaf(dsc, z[i][e], dacc[h][i][e]);
-                            dz[i][e] = fmaf(pd, dg[h][i][e], fmaf(dsc, uh[h][i][e], dz[i][e]));
-                        }
-                }
+                        for (int e = 0; e < VEC; ++e) dz[i][e] = 0.f;
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) {
-                    if (seg[i].kind == 0 && dfeat) {
+                    for (int h = 0; h < H; ++h) {
+                        const float da = part[r * H + h];
+                        const float pr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_p[h]), s));
+                        const float pd = pr * tg::dropout_keep_scale(a.seed, row, h, s0 + s, a.dropout_p);
+                        const float dsc = nb[r] == 0 ? 0.f : (pd * da - pr * cterm[h]) * a.scale;
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) atomicAdd(dfeat + fi * dfeat_ld + seg[i].col + e, dz[i][e]);
-                    } else if (seg[i].kind == 2) {
+                        for (int i = 0; i < CPL; ++i)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const float dph = -sn[i][e] * dz[i][e];
-                            gw[i][e] = fmaf(dt, dph, gw[i][e]);
-                            gb[i][e] += dph;
+                            for (int e = 0; e < VEC; ++e) {
+                                dacc[h][i][e] = fmaf(dsc, z[r][i][e], dacc[h][i][e]);
+                                dz[i][e] = fmaf(pd, dg[h][i][e], fmaf(dsc, uh[h][i][e], dz[i][e]));
+                            }
+                    }
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) {
+                        if (seg[i].kind == 0 && dfeat) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) atomicAdd(dfeat + fis[r] * dfeat_ld + seg[i].col + e, dz[i][e]);
+                        } else if (seg[i].kind == 2) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) {
+                                float sn, cs;
+                                tg::sincos_phase(fmaf(dts[r], tw[i][e], tb[i][e]), &sn, &cs);
+                                const float dph = -sn * dz[i][e];
+                                gw[i][e] = fmaf(dts[r], dph, gw[i][e]);
+                                gb[i][e] += dph;
+                            }
                         }
                     }
                 }

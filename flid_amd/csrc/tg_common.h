@@ -48,10 +48,55 @@ constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kMaxGridBlocks = 2048; // 256 CUs x 8 resident blocks: grid-stride beyond this
 
 // ---- wave64 helpers -------------------------------------------------------------------------------
+// DPP lane exchange inside the VALU (no LDS crossbar): quad swaps, 8- and 16-lane mirrors, then the two row broadcasts
+// of the GFX9 wave64 reduction; the total lands in lane 63 and is read back as a wave-uniform scalar.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+    return v + __builtin_bit_cast(float, moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);         // row_half_mirror
+    v = dpp_add<0x140>(v);         // row_mirror  -> every lane holds its 16-lane row sum
+    v = dpp_add<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// N independent sums at once, step-major so the DPP latencies overlap
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0xB1>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x4E>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x141>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x140>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x142, 0xA>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x143, 0xC>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
+}
+
+// cos / sin of a float32 phase that may reach millions of radians (time deltas up to a month in seconds times w ~ 1):
+// the phase is reduced to [-0.5, 0.5] revolutions in float64 (exact for |phase| < 2^52 / 2 pi), then the hardware
+// v_cos_f32 / v_sin_f32 (argument in revolutions) finish.  Replaces the generic cosf() whose large-argument path costs
+// ~100 VGPRs; absolute error ~1e-6, far below the 0.06..0.25 rad fp32 ulp of the phase itself.
+__device__ __forceinline__ float phase_to_rev(float phase) {
+    double r = (double)phase * 0.15915494309189535;   // 1 / (2 pi)
+    r -= __builtin_rint(r);
+    return (float)r;
+}
+__device__ __forceinline__ float cos_phase(float phase) { return __builtin_amdgcn_cosf(phase_to_rev(phase)); }
+__device__ __forceinline__ void sincos_phase(float phase, float* s, float* c) {
+    const float r = phase_to_rev(phase);
+    *s = __builtin_amdgcn_sinf(r);
+    *c = __builtin_amdgcn_cosf(r);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

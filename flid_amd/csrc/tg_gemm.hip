@@ -180,6 +180,54 @@ __global__ void __launch_bounds__(256) gemm_kernel(int64_t M, int64_t N, int64_t
     }
 }
 
+
+// ---- small problems: one wavefront = one 32x32 output tile over a K slice, operands straight from global (L2-resident) ----
+// Used when the 128-row tiling would leave most of the 256 CUs idle (layer-2 shapes: a few hundred to ~1k rows, and their
+// weight gradients).  No LDS, no barriers; the contraction is split across blockIdx.z and folded with float atomics.
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(64) gemm_small_kernel(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
+        int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+        const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics) {
+    const int lane = threadIdx.x & 63;
+    const int rl = lane & 31, kh = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.y * 32 + rl;      // A-operand row owned by this lane
+    const int64_t col = (int64_t)blockIdx.x * 32 + rl;      // B-operand column owned by this lane
+    const int64_t kbeg = (int64_t)blockIdx.z * k_chunk;
+    const int64_t kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
+    const bool row_ok = row < M, col_ok = col < N;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        float fa[8], fb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t kk = k0 + kh * 8 + q;
+            const bool k_ok = kk < kend;
+            fa[q] = (row_ok && k_ok) ? (A_KC ? A[row * lda + kk] : A[kk * lda + row]) : 0.f;
+            fb[q] = (col_ok && k_ok) ? (B_KC ? B[col * ldb + kk] : B[kk * ldb + col]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
+    }
+    if (!col_ok) return;
+    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t orow = (int64_t)blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (orow >= M) continue;
+        float v = alpha * acc[r] + bv;
+        float* p = C + orow * ldc + col;
+        if (use_atomics) {
+            atomicAdd(p, v);
+        } else {
+            if (accumulate) v += *p;
+            if (relu) v = fmaxf(v, 0.f);
+            *p = v;
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, bool VEC, int TN>
 void launch(dim3 grid, hipStream_t s, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
             int64_t ldb, float* C, int64_t ldc, const float* bias, int relu, int accumulate, int64_t k_chunk, int atomics) {
@@ -230,9 +278,36 @@ extern "C" int tg_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, floa
     const int64_t gx = (N + 32 * tn - 1) / (32 * tn), gy = (M + BM - 1) / BM;
     TG_REQUIRE(gy <= 65535 && gx <= 65535, "tg_gemm_f32: grid too large");
 
+    // Small problems (fewer 128-row tiles than half the CUs and a short contraction): one wave per 32x32 tile.
+    if (gx * gy < 128 && K < 2048) {
+        const int64_t tx = (N + 31) / 32, ty = (M + 31) / 32;
+        int64_t splits = 1;
+        if (!relu && ta && tx * ty < 256) {   // only weight-gradient shapes (A^T): forward products stay bitwise reproducible
+            splits = (512 + tx * ty - 1) / (tx * ty);
+            const int64_t max_splits = (K + 31) / 32;
+            if (splits > max_splits) splits = max_splits;
+            if (splits < 1) splits = 1;
+        }
+        int64_t k_chunk = (K + splits - 1) / splits;
+        k_chunk = (k_chunk + BK - 1) / BK * BK;
+        if (k_chunk < BK) k_chunk = BK;
+        splits = K == 0 ? 1 : (K + k_chunk - 1) / k_chunk;
+        const int atomics = splits > 1;
+        if (atomics && !accumulate) TG_HIP_CHECK(hipMemset2DAsync(d_C, ldc * sizeof(float), 0, N * sizeof(float), M, s));
+        TG_REQUIRE(ty <= 65535 && tx <= 65535, "tg_gemm_f32: grid too large");
+        dim3 grid((unsigned)tx, (unsigned)ty, (unsigned)splits);
+#define TG_SMALL(AK, BKC) gemm_small_kernel<AK, BKC><<<grid, 64, 0, s>>>(M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics)
+        if (a_kc && b_kc) TG_SMALL(true, true);
+        else if (a_kc && !b_kc) TG_SMALL(true, false);
+        else if (!a_kc && b_kc) TG_SMALL(false, true);
+        else TG_SMALL(false, false);
+#undef TG_SMALL
+        return tg::launch_status("gemm_small_kernel");
+    }
+
     // split the contraction when the output has too few tiles to fill 256 CUs (weight-gradient shapes: K = rows)
     int64_t splits = 1;
-    if (!relu && gx * gy < 256 && K >= 2048) {
+    if (!relu && ta && gx * gy < 256 && K >= 2048) {
         splits = (512 + gx * gy - 1) / (gx * gy);
         const int64_t max_splits = K / 256;
         if (splits > max_splits) splits = max_splits;

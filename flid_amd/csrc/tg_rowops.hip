@@ -138,13 +138,21 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (wave == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
+// fold the slices: block = 64 columns x 4 waves, wave w takes slices w, w+4, ...
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int slices, int cols,
                                                            float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int i = 0; i < slices; ++i) s += part[(int64_t)i * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int i = wave; i < slices; i += 4) s += part[(int64_t)i * cols + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 __global__ void __launch_bounds__(256) relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, int64_t numel) {
@@ -162,7 +170,7 @@ __global__ void __launch_bounds__(256) time_encode_kernel(const float* __restric
         float arg;
         if (fused) arg = fmaf(tv, w[j], b[j]);
         else arg = __fadd_rn(__fmul_rn(tv, w[j]), b[j]);   // keep the two roundings (no contraction)
-        out[i] = cosf(arg);
+        out[i] = tg::cos_phase(arg);
     }
 }
 
@@ -221,7 +229,7 @@ extern "C" int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const fl
 extern "C" int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, float* d_out, int accumulate, void* stream) {
     TG_REQUIRE(d_x && d_out && cols > 0 && n >= 0 && ld >= cols, "tg_colsum: arguments");
     hipStream_t s = (hipStream_t)stream;
-    int slices = (int)std::min<int64_t>(256, std::max<int64_t>(1, n / 64));
+    int slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, n / 32));
     const size_t need = (size_t)slices * cols;
     if (need > g_colsum_ws_floats) {   // grows rarely; never inside a captured region after warm-up
         if (g_colsum_ws) (void)hipFree(g_colsum_ws);
@@ -229,7 +237,7 @@ extern "C" int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, floa
         TG_HIP_CHECK(hipMalloc(&g_colsum_ws, g_colsum_ws_floats * sizeof(float)));
     }
     colsum_partial_kernel<<<dim3((cols + 63) / 64, slices), 256, 0, s>>>(d_x, ld, n, cols, g_colsum_ws);
-    colsum_final_kernel<<<(cols + 255) / 256, 256, 0, s>>>(g_colsum_ws, slices, cols, d_out, accumulate);
+    colsum_final_kernel<<<(cols + 63) / 64, 256, 0, s>>>(g_colsum_ws, slices, cols, d_out, accumulate);
     return tg::launch_status("colsum kernels");
 }
 
