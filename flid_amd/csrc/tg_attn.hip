@@ -210,12 +210,19 @@ constexpr int RBB = 4;
 template <int VEC, int CPL, int H>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_attn_desc a, const float* __restrict__ u,
         const float* __restrict__ agg, const float* __restrict__ prob, const float* __restrict__ dagg,
-        float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld, float* __restrict__ dte_part) {
+        float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld, float* __restrict__ dte_part, int64_t pad_row) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int dk = a.dn + a.de + a.dt_dim;
     const int k = a.k;
-    extern __shared__ float red[];   // WAVES_PER_BLOCK * 2 * dt_dim
+    extern __shared__ float red[];   // WAVES_PER_BLOCK * (2 * dt_dim + dn)
+    // every padded slot gathers the SAME row (pad_row): its gradient is summed in registers and leaves the workgroup as one
+    // row of atomics instead of thousands of adds onto one address (14x slower per the float-atomic contention rule)
+    float dpad[CPL][VEC];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dpad[i][e] = 0.f;
 
     Seg seg[CPL];
     float tw[CPL][VEC], tb[CPL][VEC], gw[CPL][VEC], gb[CPL][VEC];
@@ -320,8 +327,13 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
 #pragma unroll
                     for (int i = 0; i < CPL; ++i) {
                         if (seg[i].kind == 0 && dfeat) {
+                            if (nb[r] == 0 && pad_row >= 0) {
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) atomicAdd(dfeat + fis[r] * dfeat_ld + seg[i].col + e, dz[i][e]);
+                                for (int e = 0; e < VEC; ++e) dpad[i][e] += dz[i][e];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < VEC; ++e) atomicAdd(dfeat + fis[r] * dfeat_ld + seg[i].col + e, dz[i][e]);
+                            }
                         } else if (seg[i].kind == 2) {
 #pragma unroll
                             for (int e = 0; e < VEC; ++e) {
@@ -353,12 +365,28 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
                 red[wave * 2 * T + seg[i].col + e] = gw[i][e];
                 red[wave * 2 * T + T + seg[i].col + e] = gb[i][e];
             }
+    float* redp = red + WAVES_PER_BLOCK * 2 * T;
+    if (dfeat && pad_row >= 0) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i)
+            if (seg[i].kind == 0)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) redp[wave * a.dn + seg[i].col + e] = dpad[i][e];
+    }
     __syncthreads();
     for (int j = threadIdx.x; j < 2 * T; j += blockDim.x) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += red[w * 2 * T + j];
         dte_part[(int64_t)blockIdx.x * 2 * T + j] = s;
+    }
+    if (dfeat && pad_row >= 0) {
+        for (int j = threadIdx.x; j < a.dn; j += blockDim.x) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += redp[w * a.dn + j];
+            if (s != 0.f) atomicAdd(dfeat + pad_row * dfeat_ld + j, s);
+        }
     }
 }
 
@@ -376,13 +404,13 @@ int launch_fwd(const tg_attn_desc& a, const float* u, float* agg, float* prob, h
 
 template <int VEC, int CPL>
 int launch_bwd(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
-               float* dfeat, int64_t dfeat_ld, float* dte, hipStream_t s) {
+               float* dfeat, int64_t dfeat_ld, float* dte, int64_t pad_row, hipStream_t s) {
     const dim3 grid((unsigned)attn_grid(a.m)), block(WAVES_PER_BLOCK * kWave);
-    const size_t lds = sizeof(float) * WAVES_PER_BLOCK * 2 * a.dt_dim;
+    const size_t lds = sizeof(float) * WAVES_PER_BLOCK * (2 * a.dt_dim + a.dn);
     switch (a.heads) {
-        case 1: attn_bwd_kernel<VEC, CPL, 1><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte); break;
-        case 2: attn_bwd_kernel<VEC, CPL, 2><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte); break;
-        case 4: attn_bwd_kernel<VEC, CPL, 4><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte); break;
+        case 1: attn_bwd_kernel<VEC, CPL, 1><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row); break;
+        case 2: attn_bwd_kernel<VEC, CPL, 2><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row); break;
+        case 4: attn_bwd_kernel<VEC, CPL, 4><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row); break;
         default: tg::set_error("tg_attn: heads must be 1, 2 or 4"); return TG_EINVAL;
     }
     return tg::launch_status("attn_bwd_kernel");
@@ -429,8 +457,8 @@ extern "C" int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg
 extern "C" int tg_attn_bwd_parts(int64_t m) { return (int)attn_grid(m); }
 
 extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
-                           const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, float* d_dte_part,
-                           void* stream) {
+                           const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, int64_t pad_feat_row,
+                           float* d_dte_part, void* stream) {
     if (int rc = check_desc(a)) return rc;
     TG_REQUIRE(d_u && d_agg && d_prob && d_dagg && d_du && d_dte_part, "tg_attn_bwd: null pointer");
     if (a->m == 0) return TG_OK;
@@ -438,12 +466,12 @@ extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float*
     const int dk = a->dn + a->de + a->dt_dim;
     if (vec4_ok(a, d_u, d_agg, d_dagg, d_du, nullptr)) {
         const int c = (dk / 4 + 63) / 64;
-        if (c <= 1) return launch_bwd<4, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
-        if (c <= 2) return launch_bwd<4, 2>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
-        return launch_bwd<4, 4>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
+        if (c <= 1) return launch_bwd<4, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
+        if (c <= 2) return launch_bwd<4, 2>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
+        return launch_bwd<4, 4>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
     }
     const int c = (dk + 63) / 64;
-    if (c <= 1) return launch_bwd<1, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
+    if (c <= 1) return launch_bwd<1, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
     TG_REQUIRE(c <= 8, "tg_attn_bwd: unaligned rows wider than 512 floats unsupported");
-    return launch_bwd<1, 8>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, s);
+    return launch_bwd<1, 8>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
 }

@@ -45,10 +45,14 @@ class _LayerCtx:
     f1: torch.Tensor = None
 
 
+DEDUPE = True     # share repeated (node, time) rows inside a call; False reproduces the reference's row-for-row recursion
+
+
 @dataclass
 class _Ctx:
     n: int
     k: int
+    fr: "Frontier" = None
     ids_all: torch.Tensor = None
     cosb: torch.Tensor = None
     layers: List[_LayerCtx] = field(default_factory=list)
@@ -61,23 +65,56 @@ def frontier_rows(n: int, k: int, depth: int) -> int:
     return n * sum(k ** d for d in range(depth + 1))
 
 
-def sample_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torch.Tensor, k: int, num_layers: int):
+@dataclass
+class Frontier:
+    """Rows touched by one L-layer embedding call, level by level, with repeated (node, time) pairs stored ONCE.
+
+    level 0 = the n roots; level d+1 = the distinct (neighbor id, float32 neighbor time) pairs sampled from level d.
+    The embedding of a node at a time is a pure function of that pair, so rows that recur inside a batch (the same user a
+    few edges later shares 19 of its 20 most recent neighbors; every padded slot is the pair (0, 0.0)) are computed once
+    and shared: `child[r*k + j]` is the row that holds slot j of row r.  Exact -- no result changes."""
+    counts: List[int]                 # rows per level, len L+... (levels 0..L-1 are sampled; level L is never materialised)
+    ids_all: torch.Tensor             # int32 (sum(counts),)   node id of every row
+    S: tuple                          # (nbr i32, eid i32, t f32, dt f32) each (R_1, k): slot lists of levels 0..L-1
+    child: Optional[torch.Tensor]     # int32 (R_2 * k,) row index of each slot's node, for levels 0..L-2 (None if L == 1)
+    pad_rows: List[int] = field(default_factory=list)   # per level d+1: the shared row of the padding pair (0, 0.0), or -1
+
+    def rows(self, upto_level: int) -> int:
+        return sum(self.counts[:upto_level + 1])
+
+
+def sample_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torch.Tensor, k: int, num_layers: int,
+                    dedupe: bool = True) -> Frontier:
     """All sampler lookups of one embedding call: level 0 with float64 query times, deeper levels with the float32
-    neighbor times fed straight back (models/TGAT.py:110-111).  Returns S_nbr, S_eid, S_t, S_dt of shape (R_1, k)."""
-    n = ids_dev.numel()
+    neighbor times fed straight back (models/TGAT.py:110-111)."""
     dev = ids_dev.device
-    R1 = frontier_rows(n, k, num_layers - 1)
-    S = (torch.empty((R1, k), dtype=torch.int32, device=dev), torch.empty((R1, k), dtype=torch.int32, device=dev),
-         torch.empty((R1, k), dtype=torch.float32, device=dev), torch.empty((R1, k), dtype=torch.float32, device=dev))
-    graph.sample_recent(ids_dev, times_dev, k, out=tuple(t[0:n] for t in S))
-    off, cnt = 0, n
-    for _ in range(1, num_layers):
-        q_ids = S[0][off:off + cnt].reshape(-1)
-        q_t = S[2][off:off + cnt].reshape(-1)
-        lo = off + cnt
-        graph.sample_recent(q_ids, q_t, k, out=tuple(t[lo:lo + cnt * k] for t in S))
-        off, cnt = lo, cnt * k
-    return S
+    counts, ids_parts, S_parts, child_parts, pad_rows = [ids_dev.numel()], [ids_dev], [], [], []
+    q_ids, q_t, off = ids_dev, times_dev, 0
+    for d in range(num_layers):
+        S = graph.sample_recent(q_ids, q_t, k)
+        S_parts.append(S)
+        if d == num_layers - 1:
+            break
+        nbr_flat, t_flat = S[0].reshape(-1), S[2].reshape(-1)
+        nxt = off + counts[d]
+        if dedupe:
+            key = (nbr_flat.to(torch.int64) << 32) | (t_flat.view(torch.int32).to(torch.int64) & 0xFFFFFFFF)
+            uniq, inv = torch.unique(key, return_inverse=True)          # index bookkeeping only (one host sync for the count)
+            halves = uniq.view(torch.int32).view(-1, 2)                  # little endian: [:, 0] time bits, [:, 1] node id
+            q_ids, q_t = halves[:, 1].contiguous(), halves[:, 0].contiguous().view(torch.float32)
+            child_parts.append((inv + nxt).to(torch.int32))
+            # keys sort ascending and (0, +0.0) is the smallest possible key: if any slot is padded it is row `nxt`
+            pad_rows.append(nxt)
+        else:
+            pad_rows.append(-1)
+            q_ids, q_t = nbr_flat, t_flat
+            child_parts.append(torch.arange(nxt, nxt + nbr_flat.numel(), dtype=torch.int32, device=dev))
+        ids_parts.append(q_ids)
+        counts.append(q_ids.numel())
+        off = nxt
+    S_all = tuple(torch.cat([p[i] for p in S_parts]) if len(S_parts) > 1 else S_parts[0][i] for i in range(4))
+    return Frontier(counts=counts, ids_all=torch.cat(ids_parts) if len(ids_parts) > 1 else ids_parts[0], S=S_all,
+                    child=torch.cat(child_parts) if child_parts else None, pad_rows=pad_rows)
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -85,19 +122,20 @@ class _EmbedFn(torch.autograd.Function):
     7 attention + 4 merge parameters, then (optionally) the layer-0 base table when it carries gradient (TGN)."""
 
     @staticmethod
-    def forward(ctx, cfg, S, ids_dev, table, te_w, te_b, *layer_params):
+    def forward(ctx, cfg, fr, table, te_w, te_b, *layer_params):
         n, k, L, H = cfg["n"], cfg["k"], cfg["num_layers"], cfg["num_heads"]
         edge = cfg["edge_table"]
         p_drop, training = cfg["dropout"], cfg["training"]
-        dev = ids_dev.device
+        dev = table.device
         Dn, T = table.shape[1], te_w.numel()
         Dq = Dn + T
         hd = Dq // H
-        S_nbr, S_eid, S_t, S_dt = S
+        S_nbr, S_eid, S_t, S_dt = fr.S
         st = _Ctx(n=n, k=k)
         st.table = table
         st.table_grad = cfg["table_grad"]
-        ids_all = torch.cat([ids_dev, S_nbr.reshape(-1)])
+        st.fr = fr
+        ids_all = fr.ids_all
         st.ids_all = ids_all
         te_w_flat = te_w.reshape(-1)
         # time encoding of a zero interval: cos(b) (models/TGAT.py:84-85); one row, shared by every query
@@ -106,7 +144,7 @@ class _EmbedFn(torch.autograd.Function):
         H_prev = None
         for l in range(1, L + 1):
             Wq, Wk, Wv, ln_g, ln_b, Wr, br, W1, b1, W2, b2 = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
-            R = frontier_rows(n, k, L - l)
+            R = fr.rows(L - l)
             lc = _LayerCtx(R=R)
             lc.raw = ops.gather_rows(table, ids_all[:R])
             lc.own = lc.raw if l == 1 else H_prev[:R]
@@ -123,7 +161,7 @@ class _EmbedFn(torch.autograd.Function):
             if l == 1:
                 feat, feat_idx = table, S_nbr[:R].reshape(-1)
             else:
-                feat, feat_idx = H_prev, torch.arange(n, n + R * k, dtype=torch.int32, device=dev)
+                feat, feat_idx = H_prev, fr.child[:R * k]
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p_drop > 0) else 0
             lc.attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
                                    te_w_flat, te_b, k, H, hd ** -0.5, p_drop if training else 0.0, seed)
@@ -206,13 +244,16 @@ class _EmbedFn(torch.autograd.Function):
                 ops.gemm(dctx[:, h * hd:(h + 1) * hd], lc.agg[:, h, :], dWv[h * hd:(h + 1) * hd], ta=True)
             # fused attention backward: re-streams the neighbor rows once
             if l >= 2:
-                R_prev = frontier_rows(n, k, L - l + 1)
+                R_prev = st.fr.rows(L - l + 1)
                 dH_prev = torch.zeros((R_prev, Dn), device=dev)
                 dfeat = dH_prev
+                # padded slots of the rows of this layer all point at the first row of their child level (if shared)
+                pad_row = st.fr.pad_rows[0] if (l == L and st.fr.pad_rows) else -1     # one child level only
             else:
                 dH_prev = None
                 dfeat = d_table
-            du, dw_part, db_part = ops.attn_bwd(lc.attn, lc.u, lc.agg, lc.prob, dagg, dfeat)
+                pad_row = 0                      # node table: the padding node is row 0
+            du, dw_part, db_part = ops.attn_bwd(lc.attn, lc.u, lc.agg, lc.prob, dagg, dfeat, pad_row)
             d_tew += dw_part
             d_teb += db_part
             # key / query path
@@ -245,7 +286,7 @@ class _EmbedFn(torch.autograd.Function):
         sinb = torch.sin(te_b)
         d_teb -= sinb * d_cosb
         ctx.st = None
-        return (None, None, None, d_table, d_tew.view_as(te_w), d_teb, *grads)
+        return (None, None, d_table, d_tew.view_as(te_w), d_teb, *grads)
 
 
 def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, te_w, te_b, layer_params, ids: np.ndarray,
@@ -270,7 +311,7 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
         return torch.zeros((0, table.shape[1]), device=dev)
     if num_layers == 0:
         return ops.gather_rows(table, ids_dev)
-    S = sample_frontier(graph, ids_dev, times_dev, k, num_layers)
+    fr = sample_frontier(graph, ids_dev, times_dev, k, num_layers, dedupe=DEDUPE)
     cfg = dict(n=n, k=k, num_layers=num_layers, num_heads=num_heads, dropout=float(dropout), training=bool(training),
                edge_table=edge_table, table_grad=bool(table_requires_grad))
-    return _EmbedFn.apply(cfg, S, ids_dev, table, te_w, te_b, *layer_params)
+    return _EmbedFn.apply(cfg, fr, table, te_w, te_b, *layer_params)

@@ -183,7 +183,7 @@ def attn_fwd(args: AttnArgs, u: torch.Tensor):
     return agg, prob
 
 
-def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] = None):
+def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] = None, pad_row: int = -1):
     """returns du, (dw, db) of the time encoder; adds the neighbor-feature gradient into dfeat rows if given"""
     assert dagg.is_contiguous() and dagg.shape == u.shape
     du = torch.empty_like(u)
@@ -191,6 +191,6 @@ def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] =
     part = torch.empty((parts, 2 * args.dt_dim), dtype=torch.float32, device=u.device)
     with _timed("attn_bwd", args.m):
         check(lib().tg_attn_bwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _p(dagg), _p(du), _p(dfeat),
-                                0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), _p(part), _stream()), "tg_attn_bwd")
+                                0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), int(pad_row), _p(part), _stream()), "tg_attn_bwd")
     dwb = colsum(part)
     return du, dwb[:args.dt_dim], dwb[args.dt_dim:]

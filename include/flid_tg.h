@@ -90,12 +90,13 @@ int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg, float* d_
 
 /* backward of tg_attn_fwd.  d_dagg (m,heads,dk) in; d_du (m,heads,dk) out.
  * d_dfeat: if non-NULL, (rows of the feat source, ld dfeat_ld) gradient w.r.t. gathered feature rows, ADDED with
- * float atomics (rows may repeat); must be zeroed by the caller.
+ * float atomics (rows may repeat); must be zeroed by the caller.  pad_feat_row >= 0 promises that every padded slot
+ * (nbr id 0) gathers that one row: their gradients are pre-summed per workgroup instead of contending on one address.
  * d_dte_part: (parts, 2*dt_dim) per-workgroup partial sums of (dw | db); *parts is returned by tg_attn_bwd_parts(). */
 int tg_attn_bwd_parts(int64_t m);
 int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
-                const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, float* d_dte_part,
-                void* stream);
+                const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, int64_t pad_feat_row,
+                float* d_dte_part, void* stream);
 
 /* ---- dense fp32 (MFMA 32x32x2 f32, exact fp32) -----------------------------------------------------
  * replaces the aten::mm / addmm calls behind nn.Linear in models/modules.py:54-69,152-163,235.

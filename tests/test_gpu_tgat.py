@@ -122,3 +122,26 @@ def test_tgat_dropout_train_mode_statistics():
         b, _ = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
     assert not torch.equal(a, b)                        # train mode: stochastic
     assert torch.isfinite(a).all()
+
+
+def test_tgat_row_sharing_is_exact():
+    """sharing repeated (node, time) rows inside a call (engine.DEDUPE) must not change embeddings or gradients"""
+    from flid_amd import engine
+    g = load_golden("tgat_L2_K20")
+    outs = []
+    for flag in (True, False):
+        engine.DEDUPE = flag
+        try:
+            m, p, k = _model(g)
+            m.train()
+            s, d = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+            r = torch.from_numpy(g["r"]).cuda()
+            ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+            outs.append((s.detach().cpu(), d.detach().cpu(), {k_: v.grad.cpu() for k_, v in m.named_parameters()}))
+        finally:
+            engine.DEDUPE = True
+    np.testing.assert_allclose(outs[0][0].numpy(), outs[1][0].numpy(), atol=2e-6)
+    np.testing.assert_allclose(outs[0][1].numpy(), outs[1][1].numpy(), atol=2e-6)
+    for k_ in outs[0][2]:
+        ref = outs[1][2][k_].numpy()
+        np.testing.assert_allclose(outs[0][2][k_].numpy(), ref, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k_)
