@@ -35,6 +35,8 @@ SIGNATURES = {
     "tg_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_void, c_void]),
     "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
                               c_void, C.c_int, C.c_int, c_void]),
+    "tg_gemm_f32_batched": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_void,
+                                      c_i64, c_i64, C.c_int, c_void, C.c_int, C.c_int, c_void]),
     "tg_gather_rows": (C.c_int, [c_void, c_i64, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
     "tg_scatter_add_rows": (C.c_int, [c_void, c_i64, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
     "tg_add_layernorm_fwd": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),

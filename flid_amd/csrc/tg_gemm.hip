@@ -3,221 +3,222 @@
 // replaces: aten::mm / addmm behind every nn.Linear of the hot path (models/modules.py:54-69, 152-163, 235) and
 //           their autograd transposes.
 //
-// C[M,N] = alpha * op(A) * op(B) (+bias) (+C) (ReLU).  Workgroup = 4 waves stacked along M, tile 128 x (32*TN);
-// each wave owns a 32 x (32*TN) strip = TN accumulator tiles of 16 VGPRs.  K advances in steps of 16 through one LDS
-// stage; the next stage's global loads are issued before the MFMAs of the current one (register prefetch).
+// C[M,N] = alpha * op(A) * op(B) (+bias) (+C) (ReLU), optionally strided-batched (the two attention heads in one launch).
 //
-// Operand panels in LDS, P[r][kk] (r = row of op(A) / column of op(B), kk = 0..15):
-//   k-contiguous source ("KC": A not transposed, B given as N x K): stored [r][kk] with row stride 20 floats so the
-//       two ds_read_b128 per lane (k = 8*half + 0..7) are bank-conflict free;
-//   row-contiguous source ("MC": A^T, B given as K x N): stored [kk][r] (stride 128), read with ds_read_b32.
-// MFMA step s uses k = 8*(lane>>5) + s for BOTH operands, any such bijection of k is a valid contraction order.
+// Shape of the problem: M is the number of attention instances of one batch (1e3..3e4), N and K are 136..888.  The f32 MFMA
+// retires one 32x32x2 step per 64 cycles per SIMD, so the kernel is matrix-pipe bound as soon as every one of the 1024 SIMDs
+// holds 2+ waves -- the difficulty is tile quantisation, not bandwidth.  Hence: ONE 32x32 output tile per wavefront,
+// TM x TN wavefronts per workgroup (32TM x 32TN block tile, chosen per call so that there are >= 4 workgroups per CU),
+// operands staged through LDS in full 128-byte lines (BK = 32), two LDS stages and one barrier per stage; the global loads
+// of stage s+2 are in flight under the MFMAs of stage s.
+//
+// Operand panels in LDS, P[r][kk] (r = row of op(A) / column of op(B), kk = 0..31):
+//   k-contiguous source ("KC": A as M x K, B given as N x K): stored [r][kk], row stride 36 floats -> the four
+//       ds_read_b128 of a lane (k = 16*half + 0..15) are bank-conflict free;
+//   row-contiguous source ("MC": A^T, B given as K x N): stored [kk][r], read with conflict-free ds_read_b32.
+// MFMA step q uses k = 16*(lane>>5) + q for BOTH operands (any bijection of k is a valid contraction order).
+#include <stdlib.h>
+
 #include "tg_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
-constexpr int BK = 16;
+constexpr int BK = 32;
 constexpr int KC_STRIDE = BK + 4;
-constexpr int MC_STRIDE = 128;
-constexpr int PANEL_FLOATS = BM * KC_STRIDE;   // 2560 >= 16 * 128
 
-// ---- global -> registers ---------------------------------------------------------------------------
-// KC panel: ROWS x 16 floats, k contiguous in memory.  256 threads: thread t -> float4 (t&3) of rows (t>>2) + 64 j.
-template <int ROWS, bool VEC>
-__device__ __forceinline__ void load_kc(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
-                                        int64_t kend, float4 (&r)[2]) {
-    const int t = threadIdx.x;
-    const int kc = (t & 3) * 4;
+template <int R, bool KC> struct PanelFloats { static constexpr int value = KC ? R * KC_STRIDE : BK * R; };
+
+// ---- global -> registers -> LDS, one panel of R rows x 32 k ---------------------------------------------------------------
+// Branch-free in the steady state: rows beyond the matrix are CLAMPED to its last row (their products land in output rows /
+// columns that are never stored), slot indices wrap around (a few threads re-load a slot another thread also loads; both
+// write identical bytes to LDS), and only the last, partial K stage takes the predicated path.
+template <int R, int NT, bool KC, bool VEC>
+struct Panel {
+    static constexpr int TOTAL = R * 8;                       // float4 slots
+    static constexpr int PER = (TOTAL + NT - 1) / NT;
+
+    const float* src[PER];     // address of the slot at k = kbeg
+    int lds_off[PER];          // float offset inside the LDS panel
+    int kcol[PER];             // k offset of the slot inside a stage (first of its 4 floats if KC)
+    int rvalid[PER];           // non-VEC only: how many of the 4 consecutive rows exist (MC) / 1 (KC)
+
+    __device__ __forceinline__ void init(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, int64_t kbeg) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rr = (t >> 2) + 64 * j;
-        const int64_t row = row0 + rr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rr < ROWS && row < nrows) {
-            const float* p = X + row * ld + k0 + kc;
-            if constexpr (VEC) {
-                if (k0 + kc < kend) v = *reinterpret_cast<const float4*>(p);
+        for (int j = 0; j < PER; ++j) {
+            const int idx = (threadIdx.x + j * NT) % TOTAL;
+            if constexpr (KC) {
+                const int r = idx >> 3, c = (idx & 7) * 4;
+                int64_t row = row0 + r;
+                rvalid[j] = row < nrows;
+                if (row > nrows - 1) row = nrows - 1;
+                src[j] = X + row * ld + kbeg + c;
+                lds_off[j] = r * KC_STRIDE + c;
+                kcol[j] = c;
             } else {
-                if (k0 + kc + 0 < kend) v.x = p[0];
-                if (k0 + kc + 1 < kend) v.y = p[1];
-                if (k0 + kc + 2 < kend) v.z = p[2];
-                if (k0 + kc + 3 < kend) v.w = p[3];
+                constexpr int Q = R / 4;                       // float4 per k row
+                const int kr = idx / Q, c = (idx % Q) * 4;
+                int64_t row = row0 + c;
+                rvalid[j] = (int)((nrows - row) < 0 ? 0 : ((nrows - row) > 4 ? 4 : (nrows - row)));
+                if constexpr (VEC) { if (row > nrows - 4) row = nrows - 4; }
+                src[j] = X + (kbeg + kr) * ld + row;
+                lds_off[j] = kr * R + c;
+                kcol[j] = kr;
             }
         }
-        r[j] = v;
     }
-}
-template <int ROWS>
-__device__ __forceinline__ void store_kc(float* __restrict__ s, const float4 (&r)[2]) {
-    const int t = threadIdx.x;
-    const int kc = (t & 3) * 4;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rr = (t >> 2) + 64 * j;
-        if (rr < ROWS) *reinterpret_cast<float4*>(s + rr * KC_STRIDE + kc) = r[j];
-    }
-}
 
-// MC panel: 16 x ROWS floats, panel-row index contiguous in memory.  thread t -> float4 (t&31) of k rows (t>>5) + 8 j.
-template <int ROWS, bool VEC>
-__device__ __forceinline__ void load_mc(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
-                                        int64_t kend, float4 (&r)[2]) {
-    const int t = threadIdx.x;
-    const int c = (t & 31) * 4;
+    // stage starting at absolute k0 = kbeg + stage*32; `full` <=> k0 + 32 <= kend (wave-uniform)
+    __device__ __forceinline__ void gload(int64_t ld, int64_t stage_elems, int64_t k0, int64_t kend, bool full, float4 (&reg)[PER]) const {
+        if constexpr (VEC) {
+            if (full) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t kk = k0 + (t >> 5) + 8 * j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < ROWS && kk < kend) {
-            const float* p = X + kk * ld + row0 + c;
-            if constexpr (VEC) {
-                if (row0 + c < nrows) v = *reinterpret_cast<const float4*>(p);
+                for (int j = 0; j < PER; ++j) reg[j] = *reinterpret_cast<const float4*>(src[j] + stage_elems);
             } else {
-                if (row0 + c + 0 < nrows) v.x = p[0];
-                if (row0 + c + 1 < nrows) v.y = p[1];
-                if (row0 + c + 2 < nrows) v.z = p[2];
-                if (row0 + c + 3 < nrows) v.w = p[3];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k0 + kcol[j] < kend) v = *reinterpret_cast<const float4*>(src[j] + stage_elems);
+                    reg[j] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* p = src[j] + stage_elems;
+                if constexpr (KC) {
+                    const int64_t kk = k0 + kcol[j];
+                    if (rvalid[j]) {
+                        if (kk + 0 < kend) v.x = p[0];
+                        if (kk + 1 < kend) v.y = p[1];
+                        if (kk + 2 < kend) v.z = p[2];
+                        if (kk + 3 < kend) v.w = p[3];
+                    }
+                } else {
+                    if (k0 + kcol[j] < kend) {
+                        if (rvalid[j] > 0) v.x = p[0];
+                        if (rvalid[j] > 1) v.y = p[1];
+                        if (rvalid[j] > 2) v.z = p[2];
+                        if (rvalid[j] > 3) v.w = p[3];
+                    }
+                }
+                reg[j] = v;
             }
         }
-        r[j] = v;
     }
-}
-template <int ROWS>
-__device__ __forceinline__ void store_mc(float* __restrict__ s, const float4 (&r)[2]) {
-    const int t = threadIdx.x;
-    const int c = (t & 31) * 4;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        if (c < ROWS) *reinterpret_cast<float4*>(s + ((t >> 5) + 8 * j) * MC_STRIDE + c) = r[j];
-}
 
-// ---- LDS -> MFMA fragments (8 k-steps of one 32-row tile) --------------------------------------------
-template <bool KC>
-__device__ __forceinline__ void read_frag(const float* __restrict__ s, int tile_r0, float (&f)[8]) {
+    __device__ __forceinline__ void sstore(float* __restrict__ s, const float4 (&reg)[PER]) const {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) *reinterpret_cast<float4*>(s + lds_off[j]) = reg[j];
+    }
+};
+
+// ---- LDS -> MFMA fragments (16 k-steps of one 32-row tile) -------------------------------------------------------------------
+template <int R, bool KC>
+__device__ __forceinline__ void read_frag(const float* __restrict__ s, int tile_r0, float (&f)[16]) {
     const int lane = threadIdx.x & 63;
     const int rl = lane & 31, kh = lane >> 5;
     if constexpr (KC) {
-        const float4 a = *reinterpret_cast<const float4*>(s + (tile_r0 + rl) * KC_STRIDE + kh * 8);
-        const float4 b = *reinterpret_cast<const float4*>(s + (tile_r0 + rl) * KC_STRIDE + kh * 8 + 4);
-        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+        const float* p = s + (tile_r0 + rl) * KC_STRIDE + kh * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(p + 4 * g);
+            f[4 * g + 0] = v.x; f[4 * g + 1] = v.y; f[4 * g + 2] = v.z; f[4 * g + 3] = v.w;
+        }
     } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) f[q] = s[(kh * 8 + q) * MC_STRIDE + tile_r0 + rl];
+        for (int q = 0; q < 16; ++q) f[q] = s[(kh * 16 + q) * R + tile_r0 + rl];
     }
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int TN>
-__global__ void __launch_bounds__(256) gemm_kernel(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
-        int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-        const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics) {
-    constexpr int BN = 32 * TN;
-    __shared__ __attribute__((aligned(16))) float sA[PANEL_FLOATS];
-    __shared__ __attribute__((aligned(16))) float sB[B_KC ? BN * KC_STRIDE : 16 * MC_STRIDE];
+template <bool A_KC, bool B_KC, bool VEC, int TM, int TN>
+__global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64_t N, int64_t K, float alpha,
+        const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
+        const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics, int gx, int gy,
+        int64_t strideA, int64_t strideB, int64_t strideC, int nbatch) {
+    constexpr int NT = TM * TN * 64, RA = 32 * TM, RB_ = 32 * TN;
+    constexpr int FA = PanelFloats<RA, A_KC>::value, FB = PanelFloats<RB_, B_KC>::value;
+    using PA = Panel<RA, NT, A_KC, VEC>;
+    using PB = Panel<RB_, NT, B_KC, VEC>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (FA + FB)];
+    auto sA = [&](int i) -> float* { return lds + i * (FA + FB); };          // [A0 | B0 | A1 | B1]
+    auto sB = [&](int i) -> float* { return lds + i * (FA + FB) + FA; };
 
-    const int64_t bm = (int64_t)blockIdx.y * BM;
-    const int64_t bn = (int64_t)blockIdx.x * BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * k_chunk;
+    // workgroup id -> (row block, column block): XCD-aware bijective remap so that the column blocks of one row block (they
+    // share the A rows) run on the same XCD's L2.  blockIdx.z = batch * splits + split.
+    const int nwg = gx * gy;
+    const int bid = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int by = swz / gx, bx = swz % gx;
+    const int nsplit = gridDim.z / nbatch;
+    const int batch = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
+    A += batch * strideA; B += batch * strideB; C += batch * strideC;
+    if (bias) bias += batch * (int64_t)N;
+
+    const int64_t bm = (int64_t)by * RA, bn = (int64_t)bx * RB_;
+    const int64_t kbeg = (int64_t)split * k_chunk;
     const int64_t kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tm = wave / TN, tn = wave % TN;
+    const bool tile_live = (bm + tm * 32 < M) && (bn + tn * 32 < N);
 
-    f32x16 acc[TN];
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    float4 ra[2], rb[2];
-    auto gload = [&](int64_t k0) {
-        if constexpr (A_KC) load_kc<BM, VEC>(A, lda, bm, M, k0, kend, ra);
-        else load_mc<BM, VEC>(A, lda, bm, M, k0, kend, ra);
-        if constexpr (B_KC) load_kc<BN, VEC>(B, ldb, bn, N, k0, kend, rb);
-        else load_mc<BN, VEC>(B, ldb, bn, N, k0, kend, rb);
-    };
-
-    if (kbeg < kend) gload(kbeg);
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();   // everyone finished reading the previous stage
-        if constexpr (A_KC) store_kc<BM>(sA, ra); else store_mc<BM>(sA, ra);
-        if constexpr (B_KC) store_kc<BN>(sB, rb); else store_mc<BN>(sB, rb);
+    PA pa;
+    PB pb;
+    pa.init(A, lda, bm, M, kbeg);
+    pb.init(B, ldb, bn, N, kbeg);
+    const int64_t stepA = A_KC ? BK : BK * lda, stepB = B_KC ? BK : BK * ldb;     // floats per K stage
+    float4 ra[PA::PER], rb[PB::PER];
+    const int64_t nstage = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    const int64_t nfull = kend > kbeg ? (kend - kbeg) / BK : 0;
+    if (nstage > 0) {
+        pa.gload(lda, 0, kbeg, kend, nfull > 0, ra);
+        pb.gload(ldb, 0, kbeg, kend, nfull > 0, rb);
+        pa.sstore(sA(0), ra);
+        pb.sstore(sB(0), rb);
         __syncthreads();
-        if (k0 + BK < kend) gload(k0 + BK);   // in flight under the MFMAs below
-
-        float fa[8], fb[TN][8];
-        read_frag<A_KC>(sA, wave * 32, fa);
+        if (nstage > 1) {
+            pa.gload(lda, stepA, kbeg + BK, kend, nfull > 1, ra);
+            pb.gload(ldb, stepB, kbeg + BK, kend, nfull > 1, rb);
+        }
+    }
+    for (int64_t st = 0; st < nstage; ++st) {
+        const int cur = (int)(st & 1);
+        float fa[16], fb[16];
+        read_frag<RA, A_KC>(sA(cur), tm * 32, fa);
+        read_frag<RB_, B_KC>(sB(cur), tn * 32, fb);
+        if (st + 1 < nstage) {                       // registers hold stage st+1 (issued one full MFMA phase ago)
+            pa.sstore(sA(cur ^ 1), ra);
+            pb.sstore(sB(cur ^ 1), rb);
+        }
+        if (st + 2 < nstage) {                       // in flight under the MFMAs below
+            pa.gload(lda, (st + 2) * stepA, kbeg + (st + 2) * BK, kend, st + 2 < nfull, ra);
+            pb.gload(ldb, (st + 2) * stepB, kbeg + (st + 2) * BK, kend, st + 2 < nfull, rb);
+        }
+        if (tile_live) {                             // wave-uniform: tiles wholly outside C only help with the staging
 #pragma unroll
-        for (int i = 0; i < TN; ++i) read_frag<B_KC>(sB, i * 32, fb[i]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int i = 0; i < TN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[i][q], acc[i], 0, 0, 0);
+            for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
+        }
+        __syncthreads();
     }
 
     // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int rl = lane & 31, kh = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int64_t col = bn + i * 32 + rl;
-        if (col >= N) continue;
-        const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = bm + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row >= M) continue;
-            float v = alpha * acc[i][r] + bv;
-            float* p = C + row * ldc + col;
-            if (use_atomics) {
-                atomicAdd(p, v);
-            } else {
-                if (accumulate) v += *p;
-                if (relu) v = fmaxf(v, 0.f);
-                *p = v;
-            }
-        }
-    }
-}
-
-
-// ---- small problems: one wavefront = one 32x32 output tile over a K slice, operands straight from global (L2-resident) ----
-// Used when the 128-row tiling would leave most of the 256 CUs idle (layer-2 shapes: a few hundred to ~1k rows, and their
-// weight gradients).  No LDS, no barriers; the contraction is split across blockIdx.z and folded with float atomics.
-template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(64) gemm_small_kernel(int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A,
-        int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-        const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics) {
-    const int lane = threadIdx.x & 63;
-    const int rl = lane & 31, kh = lane >> 5;
-    const int64_t row = (int64_t)blockIdx.y * 32 + rl;      // A-operand row owned by this lane
-    const int64_t col = (int64_t)blockIdx.x * 32 + rl;      // B-operand column owned by this lane
-    const int64_t kbeg = (int64_t)blockIdx.z * k_chunk;
-    const int64_t kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
-    const bool row_ok = row < M, col_ok = col < N;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        float fa[8], fb[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int64_t kk = k0 + kh * 8 + q;
-            const bool k_ok = kk < kend;
-            fa[q] = (row_ok && k_ok) ? (A_KC ? A[row * lda + kk] : A[kk * lda + row]) : 0.f;
-            fb[q] = (col_ok && k_ok) ? (B_KC ? B[col * ldb + kk] : B[kk * ldb + col]) : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
-    }
-    if (!col_ok) return;
-    const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+    const int64_t col = bn + tn * 32 + rl;
+    if (col >= N) return;
+    const float bv = (bias && split == 0) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t orow = (int64_t)blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (orow >= M) continue;
+        const int64_t row = bm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row >= M) continue;
         float v = alpha * acc[r] + bv;
-        float* p = C + orow * ldc + col;
+        float* p = C + row * ldc + col;
         if (use_atomics) {
             atomicAdd(p, v);
         } else {
@@ -228,101 +229,96 @@ __global__ void __launch_bounds__(64) gemm_small_kernel(int64_t M, int64_t N, in
     }
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int TN>
-void launch(dim3 grid, hipStream_t s, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
-            int64_t ldb, float* C, int64_t ldc, const float* bias, int relu, int accumulate, int64_t k_chunk, int atomics) {
-    gemm_kernel<A_KC, B_KC, VEC, TN><<<grid, 256, 0, s>>>(M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, relu, accumulate,
-                                                          k_chunk, atomics);
+struct Args {
+    int64_t M, N, K; float alpha; const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
+    const float* bias; int relu, accumulate; int64_t k_chunk; int atomics, gx, gy; int64_t sA, sB, sC; int nbatch, splits;
+};
+
+template <bool A_KC, bool B_KC, bool VEC, int TM, int TN>
+void launch(const Args& a, hipStream_t s) {
+    const dim3 grid((unsigned)(a.gx * a.gy), 1, (unsigned)(a.nbatch * a.splits));
+    gemm_tile_kernel<A_KC, B_KC, VEC, TM, TN><<<grid, TM * TN * 64, 0, s>>>(a.M, a.N, a.K, a.alpha, a.A, a.lda, a.B, a.ldb, a.C,
+        a.ldc, a.bias, a.relu, a.accumulate, a.k_chunk, a.atomics, a.gx, a.gy, a.sA, a.sB, a.sC, a.nbatch);
 }
 
 template <bool A_KC, bool B_KC>
-void dispatch(bool vec, int tn, dim3 grid, hipStream_t s, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
-              int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu, int accumulate,
-              int64_t k_chunk, int atomics) {
-#define TG_GO(V, T) launch<A_KC, B_KC, V, T>(grid, s, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, relu, accumulate, k_chunk, atomics)
-    if (vec) {
-        if (tn == 4) TG_GO(true, 4); else if (tn == 3) TG_GO(true, 3); else TG_GO(true, 2);
+void dispatch(bool vec, int tm, int tn, const Args& a, hipStream_t s) {
+    if (!vec) { launch<A_KC, B_KC, false, 1, 2>(a, s); return; }
+    if (tm == 2) {
+        if (tn == 4) launch<A_KC, B_KC, true, 2, 4>(a, s);
+        else if (tn == 3) launch<A_KC, B_KC, true, 2, 3>(a, s);
+        else launch<A_KC, B_KC, true, 2, 2>(a, s);
     } else {
-        TG_GO(false, 2);
+        if (tn == 4) launch<A_KC, B_KC, true, 1, 4>(a, s);
+        else if (tn == 3) launch<A_KC, B_KC, true, 1, 3>(a, s);
+        else launch<A_KC, B_KC, true, 1, 2>(a, s);
     }
-#undef TG_GO
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda, int64_t strideA,
+              const float* d_B, int64_t ldb, int64_t strideB, float* d_C, int64_t ldc, int64_t strideC, int nbatch,
+              const float* d_bias, int relu, int accumulate, hipStream_t s) {
+    TG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nbatch >= 1, "tg_gemm_f32: negative size");
+    if (M == 0 || N == 0) return TG_OK;
+    TG_REQUIRE(d_A && d_B && d_C, "tg_gemm_f32: null pointer");
+    TG_REQUIRE(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "tg_gemm_f32: leading dimension too small");
+
+    // A panel: k-contiguous when A is M x K (not transposed).  B panel: k-contiguous when B is given as N x K (tb).
+    const bool a_kc = !ta, b_kc = tb != 0;
+    bool vec = al16(d_A) && al16(d_B) && lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0;
+    vec = vec && (a_kc ? K % 4 == 0 : M % 4 == 0) && (b_kc ? K % 4 == 0 : N % 4 == 0);
+
+    // Workgroup = 4 waves = 64 x 64 block tile (2 x 2 tiles of 32 x 32).  Measured on MI355X (tools/gemm_bench2.py,
+    // M = 131072 / 12235, N = K = 256): 64x64 96 / 72 TFLOP/s, 32x128 84 / 70, 64x128 91 / 62, and every 3- or 6-wave shape
+    // (32x96, 64x96) 42..69 -- waves per workgroup should divide evenly over the CU's 4 SIMDs.  Ragged edges cost only the idle
+    // wave slots of the edge blocks (tiles wholly outside C skip their MFMAs).
+    int tn = 2, tm = vec ? 2 : 1;
+    if (const char* e = getenv("FLID_GEMM_TM")) tm = atoi(e) == 2 ? 2 : 1;       // tuning overrides (tools/gemm_bench.py)
+    if (const char* e = getenv("FLID_GEMM_TN")) { const int v = atoi(e); if (vec && v >= 2 && v <= 4) tn = v; }
+    const int64_t gx = (N + 32 * tn - 1) / (32 * tn), gy = (M + 32 * tm - 1) / (32 * tm);
+    TG_REQUIRE(gx * gy < (int64_t)1 << 30, "tg_gemm_f32: grid too large");
+
+    // Split the contraction only for weight-gradient shapes (A^T: K = number of rows, small output) so that forward products
+    // stay bitwise reproducible; the partial products are folded with float atomics.
+    int64_t splits = 1;
+    if (!relu && ta && gx * gy * nbatch < 1024 && K >= 2 * BK) {
+        splits = (1536 + gx * gy * nbatch - 1) / (gx * gy * nbatch);
+        const int64_t max_splits = (K + 2 * BK - 1) / (2 * BK);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    int64_t k_chunk = (K + splits - 1) / splits;
+    k_chunk = (k_chunk + BK - 1) / BK * BK;
+    if (k_chunk < BK) k_chunk = BK;
+    splits = K == 0 ? 1 : (K + k_chunk - 1) / k_chunk;
+    TG_REQUIRE(splits * nbatch <= 65535, "tg_gemm_f32: too many splits");
+    const int atomics = splits > 1;
+    if (atomics && !accumulate)
+        for (int b = 0; b < nbatch; ++b)
+            TG_HIP_CHECK(hipMemset2DAsync(d_C + b * strideC, ldc * sizeof(float), 0, N * sizeof(float), M, s));
+
+    const Args a{M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, (int)gy,
+                 strideA, strideB, strideC, nbatch, (int)splits};
+    if (a_kc && b_kc) dispatch<true, true>(vec, tm, tn, a, s);
+    else if (a_kc && !b_kc) dispatch<true, false>(vec, tm, tn, a, s);
+    else if (!a_kc && b_kc) dispatch<false, true>(vec, tm, tn, a, s);
+    else dispatch<false, false>(vec, tm, tn, a, s);
+    return tg::launch_status("gemm_tile_kernel");
+}
 
 }  // namespace
 
 extern "C" int tg_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda,
                            const float* d_B, int64_t ldb, float* d_C, int64_t ldc, const float* d_bias, int relu,
                            int accumulate, void* stream) {
-    TG_REQUIRE(M >= 0 && N >= 0 && K >= 0, "tg_gemm_f32: negative size");
-    if (M == 0 || N == 0) return TG_OK;
-    TG_REQUIRE(d_A && d_B && d_C, "tg_gemm_f32: null pointer");
-    TG_REQUIRE(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "tg_gemm_f32: leading dimension too small");
-    hipStream_t s = (hipStream_t)stream;
+    return gemm_impl(ta, tb, M, N, K, alpha, d_A, lda, 0, d_B, ldb, 0, d_C, ldc, 0, 1, d_bias, relu, accumulate, (hipStream_t)stream);
+}
 
-    // A panel: k-contiguous when A is M x K (not transposed).  B panel: k-contiguous when B is given as N x K (tb).
-    const bool a_kc = !ta, b_kc = tb != 0;
-    bool vec = al16(d_A) && al16(d_B) && lda % 4 == 0 && ldb % 4 == 0;
-    vec = vec && (a_kc ? K % 4 == 0 : M % 4 == 0) && (b_kc ? K % 4 == 0 : N % 4 == 0);
-
-    // column-tile width: least padded N, ties to the wider tile
-    int tn = 2;
-    if (vec) {
-        int64_t best = -1;
-        for (int c : {4, 3, 2}) {
-            const int64_t padded = (N + 32 * c - 1) / (32 * c) * (32 * c);
-            if (best < 0 || padded < best) { best = padded; tn = c; }
-        }
-    }
-    const int64_t gx = (N + 32 * tn - 1) / (32 * tn), gy = (M + BM - 1) / BM;
-    TG_REQUIRE(gy <= 65535 && gx <= 65535, "tg_gemm_f32: grid too large");
-
-    // Small problems (fewer 128-row tiles than half the CUs and a short contraction): one wave per 32x32 tile.
-    if (gx * gy < 128 && K < 2048) {
-        const int64_t tx = (N + 31) / 32, ty = (M + 31) / 32;
-        int64_t splits = 1;
-        if (!relu && ta && tx * ty < 256) {   // only weight-gradient shapes (A^T): forward products stay bitwise reproducible
-            splits = (512 + tx * ty - 1) / (tx * ty);
-            const int64_t max_splits = (K + 31) / 32;
-            if (splits > max_splits) splits = max_splits;
-            if (splits < 1) splits = 1;
-        }
-        int64_t k_chunk = (K + splits - 1) / splits;
-        k_chunk = (k_chunk + BK - 1) / BK * BK;
-        if (k_chunk < BK) k_chunk = BK;
-        splits = K == 0 ? 1 : (K + k_chunk - 1) / k_chunk;
-        const int atomics = splits > 1;
-        if (atomics && !accumulate) TG_HIP_CHECK(hipMemset2DAsync(d_C, ldc * sizeof(float), 0, N * sizeof(float), M, s));
-        TG_REQUIRE(ty <= 65535 && tx <= 65535, "tg_gemm_f32: grid too large");
-        dim3 grid((unsigned)tx, (unsigned)ty, (unsigned)splits);
-#define TG_SMALL(AK, BKC) gemm_small_kernel<AK, BKC><<<grid, 64, 0, s>>>(M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics)
-        if (a_kc && b_kc) TG_SMALL(true, true);
-        else if (a_kc && !b_kc) TG_SMALL(true, false);
-        else if (!a_kc && b_kc) TG_SMALL(false, true);
-        else TG_SMALL(false, false);
-#undef TG_SMALL
-        return tg::launch_status("gemm_small_kernel");
-    }
-
-    // split the contraction when the output has too few tiles to fill 256 CUs (weight-gradient shapes: K = rows)
-    int64_t splits = 1;
-    if (!relu && ta && gx * gy < 256 && K >= 2048) {
-        splits = (512 + gx * gy - 1) / (gx * gy);
-        const int64_t max_splits = K / 256;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-    }
-    int64_t k_chunk = (K + splits - 1) / splits;
-    k_chunk = (k_chunk + BK - 1) / BK * BK;
-    splits = K == 0 ? 1 : (K + k_chunk - 1) / k_chunk;
-    const int atomics = splits > 1;
-    if (atomics && !accumulate) TG_HIP_CHECK(hipMemset2DAsync(d_C, ldc * sizeof(float), 0, N * sizeof(float), M, s));
-
-    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)splits);
-    if (a_kc && b_kc) dispatch<true, true>(vec, tn, grid, s, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics);
-    else if (a_kc && !b_kc) dispatch<true, false>(vec, tn, grid, s, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics);
-    else if (!a_kc && b_kc) dispatch<false, true>(vec, tn, grid, s, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics);
-    else dispatch<false, false>(vec, tn, grid, s, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics);
-    return tg::launch_status("gemm_kernel");
+extern "C" int tg_gemm_f32_batched(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda,
+                                   int64_t stride_a, const float* d_B, int64_t ldb, int64_t stride_b, float* d_C, int64_t ldc,
+                                   int64_t stride_c, int batch, const float* d_bias, int relu, int accumulate, void* stream) {
+    return gemm_impl(ta, tb, M, N, K, alpha, d_A, lda, stride_a, d_B, ldb, stride_b, d_C, ldc, stride_c, batch, d_bias, relu,
+                     accumulate, (hipStream_t)stream);
 }

@@ -156,8 +156,7 @@ class _EmbedFn(torch.autograd.Function):
             # u_h = Wk_h^T q_h : the query carried into key space (score = u . z)
             Dk = Wk.shape[1]
             lc.u = torch.empty((R, H, Dk), device=dev)
-            for h in range(H):
-                ops.gemm(lc.q[:, h * hd:(h + 1) * hd], Wk[h * hd:(h + 1) * hd], lc.u[:, h, :])
+            ops.gemm_batched(lc.q[:, :hd], Wk[:hd], lc.u[:, 0, :], H, hd, hd * Dk, Dk)
             if l == 1:
                 feat, feat_idx = table, S_nbr[:R].reshape(-1)
             else:
@@ -167,8 +166,7 @@ class _EmbedFn(torch.autograd.Function):
                                    te_w_flat, te_b, k, H, hd ** -0.5, p_drop if training else 0.0, seed)
             lc.agg, lc.prob = ops.attn_fwd(lc.attn, lc.u)
             lc.ctxv = torch.empty((R, Dq), device=dev)
-            for h in range(H):
-                ops.gemm(lc.agg[:, h, :], Wv[h * hd:(h + 1) * hd], lc.ctxv[:, h * hd:(h + 1) * hd], tb=True)
+            ops.gemm_batched(lc.agg[:, 0, :], Wv[:hd], lc.ctxv[:, :hd], H, Dk, hd * Dk, hd, tb=True)
             lc.res = torch.empty((R, Dq), device=dev)
             ops.gemm(lc.ctxv, Wr, lc.res, tb=True, bias=br)
             if training and p_drop > 0:                                     # modules.py:235
@@ -239,9 +237,8 @@ class _EmbedFn(torch.autograd.Function):
             # value path
             dagg = torch.empty((R, H, Dk), device=dev)
             dWv = torch.empty_like(Wv)
-            for h in range(H):
-                ops.gemm(dctx[:, h * hd:(h + 1) * hd], Wv[h * hd:(h + 1) * hd], dagg[:, h, :])
-                ops.gemm(dctx[:, h * hd:(h + 1) * hd], lc.agg[:, h, :], dWv[h * hd:(h + 1) * hd], ta=True)
+            ops.gemm_batched(dctx[:, :hd], Wv[:hd], dagg[:, 0, :], H, hd, hd * Dk, Dk)
+            ops.gemm_batched(dctx[:, :hd], lc.agg[:, 0, :], dWv[:hd], H, hd, Dk, hd * Dk, ta=True)
             # fused attention backward: re-streams the neighbor rows once
             if l >= 2:
                 R_prev = st.fr.rows(L - l + 1)
@@ -259,9 +256,8 @@ class _EmbedFn(torch.autograd.Function):
             # key / query path
             dq = torch.empty((R, Dq), device=dev)
             dWk = torch.empty_like(Wk)
-            for h in range(H):
-                ops.gemm(du[:, h, :], Wk[h * hd:(h + 1) * hd], dq[:, h * hd:(h + 1) * hd], tb=True)
-                ops.gemm(lc.q[:, h * hd:(h + 1) * hd], du[:, h, :], dWk[h * hd:(h + 1) * hd], ta=True)
+            ops.gemm_batched(du[:, 0, :], Wk[:hd], dq[:, :hd], H, Dk, hd * Dk, hd, tb=True)
+            ops.gemm_batched(lc.q[:, :hd], du[:, 0, :], dWk[:hd], H, hd, Dk, hd * Dk, ta=True)
             dWq = torch.empty_like(Wq)
             ops.gemm(dq, lc.own, dWq[:, :Dn], ta=True)
             dq_sum = ops.colsum(dq)

@@ -89,6 +89,20 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, ta=False, tb=False
     return out
 
 
+def gemm_batched(a0: torch.Tensor, b0: torch.Tensor, out0: torch.Tensor, batch: int, stride_a: int, stride_b: int, stride_c: int,
+                 ta=False, tb=False, accumulate=False):
+    """`batch` products in one launch; a0/b0/out0 are the views of problem 0, problem i starts stride_* floats further."""
+    _chk(a0, torch.float32, "a"); _chk(b0, torch.float32, "b"); _chk(out0, torch.float32, "out")
+    M, K = (a0.shape[1], a0.shape[0]) if ta else (a0.shape[0], a0.shape[1])
+    Kb, N = (b0.shape[1], b0.shape[0]) if tb else (b0.shape[0], b0.shape[1])
+    if K != Kb or out0.shape[0] != M or out0.shape[1] != N:
+        raise ValueError(f"gemm_batched: shape mismatch op(a)=({M},{K}) op(b)=({Kb},{N}) out={tuple(out0.shape)}")
+    with _timed("gemm", (M, N, K * batch)):
+        check(lib().tg_gemm_f32_batched(int(ta), int(tb), M, N, K, 1.0, _p(a0), _rowmajor_ld(a0, "a"), stride_a, _p(b0),
+                                        _rowmajor_ld(b0, "b"), stride_b, _p(out0), _rowmajor_ld(out0, "out"), stride_c, batch,
+                                        _p(None), 0, int(accumulate), _stream()), "tg_gemm_f32_batched")
+
+
 def gather_rows(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None):
     _chk(table, torch.float32, "table"); _chk(idx, torch.int32, "idx")
     n, cols = idx.numel(), table.shape[1]

@@ -107,6 +107,12 @@ int tg_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, co
                 const float* d_B, int64_t ldb, float* d_C, int64_t ldc, const float* d_bias, int relu, int accumulate,
                 void* stream);
 
+/* strided-batched form: problem b uses A + b*stride_a, B + b*stride_b, C + b*stride_c (bias + b*N).  One launch for the
+ * per-head products of models/modules.py:186-197 (head h = column / row block h of the projection weights). */
+int tg_gemm_f32_batched(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda,
+                        int64_t stride_a, const float* d_B, int64_t ldb, int64_t stride_b, float* d_C, int64_t ldc,
+                        int64_t stride_c, int batch, const float* d_bias, int relu, int accumulate, void* stream);
+
 /* ---- row-wise helpers ------------------------------------------------------------------------------ */
 /* out[i, 0:cols] = table[idx[i], 0:cols]        (models/TGAT.py:87 node_raw_features[ids]) */
 int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols,

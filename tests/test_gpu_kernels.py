@@ -306,3 +306,40 @@ def test_rowops(dev):
     dy, y = x.clone(), torch.from_numpy(rs.standard_normal((5000, 172)).astype(np.float32)).to(dev)
     ops.relu_bwd_(dy, y)
     assert torch.equal(dy, x * (y > 0))
+
+
+def test_gemm_random_shapes_and_views(dev):
+    """randomised sweep: transposes, ragged sizes, K tails, split-K (ta), column-sliced A/B/C views, accumulate"""
+    from flid_amd import ops
+    rs = np.random.RandomState(123)
+    for it in range(60):
+        ta, tb = int(rs.randint(2)), int(rs.randint(2))
+        M = int(rs.choice([1, 7, 64, 172, 272, 336, 1200, 3000]))
+        N = int(rs.choice([4, 12, 100, 136, 172, 272, 444]))
+        K = int(rs.choice([4, 20, 100, 136, 172, 336, 444, 1000, 4100]))
+        if it % 3 == 0:     # unaligned -> scalar path
+            M, N, K = M + int(rs.randint(1, 4)), N + int(rs.randint(1, 4)), K + int(rs.randint(1, 4))
+        pad_a, pad_b, pad_c = (int(rs.choice([0, 4, 100])) for _ in range(3))
+        a_full = rs.standard_normal(((K, M + pad_a) if ta else (M, K + pad_a))).astype(np.float32)
+        b_full = rs.standard_normal(((N, K + pad_b) if tb else (K, N + pad_b))).astype(np.float32)
+        c_full = rs.standard_normal((M, N + pad_c)).astype(np.float32)
+        A, B, C = torch.from_numpy(a_full).to(dev), torch.from_numpy(b_full).to(dev), torch.from_numpy(c_full).to(dev)
+        off_a = int(rs.choice([0, pad_a])) if pad_a else 0
+        off_b = int(rs.choice([0, pad_b])) if pad_b else 0
+        off_c = int(rs.choice([0, pad_c])) if pad_c else 0
+        Av = A[:, off_a:off_a + (M if ta else K)]
+        Bv = B[:, off_b:off_b + (K if tb else N)]
+        Cv = C[:, off_c:off_c + N]
+        acc = bool(rs.randint(2))
+        an, bn = a_full[:, off_a:off_a + (M if ta else K)].astype(np.float64), b_full[:, off_b:off_b + (K if tb else N)].astype(np.float64)
+        ref = (an.T if ta else an) @ (bn.T if tb else bn)
+        if acc:
+            ref = ref + c_full[:, off_c:off_c + N]
+        ops.gemm(Av, Bv, Cv, ta=bool(ta), tb=bool(tb), accumulate=acc)
+        got = C.cpu().numpy()
+        tol = 1e-5 + 3e-6 * np.sqrt(K) * max(1.0, np.abs(ref).max() / 8)
+        np.testing.assert_allclose(got[:, off_c:off_c + N], ref, atol=tol, err_msg=f"it={it} ta={ta} tb={tb} M={M} N={N} K={K} acc={acc}")
+        # bytes outside the C view must be untouched
+        mask = np.ones_like(c_full, dtype=bool)
+        mask[:, off_c:off_c + N] = False
+        assert np.array_equal(got[mask], c_full[mask]), f"it={it}: wrote outside the C view"
