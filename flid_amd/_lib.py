@@ -44,6 +44,10 @@ SIGNATURES = {
     "tg_add_layernorm_bwd": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "tg_colsum": (C.c_int, [c_void, c_i64, c_i64, C.c_int, c_void, C.c_int, c_void]),
     "tg_relu_bwd_inplace": (C.c_int, [c_void, c_void, c_i64, c_void]),
+    "tg_gru_gates_fwd": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void]),
+    "tg_gru_gates_bwd": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void]),
+    "tg_build_messages": (C.c_int, [c_void, c_i64, c_void, c_void, c_void, c_void, c_void, c_i64, c_void, c_void, c_void, c_i64,
+                                    C.c_int, C.c_int, C.c_int, c_void, c_void]),
 }
 
 _lib = None

@@ -208,3 +208,36 @@ def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] =
                                 0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), int(pad_row), _p(part), _stream()), "tg_attn_bwd")
     dwb = colsum(part)
     return du, dwb[:args.dt_dim], dwb[args.dt_dim:]
+
+
+def gru_cell_fwd(x, h, w_ih, w_hh, b_ih, b_hh):
+    """nn.GRUCell forward on the MFMA GEMM + fused gate kernel.  Returns (h_new, gi, gh) -- gi/gh are kept for backward."""
+    n, d = h.shape
+    gi = torch.empty((n, 3 * d), device=h.device)
+    gh = torch.empty((n, 3 * d), device=h.device)
+    gemm(x, w_ih, gi, tb=True, bias=b_ih)
+    gemm(h, w_hh, gh, tb=True, bias=b_hh)
+    out = torch.empty_like(h)
+    check(lib().tg_gru_gates_fwd(_p(gi), _p(gh), _p(h), n, d, _p(out), _stream()), "tg_gru_gates_fwd")
+    return out, gi, gh
+
+
+def gru_cell_bwd(x, h, gi, gh, dout, w_ih, w_hh):
+    """parameter gradients of the GRU cell (inputs x, h are detached state in TGN): dW_ih, dW_hh, db_ih, db_hh"""
+    n, d = h.shape
+    dgi, dgh = torch.empty_like(gi), torch.empty_like(gh)
+    check(lib().tg_gru_gates_bwd(_p(gi), _p(gh), _p(h), _p(dout.contiguous()), n, d, _p(dgi), _p(dgh), _p(None), _stream()),
+          "tg_gru_gates_bwd")
+    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+    gemm(dgi, x, dw_ih, ta=True)
+    gemm(dgh, h, dw_hh, ta=True)
+    return dw_ih, dw_hh, colsum(dgi), colsum(dgh)
+
+
+def build_messages(mem, last_update, a_ids, b_ids, t32, edge, eids, te_w, te_b):
+    n, d, de, T = a_ids.numel(), mem.shape[1], edge.shape[1], te_w.numel()
+    out = torch.empty((n, 2 * d + T + de), device=mem.device)
+    check(lib().tg_build_messages(_p(mem), _rowmajor_ld(mem, "mem"), _p(last_update), _p(a_ids), _p(b_ids), _p(t32), _p(edge),
+                                  _rowmajor_ld(edge, "edge"), _p(eids), _p(te_w), _p(te_b), n, d, de, T, _p(out), _stream()),
+          "tg_build_messages")
+    return out

@@ -133,6 +133,19 @@ int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, float* d_out, i
 /* dx = dy * (y > 0) in place on dy */
 int tg_relu_bwd_inplace(float* d_dy, const float* d_y, int64_t numel, void* stream);
 
+/* ---- TGN memory ------------------------------------------------------------------------------------
+ * GRU gate stage of nn.GRUCell (models/MemoryModel.py:531-543): gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh come from
+ * tg_gemm_f32, both (n, 3d) in torch's r|z|n order; out = (1-z) * tanh(gi_n + r*gh_n) + z*h. */
+int tg_gru_gates_fwd(const float* d_gi, const float* d_gh, const float* d_h, int64_t n, int d, float* d_out, void* stream);
+/* gradients w.r.t. gi, gh (n, 3d) and, if d_dh != NULL, h (n, d) given d_dout (n, d) */
+int tg_gru_gates_bwd(const float* d_gi, const float* d_gh, const float* d_h, const float* d_dout, int64_t n, int d,
+                     float* d_dgi, float* d_dgh, float* d_dh, void* stream);
+/* raw identity messages of models/MemoryModel.py:233-278: out[i] = [mem[a_i] | mem[b_i] | cos((t_i - last_update[a_i]) w + b) |
+ * edge[e_i]], width 2d + T + de; t and last_update are float32 as in the reference (:255-257). */
+int tg_build_messages(const float* d_mem, int64_t mem_ld, const float* d_last_update, const int32_t* d_a_ids,
+                      const int32_t* d_b_ids, const float* d_t32, const float* d_edge, int64_t edge_ld, const int32_t* d_eids,
+                      const float* d_te_w, const float* d_te_b, int64_t n, int d, int de, int T, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
