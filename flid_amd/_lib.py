@@ -37,6 +37,18 @@ SIGNATURES = {
                               c_void, C.c_int, C.c_int, c_void]),
     "tg_gemm_f32_batched": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_void,
                                       c_i64, c_i64, C.c_int, c_void, C.c_int, C.c_int, c_void]),
+    "tg_gemm_f32_batched2": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64,
+                                       c_i64, c_void, c_i64, c_i64, c_i64, C.c_int, C.c_int, C.c_int, c_void]),
+    "tg_time_encode_masked": (C.c_int, [c_void, c_void, c_i64, c_void, c_void, C.c_int, c_void, c_void]),
+    "tg_time_encode_bwd": (C.c_int, [c_void, c_void, c_i64, c_void, c_void, C.c_int, c_void, c_void, c_void]),
+    "tg_cooccurrence": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_i64, C.c_int, c_i64, c_void, c_void, c_void]),
+    "tg_gelu_fwd": (C.c_int, [c_void, c_i64, c_void, c_void]),
+    "tg_gelu_bwd": (C.c_int, [c_void, c_void, c_i64, c_void, c_void]),
+    "tg_softmax_fwd": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_void]),
+    "tg_softmax_bwd": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void]),
+    "tg_dropout": (C.c_int, [c_void, c_i64, c_f32, C.c_uint64, c_void, c_void]),
+    "tg_segment_mean_fwd": (C.c_int, [c_void, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void]),
+    "tg_segment_mean_bwd": (C.c_int, [c_void, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "tg_gather_rows": (C.c_int, [c_void, c_i64, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
     "tg_scatter_add_rows": (C.c_int, [c_void, c_i64, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
     "tg_add_layernorm_fwd": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),

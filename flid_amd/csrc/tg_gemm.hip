@@ -137,7 +137,7 @@ template <bool A_KC, bool B_KC, bool VEC, int TM, int TN>
 __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64_t N, int64_t K, float alpha,
         const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
         const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics, int gx, int gy,
-        int64_t strideA, int64_t strideB, int64_t strideC, int nbatch) {
+        int64_t strideA, int64_t strideB, int64_t strideC, int nbatch, int inner, int64_t innerA, int64_t innerB, int64_t innerC) {
     constexpr int NT = TM * TN * 64, RA = 32 * TM, RB_ = 32 * TN;
     constexpr int FA = PanelFloats<RA, A_KC>::value, FB = PanelFloats<RB_, B_KC>::value;
     using PA = Panel<RA, NT, A_KC, VEC>;
@@ -155,7 +155,9 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
     const int by = swz / gx, bx = swz % gx;
     const int nsplit = gridDim.z / nbatch;
     const int batch = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
-    A += batch * strideA; B += batch * strideB; C += batch * strideC;
+    // two-level batch index: problem = (batch / inner, batch % inner), e.g. (sequence, head)
+    const int bo = batch / inner, bi = batch % inner;
+    A += bo * strideA + bi * innerA; B += bo * strideB + bi * innerB; C += bo * strideC + bi * innerC;
     if (bias) bias += batch * (int64_t)N;
 
     const int64_t bm = (int64_t)by * RA, bn = (int64_t)bx * RB_;
@@ -232,13 +234,14 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
 struct Args {
     int64_t M, N, K; float alpha; const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
     const float* bias; int relu, accumulate; int64_t k_chunk; int atomics, gx, gy; int64_t sA, sB, sC; int nbatch, splits;
+    int inner; int64_t iA, iB, iC;
 };
 
 template <bool A_KC, bool B_KC, bool VEC, int TM, int TN>
 void launch(const Args& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.gx * a.gy), 1, (unsigned)(a.nbatch * a.splits));
     gemm_tile_kernel<A_KC, B_KC, VEC, TM, TN><<<grid, TM * TN * 64, 0, s>>>(a.M, a.N, a.K, a.alpha, a.A, a.lda, a.B, a.ldb, a.C,
-        a.ldc, a.bias, a.relu, a.accumulate, a.k_chunk, a.atomics, a.gx, a.gy, a.sA, a.sB, a.sC, a.nbatch);
+        a.ldc, a.bias, a.relu, a.accumulate, a.k_chunk, a.atomics, a.gx, a.gy, a.sA, a.sB, a.sC, a.nbatch, a.inner, a.iA, a.iB, a.iC);
 }
 
 template <bool A_KC, bool B_KC>
@@ -259,7 +262,8 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda, int64_t strideA,
               const float* d_B, int64_t ldb, int64_t strideB, float* d_C, int64_t ldc, int64_t strideC, int nbatch,
-              const float* d_bias, int relu, int accumulate, hipStream_t s) {
+              const float* d_bias, int relu, int accumulate, hipStream_t s, int inner = 1, int64_t innerA = 0, int64_t innerB = 0,
+              int64_t innerC = 0) {
     TG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nbatch >= 1, "tg_gemm_f32: negative size");
     if (M == 0 || N == 0) return TG_OK;
     TG_REQUIRE(d_A && d_B && d_C, "tg_gemm_f32: null pointer");
@@ -267,7 +271,8 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
 
     // A panel: k-contiguous when A is M x K (not transposed).  B panel: k-contiguous when B is given as N x K (tb).
     const bool a_kc = !ta, b_kc = tb != 0;
-    bool vec = al16(d_A) && al16(d_B) && lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0;
+    bool vec = al16(d_A) && al16(d_B) && lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 &&
+               innerA % 4 == 0 && innerB % 4 == 0;
     vec = vec && (a_kc ? K % 4 == 0 : M % 4 == 0) && (b_kc ? K % 4 == 0 : N % 4 == 0);
 
     // Workgroup = 4 waves = 64 x 64 block tile (2 x 2 tiles of 32 x 32).  Measured on MI355X (tools/gemm_bench2.py,
@@ -297,10 +302,11 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     const int atomics = splits > 1;
     if (atomics && !accumulate)
         for (int b = 0; b < nbatch; ++b)
-            TG_HIP_CHECK(hipMemset2DAsync(d_C + b * strideC, ldc * sizeof(float), 0, N * sizeof(float), M, s));
+            TG_HIP_CHECK(hipMemset2DAsync(d_C + (b / inner) * strideC + (b % inner) * innerC, ldc * sizeof(float), 0,
+                                          N * sizeof(float), M, s));
 
     const Args a{M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, (int)gy,
-                 strideA, strideB, strideC, nbatch, (int)splits};
+                 strideA, strideB, strideC, nbatch, (int)splits, inner, innerA, innerB, innerC};
     if (a_kc && b_kc) dispatch<true, true>(vec, tm, tn, a, s);
     else if (a_kc && !b_kc) dispatch<true, false>(vec, tm, tn, a, s);
     else if (!a_kc && b_kc) dispatch<false, true>(vec, tm, tn, a, s);
@@ -321,4 +327,13 @@ extern "C" int tg_gemm_f32_batched(int ta, int tb, int64_t M, int64_t N, int64_t
                                    int64_t stride_c, int batch, const float* d_bias, int relu, int accumulate, void* stream) {
     return gemm_impl(ta, tb, M, N, K, alpha, d_A, lda, stride_a, d_B, ldb, stride_b, d_C, ldc, stride_c, batch, d_bias, relu,
                      accumulate, (hipStream_t)stream);
+}
+
+extern "C" int tg_gemm_f32_batched2(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda,
+                                    int64_t outer_a, int64_t inner_a, const float* d_B, int64_t ldb, int64_t outer_b,
+                                    int64_t inner_b, float* d_C, int64_t ldc, int64_t outer_c, int64_t inner_c, int outer, int inner,
+                                    int accumulate, void* stream) {
+    TG_REQUIRE(outer >= 1 && inner >= 1 && (int64_t)outer * inner <= 65535, "tg_gemm_f32_batched2: batch counts");
+    return gemm_impl(ta, tb, M, N, K, alpha, d_A, lda, outer_a, d_B, ldb, outer_b, d_C, ldc, outer_c, outer * inner, nullptr, 0,
+                     accumulate, (hipStream_t)stream, inner, inner_a, inner_b, inner_c);
 }

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
-            x[i] = c < cols ? a[r * cols + c] + b[r * cols + c] : 0.f;
+            x[i] = c < cols ? a[r * cols + c] + (b ? b[r * cols + c] : 0.f) : 0.f;
             s += x[i];
         }
         const float mu = tg::wave_sum(s) / cols;
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
             const int c = lane + 64 * i;
             const bool ok = c < cols;
             const float d = ok ? dy[r * cols + c] : 0.f;
-            xh[i] = ok ? (a[r * cols + c] + b[r * cols + c] - mu) * rs : 0.f;
+            xh[i] = ok ? (a[r * cols + c] + (b ? b[r * cols + c] : 0.f) - mu) * rs : 0.f;
             g[i] = d * gm[i];
             s1 += g[i];
             s2 = fmaf(g[i], xh[i], s2);
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(float* __restrict__ dy, c
 }
 
 __global__ void __launch_bounds__(256) time_encode_kernel(const float* __restrict__ t, int64_t n, const float* __restrict__ w,
-        const float* __restrict__ b, int dim, int fused, float* __restrict__ out) {
+        const float* __restrict__ b, int dim, int fused, float* __restrict__ out, const int32_t* __restrict__ mask_ids) {
     const int64_t total = n * dim;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / dim;
@@ -170,8 +170,50 @@ __global__ void __launch_bounds__(256) time_encode_kernel(const float* __restric
         float arg;
         if (fused) arg = fmaf(tv, w[j], b[j]);
         else arg = __fadd_rn(__fmul_rn(tv, w[j]), b[j]);   // keep the two roundings (no contraction)
-        out[i] = tg::cos_phase(arg);
+        out[i] = (mask_ids && mask_ids[r] == 0) ? 0.f : tg::cos_phase(arg);     // DyGFormer.py:266 zeroes padded slots
     }
+}
+
+// backward of out = cos(fma(t, w, b)) (optionally masked): per-workgroup partials of dw_j = sum_i -sin(phase_ij) t_i g_ij and
+// db_j = sum_i -sin(phase_ij) g_ij.  The phase is re-evaluated with the SAME single rounding as the forward (at phases of
+// 1e6 rad one fp32 ulp is 0.1 rad, so a differently rounded phase would give an unrelated sine).
+template <int MAXC>
+__global__ void __launch_bounds__(256) time_encode_bwd_kernel(const float* __restrict__ t, const int32_t* __restrict__ mask_ids,
+        int64_t n, const float* __restrict__ w, const float* __restrict__ b, int dim, const float* __restrict__ g,
+        float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ float red[];   // 4 * 2 * dim
+    float gw[MAXC], gb[MAXC], wv[MAXC], bv[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        gw[i] = 0.f; gb[i] = 0.f;
+        wv[i] = c < dim ? w[c] : 0.f;
+        bv[i] = c < dim ? b[c] : 0.f;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        if (mask_ids && mask_ids[r] == 0) continue;
+        const float tv = t[r];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < dim) {
+                float sn, cs;
+                tg::sincos_phase(fmaf(tv, wv[i], bv[i]), &sn, &cs);
+                const float dph = -sn * g[r * dim + c];
+                gw[i] = fmaf(tv, dph, gw[i]);
+                gb[i] += dph;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < dim) { red[wave * 2 * dim + c] = gw[i]; red[wave * 2 * dim + dim + c] = gb[i]; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * dim; j += blockDim.x)
+        part[(int64_t)blockIdx.x * 2 * dim + j] = red[j] + red[2 * dim + j] + red[4 * dim + j] + red[6 * dim + j];
 }
 
 float* g_colsum_ws = nullptr;
@@ -201,7 +243,7 @@ extern "C" int tg_scatter_add_rows(const float* d_src, int64_t src_ld, const int
 
 extern "C" int tg_add_layernorm_fwd(const float* d_a, const float* d_b, int64_t n, int cols, const float* d_gamma,
                                     const float* d_beta, float* d_y, float* d_mean, float* d_rstd, void* stream) {
-    TG_REQUIRE(d_a && d_b && d_gamma && d_beta && d_y && d_mean && d_rstd, "tg_add_layernorm_fwd: null pointer");
+    TG_REQUIRE(d_a && d_gamma && d_beta && d_y && d_mean && d_rstd, "tg_add_layernorm_fwd: null pointer");
     TG_REQUIRE(cols > 0 && cols <= 1024, "tg_add_layernorm_fwd: cols must be in 1..1024");
     if (n == 0) return TG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -215,7 +257,7 @@ extern "C" int tg_add_layernorm_fwd(const float* d_a, const float* d_b, int64_t 
 extern "C" int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const float* d_dy, int64_t n, int cols,
                                     const float* d_gamma, const float* d_mean, const float* d_rstd, float* d_dx,
                                     float* d_dgb_part, void* stream) {
-    TG_REQUIRE(d_a && d_b && d_dy && d_gamma && d_mean && d_rstd && d_dx && d_dgb_part, "tg_add_layernorm_bwd: null pointer");
+    TG_REQUIRE(d_a && d_dy && d_gamma && d_mean && d_rstd && d_dx && d_dgb_part, "tg_add_layernorm_bwd: null pointer");
     TG_REQUIRE(cols > 0 && cols <= 1024, "tg_add_layernorm_bwd: cols must be in 1..1024");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)row_grid(n);
@@ -249,11 +291,31 @@ extern "C" int tg_relu_bwd_inplace(float* d_dy, const float* d_y, int64_t numel,
     return tg::launch_status("relu_bwd_kernel");
 }
 
+extern "C" int tg_time_encode_masked(const float* d_t, const int32_t* d_mask_ids, int64_t n, const float* d_w, const float* d_b,
+                                     int dim, float* d_out, void* stream) {
+    TG_REQUIRE(d_t && d_mask_ids && d_w && d_b && d_out && dim > 0 && n >= 0, "tg_time_encode_masked: arguments");
+    if (n == 0) return TG_OK;
+    const int64_t blocks = std::min<int64_t>((n * dim + 255) / 256, tg::kMaxGridBlocks);
+    time_encode_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_t, n, d_w, d_b, dim, 1, d_out, d_mask_ids);
+    return tg::launch_status("time_encode_kernel");
+}
+
 extern "C" int tg_time_encode(const float* d_t, int64_t n, const float* d_w, const float* d_b, int dim, int fused_fma,
                               float* d_out, void* stream) {
     TG_REQUIRE(d_t && d_w && d_b && d_out && dim > 0 && n >= 0, "tg_time_encode: arguments");
     if (n == 0) return TG_OK;
     const int64_t blocks = std::min<int64_t>((n * dim + 255) / 256, tg::kMaxGridBlocks);
-    time_encode_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_t, n, d_w, d_b, dim, fused_fma, d_out);
+    time_encode_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_t, n, d_w, d_b, dim, fused_fma, d_out, nullptr);
     return tg::launch_status("time_encode_kernel");
+}
+
+extern "C" int tg_time_encode_bwd(const float* d_t, const int32_t* d_mask_ids, int64_t n, const float* d_w, const float* d_b,
+                                  int dim, const float* d_g, float* d_part, void* stream) {
+    TG_REQUIRE(d_t && d_w && d_b && d_g && d_part && dim > 0 && dim <= 512 && n >= 0, "tg_time_encode_bwd: arguments (dim <= 512)");
+    const unsigned g = (unsigned)row_grid(n);
+    const size_t lds = sizeof(float) * 4 * 2 * dim;
+    hipStream_t s = (hipStream_t)stream;
+    if (dim <= 128) time_encode_bwd_kernel<2><<<g, 256, lds, s>>>(d_t, d_mask_ids, n, d_w, d_b, dim, d_g, d_part);
+    else time_encode_bwd_kernel<8><<<g, 256, lds, s>>>(d_t, d_mask_ids, n, d_w, d_b, dim, d_g, d_part);
+    return tg::launch_status("time_encode_bwd_kernel");
 }

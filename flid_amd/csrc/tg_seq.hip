@@ -1,0 +1,194 @@
+// Sequence-side kernels of the DyGFormer path (models/DyGFormer.py): neighbor co-occurrence counts, erf-GELU, row softmax,
+// counter-based dropout, per-side patch means.  Dense products run on tg_gemm_f32(_batched).
+//   tg_cooccurrence      <- models/DyGFormer.py:337-393  count_nodes_appearances (np.unique per row + python lambda)
+//   tg_gelu_*            <- F.gelu (erf form) in models/DyGFormer.py:458
+//   tg_softmax_*         <- softmax inside nn.MultiheadAttention (models/DyGFormer.py:454)
+//   tg_dropout           <- nn.Dropout (models/DyGFormer.py:456-460), mask regenerated from (seed, index) in backward
+//   tg_segment_mean_*    <- torch.mean over each side's patches (models/DyGFormer.py:185-187)
+#include <math.h>
+
+#include "tg_common.h"
+
+namespace {
+
+// one thread per (row, slot): counts of seq_a[row][slot] inside seq_a[row][:] and seq_b[row][:]  (widths <= a few dozen)
+__global__ void __launch_bounds__(256) cooc_kernel(const int32_t* __restrict__ a, int64_t lda, int wa, const int32_t* __restrict__ b,
+        int64_t ldb, int wb, int64_t n, float* __restrict__ out /* (n, wa, 2) */, int self_first) {
+    const int64_t total = n * wa;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / wa;
+        const int s = (int)(i - r * wa);
+        const int32_t v = a[r * lda + s];
+        int ca = 0, cb = 0;
+        if (v != 0) {                                   // padded id 0 counts as 0 (DyGFormer.py:387-391)
+            for (int j = 0; j < wa; ++j) ca += a[r * lda + j] == v;
+            for (int j = 0; j < wb; ++j) cb += b[r * ldb + j] == v;
+        }
+        // column order follows the reference: source rows are [in_src, in_dst], destination rows are [in_src, in_dst] too
+        out[i * 2 + 0] = (float)(self_first ? ca : cb);
+        out[i * 2 + 1] = (float)(self_first ? cb : ca);
+    }
+}
+
+__global__ void __launch_bounds__(256) gelu_fwd_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    }
+}
+__global__ void __launch_bounds__(256) gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n,
+                                                       float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+        dx[i] = dy[i] * (cdf + v * pdf);
+    }
+}
+
+// one wave per row, cols <= 64 * MAXC
+template <int MAXC>
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(const float* __restrict__ x, int64_t n, int cols, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        float v[MAXC];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < cols ? x[r * cols + c] : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+        m = tg::wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) { v[i] = (lane + 64 * i) < cols ? expf(v[i] - m) : 0.f; s += v[i]; }
+        s = tg::wave_sum(s);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) { const int c = lane + 64 * i; if (c < cols) y[r * cols + c] = v[i] * inv; }
+    }
+}
+template <int MAXC>
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, int64_t n,
+                                                          int cols, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        float p[MAXC], g[MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            p[i] = c < cols ? y[r * cols + c] : 0.f;
+            g[i] = c < cols ? dy[r * cols + c] : 0.f;
+            s = fmaf(p[i], g[i], s);
+        }
+        s = tg::wave_sum(s);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) { const int c = lane + 64 * i; if (c < cols) dx[r * cols + c] = p[i] * (g[i] - s); }
+    }
+}
+
+__global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed,
+                                                      float* __restrict__ y) {
+    const float scale = 1.f / (1.f - p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float u = (float)(tg::mix32(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
+        y[i] = u >= p ? x[i] * scale : 0.f;
+    }
+}
+
+// x: (n, s, d); out[i, :] = mean_{j in [lo, hi)} x[i, j, :]
+__global__ void __launch_bounds__(256) segment_mean_fwd_kernel(const float* __restrict__ x, int64_t n, int s, int d, int lo, int hi,
+                                                               float* __restrict__ out) {
+    const int64_t total = n * d;
+    const float inv = 1.f / (float)(hi - lo);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d;
+        const int c = (int)(i - r * d);
+        float acc = 0.f;
+        for (int j = lo; j < hi; ++j) acc += x[(r * s + j) * d + c];
+        out[i] = acc * inv;
+    }
+}
+// dx[i, j, :] (j in [lo,hi)) = dout[i, :] / (hi - lo); other positions untouched
+__global__ void __launch_bounds__(256) segment_mean_bwd_kernel(const float* __restrict__ dout, int64_t n, int s, int d, int lo, int hi,
+                                                               float* __restrict__ dx) {
+    const int64_t total = n * (hi - lo) * d;
+    const float inv = 1.f / (float)(hi - lo);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d);
+        const int64_t rj = i / d;
+        const int j = lo + (int)(rj % (hi - lo));
+        const int64_t r = rj / (hi - lo);
+        dx[(r * s + j) * d + c] = dout[r * d + c] * inv;
+    }
+}
+
+inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, tg::kMaxGridBlocks)); }
+
+}  // namespace
+
+extern "C" int tg_cooccurrence(const int32_t* d_a, int64_t lda, int wa, const int32_t* d_b, int64_t ldb, int wb, int64_t n,
+                               float* d_out_a, float* d_out_b, void* stream) {
+    TG_REQUIRE(d_a && d_b && d_out_a && d_out_b && wa > 0 && wb > 0 && n >= 0, "tg_cooccurrence: arguments");
+    if (n == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    cooc_kernel<<<ew_grid(n * wa), 256, 0, s>>>(d_a, lda, wa, d_b, ldb, wb, n, d_out_a, 1);
+    cooc_kernel<<<ew_grid(n * wb), 256, 0, s>>>(d_b, ldb, wb, d_a, lda, wa, n, d_out_b, 0);
+    return tg::launch_status("cooc_kernel");
+}
+
+extern "C" int tg_gelu_fwd(const float* d_x, int64_t n, float* d_y, void* stream) {
+    TG_REQUIRE(d_x && d_y && n >= 0, "tg_gelu_fwd: arguments");
+    if (n == 0) return TG_OK;
+    gelu_fwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, n, d_y);
+    return tg::launch_status("gelu_fwd_kernel");
+}
+extern "C" int tg_gelu_bwd(const float* d_x, const float* d_dy, int64_t n, float* d_dx, void* stream) {
+    TG_REQUIRE(d_x && d_dy && d_dx && n >= 0, "tg_gelu_bwd: arguments");
+    if (n == 0) return TG_OK;
+    gelu_bwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, d_dy, n, d_dx);
+    return tg::launch_status("gelu_bwd_kernel");
+}
+
+extern "C" int tg_softmax_fwd(const float* d_x, int64_t n, int cols, float* d_y, void* stream) {
+    TG_REQUIRE(d_x && d_y && n >= 0 && cols > 0 && cols <= 1024, "tg_softmax_fwd: cols must be in 1..1024");
+    if (n == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, tg::kMaxGridBlocks));
+    if (cols <= 64) softmax_fwd_kernel<1><<<g, 256, 0, s>>>(d_x, n, cols, d_y);
+    else if (cols <= 256) softmax_fwd_kernel<4><<<g, 256, 0, s>>>(d_x, n, cols, d_y);
+    else softmax_fwd_kernel<16><<<g, 256, 0, s>>>(d_x, n, cols, d_y);
+    return tg::launch_status("softmax_fwd_kernel");
+}
+extern "C" int tg_softmax_bwd(const float* d_y, const float* d_dy, int64_t n, int cols, float* d_dx, void* stream) {
+    TG_REQUIRE(d_y && d_dy && d_dx && n >= 0 && cols > 0 && cols <= 1024, "tg_softmax_bwd: cols must be in 1..1024");
+    if (n == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, tg::kMaxGridBlocks));
+    if (cols <= 64) softmax_bwd_kernel<1><<<g, 256, 0, s>>>(d_y, d_dy, n, cols, d_dx);
+    else if (cols <= 256) softmax_bwd_kernel<4><<<g, 256, 0, s>>>(d_y, d_dy, n, cols, d_dx);
+    else softmax_bwd_kernel<16><<<g, 256, 0, s>>>(d_y, d_dy, n, cols, d_dx);
+    return tg::launch_status("softmax_bwd_kernel");
+}
+
+extern "C" int tg_dropout(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream) {
+    TG_REQUIRE(d_x && d_y && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout: arguments");
+    if (n == 0) return TG_OK;
+    dropout_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, n, p, seed, d_y);
+    return tg::launch_status("dropout_kernel");
+}
+
+extern "C" int tg_segment_mean_fwd(const float* d_x, int64_t n, int s, int d, int lo, int hi, float* d_out, void* stream) {
+    TG_REQUIRE(d_x && d_out && n >= 0 && s > 0 && d > 0 && 0 <= lo && lo < hi && hi <= s, "tg_segment_mean_fwd: arguments");
+    if (n == 0) return TG_OK;
+    segment_mean_fwd_kernel<<<ew_grid(n * d), 256, 0, (hipStream_t)stream>>>(d_x, n, s, d, lo, hi, d_out);
+    return tg::launch_status("segment_mean_fwd_kernel");
+}
+extern "C" int tg_segment_mean_bwd(const float* d_dout, int64_t n, int s, int d, int lo, int hi, float* d_dx, void* stream) {
+    TG_REQUIRE(d_dout && d_dx && n >= 0 && s > 0 && d > 0 && 0 <= lo && lo < hi && hi <= s, "tg_segment_mean_bwd: arguments");
+    if (n == 0) return TG_OK;
+    segment_mean_bwd_kernel<<<ew_grid(n * (hi - lo) * d), 256, 0, (hipStream_t)stream>>>(d_dout, n, s, d, lo, hi, d_dx);
+    return tg::launch_status("segment_mean_bwd_kernel");
+}

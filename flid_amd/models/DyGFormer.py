@@ -1,0 +1,139 @@
+"""DyGFormer backbone -- drop-in for the reference class (models/DyGFormer.py): same constructor, forward surface,
+parameter names / shapes.  Sequences are built on the device (tg_first_hop_window, tg_cooccurrence), every product runs on
+the fp32 MFMA GEMM (plain, or two-level batched for the per-(sequence, head) attention products)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops, seqops
+from ..utils.utils import NeighborSampler
+from .modules import TimeEncoder, linear
+
+
+class NeighborCooccurrenceEncoder(nn.Module):
+    """parameter holder (models/DyGFormer.py:320-335): Linear(1, C) -> ReLU -> Linear(C, C) applied to each of the two counts"""
+
+    def __init__(self, neighbor_co_occurrence_feat_dim: int, device: str = 'cpu'):
+        super().__init__()
+        self.neighbor_co_occurrence_feat_dim = neighbor_co_occurrence_feat_dim
+        self.device = device
+        self.neighbor_co_occurrence_encode_layer = nn.Sequential(
+            nn.Linear(in_features=1, out_features=neighbor_co_occurrence_feat_dim), nn.ReLU(),
+            nn.Linear(in_features=neighbor_co_occurrence_feat_dim, out_features=neighbor_co_occurrence_feat_dim))
+
+    def encode(self, counts: torch.Tensor):
+        """(B, W, 2) counts -> (B, W, C): MLP on each count, summed over the two (:409-411)"""
+        l0, l2 = self.neighbor_co_occurrence_encode_layer[0], self.neighbor_co_occurrence_encode_layer[2]
+        h = linear(counts.unsqueeze(-1), l0.weight, l0.bias, relu=True)
+        return linear(h, l2.weight, l2.bias).sum(dim=2)
+
+
+class TransformerEncoder(nn.Module):
+    """pre-LN block (models/DyGFormer.py:418-461); nn.MultiheadAttention is kept as the parameter holder"""
+
+    def __init__(self, attention_dim: int, num_heads: int, dropout: float = 0.1):
+        super().__init__()
+        self.multi_head_attention = nn.MultiheadAttention(embed_dim=attention_dim, num_heads=num_heads, dropout=dropout)
+        self.num_heads, self.p = num_heads, dropout
+        self.dropout = nn.Dropout(dropout)
+        self.linear_layers = nn.ModuleList([nn.Linear(attention_dim, 4 * attention_dim), nn.Linear(4 * attention_dim, attention_dim)])
+        self.norm_layers = nn.ModuleList([nn.LayerNorm(attention_dim), nn.LayerNorm(attention_dim)])
+
+    def forward(self, inputs: torch.Tensor):
+        mha, tr, p = self.multi_head_attention, self.training, self.p
+        y = seqops.layer_norm(inputs, self.norm_layers[0].weight, self.norm_layers[0].bias)
+        qkv = linear(y, mha.in_proj_weight, mha.in_proj_bias)
+        att = seqops.self_attention(qkv, self.num_heads, p, tr)
+        att = linear(att, mha.out_proj.weight, mha.out_proj.bias)
+        outputs = inputs + seqops.dropout(att, p, tr)
+        y = seqops.layer_norm(outputs, self.norm_layers[1].weight, self.norm_layers[1].bias)
+        h = seqops.gelu(linear(y, self.linear_layers[0].weight, self.linear_layers[0].bias))
+        h = linear(seqops.dropout(h, p, tr), self.linear_layers[1].weight, self.linear_layers[1].bias)
+        return outputs + seqops.dropout(h, p, tr)
+
+
+class DyGFormer(nn.Module):
+
+    def __init__(self, node_raw_features: np.ndarray, edge_raw_features: np.ndarray, neighbor_sampler: NeighborSampler,
+                 time_feat_dim: int, channel_embedding_dim: int, patch_size: int = 1, num_layers: int = 2, num_heads: int = 2,
+                 dropout: float = 0.1, max_input_sequence_length: int = 512, device: str = 'cpu'):
+        super().__init__()
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("flid_amd.DyGFormer runs on a ROCm device only; there is no CPU path")
+        self.node_raw_features = torch.from_numpy(node_raw_features.astype(np.float32)).to(device).contiguous()
+        self.edge_raw_features = torch.from_numpy(edge_raw_features.astype(np.float32)).to(device).contiguous()
+        self.neighbor_sampler = neighbor_sampler
+        self.node_feat_dim, self.edge_feat_dim = self.node_raw_features.shape[1], self.edge_raw_features.shape[1]
+        self.time_feat_dim, self.channel_embedding_dim, self.patch_size = time_feat_dim, channel_embedding_dim, patch_size
+        self.num_layers, self.num_heads, self.dropout = num_layers, num_heads, dropout
+        self.max_input_sequence_length, self.device = max_input_sequence_length, device
+        self.time_encoder = TimeEncoder(time_dim=time_feat_dim)
+        self.neighbor_co_occurrence_feat_dim = self.channel_embedding_dim
+        self.neighbor_co_occurrence_encoder = NeighborCooccurrenceEncoder(self.neighbor_co_occurrence_feat_dim, device=device)
+        self.projection_layer = nn.ModuleDict({
+            'node': nn.Linear(self.patch_size * self.node_feat_dim, self.channel_embedding_dim, bias=True),
+            'edge': nn.Linear(self.patch_size * self.edge_feat_dim, self.channel_embedding_dim, bias=True),
+            'time': nn.Linear(self.patch_size * self.time_feat_dim, self.channel_embedding_dim, bias=True),
+            'neighbor_co_occurrence': nn.Linear(self.patch_size * self.neighbor_co_occurrence_feat_dim, self.channel_embedding_dim, bias=True)})
+        self.num_channels = 4
+        self.transformers = nn.ModuleList([TransformerEncoder(self.num_channels * self.channel_embedding_dim, self.num_heads, self.dropout)
+                                           for _ in range(self.num_layers)])
+        self.output_layer = nn.Linear(self.num_channels * self.channel_embedding_dim, self.node_feat_dim, bias=True)
+
+    # ----------------------------------------------------------------------------------------------------------------------
+    def _windows(self, ids_dev, t_dev):
+        """device restatement of get_all_first_hop_neighbors + pad_sequences (utils/utils.py:254-273, DyGFormer.py:196-245)"""
+        P, L = self.patch_size, self.max_input_sequence_length
+        wmax = (L + P - 1) // P * P
+        return self.neighbor_sampler.graph.first_hop_window(ids_dev, t_dev, L, wmax)
+
+    def compute_src_dst_node_temporal_embeddings(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray, node_interact_times: np.ndarray):
+        dev = self.node_raw_features.device
+        g = self.neighbor_sampler.graph
+        src_node_ids, dst_node_ids = np.asarray(src_node_ids), np.asarray(dst_node_ids)
+        for ids in (src_node_ids, dst_node_ids):
+            if len(ids) and (int(ids.max()) >= g.num_rows or int(ids.min()) < 0):
+                raise IndexError("list index out of range")
+        B, P = len(src_node_ids), self.patch_size
+        t_dev = torch.from_numpy(np.ascontiguousarray(node_interact_times, dtype=np.float64)).to(dev)
+        sides = []
+        for ids in (src_node_ids, dst_node_ids):
+            ids_dev = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(dev)
+            sides.append(self._windows(ids_dev, t_dev))
+        # the reference pads every side to ITS OWN longest sequence of the batch (+ the node itself, rounded up to a patch
+        # multiple): the unmasked transformer sees the padded positions, so the width is part of the result.  One tiny readback.
+        lens = torch.stack([sides[0][3].max(), sides[1][3].max()]).cpu().tolist() if B else [1, 1]
+        widths = [(int(l) + P - 1) // P * P for l in lens]
+        seqs = [tuple(t[:, :w].contiguous() for t in side[:3]) for side, w in zip(sides, widths)]
+        counts = ops.cooccurrence(seqs[0][0], seqs[1][0])                                 # DyGFormer.py:104-106
+        num_edges_rows = self.edge_raw_features.shape[0]
+        enc = self.time_encoder
+        chans_per_side = []
+        for (nbr, eid, tt), cnt, w in zip(seqs, counts, widths):
+            flat = nbr.reshape(-1)
+            nf = ops.gather_rows(self.node_raw_features, flat).reshape(B, w, -1)           # :259
+            # FLiD-specific `edge_ids - 1` gather (:261): slot / edge id 0 wraps to the LAST edge row
+            eidx = torch.remainder(eid.reshape(-1) - 1, num_edges_rows).to(torch.int32)
+            ef = ops.gather_rows(self.edge_raw_features, eidx).reshape(B, w, -1)
+            dt = (t_dev.unsqueeze(1) - tt.double()).float()                                # :263 float64 - float32 -> float32
+            tf = seqops.masked_time_encode(dt, nbr, enc.w.weight, enc.w.bias)              # :263-266
+            cf = self.neighbor_co_occurrence_encoder.encode(cnt)
+            chans = []
+            for name, x in (("node", nf), ("edge", ef), ("time", tf), ("neighbor_co_occurrence", cf)):
+                lin = self.projection_layer[name]
+                chans.append(linear(x.reshape(B, w // P, -1), lin.weight, lin.bias))       # get_patches + projection (:270-306, :148-157)
+            chans_per_side.append(torch.stack(chans, dim=2).reshape(B, w // P, -1))
+        ns = chans_per_side[0].shape[1]
+        x = torch.cat(chans_per_side, dim=1).contiguous()                                  # :164-174
+        for block in self.transformers:
+            x = block(x)
+        nt = x.shape[1]
+        s_out, d_out = seqops.segment_mean(x, 0, ns), seqops.segment_mean(x, ns, nt)       # :185-187
+        return (linear(s_out, self.output_layer.weight, self.output_layer.bias),
+                linear(d_out, self.output_layer.weight, self.output_layer.bias))
+
+    def set_neighbor_sampler(self, neighbor_sampler: NeighborSampler):
+        self.neighbor_sampler = neighbor_sampler
+        if self.neighbor_sampler.sample_neighbor_strategy in ['uniform', 'time_interval_aware']:
+            assert self.neighbor_sampler.seed is not None
+            self.neighbor_sampler.reset_random_state()

@@ -49,11 +49,8 @@ class _TimeEncodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         t, w, b = ctx.saved_tensors
-        arg = t.unsqueeze(-1) * w.reshape(-1) + b
-        dphase = -torch.sin(arg) * g
-        flat = dphase.reshape(-1, dphase.shape[-1])
-        dw = (flat * t.reshape(-1, 1)).sum(0).reshape(w.shape)
-        return (dphase * w.reshape(-1)).sum(-1), dw, flat.sum(0), None
+        dw, db = ops.time_encode_bwd(t, None, w.reshape(-1), b, g)      # timestamps are data: no gradient w.r.t. t
+        return None, dw.reshape(w.shape), db, None
 
 
 class TimeEncoder(nn.Module):

@@ -125,7 +125,7 @@ def add_layernorm_fwd(a, b, gamma, beta):
     y = torch.empty_like(a)
     mean = torch.empty(n, dtype=torch.float32, device=a.device)
     rstd = torch.empty(n, dtype=torch.float32, device=a.device)
-    assert a.is_contiguous() and b.is_contiguous()
+    assert a.is_contiguous() and (b is None or b.is_contiguous())
     check(lib().tg_add_layernorm_fwd(_p(a), _p(b), n, cols, _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _stream()),
           "tg_add_layernorm_fwd")
     return y, mean, rstd
@@ -134,7 +134,7 @@ def add_layernorm_fwd(a, b, gamma, beta):
 def add_layernorm_bwd(a, b, dy, gamma, mean, rstd):
     """returns dx (n, cols) and (dgamma, dbeta)"""
     n, cols = a.shape
-    assert a.is_contiguous() and b.is_contiguous() and dy.is_contiguous()
+    assert a.is_contiguous() and (b is None or b.is_contiguous()) and dy.is_contiguous()
     parts = lib().tg_rowop_parts(n)
     dx = torch.empty_like(a)
     part = torch.empty((parts, 2 * cols), dtype=torch.float32, device=a.device)
@@ -241,3 +241,89 @@ def build_messages(mem, last_update, a_ids, b_ids, t32, edge, eids, te_w, te_b):
                                   _rowmajor_ld(edge, "edge"), _p(eids), _p(te_w), _p(te_b), n, d, de, T, _p(out), _stream()),
           "tg_build_messages")
     return out
+
+
+def gemm_batched2(a00, b00, c00, outer, inner, sa, sb, sc, ta=False, tb=False, alpha=1.0, accumulate=False):
+    """two-level strided batch: a00/b00/c00 are the views of problem (0, 0); sa/sb/sc = (outer stride, inner stride) in floats"""
+    M, K = (a00.shape[1], a00.shape[0]) if ta else (a00.shape[0], a00.shape[1])
+    Kb, N = (b00.shape[1], b00.shape[0]) if tb else (b00.shape[0], b00.shape[1])
+    if K != Kb or c00.shape[0] != M or c00.shape[1] != N:
+        raise ValueError(f"gemm_batched2: shape mismatch op(a)=({M},{K}) op(b)=({Kb},{N}) out={tuple(c00.shape)}")
+    with _timed("gemm", (M, N, K * outer * inner)):
+        check(lib().tg_gemm_f32_batched2(int(ta), int(tb), M, N, K, float(alpha), _p(a00), _rowmajor_ld(a00, "a"), sa[0], sa[1],
+                                         _p(b00), _rowmajor_ld(b00, "b"), sb[0], sb[1], _p(c00), _rowmajor_ld(c00, "c"), sc[0], sc[1],
+                                         int(outer), int(inner), int(accumulate), _stream()), "tg_gemm_f32_batched2")
+
+
+def time_encode_masked(t, mask_ids, w, b):
+    t = t.contiguous()
+    out = torch.empty(tuple(t.shape) + (w.numel(),), dtype=torch.float32, device=t.device)
+    check(lib().tg_time_encode_masked(_p(t), _p(mask_ids.contiguous()), t.numel(), _p(w), _p(b), w.numel(), _p(out), _stream()),
+          "tg_time_encode_masked")
+    return out
+
+
+def cooccurrence(src_ids, dst_ids):
+    """(n, ws), (n, wd) int32 -> (n, ws, 2), (n, wd, 2) float32"""
+    n, ws = src_ids.shape
+    wd = dst_ids.shape[1]
+    o1 = torch.empty((n, ws, 2), device=src_ids.device)
+    o2 = torch.empty((n, wd, 2), device=src_ids.device)
+    check(lib().tg_cooccurrence(_p(src_ids), src_ids.stride(0), ws, _p(dst_ids), dst_ids.stride(0), wd, n, _p(o1), _p(o2), _stream()),
+          "tg_cooccurrence")
+    return o1, o2
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    check(lib().tg_gelu_fwd(_p(x), x.numel(), _p(y), _stream()), "tg_gelu_fwd")
+    return y
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(lib().tg_gelu_bwd(_p(x), _p(dy), x.numel(), _p(dx), _stream()), "tg_gelu_bwd")
+    return dx
+
+
+def softmax_fwd(x):
+    y = torch.empty_like(x)
+    check(lib().tg_softmax_fwd(_p(x), x.numel() // x.shape[-1], x.shape[-1], _p(y), _stream()), "tg_softmax_fwd")
+    return y
+
+
+def softmax_bwd(y, dy):
+    dx = torch.empty_like(y)
+    check(lib().tg_softmax_bwd(_p(y), _p(dy), y.numel() // y.shape[-1], y.shape[-1], _p(dx), _stream()), "tg_softmax_bwd")
+    return dx
+
+
+def dropout(x, p, seed):
+    y = torch.empty_like(x)
+    check(lib().tg_dropout(_p(x), x.numel(), float(p), int(seed), _p(y), _stream()), "tg_dropout")
+    return y
+
+
+def segment_mean_fwd(x, lo, hi):
+    n, s, d = x.shape
+    out = torch.empty((n, d), device=x.device)
+    check(lib().tg_segment_mean_fwd(_p(x), n, s, d, lo, hi, _p(out), _stream()), "tg_segment_mean_fwd")
+    return out
+
+
+def segment_mean_bwd(dout, shape, lo, hi):
+    n, s, d = shape
+    dx = torch.zeros(shape, device=dout.device)
+    check(lib().tg_segment_mean_bwd(_p(dout.contiguous()), n, s, d, lo, hi, _p(dx), _stream()), "tg_segment_mean_bwd")
+    return dx
+
+
+def time_encode_bwd(t, mask_ids, w, b, g):
+    """(dw, db) of cos(fma(t, w, b)) [masked]; t (n,), g (n, dim)"""
+    t = t.contiguous().reshape(-1)
+    g = g.contiguous().reshape(t.numel(), -1)
+    dim = w.numel()
+    part = torch.empty((lib().tg_rowop_parts(t.numel()), 2 * dim), device=t.device)
+    check(lib().tg_time_encode_bwd(_p(t), _p(mask_ids), t.numel(), _p(w), _p(b), dim, _p(g), _p(part), _stream()), "tg_time_encode_bwd")
+    s = colsum(part)
+    return s[:dim], s[dim:]

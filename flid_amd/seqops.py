@@ -1,0 +1,146 @@
+"""Autograd wrappers (HIP forward AND backward) for the sequence-side operators of the DyGFormer path."""
+import torch
+
+from . import ops
+
+
+def _seed(training, p):
+    return int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p > 0) else 0
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y, mean, rstd = ops.add_layernorm_fwd(x2, None, gamma, beta)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.add_layernorm_bwd(x2, None, dy.reshape(x2.shape).contiguous(), gamma, mean, rstd)
+        return dx.reshape(ctx.shape), dg, db
+
+
+def layer_norm(x, gamma, beta):
+    return _LayerNormFn.apply(x, gamma, beta)
+
+
+class _GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(x, dy.contiguous())
+
+
+def gelu(x):
+    return _GeluFn.apply(x)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0:
+        return x
+    return _DropoutFn.apply(x, p, _seed(training, p))
+
+
+class _SegmentMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        ctx.shape, ctx.lo, ctx.hi = x.shape, lo, hi
+        return ops.segment_mean_fwd(x.contiguous(), lo, hi)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.segment_mean_bwd(dout, ctx.shape, ctx.lo, ctx.hi), None, None
+
+
+def segment_mean(x, lo, hi):
+    return _SegmentMeanFn.apply(x, lo, hi)
+
+
+class _SelfAttentionFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(hd)) V per (sequence, head) on the packed (B, S, 3d) in-projection, as nn.MultiheadAttention does
+    (models/DyGFormer.py:454; no masks).  All five products run on the two-level batched MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, p_drop, seed):
+        B, S, d3 = qkv.shape
+        d = d3 // 3
+        hd = d // heads
+        qkv = qkv.contiguous()
+        q00, k00, v00 = qkv[0, :, 0:hd], qkv[0, :, d:d + hd], qkv[0, :, 2 * d:2 * d + hd]
+        sq = (S * d3, hd)
+        scores = torch.empty((B, heads, S, S), device=qkv.device)
+        ops.gemm_batched2(q00, k00, scores[0, 0], B, heads, sq, sq, (heads * S * S, S * S), tb=True, alpha=hd ** -0.5)
+        prob = ops.softmax_fwd(scores)
+        pd = ops.dropout(prob, p_drop, seed) if p_drop > 0 else prob
+        out = torch.empty((B, S, d), device=qkv.device)
+        ops.gemm_batched2(pd[0, 0], v00, out[0, :, 0:hd], B, heads, (heads * S * S, S * S), sq, (S * d, hd))
+        ctx.save_for_backward(qkv, prob, pd)
+        ctx.cfg = (heads, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, prob, pd = ctx.saved_tensors
+        heads, p_drop, seed = ctx.cfg
+        B, S, d3 = qkv.shape
+        d = d3 // 3
+        hd = d // heads
+        dout = dout.contiguous()
+        sq, sp, so = (S * d3, hd), (heads * S * S, S * S), (S * d, hd)
+        q00, k00, v00 = qkv[0, :, 0:hd], qkv[0, :, d:d + hd], qkv[0, :, 2 * d:2 * d + hd]
+        dqkv = torch.empty_like(qkv)
+        dpd = torch.empty_like(prob)
+        ops.gemm_batched2(dout[0, :, 0:hd], v00, dpd[0, 0], B, heads, so, sq, sp, tb=True)                  # dP = dO V^T
+        ops.gemm_batched2(pd[0, 0], dout[0, :, 0:hd], dqkv[0, :, 2 * d:2 * d + hd], B, heads, sp, so, sq, ta=True)   # dV = P^T dO
+        dp = ops.dropout(dpd, p_drop, seed) if p_drop > 0 else dpd
+        ds = ops.softmax_bwd(prob, dp)
+        scale = hd ** -0.5
+        ops.gemm_batched2(ds[0, 0], k00, dqkv[0, :, 0:hd], B, heads, sp, sq, sq, alpha=scale)               # dQ = dS K
+        ops.gemm_batched2(ds[0, 0], q00, dqkv[0, :, d:d + hd], B, heads, sp, sq, sq, ta=True, alpha=scale)  # dK = dS^T Q
+        return dqkv, None, None, None
+
+
+def self_attention(qkv, heads, p_drop, training):
+    p = p_drop if training else 0.0
+    return _SelfAttentionFn.apply(qkv, heads, p, _seed(training, p))
+
+
+class _MaskedTimeEncodeFn(torch.autograd.Function):
+    """cos(dt w + b), zero where the slot is padding (models/DyGFormer.py:263-266)"""
+
+    @staticmethod
+    def forward(ctx, dt, mask_ids, w, b):
+        out = ops.time_encode_masked(dt, mask_ids, w.reshape(-1), b)
+        ctx.save_for_backward(dt, mask_ids, w, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dt, mask_ids, w, b = ctx.saved_tensors
+        dw, db = ops.time_encode_bwd(dt, mask_ids.contiguous().reshape(-1), w.reshape(-1), b, g)
+        return None, None, dw.reshape(w.shape), db
+
+
+def masked_time_encode(dt, mask_ids, w, b):
+    return _MaskedTimeEncodeFn.apply(dt, mask_ids, w, b)

@@ -67,6 +67,14 @@ int tg_first_hop_window(const tg_graph* g, const int32_t* d_ids, const double* d
 int tg_time_encode(const float* d_t, int64_t n, const float* d_w, const float* d_b, int dim, int fused_fma,
                    float* d_out, void* stream);
 
+/* same, but rows whose mask id is 0 come out as zeros (models/DyGFormer.py:263-266: padded slots of a sequence) */
+int tg_time_encode_masked(const float* d_t, const int32_t* d_mask_ids, int64_t n, const float* d_w, const float* d_b, int dim,
+                          float* d_out, void* stream);
+
+/* backward w.r.t. (w, b): d_part (tg_rowop_parts(n), 2*dim) per-workgroup partial sums of (dw | db); d_mask_ids may be NULL */
+int tg_time_encode_bwd(const float* d_t, const int32_t* d_mask_ids, int64_t n, const float* d_w, const float* d_b, int dim,
+                       const float* d_g, float* d_part, void* stream);
+
 /* ---- single-query temporal attention, gather-fused ------------------------------------------------
  * replaces the neighbor side of models/modules.py:167-245 MultiHeadAttention.forward together with the
  * gathers of models/TGAT.py:110-129.  Exact reassociation: score = (Wk^T q) . z, ctx = Wv (sum a z), so the
@@ -113,6 +121,13 @@ int tg_gemm_f32_batched(int ta, int tb, int64_t M, int64_t N, int64_t K, float a
                         int64_t stride_a, const float* d_B, int64_t ldb, int64_t stride_b, float* d_C, int64_t ldc,
                         int64_t stride_c, int batch, const float* d_bias, int relu, int accumulate, void* stream);
 
+/* two-level batch: problem (o, i), o < outer, i < inner, uses X + o*outer_x + i*inner_x.  The (sequence, head) products of
+ * nn.MultiheadAttention (models/DyGFormer.py:454): Q K^T, P V and their gradients, straight on the packed qkv layout. */
+int tg_gemm_f32_batched2(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda,
+                         int64_t outer_a, int64_t inner_a, const float* d_B, int64_t ldb, int64_t outer_b, int64_t inner_b,
+                         float* d_C, int64_t ldc, int64_t outer_c, int64_t inner_c, int outer, int inner, int accumulate,
+                         void* stream);
+
 /* ---- row-wise helpers ------------------------------------------------------------------------------ */
 /* out[i, 0:cols] = table[idx[i], 0:cols]        (models/TGAT.py:87 node_raw_features[ids]) */
 int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols,
@@ -120,7 +135,8 @@ int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx,
 /* table[idx[i], :] += src[i, :] with float atomics */
 int tg_scatter_add_rows(const float* d_src, int64_t src_ld, const int32_t* d_idx, int64_t n, int cols,
                         float* d_table, int64_t table_ld, void* stream);
-/* y = LayerNorm(a + b) * gamma + beta, eps 1e-5 (modules.py:238).  Saves mean/rstd (n each) for backward. */
+/* y = LayerNorm(a + b) * gamma + beta, eps 1e-5 (modules.py:238); d_b may be NULL (plain LayerNorm, DyGFormer.py:452,458).
+ * Saves mean/rstd (n each) for backward. */
 int tg_add_layernorm_fwd(const float* d_a, const float* d_b, int64_t n, int cols, const float* d_gamma,
                          const float* d_beta, float* d_y, float* d_mean, float* d_rstd, void* stream);
 /* dx = dLN(dy); d_dgb_part (parts, 2*cols) partial sums of (dgamma | dbeta); parts = tg_rowop_parts(n). */
@@ -145,6 +161,24 @@ int tg_gru_gates_bwd(const float* d_gi, const float* d_gh, const float* d_h, con
 int tg_build_messages(const float* d_mem, int64_t mem_ld, const float* d_last_update, const int32_t* d_a_ids,
                       const int32_t* d_b_ids, const float* d_t32, const float* d_edge, int64_t edge_ld, const int32_t* d_eids,
                       const float* d_te_w, const float* d_te_b, int64_t n, int d, int de, int T, float* d_out, void* stream);
+
+/* ---- DyGFormer sequence side --------------------------------------------------------------------------
+ * neighbor co-occurrence counts (models/DyGFormer.py:337-393): for every slot of the source rows (n, wa) and destination
+ * rows (n, wb): how often that node id occurs in the source row and in the destination row -> out (n, w, 2) float32 in the
+ * reference's column order [count in src, count in dst]; padded id 0 -> (0, 0). */
+int tg_cooccurrence(const int32_t* d_src_ids, int64_t ld_src, int w_src, const int32_t* d_dst_ids, int64_t ld_dst, int w_dst,
+                    int64_t n, float* d_out_src, float* d_out_dst, void* stream);
+/* erf GELU (F.gelu default) and its gradient w.r.t. the pre-activation x */
+int tg_gelu_fwd(const float* d_x, int64_t n, float* d_y, void* stream);
+int tg_gelu_bwd(const float* d_x, const float* d_dy, int64_t n, float* d_dx, void* stream);
+/* row softmax over the last dimension (cols <= 1024) and its backward from the probabilities */
+int tg_softmax_fwd(const float* d_x, int64_t n, int cols, float* d_y, void* stream);
+int tg_softmax_bwd(const float* d_y, const float* d_dy, int64_t n, int cols, float* d_dx, void* stream);
+/* y[i] = x[i] / (1-p) if hash(seed, i) >= p else 0.  Applying it to dy with the same seed is the backward. */
+int tg_dropout(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream);
+/* out[i, :] = mean over positions [lo, hi) of x (n, s, d); backward writes dout/(hi-lo) into those positions of dx */
+int tg_segment_mean_fwd(const float* d_x, int64_t n, int s, int d, int lo, int hi, float* d_out, void* stream);
+int tg_segment_mean_bwd(const float* d_dout, int64_t n, int s, int d, int lo, int hi, float* d_dx, void* stream);
 
 #ifdef __cplusplus
 }

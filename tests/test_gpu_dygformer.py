@@ -1,0 +1,112 @@
+"""GPU parity: flid_amd.models.DyGFormer against the reference's golden vectors (padded sequences, co-occurrence counts,
+the FLiD-specific edge_id-1 gather, patch sizes 1 and 2, embeddings and all parameter gradients) and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, assert_grads_match
+from oracle import flid_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+class _Data:
+    def __init__(self, g):
+        self.src_node_ids, self.dst_node_ids, self.edge_ids, self.node_interact_times = g["src"], g["dst"], g["eid"], g["t"]
+
+
+def _model(g, dropout=0.0):
+    from flid_amd.models.DyGFormer import DyGFormer
+    from flid_amd.utils.utils import get_neighbor_sampler
+    dn, de, dt, c, patch, layers, heads, max_len = [int(v) for v in g["dims"]]
+    sampler = get_neighbor_sampler(_Data(g), "recent", seed=0)
+    m = DyGFormer(g["node_feat"], g["edge_feat"], sampler, time_feat_dim=dt, channel_embedding_dim=c, patch_size=patch,
+                  num_layers=layers, num_heads=heads, dropout=dropout, max_input_sequence_length=max_len, device="cuda:0")
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict(O.seeded_like(O.dyg_shapes(dn, de, dt, c, patch, layers), int(g["seed"]), float(g["scale"])))
+    return m.to("cuda:0")
+
+
+@pytest.mark.parametrize("name", ["dyg_p1", "dyg_p2"])
+def test_dygformer_matches_reference_golden(name):
+    from flid_amd import ops
+    g = load_golden(name)
+    m = _model(g).train()
+    dev = torch.device("cuda:0")
+    # device-built sequences and counts vs what the reference's pad_sequences / count_nodes_appearances produced
+    t_dev = torch.from_numpy(g["bt"]).to(dev)
+    sn, se, st, sl = m._windows(torch.from_numpy(g["bs"].astype(np.int32)).to(dev), t_dev)
+    dn_, de_, dt_, dl = m._windows(torch.from_numpy(g["bd"].astype(np.int32)).to(dev), t_dev)
+    ws, wd = g["pn"].shape[1], g["qn"].shape[1]
+    assert np.array_equal(sn.cpu().numpy()[:, :ws], g["pn"]) and np.array_equal(se.cpu().numpy()[:, :ws], g["pe"])
+    assert np.array_equal(st.cpu().numpy()[:, :ws], g["pt"]) and np.array_equal(dn_.cpu().numpy()[:, :wd], g["qn"])
+    sc, dc = ops.cooccurrence(sn[:, :ws].contiguous(), dn_[:, :wd].contiguous())
+    assert np.array_equal(sc.cpu().numpy(), g["sc"]) and np.array_equal(dc.cpu().numpy(), g["dc"])
+    s, d = m.compute_src_dst_node_temporal_embeddings(src_node_ids=g["bs"], dst_node_ids=g["bd"], node_interact_times=g["bt"])
+    np.testing.assert_allclose(s.detach().cpu().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), g["d_emb"], atol=TOL)
+    r = torch.from_numpy(g["r"]).cuda()
+    ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.cpu().numpy() for k_, v in m.named_parameters()}, atol=1e-4, rtol=1e-3)
+
+
+def test_dygformer_reddit_shape_against_oracle():
+    """config-4 shape (172/172/100, C=50, P=1, L=2, H=2, max_len 32) on a reduced Reddit-like graph, 64 edges vs the oracle"""
+    from flid_amd.synth import reddit_like
+    from flid_amd.models.DyGFormer import DyGFormer
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = reddit_like(num_edges=20000, num_users=1500, num_items=200, seed=4)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, 100, 50, 1, 2, 2, 0.0, 32, "cuda:0").to("cuda:0").eval()
+    p = O.seeded_like(O.dyg_shapes(172, 172, 100, 50, 1, 2), 91, 0.04)
+    p["time_encoder.w.bias"].zero_()
+    m.load_state_dict(p)
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    orc = O.DyGFormerOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 50, 1, 2, 2, 32)
+    sl = slice(15000, 15064)
+    args = (data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl])
+    with torch.no_grad():
+        s, d = m.compute_src_dst_node_temporal_embeddings(*args)
+        os_, od_ = orc.src_dst(*args)
+    np.testing.assert_allclose(s.cpu().numpy(), os_.numpy(), atol=TOL)
+    np.testing.assert_allclose(d.cpu().numpy(), od_.numpy(), atol=TOL)
+    # train-mode dropout runs and is stochastic
+    m.train()
+    m.dropout = 0.1
+    for blk in m.transformers:
+        blk.p = 0.1
+    a, _ = m.compute_src_dst_node_temporal_embeddings(*args)
+    b, _ = m.compute_src_dst_node_temporal_embeddings(*args)
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+def test_sequence_ops_vs_torch():
+    from flid_amd import seqops
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    x = torch.randn(37, 24, device=dev, requires_grad=True)
+    ref = torch.nn.functional.gelu(x.double())
+    y = seqops.gelu(x)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=1e-6)
+    g = torch.randn_like(y)
+    y.backward(g)
+    (gx,) = torch.autograd.grad(ref, x, g.double(), retain_graph=False, allow_unused=True) if False else (None,)
+    xr = x.detach().double().requires_grad_(True)
+    torch.nn.functional.gelu(xr).backward(g.double())
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), atol=1e-5)
+    # self-attention vs nn.MultiheadAttention math
+    B, S, d, H = 5, 11, 24, 2
+    qkv = torch.randn(B, S, 3 * d, device=dev, requires_grad=True)
+    out = seqops.self_attention(qkv, H, 0.0, False)
+    q, k, v = qkv.detach().double().split(d, dim=2)
+    sh = lambda t: t.reshape(B, S, H, d // H).permute(0, 2, 1, 3)
+    qd = qkv.detach().double().requires_grad_(True)
+    q, k, v = qd.split(d, dim=2)
+    a = torch.softmax(sh(q) @ sh(k).transpose(2, 3) * (d // H) ** -0.5, dim=-1)
+    ref = (a @ sh(v)).permute(0, 2, 1, 3).reshape(B, S, d)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=1e-5)
+    go = torch.randn_like(out)
+    out.backward(go)
+    ref.backward(go.double())
+    np.testing.assert_allclose(qkv.grad.cpu().numpy(), qd.grad.cpu().numpy(), atol=1e-4)
