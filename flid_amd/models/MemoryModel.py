@@ -228,17 +228,32 @@ class MemoryModel(torch.nn.Module):
 
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray, node_interact_times: np.ndarray,
                                                  edge_ids: np.ndarray, edges_are_positive: bool = True, num_neighbors: int = 20):
+        return self._step(src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, None)
+
+    def compute_shard_embeddings_and_advance(self, src_node_ids, dst_node_ids, node_interact_times, edge_ids, shard,
+                                             edges_are_positive: bool = True, num_neighbors: int = 20):
+        """Data-parallel form (one process per GPU): embed only edges [lo, hi) = `shard` of the global batch, but advance the
+        memory / pending-message state with the WHOLE batch.  Within a batch every root reads the same pre-batch state and the
+        update depends only on that state and the batch's (src, dst, t, eid), all of which are replicated -- so every rank
+        computes the identical update locally and the replicas stay bit-identical with no message exchange; the only
+        collective of a TGN step is the gradient all-reduce (flid_amd.dist.GradAllReducer)."""
+        return self._step(src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, shard)
+
+    def _step(self, src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, shard):
         src_node_ids = np.asarray(src_node_ids)
         dst_node_ids = np.asarray(dst_node_ids)
         node_interact_times = np.asarray(node_interact_times, dtype=np.float64)
         node_ids = np.concatenate([src_node_ids, dst_node_ids])
         bank = self.memory_bank
         base, pend_ids, new_rows = self._updated_table()                                   # reference :117
+        lo, hi = (0, len(src_node_ids)) if shard is None else shard
+        emb_ids = np.concatenate([src_node_ids[lo:hi], dst_node_ids[lo:hi]])
+        emb_t = np.concatenate([node_interact_times[lo:hi], node_interact_times[lo:hi]])
         emb = engine.embed(self.embedding_module.neighbor_sampler.graph, base, self.edge_raw_features,
                            self.time_encoder.w.weight, self.time_encoder.w.bias, self.embedding_module.layer_params(),
-                           node_ids, np.concatenate([node_interact_times, node_interact_times]), num_neighbors, self.num_layers,
+                           emb_ids, emb_t, num_neighbors, self.num_layers,
                            self.num_heads, self.dropout, self.training, table_requires_grad=torch.is_grad_enabled())
-        src_emb, dst_emb = emb[:len(src_node_ids)], emb[len(src_node_ids):]
+        src_emb, dst_emb = emb[:hi - lo], emb[hi - lo:]
         if edges_are_positive:
             assert edge_ids is not None
             dev = self.node_raw_features.device

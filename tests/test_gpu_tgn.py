@@ -114,3 +114,29 @@ def test_tgn_reddit_shape_against_oracle():
         np.testing.assert_allclose(s.cpu().numpy(), os_.numpy(), atol=TOL, err_msg=f"batch {b}")
         np.testing.assert_allclose(d.cpu().numpy(), od_.numpy(), atol=TOL, err_msg=f"batch {b}")
         np.testing.assert_allclose(m.memory_bank.node_memories.cpu().numpy(), orc.memory.numpy(), atol=TOL)
+
+
+def test_tgn_sharded_step_keeps_replicas_identical():
+    """data-parallel form: two 'ranks' embed halves of each batch and advance the state with the whole batch; embeddings and
+    state must equal the single-process run"""
+    g = load_golden("tgn_small")
+    ref, p, k = _model(g)
+    r0, _, _ = _model(g)
+    r1, _, _ = _model(g)
+    for m in (ref, r0, r1):
+        m.eval()
+        m.memory_bank.__init_memory_bank__()
+    bsz = 12
+    for b in range(5):
+        sl = slice(b * bsz, (b + 1) * bsz)
+        args = (g["src"][sl], g["dst"][sl], g["t"][sl], g["eid"][sl])
+        with torch.no_grad():
+            s, d = ref.compute_src_dst_node_temporal_embeddings(*args, True, k)
+            s0, d0 = r0.compute_shard_embeddings_and_advance(*args, (0, 5), True, k)
+            s1, d1 = r1.compute_shard_embeddings_and_advance(*args, (5, bsz), True, k)
+        np.testing.assert_allclose(torch.cat([s0, s1]).cpu().numpy(), s.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(torch.cat([d0, d1]).cpu().numpy(), d.cpu().numpy(), atol=1e-6)
+        for m in (r0, r1):
+            assert torch.equal(m.memory_bank.node_memories, ref.memory_bank.node_memories)
+            assert torch.equal(m.memory_bank._msg, ref.memory_bank._msg)
+            assert np.array_equal(m.memory_bank._has, ref.memory_bank._has)
