@@ -115,61 +115,43 @@ def main():
 
     for s in range(args.warmup):
         step(s)
-    ops.KernelTimer.enable({args.roofline_kernel})
+    torch.cuda.synchronize()
+    ops.profile_enable(True)          # HIP events around the attention / GEMM launches, on their own stream (C side)
+    for tag in ("attn_fwd", "attn_bwd", "gemm"):
+        ops.profile_collect(tag)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
         step(s)
     barrier()
     elapsed = time.perf_counter() - t0
-    timed = ops.KernelTimer.collect()
-    ops.KernelTimer.disable()
+    fam = {tag: ops.profile_collect(tag) for tag in ("attn_fwd", "attn_bwd", "gemm")}
+    ops.profile_enable(False)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    # one extra UNTIMED instrumented step: where a step's device time goes, per kernel family
-    ops.KernelTimer.enable({"attn_fwd", "attn_bwd", "gemm"})
-    torch.cuda.synchronize()
-    w0 = time.perf_counter()
-    step(total_steps - 1)
-    fam = ops.KernelTimer.collect()
-    ops.KernelTimer.disable()
-    wall_instr = time.perf_counter() - w0
-    breakdown = {k_: round(sum(ms for ms, _ in v), 4) for k_, v in fam.items()}
-    if os.environ.get("FLID_BENCH_DUMP") and rank == 0:
-        for ms, (m, n, k) in fam.get("gemm", []):
-            print(f"gemm M={m} N={n} K={k} {ms*1e3:.1f} us  {2.0*m*n*k/ms/1e9:.1f} TFLOP/s", file=sys.stderr)
-        for nm in ("attn_fwd", "attn_bwd"):
-            for ms, m in fam.get(nm, []):
-                print(f"{nm} m={m} {ms*1e3:.1f} us", file=sys.stderr)
-    breakdown["step_wall_ms_instrumented"] = round(wall_instr * 1e3, 3)
+    breakdown = {k_: round(v[0] / args.steps, 4) for k_, v in fam.items()}
 
     edges = args.steps * BATCH * world
     value = edges / elapsed
     bpe = tgat_bytes_per_edge()
 
-    # roofline of the dominant kernel, HIP events on its launch stream over the timed region
-    recs = timed.get(args.roofline_kernel, [])
+    # roofline of the selected kernel family: HIP events on its launch stream over the timed region
+    ms, units, cnt = fam[args.roofline_kernel]
+    secs = max(ms * 1e-3, 1e-12)
     if args.roofline_kernel == "gemm":
-        flops = sum(2.0 * m * n * k for _, (m, n, k) in recs)
-        secs = sum(ms for ms, _ in recs) * 1e-3
-        roof = {"bound": "mfma", "kernel": "gemm_kernel (tg_gemm_f32, all shapes of a step)",
-                "achieved": round(flops / secs / 1e12, 3), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
-                "frac": round(flops / secs / MFMA_F32_PEAK, 4), "traffic": None, "launches": len(recs),
-                "avg_launch_ms": round(secs * 1e3 / max(1, len(recs)), 4)}
+        roof = {"bound": "mfma", "kernel": "gemm_tile_kernel (tg_gemm_f32*, all shapes of a step)",
+                "achieved": round(units / secs / 1e12, 3), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
+                "frac": round(units / secs / MFMA_F32_PEAK, 4), "traffic": None, "launches": cnt,
+                "avg_launch_ms": round(ms / max(1, cnt), 4), "flops_per_step": units / args.steps}
     else:
         bwd = args.roofline_kernel == "attn_bwd"
-        # the layer-1 launch (n(1+k) instances) dominates; price each launch by its own instance count
-        nbytes = sum(m * attn_bytes_per_instance(backward=bwd) for _, m in recs)
-        secs = sum(ms for ms, _ in recs) * 1e-3
-        big = [ms for ms, m in recs if m == 2 * BATCH * (1 + K)]
         roof = {"bound": "hbm", "kernel": "attn_bwd_kernel<4,2,2>" if bwd else "attn_fwd_kernel<4,2,2>",
-                "achieved": round(nbytes / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": round(nbytes / secs / HBM_PEAK, 4), "traffic": None, "launches": len(recs),
-                "avg_launch_ms_layer1": round(sum(big) / max(1, len(big)), 4),
-                "bytes_per_launch_layer1": 2 * BATCH * (1 + K) * attn_bytes_per_instance(backward=bwd)}
+                "achieved": round(units / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(units / secs / HBM_PEAK, 4), "traffic": None, "launches": cnt,
+                "avg_launch_ms": round(ms / max(1, cnt), 4), "bytes_per_instance": attn_bytes_per_instance(backward=bwd),
+                "bytes_per_launch_avg": round(units / max(1, cnt), 1)}
         tr = os.path.join(REPO, "profiles", "traffic_r01.json")
         if os.path.exists(tr):
             try:

@@ -18,10 +18,35 @@ class AttnDesc(C.Structure):
                 ("scale", c_f32), ("dropout_p", c_f32), ("seed", C.c_uint64)]
 
 
+_PARAM_NAMES = ("Wq", "Wk", "Wv", "ln_g", "ln_b", "Wr", "br", "W1", "b1", "W2", "b2")
+
+
+class LayerParams(C.Structure):
+    """struct tg_layer_params / tg_layer_grads (same layout)"""
+    _fields_ = [(n, c_void) for n in _PARAM_NAMES]
+
+
+class LayerDesc(C.Structure):
+    """struct tg_layer_desc"""
+    _fields_ = [("attn", AttnDesc), ("params", LayerParams), ("own", c_void), ("own_ld", c_i64), ("raw", c_void), ("raw_ld", c_i64),
+                ("cosb", c_void), ("res_dropout_p", c_f32), ("res_seed", C.c_uint64)] + \
+               [(n, c_void) for n in ("qbias", "q", "u", "agg", "prob", "ctx", "res", "y", "mean", "rstd", "f1", "out")]
+
+
+class LayerBwdDesc(C.Structure):
+    """struct tg_layer_bwd_desc"""
+    _fields_ = [("grads", LayerParams), ("dout", c_void)] + \
+               [(n, c_void) for n in ("df1", "dy", "dsum", "dres", "dctx", "dagg", "du", "dq", "part", "vec", "d_cosb", "d_tew", "d_teb")] + \
+               [("dfeat", c_void), ("dfeat_ld", c_i64), ("pad_row", c_i64), ("d_own", c_void), ("d_own_ld", c_i64),
+                ("d_own_accumulate", C.c_int), ("d_raw", c_void)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/flid_tg.h
 SIGNATURES = {
     "tg_last_error": (C.c_char_p, []),
     "tg_version": (C.c_int, []),
+    "tg_profile_enable": (None, [C.c_int]),
+    "tg_profile_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.c_int]),
     "tg_graph_create": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, C.POINTER(c_void)]),
     "tg_graph_destroy": (None, [c_void]),
     "tg_graph_num_rows": (c_i64, [c_void]),
@@ -33,6 +58,9 @@ SIGNATURES = {
     "tg_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void]),
     "tg_attn_bwd_parts": (C.c_int, [c_i64]),
     "tg_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_void, c_void]),
+    "tg_tgat_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), c_void]),
+    "tg_tgat_layer_part_floats": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
+    "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),
     "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
                               c_void, C.c_int, C.c_int, c_void]),
     "tg_gemm_f32_batched": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_void,

@@ -442,6 +442,8 @@ extern "C" int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg
     if (a->m == 0) return TG_OK;
     hipStream_t s = (hipStream_t)stream;
     const int dk = a->dn + a->de + a->dt_dim;
+    // algorithmic bytes: k neighbor rows (node + edge) + 16 B slot metadata each, u in, agg out, prob out
+    tg::ProfScope prof("attn_fwd", (double)a->m * (a->k * 4.0 * (a->dn + a->de) + a->k * 16.0 + 2.0 * a->heads * dk * 4 + a->heads * a->k * 4.0), s);
     if (vec4_ok(a, d_u, d_agg, nullptr, nullptr, nullptr)) {
         const int c = (dk / 4 + 63) / 64;
         if (c <= 1) return launch_fwd<4, 1>(*a, d_u, d_agg, d_prob, s);
@@ -464,6 +466,8 @@ extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float*
     if (a->m == 0) return TG_OK;
     hipStream_t s = (hipStream_t)stream;
     const int dk = a->dn + a->de + a->dt_dim;
+    // as forward, plus dagg and agg in, du out
+    tg::ProfScope prof("attn_bwd", (double)a->m * (a->k * 4.0 * (a->dn + a->de) + a->k * 16.0 + 4.0 * a->heads * dk * 4 + a->heads * a->k * 4.0), s);
     if (vec4_ok(a, d_u, d_agg, d_dagg, d_du, nullptr)) {
         const int c = (dk / 4 + 63) / 64;
         if (c <= 1) return launch_bwd<4, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);

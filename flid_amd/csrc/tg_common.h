@@ -44,6 +44,15 @@ struct __attribute__((aligned(16))) Incidence {
     double t;
 };
 
+// Optional HIP-event timing of kernel families on the stream they are launched on (bench.py roofline leg):
+// tg_profile_enable(1); run; tg_profile_collect("attn_bwd", ...).  A disabled scope costs one branch.
+struct ProfScope {
+    ProfScope(const char* tag, double units, hipStream_t s);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kMaxGridBlocks = 2048; // 256 CUs x 8 resident blocks: grid-stride beyond this
 

@@ -136,7 +136,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int tile_
 template <bool A_KC, bool B_KC, bool VEC, int TM, int TN>
 __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64_t N, int64_t K, float alpha,
         const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-        const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics, int gx, int gy,
+        const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics, int gx, int gy_in,
         int64_t strideA, int64_t strideB, int64_t strideC, int nbatch, int inner, int64_t innerA, int64_t innerB, int64_t innerC) {
     constexpr int NT = TM * TN * 64, RA = 32 * TM, RB_ = 32 * TN;
     constexpr int FA = PanelFloats<RA, A_KC>::value, FB = PanelFloats<RB_, B_KC>::value;
@@ -148,10 +148,12 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
 
     // workgroup id -> (row block, column block): XCD-aware bijective remap so that the column blocks of one row block (they
     // share the A rows) run on the same XCD's L2.  blockIdx.z = batch * splits + split.
-    const int nwg = gx * gy;
+    int gy = gy_in;
+    const int nwg = gx * (gy < 0 ? -gy : gy);
     const int bid = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int swz = gy < 0 ? bid : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    if (gy < 0) gy = -gy;
     const int by = swz / gx, bx = swz % gx;
     const int nsplit = gridDim.z / nbatch;
     const int batch = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
@@ -239,7 +241,7 @@ struct Args {
 
 template <bool A_KC, bool B_KC, bool VEC, int TM, int TN>
 void launch(const Args& a, hipStream_t s) {
-    const dim3 grid((unsigned)(a.gx * a.gy), 1, (unsigned)(a.nbatch * a.splits));
+    const dim3 grid((unsigned)(a.gx * (a.gy < 0 ? -a.gy : a.gy)), 1, (unsigned)(a.nbatch * a.splits));
     gemm_tile_kernel<A_KC, B_KC, VEC, TM, TN><<<grid, TM * TN * 64, 0, s>>>(a.M, a.N, a.K, a.alpha, a.A, a.lda, a.B, a.ldb, a.C,
         a.ldc, a.bias, a.relu, a.accumulate, a.k_chunk, a.atomics, a.gx, a.gy, a.sA, a.sB, a.sC, a.nbatch, a.inner, a.iA, a.iB, a.iC);
 }
@@ -247,7 +249,10 @@ void launch(const Args& a, hipStream_t s) {
 template <bool A_KC, bool B_KC>
 void dispatch(bool vec, int tm, int tn, const Args& a, hipStream_t s) {
     if (!vec) { launch<A_KC, B_KC, false, 1, 2>(a, s); return; }
-    if (tm == 2) {
+    if (tm == 4) {
+        if (tn == 2) launch<A_KC, B_KC, true, 4, 2>(a, s);
+        else launch<A_KC, B_KC, true, 4, 1>(a, s);
+    } else if (tm == 2) {
         if (tn == 4) launch<A_KC, B_KC, true, 2, 4>(a, s);
         else if (tn == 3) launch<A_KC, B_KC, true, 2, 3>(a, s);
         else launch<A_KC, B_KC, true, 2, 2>(a, s);
@@ -280,8 +285,10 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     // (32x96, 64x96) 42..69 -- waves per workgroup should divide evenly over the CU's 4 SIMDs.  Ragged edges cost only the idle
     // wave slots of the edge blocks (tiles wholly outside C skip their MFMAs).
     int tn = 2, tm = vec ? 2 : 1;
-    if (const char* e = getenv("FLID_GEMM_TM")) tm = atoi(e) == 2 ? 2 : 1;       // tuning overrides (tools/gemm_bench.py)
-    if (const char* e = getenv("FLID_GEMM_TN")) { const int v = atoi(e); if (vec && v >= 2 && v <= 4) tn = v; }
+    if (const char* e = getenv("FLID_GEMM_TM")) { const int v = atoi(e); if (vec && (v == 1 || v == 2 || v == 4)) tm = v; }   // tuning overrides
+    if (const char* e = getenv("FLID_GEMM_TN")) { const int v = atoi(e); if (vec && v >= 1 && v <= 4) tn = v; }
+    if (tm == 4 && tn > 2) tn = 2;
+    if (tm != 4 && tn == 1) tn = 2;
     const int64_t gx = (N + 32 * tn - 1) / (32 * tn), gy = (M + 32 * tm - 1) / (32 * tm);
     TG_REQUIRE(gx * gy < (int64_t)1 << 30, "tg_gemm_f32: grid too large");
 
@@ -305,7 +312,9 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
             TG_HIP_CHECK(hipMemset2DAsync(d_C + (b / inner) * strideC + (b % inner) * innerC, ldc * sizeof(float), 0,
                                           N * sizeof(float), M, s));
 
-    const Args a{M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, (int)gy,
+    tg::ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
+    const bool noswz = getenv("FLID_GEMM_NOSWZ") != nullptr;
+    const Args a{M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, noswz ? -(int)gy : (int)gy,
                  strideA, strideB, strideC, nbatch, (int)splits, inner, innerA, innerB, innerC};
     if (a_kc && b_kc) dispatch<true, true>(vec, tm, tn, a, s);
     else if (a_kc && !b_kc) dispatch<true, false>(vec, tm, tn, a, s);

@@ -11,7 +11,48 @@
 namespace tg {
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
+
+struct ProfRec { std::string tag; double units; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+ProfScope::ProfScope(const char* tag, double units, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    ProfRec r{tag, units, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream);
+}
 }  // namespace tg
+
+extern "C" void tg_profile_enable(int on) { tg::g_prof_on = on != 0; }
+
+// Sum of elapsed ms / units / launches recorded under `tag` since the last reset.  Synchronises the device.
+extern "C" int tg_profile_collect(const char* tag, double* ms, double* units, int64_t* count, int reset) {
+    TG_HIP_CHECK(hipDeviceSynchronize());
+    double m = 0, u = 0;
+    int64_t c = 0;
+    for (auto& r : tg::g_prof) {
+        if (r.tag != tag) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { m += t; u += r.units; ++c; }
+    }
+    if (ms) *ms = m;
+    if (units) *units = u;
+    if (count) *count = c;
+    if (reset) {
+        std::vector<tg::ProfRec> keep;
+        for (auto& r : tg::g_prof) {
+            if (r.tag == tag) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+            else keep.push_back(r);
+        }
+        tg::g_prof.swap(keep);
+    }
+    return TG_OK;
+}
 
 struct tg_graph {
     int64_t num_rows = 0;

@@ -1,0 +1,305 @@
+// One temporal-attention layer (attention block + merge MLP), forward and backward, as ONE native call each:
+// the launch sequence that flid_amd/engine.py otherwise issues op by op from Python, plus the fusions that only make sense
+// here (dropout + split residual inside LayerNorm, ReLU mask + bias gradient, LayerNorm backward emitting every column sum the
+// layer needs).
+//
+// replaces per layer: models/modules.py:167-245 (MultiHeadAttention.forward) + :58-69 (MergeLayer.forward) as called from
+//                     models/TGAT.py:132-142 / models/MemoryModel.py:703-713, and their autograd.
+#include <math.h>
+
+#include "tg_common.h"
+
+namespace {
+
+using tg::kWave;
+constexpr int ROW_WAVES = 4;
+
+__host__ __device__ inline int64_t row_grid(int64_t n) {
+    int64_t b = (n + ROW_WAVES - 1) / ROW_WAVES;
+    return b < 1 ? 1 : (b > tg::kMaxGridBlocks ? tg::kMaxGridBlocks : b);
+}
+
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p) {
+    if (p <= 0.f) return 1.f;
+    const float u = (float)(tg::mix32(seed ^ ((uint64_t)idx * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    return u >= p ? 1.f / (1.f - p) : 0.f;
+}
+
+// y = LayerNorm(dropout(res) + [own | cosb]) * gamma + beta        (modules.py:235-238 with residual = cat[node, time(0)])
+template <int MAXC>
+__global__ void __launch_bounds__(256) ln_res_fwd_kernel(const float* __restrict__ res, const float* __restrict__ own, int64_t own_ld,
+        const float* __restrict__ cosb, int64_t n, int dn, int cols, float p, uint64_t seed, const float* __restrict__ gamma,
+        const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
+        float x[MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            float v = 0.f;
+            if (c < cols) {
+                v = res[r * cols + c] * keep_scale(seed, r * cols + c, p);
+                v += c < dn ? own[r * own_ld + c] : cosb[c - dn];
+            }
+            x[i] = v;
+            s += v;
+        }
+        const float mu = tg::wave_sum(s) / cols;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const float d = (lane + 64 * i) < cols ? x[i] - mu : 0.f;
+            q = fmaf(d, d, q);
+        }
+        const float rs = rsqrtf(tg::wave_sum(q) / cols + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) y[r * cols + c] = (x[i] - mu) * rs * gamma[c] + beta[c];
+        }
+        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+}
+
+// dsum = dLN(dy); dres = dsum * dropout mask.  Workgroup slab (4 * cols): [dgamma | dbeta | colsum(dsum) | colsum(dres)].
+template <int MAXC>
+__global__ void __launch_bounds__(256) ln_res_bwd_kernel(const float* __restrict__ res, const float* __restrict__ own, int64_t own_ld,
+        const float* __restrict__ cosb, const float* __restrict__ dy, int64_t n, int dn, int cols, float p, uint64_t seed,
+        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dsum,
+        float* __restrict__ dres, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ float red[];   // ROW_WAVES * 4 * cols
+    float a0[MAXC], a1[MAXC], a2[MAXC], a3[MAXC], gm[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        a0[i] = a1[i] = a2[i] = a3[i] = 0.f;
+        const int c = lane + 64 * i;
+        gm[i] = c < cols ? gamma[c] : 0.f;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
+        const float mu = mean[r], rs = rstd[r];
+        float xh[MAXC], g[MAXC], ks[MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = c < cols;
+            ks[i] = ok ? keep_scale(seed, r * cols + c, p) : 0.f;
+            float v = 0.f;
+            if (ok) {
+                v = res[r * cols + c] * ks[i];
+                v += c < dn ? own[r * own_ld + c] : cosb[c - dn];
+            }
+            const float d = ok ? dy[r * cols + c] : 0.f;
+            xh[i] = ok ? (v - mu) * rs : 0.f;
+            g[i] = d * gm[i];
+            s1 += g[i];
+            s2 = fmaf(g[i], xh[i], s2);
+            a0[i] = fmaf(d, xh[i], a0[i]);
+            a1[i] += d;
+        }
+        const float m1 = tg::wave_sum(s1) / cols, m2 = tg::wave_sum(s2) / cols;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) {
+                const float dx = rs * (g[i] - m1 - xh[i] * m2);
+                const float dr = dx * ks[i];
+                dsum[r * cols + c] = dx;
+                if (dres != dsum) dres[r * cols + c] = dr;
+                a2[i] += dx;
+                a3[i] += dr;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cols) {
+            float* w = red + wave * 4 * cols;
+            w[c] = a0[i]; w[cols + c] = a1[i]; w[2 * cols + c] = a2[i]; w[3 * cols + c] = a3[i];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 4 * cols; j += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < ROW_WAVES; ++w) s += red[w * 4 * cols + j];
+        part[(int64_t)blockIdx.x * 4 * cols + j] = s;
+    }
+}
+
+// dy *= (y > 0) in place; slab (cols) of column sums of the masked dy per workgroup.  Thread t owns columns t, t+256, ...
+template <int MAXC>
+__global__ void __launch_bounds__(256) relu_bwd_colsum_kernel(float* __restrict__ dy, const float* __restrict__ y, int64_t n, int cols,
+                                                              int64_t rows_per_block, float* __restrict__ part) {
+    float acc[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) acc[i] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            if (c < cols) {
+                const int64_t o = r * cols + c;
+                const float v = y[o] > 0.f ? dy[o] : 0.f;
+                dy[o] = v;
+                acc[i] += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < cols) part[(int64_t)blockIdx.x * cols + c] = acc[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) add_cols_kernel(float* __restrict__ dst, int64_t dld, const float* __restrict__ src, int64_t sld,
+                                                       int64_t n, int cols) {
+    const int64_t total = n * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * dld + c] += src[r * sld + c];
+    }
+}
+
+// out[i, j] = a[i] * b[j]      (the constant-column block of dWq)
+__global__ void __launch_bounds__(256) outer_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
+                                                    float* __restrict__ out, int64_t old) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na * nb; i += gridDim.x * blockDim.x) {
+        const int r = i / nb, c = i - r * nb;
+        out[(int64_t)r * old + c] = a[r] * b[c];
+    }
+}
+
+// dst[j] += src[j]   (tiny vectors: time-encoder gradient partials)
+__global__ void __launch_bounds__(256) vec_add_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, tg::kMaxGridBlocks)); }
+
+#define TG_TRY(expr) do { int _rc = (expr); if (_rc != TG_OK) return _rc; } while (0)
+
+}  // namespace
+
+extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
+    TG_REQUIRE(L, "tg_tgat_layer_fwd: null descriptor");
+    const tg_attn_desc& a = L->attn;
+    const int64_t R = a.m;
+    const int H = a.heads, dn = a.dn, T = a.dt_dim, dq = dn + T, dk = dn + a.de + T, hd = dq / H;
+    TG_REQUIRE(dq % H == 0, "The sum of node_feat_dim and time_feat_dim should be divided by num_heads!");
+    TG_REQUIRE(dq <= 1024, "tg_tgat_layer_fwd: query dim > 1024 unsupported");
+    if (R == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const tg_layer_params& P = L->params;
+    // q = [own | cos b] Wq^T : the constant half is a bias row
+    TG_TRY(tg_gemm_f32(0, 1, 1, dq, T, 1.f, L->cosb, T, P.Wq + dn, dq, L->qbias, dq, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
+    // u_h = Wk_h^T q_h
+    TG_TRY(tg_gemm_f32_batched(0, 0, R, dk, hd, 1.f, L->q, dq, hd, P.Wk, dk, (int64_t)hd * dk, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
+    TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
+    // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
+    TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
+    const unsigned g = (unsigned)row_grid(R);
+    if (dq <= 64) ln_res_fwd_kernel<1><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
+    else if (dq <= 320) ln_res_fwd_kernel<5><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
+    else ln_res_fwd_kernel<16><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
+    TG_TRY(tg::launch_status("ln_res_fwd_kernel"));
+    // merge: relu([y | raw] W1^T + b1) W2^T + b2
+    const int64_t w1ld = dq + dn;
+    TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, L->y, dq, P.W1, w1ld, L->f1, dn, P.b1, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, L->raw, L->raw_ld, P.W1 + dq, w1ld, L->f1, dn, nullptr, 1, 1, stream));
+    TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, L->f1, dn, P.W2, dn, L->out, dn, P.b2, 0, 0, stream));
+    return TG_OK;
+}
+
+extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
+    const int64_t a = ((rows + 63) / 64) * dn;                       // ReLU-mask slabs
+    const int64_t b = row_grid(rows) * 4 * dq;                       // LayerNorm slabs
+    const int64_t c = (int64_t)tg_attn_bwd_parts(rows) * 2 * dt_dim; // time-encoder slabs
+    return std::max<int64_t>(16, std::max(a, std::max(b, c)));
+}
+
+extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, void* stream) {
+    TG_REQUIRE(L && Bw, "tg_tgat_layer_bwd: null descriptor");
+    const tg_attn_desc& a = L->attn;
+    const int64_t R = a.m;
+    const int H = a.heads, dn = a.dn, T = a.dt_dim, dq = dn + T, dk = dn + a.de + T, hd = dq / H;
+    if (R == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const tg_layer_params& P = L->params;
+    const tg_layer_grads& G = Bw->grads;
+    const int64_t w1ld = dq + dn;
+    float* vec = Bw->vec;                                   // >= 4 * dq + 2 * T floats of scratch
+    // ---- merge layer -------------------------------------------------------------------------------------------------------
+    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 0, stream));
+    TG_TRY(tg_colsum(Bw->dout, dn, R, dn, G.b2, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 0, R, dn, dn, 1.f, Bw->dout, dn, P.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
+    {
+        const int64_t rpb = 64;
+        const int64_t blocks = (R + rpb - 1) / rpb;
+        TG_REQUIRE(dn <= 1024, "tg_tgat_layer_bwd: node dim > 1024 unsupported");
+        if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, rpb, Bw->part);
+        else relu_bwd_colsum_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, rpb, Bw->part);
+        TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
+        TG_TRY(tg_colsum(Bw->part, dn, blocks, dn, G.b1, 0, stream));
+    }
+    TG_TRY(tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 0, R, dq, dn, 1.f, Bw->df1, dn, P.W1, w1ld, Bw->dy, dq, nullptr, 0, 0, stream));
+    if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 0, R, dn, dn, 1.f, Bw->df1, dn, P.W1 + dq, w1ld, Bw->d_raw, dn, nullptr, 0, 0, stream));
+    // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
+    {
+        const unsigned g = (unsigned)row_grid(R);
+        const size_t lds = sizeof(float) * ROW_WAVES * 4 * dq;
+        float* dres = L->res_dropout_p > 0.f ? Bw->dres : Bw->dsum;
+        if (dq <= 64) ln_res_bwd_kernel<1><<<g, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, Bw->part);
+        else if (dq <= 320) ln_res_bwd_kernel<5><<<g, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, Bw->part);
+        else ln_res_bwd_kernel<16><<<g, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, Bw->part);
+        TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
+        TG_TRY(tg_colsum(Bw->part, 4 * dq, g, 4 * dq, vec, 0, stream));          // [dgamma | dbeta | sum dsum | sum dres]
+        TG_HIP_CHECK(hipMemcpyAsync(G.ln_g, vec, sizeof(float) * dq, hipMemcpyDeviceToDevice, s));
+        TG_HIP_CHECK(hipMemcpyAsync(G.ln_b, vec + dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, s));
+        TG_HIP_CHECK(hipMemcpyAsync(G.br, vec + 3 * dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, s));
+        vec_add_kernel<<<1, 256, 0, s>>>(Bw->d_cosb, vec + 2 * dq + dn, T);          // d cos(b) from the residual's time half
+        TG_TRY(tg::launch_status("vec_add_kernel"));
+        // ---- output projection ------------------------------------------------------------------------------------------------
+        TG_TRY(tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 0, stream));
+        TG_TRY(tg_gemm_f32(0, 0, R, dq, dq, 1.f, dres, dq, P.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
+    }
+    // ---- value path -------------------------------------------------------------------------------------------------------------
+    TG_TRY(tg_gemm_f32_batched(0, 0, R, dk, hd, 1.f, Bw->dctx, dq, hd, P.Wv, dk, (int64_t)hd * dk, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 0, stream));
+    // ---- fused attention backward ---------------------------------------------------------------------------------------------
+    TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, Bw->part, stream));
+    {
+        const int parts = tg_attn_bwd_parts(R);
+        float* tv = vec + 4 * dq;
+        TG_TRY(tg_colsum(Bw->part, 2 * T, parts, 2 * T, tv, 0, stream));
+        vec_add_kernel<<<1, 256, 0, s>>>(Bw->d_tew, tv, T);
+        vec_add_kernel<<<1, 256, 0, s>>>(Bw->d_teb, tv + T, T);
+        TG_TRY(tg::launch_status("vec_add_kernel"));
+    }
+    // ---- key / query path --------------------------------------------------------------------------------------------------------
+    TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 0, stream));
+    TG_TRY(tg_colsum(Bw->dq, dq, R, dq, vec, 0, stream));                                  // sum_rows dq
+    outer_kernel<<<ew_grid((int64_t)dq * T), 256, 0, s>>>(vec, dq, L->cosb, T, G.Wq + dn, dq);
+    TG_TRY(tg::launch_status("outer_kernel"));
+    TG_TRY(tg_gemm_f32(0, 0, 1, T, dq, 1.f, vec, dq, P.Wq + dn, dq, Bw->d_cosb, T, nullptr, 0, 1, stream));   // += (sum dq) Wq[:, dn:]
+    if (Bw->d_own) {
+        TG_TRY(tg_gemm_f32(0, 0, R, dn, dq, 1.f, Bw->dq, dq, P.Wq, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
+        add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
+        TG_TRY(tg::launch_status("add_cols_kernel"));
+    }
+    return TG_OK;
+}

@@ -285,6 +285,131 @@ class _EmbedFn(torch.autograd.Function):
         return (None, None, d_table, d_tew.view_as(te_w), d_teb, *grads)
 
 
+NATIVE = True     # one native call per layer (tg_tgat_layer_fwd/bwd); False = the op-by-op Python composition below (same kernels)
+
+
+class _NativeLayer:
+    """buffers + C descriptors of one tg_tgat_layer_fwd/bwd call pair"""
+
+    def __init__(self, attn: ops.AttnArgs, params, own, raw, cosb, p_res, seed_res):
+        from ._lib import LayerDesc, LayerParams
+        dev = own.device
+        R, H, Dn, T, Dk = attn.m, attn.heads, attn.dn, attn.dt_dim, attn.dk
+        Dq = Dn + T
+        self.attn, self.R, self.dims = attn, R, (H, Dn, T, Dq, Dk)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self.buf = dict(qbias=e(Dq), q=e(R, Dq), u=e(R, H, Dk), agg=e(R, H, Dk), prob=e(R, H, attn.k), ctx=e(R, Dq), res=e(R, Dq),
+                        y=e(R, Dq), mean=e(R), rstd=e(R), f1=e(R, Dn), out=e(R, Dn))
+        self.keep = (params, own, raw, cosb)
+        d = LayerDesc()
+        d.attn = attn.desc
+        d.params = LayerParams(*[ops._p(t) for t in params])
+        d.own, d.own_ld, d.raw, d.raw_ld, d.cosb = ops._p(own), ops._rowmajor_ld(own, "own"), ops._p(raw), ops._rowmajor_ld(raw, "raw"), ops._p(cosb)
+        d.res_dropout_p, d.res_seed = float(p_res), int(seed_res)
+        for k_, v in self.buf.items():
+            setattr(d, k_, ops._p(v))
+        self.desc = d
+
+    def forward(self):
+        import ctypes as C
+        from ._lib import check, lib
+        with ops._timed("layer_fwd", self.R):
+            check(lib().tg_tgat_layer_fwd(C.byref(self.desc), ops._stream()), "tg_tgat_layer_fwd")
+        return self.buf["out"]
+
+    def backward(self, dout, params, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, d_own_accumulate, want_d_raw):
+        import ctypes as C
+        from ._lib import LayerBwdDesc, LayerParams, check, lib
+        H, Dn, T, Dq, Dk = self.dims
+        R, dev = self.R, dout.device
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        grads = [torch.empty_like(p) for p in params]
+        ws = dict(df1=e(R, Dn), dy=e(R, Dq), dsum=e(R, Dq), dres=e(R, Dq) if self.desc.res_dropout_p > 0 else None, dctx=e(R, Dq),
+                  dagg=e(R, H, Dk), du=e(R, H, Dk), dq=e(R, Dq),
+                  part=e(int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T))), vec=e(4 * Dq + 2 * T))
+        d_raw = e(R, Dn) if want_d_raw else None
+        b = LayerBwdDesc()
+        b.grads = LayerParams(*[ops._p(t) for t in grads])
+        b.dout = ops._p(dout)
+        for k_, v in ws.items():
+            setattr(b, k_, ops._p(v))
+        b.d_cosb, b.d_tew, b.d_teb = ops._p(d_cosb), ops._p(d_tew), ops._p(d_teb)
+        b.dfeat, b.dfeat_ld, b.pad_row = ops._p(dfeat), (0 if dfeat is None else ops._rowmajor_ld(dfeat, "dfeat")), int(pad_row)
+        b.d_own, b.d_own_ld, b.d_own_accumulate = ops._p(d_own), (0 if d_own is None else ops._rowmajor_ld(d_own, "d_own")), int(d_own_accumulate)
+        b.d_raw = ops._p(d_raw)
+        with ops._timed("layer_bwd", self.R):
+            check(lib().tg_tgat_layer_bwd(C.byref(self.desc), C.byref(b), ops._stream()), "tg_tgat_layer_bwd")
+        return grads, d_raw
+
+
+class _EmbedFnNative(torch.autograd.Function):
+    """Same contract as _EmbedFn; every layer is one native forward call and one native backward call."""
+
+    @staticmethod
+    def forward(ctx, cfg, fr, table, te_w, te_b, *layer_params):
+        n, k, L, H = cfg["n"], cfg["k"], cfg["num_layers"], cfg["num_heads"]
+        edge, p_drop, training = cfg["edge_table"], cfg["dropout"], cfg["training"]
+        dev = table.device
+        Dn, T = table.shape[1], te_w.numel()
+        hd = (Dn + T) // H
+        S_nbr, S_eid, S_t, S_dt = fr.S
+        te_w_flat = te_w.reshape(-1)
+        cosb = ops.time_encode(torch.zeros(1, device=dev), te_w_flat, te_b).reshape(-1)
+        p_eff = p_drop if training else 0.0
+        layers, H_prev = [], None
+        for l in range(1, L + 1):
+            params = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
+            R = fr.rows(L - l)
+            raw = ops.gather_rows(table, fr.ids_all[:R])
+            own = raw if l == 1 else H_prev[:R]
+            feat, feat_idx = (table, S_nbr[:R].reshape(-1)) if l == 1 else (H_prev, fr.child[:R * k])
+            seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if p_eff > 0 else [0, 0]
+            attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
+                                te_w_flat, te_b, k, H, hd ** -0.5, p_eff, seeds[0])
+            lay = _NativeLayer(attn, params, own, raw, cosb, p_eff, seeds[1])
+            H_prev = lay.forward()
+            layers.append(lay)
+        ctx.layers, ctx.cfg, ctx.fr, ctx.table, ctx.cosb = layers, cfg, fr, table, cosb
+        ctx.save_for_backward(te_w, te_b, *layer_params)
+        return H_prev
+
+    @staticmethod
+    def backward(ctx, dH):
+        cfg, fr, table, cosb = ctx.cfg, ctx.fr, ctx.table, ctx.cosb
+        te_w, te_b, *layer_params = ctx.saved_tensors
+        n, k, L = cfg["n"], cfg["k"], cfg["num_layers"]
+        table_grad = cfg["table_grad"]
+        dev = dH.device
+        Dn, T = table.shape[1], te_w.numel()
+        grads = [None] * len(layer_params)
+        d_tew, d_teb, d_cosb = (torch.zeros(T, device=dev) for _ in range(3))
+        d_table = torch.zeros_like(table) if table_grad else None
+        dH = dH.contiguous()
+        for l in range(L, 0, -1):
+            lay = ctx.layers[l - 1]
+            R = lay.R
+            params = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
+            if l >= 2:
+                dH_prev = torch.zeros((fr.rows(L - l + 1), Dn), device=dev)
+                dfeat, pad_row = dH_prev, (fr.pad_rows[0] if (l == L and fr.pad_rows) else -1)
+                d_own, acc = dH_prev[:R], True               # rows [0, R) of the lower layer's gradient: its "own" inputs
+            else:
+                dH_prev, dfeat, pad_row = None, d_table, 0
+                d_own, acc = (torch.empty((R, Dn), device=dev), False) if table_grad else (None, False)
+            g, d_raw = lay.backward(dH[:R], params, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, acc, table_grad)
+            if table_grad:
+                if l >= 2:
+                    ops.scatter_add_rows(d_raw, fr.ids_all[:R], d_table)
+                else:
+                    d_own += d_raw
+                    ops.scatter_add_rows(d_own, fr.ids_all[:R], d_table)
+            grads[(l - 1) * 11:(l - 1) * 11 + 11] = g
+            dH = dH_prev
+        d_teb -= torch.sin(te_b) * d_cosb          # d cos(b) -> d b (zero interval: no weight gradient)
+        ctx.layers = None
+        return (None, None, d_table, d_tew.view_as(te_w), d_teb, *grads)
+
+
 def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, te_w, te_b, layer_params, ids: np.ndarray,
           times: np.ndarray, k: int, num_layers: int, num_heads: int, dropout: float, training: bool,
           table_requires_grad: bool = False):
@@ -310,4 +435,5 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
     fr = sample_frontier(graph, ids_dev, times_dev, k, num_layers, dedupe=DEDUPE)
     cfg = dict(n=n, k=k, num_layers=num_layers, num_heads=num_heads, dropout=float(dropout), training=bool(training),
                edge_table=edge_table, table_grad=bool(table_requires_grad))
-    return _EmbedFn.apply(cfg, fr, table, te_w, te_b, *layer_params)
+    fn = _EmbedFnNative if NATIVE else _EmbedFn
+    return fn.apply(cfg, fr, table, te_w, te_b, *layer_params)

@@ -327,3 +327,14 @@ def time_encode_bwd(t, mask_ids, w, b, g):
     check(lib().tg_time_encode_bwd(_p(t), _p(mask_ids), t.numel(), _p(w), _p(b), dim, _p(g), _p(part), _stream()), "tg_time_encode_bwd")
     s = colsum(part)
     return s[:dim], s[dim:]
+
+
+def profile_enable(on: bool):
+    lib().tg_profile_enable(int(on))
+
+
+def profile_collect(tag: str, reset=True):
+    """(total ms, total units, launches) of a kernel family since the last reset (HIP events on the launch stream)"""
+    ms, units, cnt = C.c_double(), C.c_double(), C.c_int64()
+    check(lib().tg_profile_collect(tag.encode(), C.byref(ms), C.byref(units), C.byref(cnt), int(reset)), "tg_profile_collect")
+    return ms.value, units.value, cnt.value

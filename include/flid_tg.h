@@ -27,6 +27,11 @@ typedef struct tg_graph tg_graph; /* opaque: device CSR of time-sorted incidence
 const char* tg_last_error(void);
 int tg_version(void);
 
+/* optional HIP-event timing of the kernel families "attn_fwd", "attn_bwd" (units = algorithmic bytes) and "gemm"
+ * (units = flops), recorded on the launch stream; tg_profile_collect synchronises the device. */
+void tg_profile_enable(int on);
+int tg_profile_collect(const char* tag, double* ms, double* units, int64_t* count, int reset);
+
 /* ---- temporal adjacency ---------------------------------------------------------------------------
  * replaces utils/utils.py:283-302 get_neighbor_sampler + :73-110 NeighborSampler.__init__
  * HOST arrays of length num_edges.  Every edge is filed under both endpoints; per node the incidences are
@@ -105,6 +110,42 @@ int tg_attn_bwd_parts(int64_t m);
 int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
                 const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, int64_t pad_feat_row,
                 float* d_dte_part, void* stream);
+
+/* ---- one whole temporal-attention layer per call -----------------------------------------------------
+ * replaces, per layer, models/modules.py:167-245 + :58-69 as called from models/TGAT.py:132-142 (and MemoryModel.py:703-713)
+ * and their autograd: the same kernels as above, launched natively in sequence, with dropout + the split residual
+ * [own | cos b] fused into the LayerNorm kernels and every bias / LayerNorm / time-encoder column sum taken from slabs.
+ * All buffers are caller-allocated device memory, row-major; shapes with R = attn.m rows, dq = dn + dt_dim, dk = dn + de + dt_dim:
+ *   own (R, dn; own_ld)  query-side features h^(l-1);  raw (R, dn; raw_ld)  second input of the merge layer;  cosb (dt_dim) = cos(b)
+ *   saved by forward for backward: qbias (dq), q (R,dq), u/agg (R,heads,dk), prob (R,heads,k), ctx/res/y (R,dq), mean/rstd (R),
+ *   f1 (R,dn); out (R,dn) = h^l. */
+typedef struct tg_layer_params { const float *Wq, *Wk, *Wv, *ln_g, *ln_b, *Wr, *br, *W1, *b1, *W2, *b2; } tg_layer_params;
+typedef struct tg_layer_grads { float *Wq, *Wk, *Wv, *ln_g, *ln_b, *Wr, *br, *W1, *b1, *W2, *b2; } tg_layer_grads;
+typedef struct tg_layer_desc {
+    tg_attn_desc attn;
+    tg_layer_params params;
+    const float* own; int64_t own_ld;
+    const float* raw; int64_t raw_ld;
+    const float* cosb;
+    float res_dropout_p; uint64_t res_seed;      /* dropout after residual_fc (modules.py:235) */
+    float *qbias, *q, *u, *agg, *prob, *ctx, *res, *y, *mean, *rstd, *f1, *out;
+} tg_layer_desc;
+/* backward: dout (R, dn) in; grads.* are OVERWRITTEN with this layer's parameter gradients; d_cosb / d_tew / d_teb (dt_dim)
+ * are ACCUMULATED into (caller zeroes them once per call); dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional
+ * gradient w.r.t. own (accumulated into if d_own_accumulate); d_raw (R, dn) optional gradient w.r.t. raw.
+ * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats), vec (4 dq + 2 dt_dim). */
+typedef struct tg_layer_bwd_desc {
+    tg_layer_grads grads;
+    const float* dout;
+    float *df1, *dy, *dsum, *dres, *dctx, *dagg, *du, *dq, *part, *vec;
+    float *d_cosb, *d_tew, *d_teb;
+    float* dfeat; int64_t dfeat_ld; int64_t pad_row;
+    float* d_own; int64_t d_own_ld; int d_own_accumulate;
+    float* d_raw;
+} tg_layer_bwd_desc;
+int tg_tgat_layer_fwd(const tg_layer_desc* layer, void* stream);
+int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim);
+int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, void* stream);
 
 /* ---- dense fp32 (MFMA 32x32x2 f32, exact fp32) -----------------------------------------------------
  * replaces the aten::mm / addmm calls behind nn.Linear in models/modules.py:54-69,152-163,235.

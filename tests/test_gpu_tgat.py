@@ -145,3 +145,26 @@ def test_tgat_row_sharing_is_exact():
     for k_ in outs[0][2]:
         ref = outs[1][2][k_].numpy()
         np.testing.assert_allclose(outs[0][2][k_].numpy(), ref, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k_)
+
+
+def test_native_layer_path_equals_op_by_op_path():
+    """engine.NATIVE (one C call per layer, fused LN/dropout/colsum kernels) vs the Python op-by-op composition"""
+    from flid_amd import engine
+    g = load_golden("tgat_L2_K20_full")
+    outs = []
+    for flag in (True, False):
+        engine.NATIVE = flag
+        try:
+            m, p, k = _model(g)
+            m.train()
+            s, d = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+            r = torch.from_numpy(g["r"]).cuda()
+            ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+            outs.append((s.detach().cpu(), d.detach().cpu(), {k_: v.grad.cpu() for k_, v in m.named_parameters()}))
+        finally:
+            engine.NATIVE = True
+    np.testing.assert_allclose(outs[0][0].numpy(), outs[1][0].numpy(), atol=2e-6)
+    np.testing.assert_allclose(outs[0][1].numpy(), outs[1][1].numpy(), atol=2e-6)
+    for k_ in outs[0][2]:
+        ref = outs[1][2][k_].numpy()
+        np.testing.assert_allclose(outs[0][2][k_].numpy(), ref, atol=3e-5 * max(1.0, np.abs(ref).max()), err_msg=k_)
