@@ -77,7 +77,7 @@ def main():
     model = TGAT(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=DT, num_layers=L, num_heads=H,
                  dropout=args.dropout, device=str(dev)).to(dev).train()
     fdist.broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)                              # load_configs.py:119,123
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)                  # load_configs.py:119,123 (one fused update kernel)
     reducer = fdist.GradAllReducer(model.parameters()) if world > 1 else None
 
     total_steps = args.warmup + args.steps

@@ -205,6 +205,42 @@ __global__ void __launch_bounds__(256) first_hop_window_kernel(const int64_t* __
     }
 }
 
+// ---- distinct (node id, float32 time) pairs of a sampled level ----------------------------------------------------------------
+// Open-addressing hash set in global memory: the first slot to claim a key owns it and draws the next compact row index.
+__device__ __forceinline__ uint32_t hash_pair(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return (uint32_t)k;
+}
+__global__ void __launch_bounds__(256) dedupe_insert_kernel(const int32_t* __restrict__ ids, const float* __restrict__ t, int64_t n,
+        uint32_t mask, unsigned long long* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ pos,
+        int32_t* __restrict__ out_ids, float* __restrict__ out_t, int32_t* __restrict__ count_pad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t id = ids[i];
+        const float tt = t[i];
+        const unsigned long long key = ((unsigned long long)(uint32_t)id << 32) | (unsigned long long)__float_as_uint(tt);
+        uint32_t h = hash_pair(key) & mask;
+        while (true) {
+            const unsigned long long prev = atomicCAS(&keys[h], ~0ULL, key);
+            if (prev == ~0ULL) {                       // this slot owns the pair
+                const int32_t idx = atomicAdd(&count_pad[0], 1);
+                vals[h] = idx;
+                out_ids[idx] = id;
+                out_t[idx] = tt;
+                if (key == 0ULL) count_pad[1] = idx;   // the padding pair (0, +0.0f)
+                break;
+            }
+            if (prev == key) break;
+            h = (h + 1) & mask;
+        }
+        pos[i] = (int32_t)h;
+    }
+}
+__global__ void __launch_bounds__(256) dedupe_lookup_kernel(const int32_t* __restrict__ pos, const int32_t* __restrict__ vals, int64_t n,
+                                                            int32_t offset, int32_t* __restrict__ inv) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        inv[i] = vals[pos[i]] + offset;
+}
+
 inline int grid_for(int64_t work_items, int64_t per_block) {
     int64_t b = (work_items + per_block - 1) / per_block;
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, 8 * tg::kMaxGridBlocks));
@@ -240,4 +276,26 @@ extern "C" int tg_first_hop_window(const tg_graph* g, const int32_t* d_ids, cons
     first_hop_window_kernel<<<grid_for(n, 8), 256, 0, (hipStream_t)stream>>>(g->d_row_ptr, g->d_inc, g->num_rows, d_ids,
         d_times64, n, max_len, width, d_out_nbr, d_out_eid, d_out_t, d_out_len);
     return tg::launch_status("first_hop_window_kernel");
+}
+
+extern "C" int64_t tg_dedupe_capacity(int64_t n) {
+    int64_t c = 1024;
+    while (c < 2 * n) c <<= 1;
+    return c;
+}
+
+extern "C" int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n, int64_t capacity, void* d_keys_ws,
+                               int32_t* d_vals_ws, int32_t* d_pos_ws, int32_t row_offset, int32_t* d_out_ids, float* d_out_t,
+                               int32_t* d_out_row, int32_t* d_count_pad, void* stream) {
+    TG_REQUIRE(d_ids && d_t && d_keys_ws && d_vals_ws && d_pos_ws && d_out_ids && d_out_t && d_out_row && d_count_pad, "tg_dedupe_pairs: null pointer");
+    TG_REQUIRE(n >= 0 && capacity >= 2 * n && (capacity & (capacity - 1)) == 0 && capacity <= ((int64_t)1 << 31), "tg_dedupe_pairs: capacity must be a power of two >= 2n");
+    hipStream_t s = (hipStream_t)stream;
+    TG_HIP_CHECK(hipMemsetAsync(d_keys_ws, 0xFF, sizeof(unsigned long long) * capacity, s));
+    TG_HIP_CHECK(hipMemsetAsync(d_count_pad, 0, sizeof(int32_t), s));
+    TG_HIP_CHECK(hipMemsetAsync(d_count_pad + 1, 0xFF, sizeof(int32_t), s));      // pad row = -1 until seen
+    if (n == 0) return TG_OK;
+    dedupe_insert_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_ids, d_t, n, (uint32_t)(capacity - 1), (unsigned long long*)d_keys_ws, d_vals_ws,
+                                                          d_pos_ws, d_out_ids, d_out_t, d_count_pad);
+    dedupe_lookup_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_pos_ws, d_vals_ws, n, row_offset, d_out_row);
+    return tg::launch_status("dedupe kernels");
 }

@@ -98,13 +98,9 @@ def sample_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torc
         nbr_flat, t_flat = S[0].reshape(-1), S[2].reshape(-1)
         nxt = off + counts[d]
         if dedupe:
-            key = (nbr_flat.to(torch.int64) << 32) | (t_flat.view(torch.int32).to(torch.int64) & 0xFFFFFFFF)
-            uniq, inv = torch.unique(key, return_inverse=True)          # index bookkeeping only (one host sync for the count)
-            halves = uniq.view(torch.int32).view(-1, 2)                  # little endian: [:, 0] time bits, [:, 1] node id
-            q_ids, q_t = halves[:, 1].contiguous(), halves[:, 0].contiguous().view(torch.float32)
-            child_parts.append((inv + nxt).to(torch.int32))
-            # keys sort ascending and (0, +0.0) is the smallest possible key: if any slot is padded it is row `nxt`
-            pad_rows.append(nxt)
+            q_ids, q_t, rows, pad = graph.dedupe_pairs(nbr_flat, t_flat, nxt)            # hash set on the device (tg_dedupe_pairs)
+            child_parts.append(rows)
+            pad_rows.append(pad)
         else:
             pad_rows.append(-1)
             q_ids, q_t = nbr_flat, t_flat

@@ -82,3 +82,22 @@ class TemporalGraph:
         check(lib().tg_first_hop_window(self._h, _p(ids), _p(times), n, int(max_len), int(width), _p(nbr), _p(eid), _p(tt),
                                         _p(ln), _stream()), "tg_first_hop_window")
         return nbr, eid, tt, ln
+
+    def dedupe_pairs(self, ids: torch.Tensor, t32: torch.Tensor, row_offset: int):
+        """distinct (id, float32 time) pairs of a sampled level -> (uniq_ids i32, uniq_t f32, row_of_slot i32, pad_row or -1).
+        One 8-byte readback (the count sizes the next level)."""
+        n, dev = ids.numel(), ids.device
+        cap = int(lib().tg_dedupe_capacity(n))
+        ws = getattr(self, "_dedupe_ws", None)
+        if ws is None or ws[0].numel() < cap or ws[2].numel() < n:
+            ws = (torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                  torch.empty(max(n, 1), dtype=torch.int32, device=dev))
+            self._dedupe_ws = ws
+        out_ids = torch.empty(n, dtype=torch.int32, device=dev)
+        out_t = torch.empty(n, dtype=torch.float32, device=dev)
+        row = torch.empty(n, dtype=torch.int32, device=dev)
+        cp = torch.empty(2, dtype=torch.int32, device=dev)
+        check(lib().tg_dedupe_pairs(_p(ids), _p(t32), n, cap, _p(ws[0]), _p(ws[1]), _p(ws[2]), int(row_offset), _p(out_ids), _p(out_t),
+                                    _p(row), _p(cp), _stream()), "tg_dedupe_pairs")
+        count, pad = cp.cpu().tolist()
+        return out_ids[:count], out_t[:count], row, (pad + row_offset if pad >= 0 else -1)

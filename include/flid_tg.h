@@ -58,6 +58,16 @@ int tg_sample_recent(const tg_graph* g, const int32_t* d_ids, const double* d_ti
                      int64_t n, int k, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, float* d_out_dt,
                      int32_t* d_status, void* stream);
 
+/* Distinct (node id, float32 time) pairs of a sampled level (flid_amd/engine.py row sharing): the embedding of a node at a
+ * time is a function of that pair only, so repeated pairs inside a batch are computed once.  n input slots; outputs: the
+ * distinct pairs (d_out_ids / d_out_t, at most n, in arrival order), d_out_row[i] = row_offset + index of slot i's pair,
+ * d_count_pad[0] = number of distinct pairs, d_count_pad[1] = index of the padding pair (0, 0.0f) or -1.
+ * Workspaces: keys (capacity x 8 B), vals / pos (capacity, n int32); capacity = tg_dedupe_capacity(n) (power of two >= 2n). */
+int64_t tg_dedupe_capacity(int64_t n);
+int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n, int64_t capacity, void* d_keys_ws, int32_t* d_vals_ws,
+                    int32_t* d_pos_ws, int32_t row_offset, int32_t* d_out_ids, float* d_out_t, int32_t* d_out_row,
+                    int32_t* d_count_pad, void* stream);
+
 /* DyGFormer first-hop window: replaces utils/utils.py:254-273 get_all_first_hop_neighbors +
  * models/DyGFormer.py:196-245 pad_sequences (cut to the newest max_len-1, self in slot 0, left-aligned).
  * Outputs are (n, width) row-major with width = max_len rounded up to a patch multiple by the caller;
