@@ -60,6 +60,7 @@ SIGNATURES = {
     "tg_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void]),
     "tg_attn_bwd_parts": (C.c_int, [c_i64]),
     "tg_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_void, c_void]),
+    "tg_set_overlap": (None, [C.c_int]),
     "tg_tgat_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), c_void]),
     "tg_tgat_layer_part_floats": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),

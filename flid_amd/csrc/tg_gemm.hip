@@ -295,9 +295,13 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     // Split the contraction only for weight-gradient shapes (A^T: K = number of rows, small output) so that forward products
     // stay bitwise reproducible; the partial products are folded with float atomics.
     int64_t splits = 1;
-    if (!relu && ta && gx * gy * nbatch < 1024 && K >= 2 * BK) {
-        splits = (1536 + gx * gy * nbatch - 1) / (gx * gy * nbatch);
-        const int64_t max_splits = (K + 2 * BK - 1) / (2 * BK);
+    if (!relu && ta && gx * gy * nbatch < 512 && K >= 2 * BK) {
+        // ~2 workgroups per CU, each with at least 8 K-stages: many short slices would only multiply the atomic traffic onto
+        // a small output (a 172 x 172 gradient split 131 ways spent 48 us; 57 ways ...)
+        const char* e = getenv("FLID_GEMM_SPLIT_BLOCKS");
+        const int64_t target = e ? atoi(e) : 512;
+        splits = (target + gx * gy * nbatch - 1) / (gx * gy * nbatch);
+        const int64_t max_splits = (K + 8 * BK - 1) / (8 * BK);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }

@@ -187,6 +187,37 @@ inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::
 
 #define TG_TRY(expr) do { int _rc = (expr); if (_rc != TG_OK) return _rc; } while (0)
 
+// Weight-gradient products run on a side stream: they depend on the main chain only through their two operands, and the
+// main chain is alternately HBM-bound (fused attention backward) and latency-bound (one GEMM after another), so the matrix
+// cores are free for them.  fork(): side waits for everything issued on main so far; join(): main waits for side.
+struct SideStream {
+    hipStream_t side = nullptr;
+    hipEvent_t ev[8];
+    int next = 0;
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+        for (auto& e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+    int fork(hipStream_t main) {
+        hipEvent_t e = ev[next++ & 7];
+        TG_HIP_CHECK(hipEventRecord(e, main));
+        TG_HIP_CHECK(hipStreamWaitEvent(side, e, 0));
+        return TG_OK;
+    }
+    int join(hipStream_t main) {
+        hipEvent_t e = ev[next++ & 7];
+        TG_HIP_CHECK(hipEventRecord(e, side));
+        TG_HIP_CHECK(hipStreamWaitEvent(main, e, 0));
+        return TG_OK;
+    }
+};
+SideStream g_side;
+bool g_overlap = true;
+
 }  // namespace
 
 extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
@@ -239,8 +270,11 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const tg_layer_grads& G = Bw->grads;
     const int64_t w1ld = dq + dn;
     float* vec = Bw->vec;                                   // >= 4 * dq + 2 * T floats of scratch
+    const bool overlap = g_overlap && g_side.init();
+    void* wstream = overlap ? (void*)g_side.side : stream;        // where the weight-gradient products go
     // ---- merge layer -------------------------------------------------------------------------------------------------------
-    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 0, stream));
+    if (overlap) TG_TRY(g_side.fork(s));                           // dout is ready
+    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 0, wstream));
     TG_TRY(tg_colsum(Bw->dout, dn, R, dn, G.b2, 0, stream));
     TG_TRY(tg_gemm_f32(0, 0, R, dn, dn, 1.f, Bw->dout, dn, P.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
     {
@@ -252,8 +286,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
         TG_TRY(tg_colsum(Bw->part, dn, blocks, dn, G.b1, 0, stream));
     }
-    TG_TRY(tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 0, stream));
-    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 0, stream));
+    if (overlap) TG_TRY(g_side.fork(s));                           // df1 is final
+    TG_TRY(tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 0, wstream));
+    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 0, wstream));
     TG_TRY(tg_gemm_f32(0, 0, R, dq, dn, 1.f, Bw->df1, dn, P.W1, w1ld, Bw->dy, dq, nullptr, 0, 0, stream));
     if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 0, R, dn, dn, 1.f, Bw->df1, dn, P.W1 + dq, w1ld, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
@@ -265,6 +300,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         else if (dq <= 320) ln_res_bwd_kernel<5><<<g, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, Bw->part);
         else ln_res_bwd_kernel<16><<<g, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, Bw->part);
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
+        if (overlap) TG_TRY(g_side.fork(s));                       // dres is final
+        TG_TRY(tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 0, wstream));
         TG_TRY(tg_colsum(Bw->part, 4 * dq, g, 4 * dq, vec, 0, stream));          // [dgamma | dbeta | sum dsum | sum dres]
         TG_HIP_CHECK(hipMemcpyAsync(G.ln_g, vec, sizeof(float) * dq, hipMemcpyDeviceToDevice, s));
         TG_HIP_CHECK(hipMemcpyAsync(G.ln_b, vec + dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, s));
@@ -272,14 +309,16 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         vec_add_kernel<<<1, 256, 0, s>>>(Bw->d_cosb, vec + 2 * dq + dn, T);          // d cos(b) from the residual's time half
         TG_TRY(tg::launch_status("vec_add_kernel"));
         // ---- output projection ------------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 0, stream));
         TG_TRY(tg_gemm_f32(0, 0, R, dq, dq, 1.f, dres, dq, P.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
     }
     // ---- value path -------------------------------------------------------------------------------------------------------------
+    if (overlap) TG_TRY(g_side.fork(s));                           // dctx is final
+    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 0, wstream));
     TG_TRY(tg_gemm_f32_batched(0, 0, R, dk, hd, 1.f, Bw->dctx, dq, hd, P.Wv, dk, (int64_t)hd * dk, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
-    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 0, stream));
-    // ---- fused attention backward ---------------------------------------------------------------------------------------------
+    // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
     TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, Bw->part, stream));
+    if (overlap) TG_TRY(g_side.fork(s));                           // du is final
+    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 0, wstream));
     {
         const int parts = tg_attn_bwd_parts(R);
         float* tv = vec + 4 * dq;
@@ -290,8 +329,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     }
     // ---- key / query path --------------------------------------------------------------------------------------------------------
     TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
-    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 0, stream));
-    TG_TRY(tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 0, stream));
+    if (overlap) TG_TRY(g_side.fork(s));                           // dq is final
+    TG_TRY(tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 0, wstream));
     TG_TRY(tg_colsum(Bw->dq, dq, R, dq, vec, 0, stream));                                  // sum_rows dq
     outer_kernel<<<ew_grid((int64_t)dq * T), 256, 0, s>>>(vec, dq, L->cosb, T, G.Wq + dn, dq);
     TG_TRY(tg::launch_status("outer_kernel"));
@@ -301,5 +340,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
         TG_TRY(tg::launch_status("add_cols_kernel"));
     }
+    if (overlap) TG_TRY(g_side.join(s));
     return TG_OK;
 }
+
+extern "C" void tg_set_overlap(int on) { g_overlap = on != 0; }

@@ -156,6 +156,8 @@ typedef struct tg_layer_bwd_desc {
 int tg_tgat_layer_fwd(const tg_layer_desc* layer, void* stream);
 int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim);
 int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, void* stream);
+/* weight-gradient products of tg_tgat_layer_bwd on an internal side stream (default on); they are joined before it returns */
+void tg_set_overlap(int on);
 
 /* ---- dense fp32 (MFMA 32x32x2 f32, exact fp32) -----------------------------------------------------
  * replaces the aten::mm / addmm calls behind nn.Linear in models/modules.py:54-69,152-163,235.
