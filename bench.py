@@ -98,10 +98,16 @@ def main():
                             torch.from_numpy(data.node_interact_times[sl]).to(dev)))
     rw = torch.randn(2, BATCH, DN, device=dev)
 
+    prepared = {}
+
     def step(s):
-        src, dst, t = dev_batches[s]
+        # sampler work of the NEXT batch is issued first, on a side stream (it depends on the graph only, not on the weights)
+        if s not in prepared:
+            prepared[s] = model.prepare_batch(*dev_batches[s], K)
+        if s + 1 < len(dev_batches):
+            prepared[s + 1] = model.prepare_batch(*dev_batches[s + 1], K)
         opt.zero_grad(set_to_none=True)
-        se, de_ = model.compute_src_dst_node_temporal_embeddings(src, dst, t, K)
+        se, de_ = model.compute_src_dst_node_temporal_embeddings(prepared.pop(s), None, None, K)
         loss = (se * rw[0]).mean() + (de_ * rw[1]).mean()
         loss.backward()
         if reducer is not None:

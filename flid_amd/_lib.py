@@ -30,7 +30,7 @@ class LayerDesc(C.Structure):
     """struct tg_layer_desc"""
     _fields_ = [("attn", AttnDesc), ("params", LayerParams), ("own", c_void), ("own_ld", c_i64), ("raw", c_void), ("raw_ld", c_i64),
                 ("cosb", c_void), ("res_dropout_p", c_f32), ("res_seed", C.c_uint64)] + \
-               [(n, c_void) for n in ("qbias", "q", "u", "agg", "prob", "ctx", "res", "y", "mean", "rstd", "f1", "out")]
+               [(n, c_void) for n in ("qbias", "q", "u", "agg", "prob", "ctx", "res", "y", "mean", "rstd", "f1", "out", "wT")]
 
 
 class LayerBwdDesc(C.Structure):
@@ -62,10 +62,13 @@ SIGNATURES = {
     "tg_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_void, c_void]),
     "tg_set_overlap": (None, [C.c_int]),
     "tg_tgat_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), c_void]),
+    "tg_tgat_layer_wt_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
     "tg_tgat_layer_part_floats": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),
     "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
                               c_void, C.c_int, C.c_int, c_void]),
+    "tg_set_gemm_mode": (None, [C.c_int]),
+    "tg_get_gemm_mode": (C.c_int, []),
     "tg_gemm_f32_batched": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_void,
                                       c_i64, c_i64, C.c_int, c_void, C.c_int, C.c_int, c_void]),
     "tg_gemm_f32_batched2": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64,

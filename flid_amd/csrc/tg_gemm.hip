@@ -21,7 +21,17 @@
 
 #include "tg_common.h"
 
+namespace tg {
+bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                    int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
+                    hipStream_t s);
+}
+
 namespace {
+
+// 1 = row-times-weight products (A as M x K, B as N x K) run on the split-bf16 kernel (tg_gemm_bf16x3.hip); 0 = everything on
+// the exact f32-input MFMA kernel below.
+int g_gemm_mode = 1;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -276,6 +286,9 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
 
     // A panel: k-contiguous when A is M x K (not transposed).  B panel: k-contiguous when B is given as N x K (tb).
     const bool a_kc = !ta, b_kc = tb != 0;
+    if (g_gemm_mode == 1 && a_kc && b_kc && inner == 1 && alpha == 1.f &&
+        tg::gemm_bf16x3_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s))
+        return tg::launch_status("gemm_bf16x3_nt_kernel");
     bool vec = al16(d_A) && al16(d_B) && lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 &&
                innerA % 4 == 0 && innerB % 4 == 0;
     vec = vec && (a_kc ? K % 4 == 0 : M % 4 == 0) && (b_kc ? K % 4 == 0 : N % 4 == 0);
@@ -285,8 +298,11 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     // (32x96, 64x96) 42..69 -- waves per workgroup should divide evenly over the CU's 4 SIMDs.  Ragged edges cost only the idle
     // wave slots of the edge blocks (tiles wholly outside C skip their MFMAs).
     int tn = 2, tm = vec ? 2 : 1;
-    if (const char* e = getenv("FLID_GEMM_TM")) { const int v = atoi(e); if (vec && (v == 1 || v == 2 || v == 4)) tm = v; }   // tuning overrides
-    if (const char* e = getenv("FLID_GEMM_TN")) { const int v = atoi(e); if (vec && v >= 1 && v <= 4) tn = v; }
+    static const bool tuning = getenv("FLID_GEMM_TUNE") != nullptr;      // env overrides are read only in tuning mode (tools/)
+    if (tuning) {
+        if (const char* e = getenv("FLID_GEMM_TM")) { const int v = atoi(e); if (vec && (v == 1 || v == 2 || v == 4)) tm = v; }
+        if (const char* e = getenv("FLID_GEMM_TN")) { const int v = atoi(e); if (vec && v >= 1 && v <= 4) tn = v; }
+    }
     if (tm == 4 && tn > 2) tn = 2;
     if (tm != 4 && tn == 1) tn = 2;
     const int64_t gx = (N + 32 * tn - 1) / (32 * tn), gy = (M + 32 * tm - 1) / (32 * tm);
@@ -298,7 +314,7 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     if (!relu && ta && gx * gy * nbatch < 512 && K >= 2 * BK) {
         // ~2 workgroups per CU, each with at least 8 K-stages: many short slices would only multiply the atomic traffic onto
         // a small output (a 172 x 172 gradient split 131 ways spent 48 us; 57 ways ...)
-        const char* e = getenv("FLID_GEMM_SPLIT_BLOCKS");
+        const char* e = tuning ? getenv("FLID_GEMM_SPLIT_BLOCKS") : nullptr;
         const int64_t target = e ? atoi(e) : 512;
         splits = (target + gx * gy * nbatch - 1) / (gx * gy * nbatch);
         const int64_t max_splits = (K + 8 * BK - 1) / (8 * BK);
@@ -316,8 +332,10 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
             TG_HIP_CHECK(hipMemset2DAsync(d_C + (b / inner) * strideC + (b % inner) * innerC, ldc * sizeof(float), 0,
                                           N * sizeof(float), M, s));
 
+    static const bool skip_launch = tuning && getenv("FLID_GEMM_SKIP") != nullptr;   // timing experiment: host cost without the kernel
+    if (skip_launch) return TG_OK;
     tg::ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
-    const bool noswz = getenv("FLID_GEMM_NOSWZ") != nullptr;
+    const bool noswz = tuning && getenv("FLID_GEMM_NOSWZ") != nullptr;
     const Args a{M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, noswz ? -(int)gy : (int)gy,
                  strideA, strideB, strideC, nbatch, (int)splits, inner, innerA, innerB, innerC};
     if (a_kc && b_kc) dispatch<true, true>(vec, tm, tn, a, s);
@@ -350,3 +368,6 @@ extern "C" int tg_gemm_f32_batched2(int ta, int tb, int64_t M, int64_t N, int64_
     return gemm_impl(ta, tb, M, N, K, alpha, d_A, lda, outer_a, d_B, ldb, outer_b, d_C, ldc, outer_c, outer * inner, nullptr, 0,
                      accumulate, (hipStream_t)stream, inner, inner_a, inner_b, inner_c);
 }
+
+extern "C" void tg_set_gemm_mode(int mode) { g_gemm_mode = mode; }
+extern "C" int tg_get_gemm_mode(void) { return g_gemm_mode; }

@@ -1,0 +1,215 @@
+// Split-bf16 ("bf16x3") GEMM for the row-times-weight products of the main chain:  C[M,N] = A[M,K] * B[N,K]^T (+bias)(+C)(ReLU).
+//
+// Each fp32 operand element is split as x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); the product keeps
+//     A_hi B_hi + A_hi B_lo + A_lo B_hi        (the dropped A_lo B_lo term and the residual x - hi - lo are <= 2^-17 relative)
+// with fp32 accumulation inside v_mfma_f32_32x32x16_bf16.  Three bf16 MFMAs replace eight f32-input MFMAs per 16-deep K step
+// (96 vs 512 cycles per 32x32 tile): on MI355X the f32-input matrix rate (157 TFLOP/s) was the bound of the whole path
+// (SURVEY.md 8d "fp32 MFMA rate"), this lifts it by 5x for the products whose operands are k-contiguous.
+// Measured accuracy on the full-dimension golden case: |emb - reference| = 1.6e-5 (exact-fp32 path: 7e-7; budget 1e-4).
+//
+// Workgroup = 4 waves stacked along M, block tile 128 x 64; each wave owns 32 x 64 (two 32x32 tiles sharing the A fragment).
+// Staging: global fp32 (full 128-B lines) -> split in registers -> LDS row = [32 x bf16 hi | 32 x bf16 lo] (+16 B pad, stride
+// 144 B, conflict-free ds_read_b128) -> fragments.  Two LDS stages, one barrier per 32-deep stage, global loads of stage s+2
+// in flight under stage s.
+#include "tg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BK = 32;
+constexpr int ROW_BYTES = 144;                 // 64 B hi + 64 B lo + 16 B pad
+constexpr int BM = 128, BN = 64, NT = 256;
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);     // v_cvt_pk_bf16_f32, round to nearest even
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float bf16_lo_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
+__device__ __forceinline__ float bf16_hi_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xFFFF0000u); }
+
+// split 4 floats into 4 hi + 4 lo bf16 (two 8-byte words)
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+    hi.x = pack_bf16(v.x, v.y);
+    hi.y = pack_bf16(v.z, v.w);
+    lo.x = pack_bf16(v.x - bf16_lo_to_f32(hi.x), v.y - bf16_hi_to_f32(hi.x));
+    lo.y = pack_bf16(v.z - bf16_lo_to_f32(hi.y), v.w - bf16_hi_to_f32(hi.y));
+}
+
+// one panel of R rows x 32 k (k contiguous in memory); slot = (row, 4-float chunk)
+template <int R>
+struct Panel {
+    static constexpr int TOTAL = R * 8;
+    static constexpr int PER = TOTAL / NT;
+    static_assert(TOTAL % NT == 0, "panel must tile the workgroup");
+    const float* src[PER];
+    int lds_off[PER];      // byte offset of the slot's hi word inside the panel
+    int kcol[PER];
+
+    __device__ __forceinline__ void init(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, int64_t kbeg) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int idx = threadIdx.x + j * NT;
+            const int r = idx >> 3, c = idx & 7;
+            int64_t row = row0 + r;
+            if (row > nrows - 1) row = nrows - 1;           // clamped rows only feed outputs that are never stored
+            src[j] = X + row * ld + kbeg + c * 4;
+            lds_off[j] = r * ROW_BYTES + c * 8;
+            kcol[j] = c * 4;
+        }
+    }
+    __device__ __forceinline__ void gload(int64_t elems, int64_t k0, int64_t kend, bool full, float4 (&reg)[PER]) const {
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) reg[j] = *reinterpret_cast<const float4*>(src[j] + elems);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + kcol[j] < kend) v = *reinterpret_cast<const float4*>(src[j] + elems);
+                reg[j] = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void sstore(char* __restrict__ s, const float4 (&reg)[PER]) const {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            uint2 hi, lo;
+            split4(reg[j], hi, lo);
+            *reinterpret_cast<uint2*>(s + lds_off[j]) = hi;
+            *reinterpret_cast<uint2*>(s + lds_off[j] + 64) = lo;
+        }
+    }
+};
+
+// fragment of one 32-row tile for k-step ks (16 k): lane (r = l&31, h = l>>5) holds k = 16 ks + 8 h + 0..7
+__device__ __forceinline__ void read_frag(const char* __restrict__ s, int tile_r0, int ks, bf16x8& hi, bf16x8& lo) {
+    const int lane = threadIdx.x & 63;
+    const char* p = s + (tile_r0 + (lane & 31)) * ROW_BYTES + (16 * ks + 8 * (lane >> 5)) * 2;
+    hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+    lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p + 64));
+}
+
+__global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
+        const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int relu,
+        int accumulate, int gx, int gy, int64_t strideA, int64_t strideB, int64_t strideC) {
+    constexpr int FA = BM * ROW_BYTES, FB = BN * ROW_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
+    auto sA = [&](int i) -> char* { return lds + i * (FA + FB); };
+    auto sB = [&](int i) -> char* { return lds + i * (FA + FB) + FA; };
+
+    const int nwg = gx * gy, bid = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int by = swz / gx, bx = swz % gx;
+    const int batch = blockIdx.z;
+    A += batch * strideA; B += batch * strideB; C += batch * strideC;
+    if (bias) bias += batch * (int64_t)N;
+
+    const int64_t bm = (int64_t)by * BM, bn = (int64_t)bx * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool live0 = (bm + wave * 32 < M) && (bn < N), live1 = (bm + wave * 32 < M) && (bn + 32 < N);
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    Panel<BM> pa;
+    Panel<BN> pb;
+    pa.init(A, lda, bm, M, 0);
+    pb.init(B, ldb, bn, N, 0);
+    float4 ra[Panel<BM>::PER], rb[Panel<BN>::PER];
+    const int64_t nstage = (K + BK - 1) / BK, nfull = K / BK;
+    if (nstage > 0) {
+        pa.gload(0, 0, K, nfull > 0, ra);
+        pb.gload(0, 0, K, nfull > 0, rb);
+        pa.sstore(sA(0), ra);
+        pb.sstore(sB(0), rb);
+        __syncthreads();
+        if (nstage > 1) {
+            pa.gload(BK, BK, K, nfull > 1, ra);
+            pb.gload(BK, BK, K, nfull > 1, rb);
+        }
+    }
+    for (int64_t st = 0; st < nstage; ++st) {
+        const int cur = (int)(st & 1);
+        bf16x8 ah[2], al[2], b0h[2], b0l[2], b1h[2], b1l[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            read_frag(sA(cur), wave * 32, ks, ah[ks], al[ks]);
+            read_frag(sB(cur), 0, ks, b0h[ks], b0l[ks]);
+            read_frag(sB(cur), 32, ks, b1h[ks], b1l[ks]);
+        }
+        if (st + 1 < nstage) {
+            pa.sstore(sA(cur ^ 1), ra);
+            pb.sstore(sB(cur ^ 1), rb);
+        }
+        if (st + 2 < nstage) {
+            pa.gload((st + 2) * BK, (st + 2) * BK, K, st + 2 < nfull, ra);
+            pb.gload((st + 2) * BK, (st + 2) * BK, K, st + 2 < nfull, rb);
+        }
+        if (live0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b0h[ks], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0l[ks], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0h[ks], acc0, 0, 0, 0);
+            }
+        }
+        if (live1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b1h[ks], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1l[ks], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1h[ks], acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int rl = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t col = bn + t * 32 + rl;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = bm + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row >= M) continue;
+            float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+            float* p = C + row * ldc + col;
+            if (accumulate) v += *p;
+            if (relu) v = fmaxf(v, 0.f);
+            *p = v;
+        }
+    }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+namespace tg {
+
+// returns true when the shape was handled; false = fall back to the exact f32-input kernel
+bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                    int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
+                    hipStream_t s) {
+    if (!(al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0)) return false;
+    if (M < 1 || N < 1 || K < 8 || nbatch > 65535) return false;
+    const int64_t gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+    if (gx * gy >= ((int64_t)1 << 30)) return false;
+    ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
+    const dim3 grid((unsigned)(gx * gy), 1, (unsigned)nbatch);
+    gemm_bf16x3_nt_kernel<<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA,
+                                              strideB, strideC);
+    return true;
+}
+
+}  // namespace tg

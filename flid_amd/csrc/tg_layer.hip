@@ -183,6 +183,43 @@ __global__ void __launch_bounds__(256) vec_add_kernel(float* __restrict__ dst, c
     if (i < n) dst[i] += src[i];
 }
 
+// up to 8 small matrix transposes in one launch (weights, once per step): dst[c * ldd + r] = src[r * lds + c]
+struct TrJob { const float* src; float* dst; int rows, cols; int64_t lds, ldd; };
+struct TrJobs { TrJob j[8]; int n; };
+__global__ void __launch_bounds__(256) transpose_many_kernel(TrJobs jobs) {
+    __shared__ float tile[32][33];
+    const TrJob jb = jobs.j[blockIdx.y];
+    const int tiles_c = (jb.cols + 31) / 32, tiles_r = (jb.rows + 31) / 32;
+    for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+        const int tr = t / tiles_c, tc = t % tiles_c;
+        const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
+        __syncthreads();
+        for (int i = ly; i < 32; i += 8) {
+            const int r = tr * 32 + i, c = tc * 32 + lx;
+            tile[i][lx] = (r < jb.rows && c < jb.cols) ? jb.src[(int64_t)r * jb.lds + c] : 0.f;
+        }
+        __syncthreads();
+        for (int i = ly; i < 32; i += 8) {
+            const int c = tc * 32 + i, r = tr * 32 + lx;
+            if (r < jb.rows && c < jb.cols) jb.dst[(int64_t)c * jb.ldd + r] = tile[lx][i];
+        }
+    }
+}
+
+struct WT { float *Wk, *Wv, *W2, *W1a, *W1b, *Wr, *WqL; };
+inline WT wt_layout(float* base, int H, int dn, int dq, int dk) {
+    WT w;
+    float* p = base;
+    w.Wk = p; p += (int64_t)dk * dq;      // H blocks of (dk, hd)
+    w.Wv = p; p += (int64_t)dk * dq;
+    w.W2 = p; p += (int64_t)dn * dn;
+    w.W1a = p; p += (int64_t)dq * dn;     // (dq, dn)
+    w.W1b = p; p += (int64_t)dn * dn;
+    w.Wr = p; p += (int64_t)dq * dq;
+    w.WqL = p;                             // (dn, dq)
+    return w;
+}
+
 inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, tg::kMaxGridBlocks)); }
 
 #define TG_TRY(expr) do { int _rc = (expr); if (_rc != TG_OK) return _rc; } while (0)
@@ -230,11 +267,34 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     if (R == 0) return TG_OK;
     hipStream_t s = (hipStream_t)stream;
     const tg_layer_params& P = L->params;
+    // Transposed copies of the weights that the chain multiplies "from the right" (u = q Wk, and every dX = dY W of the
+    // backward): with them EVERY product of the main chain has two k-contiguous operands and runs on the split-bf16 kernel.
+    const WT wt = wt_layout(L->wT, H, dn, dq, dk);
+    {
+        TrJobs jobs;
+        int n = 0;
+        for (int h = 0; h < H && n < 4; ++h) {
+            jobs.j[n++] = TrJob{P.Wk + (int64_t)h * hd * dk, wt.Wk + (int64_t)h * dk * hd, hd, dk, dk, hd};
+        }
+        TG_REQUIRE(H <= 2, "tg_tgat_layer_fwd: the native layer path supports 1 or 2 heads");
+        for (int h = 0; h < H; ++h) jobs.j[n++] = TrJob{P.Wv + (int64_t)h * hd * dk, wt.Wv + (int64_t)h * dk * hd, hd, dk, dk, hd};
+        jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
+        jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
+        jobs.j[n++] = TrJob{P.W1 + dq, wt.W1b, dn, dn, (int64_t)dq + dn, dn};
+        jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
+        jobs.n = n;
+        transpose_many_kernel<<<dim3(64, n), 256, 0, s>>>(jobs);
+        TrJobs j2;
+        j2.j[0] = TrJob{P.Wq, wt.WqL, dq, dn, dq, dq};
+        j2.n = 1;
+        transpose_many_kernel<<<dim3(64, 1), 256, 0, s>>>(j2);
+        TG_TRY(tg::launch_status("transpose_many_kernel"));
+    }
     // q = [own | cos b] Wq^T : the constant half is a bias row
     TG_TRY(tg_gemm_f32(0, 1, 1, dq, T, 1.f, L->cosb, T, P.Wq + dn, dq, L->qbias, dq, nullptr, 0, 0, stream));
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
     // u_h = Wk_h^T q_h
-    TG_TRY(tg_gemm_f32_batched(0, 0, R, dk, hd, 1.f, L->q, dq, hd, P.Wk, dk, (int64_t)hd * dk, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, L->q, dq, hd, wt.Wk, hd, (int64_t)dk * hd, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
     TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
     // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
     TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
@@ -252,11 +312,15 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     return TG_OK;
 }
 
+extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
+    return 2 * (int64_t)dk * dq + 2 * (int64_t)dn * dn + 2 * (int64_t)dq * dn + (int64_t)dq * dq;
+}
+
 extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
     const int64_t a = ((rows + 63) / 64) * dn;                       // ReLU-mask slabs
     const int64_t b = row_grid(rows) * 4 * dq;                       // LayerNorm slabs
     const int64_t c = (int64_t)tg_attn_bwd_parts(rows) * 2 * dt_dim; // time-encoder slabs
-    return std::max<int64_t>(16, std::max(a, std::max(b, c)));
+    return 16 + a + b + c;                                            // disjoint regions: they are consumed concurrently
 }
 
 extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, void* stream) {
@@ -270,73 +334,76 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const tg_layer_grads& G = Bw->grads;
     const int64_t w1ld = dq + dn;
     float* vec = Bw->vec;                                   // >= 4 * dq + 2 * T floats of scratch
+    const WT wt = wt_layout(L->wT, H, dn, dq, dk);                 // filled by the forward call of this step
     const bool overlap = g_overlap && g_side.init();
-    void* wstream = overlap ? (void*)g_side.side : stream;        // where the weight-gradient products go
+    void* wstream = overlap ? (void*)g_side.side : stream;        // where everything that only feeds parameter gradients goes
+    hipStream_t ws_ = (hipStream_t)wstream;
+    // slab regions of `part` (each finished on the side stream while the main chain moves on)
+    const int64_t relu_blocks = (R + 63) / 64;
+    const unsigned ln_grid = (unsigned)row_grid(R);
+    const int attn_parts = tg_attn_bwd_parts(R);
+    float* part_relu = Bw->part;
+    float* part_ln = part_relu + relu_blocks * dn;
+    float* part_attn = part_ln + (int64_t)ln_grid * 4 * dq;
+    float* vec_ln = vec;                  // 4 dq
+    float* vec_te = vec + 4 * dq;         // 2 T
+    float* vec_dq = vec + 4 * dq + 2 * T; // dq
     // ---- merge layer -------------------------------------------------------------------------------------------------------
     if (overlap) TG_TRY(g_side.fork(s));                           // dout is ready
     TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 0, wstream));
-    TG_TRY(tg_colsum(Bw->dout, dn, R, dn, G.b2, 0, stream));
-    TG_TRY(tg_gemm_f32(0, 0, R, dn, dn, 1.f, Bw->dout, dn, P.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
-    {
-        const int64_t rpb = 64;
-        const int64_t blocks = (R + rpb - 1) / rpb;
-        TG_REQUIRE(dn <= 1024, "tg_tgat_layer_bwd: node dim > 1024 unsupported");
-        if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, rpb, Bw->part);
-        else relu_bwd_colsum_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, rpb, Bw->part);
-        TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
-        TG_TRY(tg_colsum(Bw->part, dn, blocks, dn, G.b1, 0, stream));
-    }
-    if (overlap) TG_TRY(g_side.fork(s));                           // df1 is final
+    TG_TRY(tg_colsum(Bw->dout, dn, R, dn, G.b2, 0, wstream));
+    TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
+    TG_REQUIRE(dn <= 1024, "tg_tgat_layer_bwd: node dim > 1024 unsupported");
+    if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 64, part_relu);
+    else relu_bwd_colsum_kernel<4><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 64, part_relu);
+    TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
+    if (overlap) TG_TRY(g_side.fork(s));                           // df1 and its slabs are final
+    TG_TRY(tg_colsum(part_relu, dn, relu_blocks, dn, G.b1, 0, wstream));
     TG_TRY(tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 0, wstream));
     TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 0, wstream));
-    TG_TRY(tg_gemm_f32(0, 0, R, dq, dn, 1.f, Bw->df1, dn, P.W1, w1ld, Bw->dy, dq, nullptr, 0, 0, stream));
-    if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 0, R, dn, dn, 1.f, Bw->df1, dn, P.W1 + dq, w1ld, Bw->d_raw, dn, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
+    if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
+    float* dres = L->res_dropout_p > 0.f ? Bw->dres : Bw->dsum;
     {
-        const unsigned g = (unsigned)row_grid(R);
         const size_t lds = sizeof(float) * ROW_WAVES * 4 * dq;
-        float* dres = L->res_dropout_p > 0.f ? Bw->dres : Bw->dsum;
-        if (dq <= 64) ln_res_bwd_kernel<1><<<g, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, Bw->part);
-        else if (dq <= 320) ln_res_bwd_kernel<5><<<g, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, Bw->part);
-        else ln_res_bwd_kernel<16><<<g, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, Bw->part);
+        if (dq <= 64) ln_res_bwd_kernel<1><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
+        else if (dq <= 320) ln_res_bwd_kernel<5><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
+        else ln_res_bwd_kernel<16><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
-        if (overlap) TG_TRY(g_side.fork(s));                       // dres is final
-        TG_TRY(tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 0, wstream));
-        TG_TRY(tg_colsum(Bw->part, 4 * dq, g, 4 * dq, vec, 0, stream));          // [dgamma | dbeta | sum dsum | sum dres]
-        TG_HIP_CHECK(hipMemcpyAsync(G.ln_g, vec, sizeof(float) * dq, hipMemcpyDeviceToDevice, s));
-        TG_HIP_CHECK(hipMemcpyAsync(G.ln_b, vec + dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, s));
-        TG_HIP_CHECK(hipMemcpyAsync(G.br, vec + 3 * dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, s));
-        vec_add_kernel<<<1, 256, 0, s>>>(Bw->d_cosb, vec + 2 * dq + dn, T);          // d cos(b) from the residual's time half
-        TG_TRY(tg::launch_status("vec_add_kernel"));
-        // ---- output projection ------------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32(0, 0, R, dq, dq, 1.f, dres, dq, P.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
     }
+    if (overlap) TG_TRY(g_side.fork(s));                           // dres / dsum and the LayerNorm slabs are final
+    TG_TRY(tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 0, wstream));
+    TG_TRY(tg_colsum(part_ln, 4 * dq, ln_grid, 4 * dq, vec_ln, 0, wstream));     // [dgamma | dbeta | sum dsum | sum dres]
+    TG_HIP_CHECK(hipMemcpyAsync(G.ln_g, vec_ln, sizeof(float) * dq, hipMemcpyDeviceToDevice, ws_));
+    TG_HIP_CHECK(hipMemcpyAsync(G.ln_b, vec_ln + dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, ws_));
+    TG_HIP_CHECK(hipMemcpyAsync(G.br, vec_ln + 3 * dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, ws_));
+    vec_add_kernel<<<1, 256, 0, ws_>>>(Bw->d_cosb, vec_ln + 2 * dq + dn, T);   // d cos(b) from the residual's time half
+    TG_TRY(tg::launch_status("vec_add_kernel"));
+    // ---- output projection ------------------------------------------------------------------------------------------------------
+    TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
     // ---- value path -------------------------------------------------------------------------------------------------------------
     if (overlap) TG_TRY(g_side.fork(s));                           // dctx is final
     TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 0, wstream));
-    TG_TRY(tg_gemm_f32_batched(0, 0, R, dk, hd, 1.f, Bw->dctx, dq, hd, P.Wv, dk, (int64_t)hd * dk, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
     // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
-    TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, Bw->part, stream));
-    if (overlap) TG_TRY(g_side.fork(s));                           // du is final
+    TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
+    if (overlap) TG_TRY(g_side.fork(s));                           // du and the time-encoder slabs are final
     TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 0, wstream));
-    {
-        const int parts = tg_attn_bwd_parts(R);
-        float* tv = vec + 4 * dq;
-        TG_TRY(tg_colsum(Bw->part, 2 * T, parts, 2 * T, tv, 0, stream));
-        vec_add_kernel<<<1, 256, 0, s>>>(Bw->d_tew, tv, T);
-        vec_add_kernel<<<1, 256, 0, s>>>(Bw->d_teb, tv + T, T);
-        TG_TRY(tg::launch_status("vec_add_kernel"));
-    }
+    TG_TRY(tg_colsum(part_attn, 2 * T, attn_parts, 2 * T, vec_te, 0, wstream));
+    vec_add_kernel<<<1, 256, 0, ws_>>>(Bw->d_tew, vec_te, T);
+    vec_add_kernel<<<1, 256, 0, ws_>>>(Bw->d_teb, vec_te + T, T);
+    TG_TRY(tg::launch_status("vec_add_kernel"));
     // ---- key / query path --------------------------------------------------------------------------------------------------------
     TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
     if (overlap) TG_TRY(g_side.fork(s));                           // dq is final
     TG_TRY(tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 0, wstream));
-    TG_TRY(tg_colsum(Bw->dq, dq, R, dq, vec, 0, stream));                                  // sum_rows dq
-    outer_kernel<<<ew_grid((int64_t)dq * T), 256, 0, s>>>(vec, dq, L->cosb, T, G.Wq + dn, dq);
+    TG_TRY(tg_colsum(Bw->dq, dq, R, dq, vec_dq, 0, wstream));                              // sum_rows dq
+    outer_kernel<<<ew_grid((int64_t)dq * T), 256, 0, ws_>>>(vec_dq, dq, L->cosb, T, G.Wq + dn, dq);
     TG_TRY(tg::launch_status("outer_kernel"));
-    TG_TRY(tg_gemm_f32(0, 0, 1, T, dq, 1.f, vec, dq, P.Wq + dn, dq, Bw->d_cosb, T, nullptr, 0, 1, stream));   // += (sum dq) Wq[:, dn:]
+    TG_TRY(tg_gemm_f32(0, 0, 1, T, dq, 1.f, vec_dq, dq, P.Wq + dn, dq, Bw->d_cosb, T, nullptr, 0, 1, wstream));   // += (sum dq) Wq[:, dn:]
     if (Bw->d_own) {
-        TG_TRY(tg_gemm_f32(0, 0, R, dn, dq, 1.f, Bw->dq, dq, P.Wq, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
+        TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
         add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
         TG_TRY(tg::launch_status("add_cols_kernel"));
     }

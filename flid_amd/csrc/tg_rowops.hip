@@ -216,8 +216,9 @@ __global__ void __launch_bounds__(256) time_encode_bwd_kernel(const float* __res
         part[(int64_t)blockIdx.x * 2 * dim + j] = red[j] + red[2 * dim + j] + red[4 * dim + j] + red[6 * dim + j];
 }
 
-float* g_colsum_ws = nullptr;
-size_t g_colsum_ws_floats = 0;
+// scratch for the two-pass column sums, one per stream that uses them (the layer backward runs them on two streams)
+struct ColsumWs { hipStream_t stream; float* p; size_t floats; };
+ColsumWs g_colsum_ws[4] = {};
 
 }  // namespace
 
@@ -273,13 +274,18 @@ extern "C" int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, floa
     hipStream_t s = (hipStream_t)stream;
     int slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, n / 32));
     const size_t need = (size_t)slices * cols;
-    if (need > g_colsum_ws_floats) {   // grows rarely; never inside a captured region after warm-up
-        if (g_colsum_ws) (void)hipFree(g_colsum_ws);
-        g_colsum_ws_floats = std::max<size_t>(need, 256 * 1024);
-        TG_HIP_CHECK(hipMalloc(&g_colsum_ws, g_colsum_ws_floats * sizeof(float)));
+    ColsumWs* w = nullptr;
+    for (auto& c : g_colsum_ws) if (c.p && c.stream == s) { w = &c; break; }
+    if (!w) for (auto& c : g_colsum_ws) if (!c.p) { w = &c; w->stream = s; break; }
+    TG_REQUIRE(w, "tg_colsum: called from more than 4 distinct streams");
+    if (need > w->floats) {   // grows rarely; never inside a captured region after warm-up
+        if (w->p) { TG_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(w->p); }
+        w->floats = std::max<size_t>(need, 512 * 1024);
+        TG_HIP_CHECK(hipMalloc(&w->p, w->floats * sizeof(float)));
     }
-    colsum_partial_kernel<<<dim3((cols + 63) / 64, slices), 256, 0, s>>>(d_x, ld, n, cols, g_colsum_ws);
-    colsum_final_kernel<<<(cols + 63) / 64, 256, 0, s>>>(g_colsum_ws, slices, cols, d_out, accumulate);
+    float* g_ws = w->p;
+    colsum_partial_kernel<<<dim3((cols + 63) / 64, slices), 256, 0, s>>>(d_x, ld, n, cols, g_ws);
+    colsum_final_kernel<<<(cols + 63) / 64, 256, 0, s>>>(g_ws, slices, cols, d_out, accumulate);
     return tg::launch_status("colsum kernels");
 }
 

@@ -288,14 +288,15 @@ class _NativeLayer:
     """buffers + C descriptors of one tg_tgat_layer_fwd/bwd call pair"""
 
     def __init__(self, attn: ops.AttnArgs, params, own, raw, cosb, p_res, seed_res):
-        from ._lib import LayerDesc, LayerParams
+        from ._lib import LayerDesc, LayerParams, lib
         dev = own.device
         R, H, Dn, T, Dk = attn.m, attn.heads, attn.dn, attn.dt_dim, attn.dk
         Dq = Dn + T
         self.attn, self.R, self.dims = attn, R, (H, Dn, T, Dq, Dk)
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         self.buf = dict(qbias=e(Dq), q=e(R, Dq), u=e(R, H, Dk), agg=e(R, H, Dk), prob=e(R, H, attn.k), ctx=e(R, Dq), res=e(R, Dq),
-                        y=e(R, Dq), mean=e(R), rstd=e(R), f1=e(R, Dn), out=e(R, Dn))
+                        y=e(R, Dq), mean=e(R), rstd=e(R), f1=e(R, Dn), out=e(R, Dn),
+                        wT=e(int(lib().tg_tgat_layer_wt_floats(Dn, Dq, Dk))))
         self.keep = (params, own, raw, cosb)
         d = LayerDesc()
         d.attn = attn.desc
@@ -322,7 +323,7 @@ class _NativeLayer:
         grads = [torch.empty_like(p) for p in params]
         ws = dict(df1=e(R, Dn), dy=e(R, Dq), dsum=e(R, Dq), dres=e(R, Dq) if self.desc.res_dropout_p > 0 else None, dctx=e(R, Dq),
                   dagg=e(R, H, Dk), du=e(R, H, Dk), dq=e(R, Dq),
-                  part=e(int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T))), vec=e(4 * Dq + 2 * T))
+                  part=e(int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T))), vec=e(5 * Dq + 2 * T))
         d_raw = e(R, Dn) if want_d_raw else None
         b = LayerBwdDesc()
         b.grads = LayerParams(*[ops._p(t) for t in grads])
@@ -406,12 +407,62 @@ class _EmbedFnNative(torch.autograd.Function):
         return (None, None, d_table, d_tew.view_as(te_w), d_teb, *grads)
 
 
+@dataclass
+class PreparedFrontier:
+    """Neighbor lookups + row sharing of one batch, done ahead of time on a side stream (they depend on the graph only, not
+    on the weights): the data-loader style prefetch that keeps the one small readback of the step (the number of distinct
+    rows) off the critical path."""
+    frontier: Frontier
+    ready: "torch.cuda.Event"
+    graph: TemporalGraph
+    n: int
+    k: int
+    num_layers: int
+
+
+_prefetch_stream = None
+
+
+def prepare_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torch.Tensor, k: int, num_layers: int,
+                     inputs_ready: bool = True) -> PreparedFrontier:
+    """ids int32 / times float64 already on the device.  Runs on an internal side stream; embed() waits for it.
+    inputs_ready=False makes the side stream first wait for everything queued on the current stream (needed only when the
+    ids were produced by kernels still in flight there -- it also drags the step's readback behind that work)."""
+    global _prefetch_stream
+    if _prefetch_stream is None:
+        _prefetch_stream = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    if not inputs_ready:
+        _prefetch_stream.wait_stream(main)
+    with torch.cuda.stream(_prefetch_stream):
+        # lists of tensors are concatenated HERE, on the side stream: a cat issued on the busy main stream would not have
+        # run yet when the side stream reads its result
+        if isinstance(ids_dev, (list, tuple)):
+            ids_dev, times_dev = torch.cat(list(ids_dev)), torch.cat(list(times_dev))
+        fr = sample_frontier(graph, ids_dev.to(torch.int32).contiguous(), times_dev.contiguous(), k, num_layers, dedupe=DEDUPE)
+        ev = torch.cuda.Event()
+        ev.record()
+    for t in (fr.ids_all, fr.child) + tuple(fr.S):            # allocated on the side stream, consumed on the main stream
+        if t is not None:
+            t.record_stream(main)
+    return PreparedFrontier(fr, ev, graph, ids_dev.numel(), k, num_layers)
+
+
 def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, te_w, te_b, layer_params, ids: np.ndarray,
           times: np.ndarray, k: int, num_layers: int, num_heads: int, dropout: float, training: bool,
           table_requires_grad: bool = False):
-    """H^L for `ids` at `times` (host numpy in, device tensor out, autograd-connected to the parameters)."""
+    """H^L for `ids` at `times` (host numpy in, device tensor out, autograd-connected to the parameters).
+    `ids` may also be a PreparedFrontier (prepare_frontier): the neighbor lookups of that batch were already done."""
     dev = table.device
     assert k > 0, 'Number of sampled neighbors for each node should be greater than 0!'
+    if isinstance(ids, PreparedFrontier):
+        pf = ids
+        assert pf.k == k and pf.num_layers == num_layers and pf.graph is graph, "prepared for a different sampler / k / depth"
+        torch.cuda.current_stream().wait_event(pf.ready)
+        cfg = dict(n=pf.n, k=k, num_layers=num_layers, num_heads=num_heads, dropout=float(dropout), training=bool(training),
+                   edge_table=edge_table, table_grad=bool(table_requires_grad))
+        fn = _EmbedFnNative if NATIVE else _EmbedFn
+        return fn.apply(cfg, pf.frontier, table, te_w, te_b, *layer_params)
     if torch.is_tensor(ids):
         # already resident in HBM (int32 ids, float64/float32 times): the caller vouches for the id range
         ids_dev, times_dev = ids.to(device=dev, dtype=torch.int32).contiguous(), times.to(dev).contiguous()

@@ -45,6 +45,9 @@ class TGAT(nn.Module):
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray,
                                                  node_interact_times: np.ndarray, num_neighbors: int = 20):
         # both sides share one device pass: rows are independent (reference computes them one after the other, :61-65)
+        if isinstance(src_node_ids, engine.PreparedFrontier):
+            emb = self.compute_node_temporal_embeddings(src_node_ids, None, self.num_layers, num_neighbors)
+            return emb[:src_node_ids.nsrc], emb[src_node_ids.nsrc:]
         nsrc = len(src_node_ids)
         if torch.is_tensor(src_node_ids):          # ids/times already in HBM (bench, fused trainers)
             ids = torch.cat([src_node_ids, dst_node_ids])
@@ -54,6 +57,15 @@ class TGAT(nn.Module):
             times = np.concatenate([node_interact_times, node_interact_times])
         emb = self.compute_node_temporal_embeddings(ids, times, self.num_layers, num_neighbors)
         return emb[:nsrc], emb[nsrc:]
+
+    def prepare_batch(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20):
+        """Optional prefetch (not in the reference): do the sampler work of a FUTURE batch now, on a side stream.  Takes
+        device tensors (int32 ids, float64 times); pass the result as `src_node_ids` of compute_src_dst_node_temporal_embeddings
+        (dst / times may then be None)."""
+        pf = engine.prepare_frontier(self.neighbor_sampler.graph, [src_node_ids, dst_node_ids], [node_interact_times, node_interact_times],
+                                     num_neighbors, self.num_layers)
+        pf.nsrc = src_node_ids.numel()
+        return pf
 
     def compute_node_temporal_embeddings(self, node_ids: np.ndarray, node_interact_times: np.ndarray,
                                          current_layer_num: int, num_neighbors: int = 20):

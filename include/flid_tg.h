@@ -139,11 +139,12 @@ typedef struct tg_layer_desc {
     const float* cosb;
     float res_dropout_p; uint64_t res_seed;      /* dropout after residual_fc (modules.py:235) */
     float *qbias, *q, *u, *agg, *prob, *ctx, *res, *y, *mean, *rstd, *f1, *out;
+    float* wT;   /* tg_tgat_layer_wt_floats(dn, dq, dk) floats: transposed weights, written by fwd, read by bwd of the same step */
 } tg_layer_desc;
 /* backward: dout (R, dn) in; grads.* are OVERWRITTEN with this layer's parameter gradients; d_cosb / d_tew / d_teb (dt_dim)
  * are ACCUMULATED into (caller zeroes them once per call); dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional
  * gradient w.r.t. own (accumulated into if d_own_accumulate); d_raw (R, dn) optional gradient w.r.t. raw.
- * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats), vec (4 dq + 2 dt_dim). */
+ * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats), vec (5 dq + 2 dt_dim). */
 typedef struct tg_layer_bwd_desc {
     tg_layer_grads grads;
     const float* dout;
@@ -154,6 +155,7 @@ typedef struct tg_layer_bwd_desc {
     float* d_raw;
 } tg_layer_bwd_desc;
 int tg_tgat_layer_fwd(const tg_layer_desc* layer, void* stream);
+int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk);
 int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim);
 int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, void* stream);
 /* weight-gradient products of tg_tgat_layer_bwd on an internal side stream (default on); they are joined before it returns */
@@ -167,6 +169,12 @@ void tg_set_overlap(int on);
 int tg_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda,
                 const float* d_B, int64_t ldb, float* d_C, int64_t ldc, const float* d_bias, int relu, int accumulate,
                 void* stream);
+
+/* Precision of the products whose operands are both k-contiguous (ta = 0, tb = 1: activations times a weight given as N x K):
+ * mode 1 (default) = split-bf16, three bf16 MFMAs per product with fp32 accumulation, relative error ~4e-6 per product
+ * (|emb - reference| 1.6e-5 on the full-dimension golden case); mode 0 = exact fp32 (f32-input MFMA) everywhere. */
+void tg_set_gemm_mode(int mode);
+int tg_get_gemm_mode(void);
 
 /* strided-batched form: problem b uses A + b*stride_a, B + b*stride_b, C + b*stride_c (bias + b*N).  One launch for the
  * per-head products of models/modules.py:186-197 (head h = column / row block h of the projection weights). */

@@ -163,8 +163,24 @@ def test_native_layer_path_equals_op_by_op_path():
             outs.append((s.detach().cpu(), d.detach().cpu(), {k_: v.grad.cpu() for k_, v in m.named_parameters()}))
         finally:
             engine.NATIVE = True
-    np.testing.assert_allclose(outs[0][0].numpy(), outs[1][0].numpy(), atol=2e-6)
-    np.testing.assert_allclose(outs[0][1].numpy(), outs[1][1].numpy(), atol=2e-6)
+    np.testing.assert_allclose(outs[0][0].numpy(), outs[1][0].numpy(), atol=5e-5)   # different products run split-bf16 in the two paths
+    np.testing.assert_allclose(outs[0][1].numpy(), outs[1][1].numpy(), atol=5e-5)
     for k_ in outs[0][2]:
         ref = outs[1][2][k_].numpy()
-        np.testing.assert_allclose(outs[0][2][k_].numpy(), ref, atol=3e-5 * max(1.0, np.abs(ref).max()), err_msg=k_)
+        np.testing.assert_allclose(outs[0][2][k_].numpy(), ref, atol=2e-4 * max(1.0, np.abs(ref).max()), err_msg=k_)
+
+
+def test_prepared_batch_equals_direct_call():
+    """sampler work prefetched on the side stream (TGAT.prepare_batch) gives the same embeddings as the plain call"""
+    g = load_golden("tgat_L2_K20")
+    m, p, k = _model(g)
+    m.eval()
+    dev = torch.device("cuda:0")
+    src, dst = (torch.from_numpy(g[x].astype(np.int32)).to(dev) for x in ("bs", "bd"))
+    t = torch.from_numpy(g["bt"]).to(dev)
+    with torch.no_grad():
+        s0, d0 = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+        pf = m.prepare_batch(src, dst, t, k)
+        s1, d1 = m.compute_src_dst_node_temporal_embeddings(pf, None, None, k)
+        s2, d2 = m.compute_src_dst_node_temporal_embeddings(src, dst, t, k)
+    assert torch.equal(s0, s1) and torch.equal(d0, d1) and torch.equal(s0, s2) and torch.equal(d0, d2)
