@@ -7,7 +7,8 @@
 // (SURVEY.md 8d "fp32 MFMA rate"), this lifts it by 5x for the products whose operands are k-contiguous.
 // Measured accuracy on the full-dimension golden case: |emb - reference| = 1.6e-5 (exact-fp32 path: 7e-7; budget 1e-4).
 //
-// Workgroup = 4 waves stacked along M, block tile 128 x 64; each wave owns 32 x 64 (two 32x32 tiles sharing the A fragment).
+// Workgroup = 4 waves stacked along M, block tile 128 x 96 (or 128 x 64); each wave owns 32 x 96 (three 32x32 tiles sharing the
+// A fragment).
 // Staging: global fp32 (full 128-B lines) -> split in registers -> LDS row = [32 x bf16 hi | 32 x bf16 lo] (+16 B pad, stride
 // 144 B, conflict-free ds_read_b128) -> fragments.  Two LDS stages, one barrier per 32-deep stage, global loads of stage s+2
 // in flight under stage s.
@@ -20,7 +21,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;
 constexpr int ROW_BYTES = 144;                 // 64 B hi + 64 B lo + 16 B pad
-constexpr int BM = 128, BN = 64, NT = 256;
+constexpr int BM = 128, NT = 256;
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -94,10 +95,13 @@ __device__ __forceinline__ void read_frag(const char* __restrict__ s, int tile_r
     lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p + 64));
 }
 
+// TNW = 32-column tiles per wave (block tile 128 x 32*TNW): 3 fits N = 272 / 172 / 444 (-> 288 / 192 / 480), 2 fits N <= 64k+..
+template <int TNW>
 __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
         const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int relu,
         int accumulate, int gx, int gy, int64_t strideA, int64_t strideB, int64_t strideC) {
-    constexpr int FA = BM * ROW_BYTES, FB = BN * ROW_BYTES;
+    constexpr int BNt = 32 * TNW;
+    constexpr int FA = BM * ROW_BYTES, FB = BNt * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
     auto sA = [&](int i) -> char* { return lds + i * (FA + FB); };
     auto sB = [&](int i) -> char* { return lds + i * (FA + FB) + FA; };
@@ -110,71 +114,77 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
     A += batch * strideA; B += batch * strideB; C += batch * strideC;
     if (bias) bias += batch * (int64_t)N;
 
-    const int64_t bm = (int64_t)by * BM, bn = (int64_t)bx * BN;
+    const int64_t bm = (int64_t)by * BM, bn = (int64_t)bx * BNt;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool live0 = (bm + wave * 32 < M) && (bn < N), live1 = (bm + wave * 32 < M) && (bn + 32 < N);
-
-    f32x16 acc0, acc1;
+    bool live[TNW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int t = 0; t < TNW; ++t) live[t] = (bm + wave * 32 < M) && (bn + 32 * t < N);
+
+    f32x16 acc[TNW];
+#pragma unroll
+    for (int t = 0; t < TNW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     Panel<BM> pa;
-    Panel<BN> pb;
+    Panel<BNt> pb;
     pa.init(A, lda, bm, M, 0);
     pb.init(B, ldb, bn, N, 0);
-    float4 ra[Panel<BM>::PER], rb[Panel<BN>::PER];
+    // two register sets: the loads of stage s+2 and s+3 are in flight while stage s computes (the stages are short -- 12..18
+    // bf16 MFMAs -- so one stage of look-ahead does not cover an L2 round trip)
+    float4 ra0[Panel<BM>::PER], rb0[Panel<BNt>::PER], ra1[Panel<BM>::PER], rb1[Panel<BNt>::PER];
     const int64_t nstage = (K + BK - 1) / BK, nfull = K / BK;
-    if (nstage > 0) {
-        pa.gload(0, 0, K, nfull > 0, ra);
-        pb.gload(0, 0, K, nfull > 0, rb);
-        pa.sstore(sA(0), ra);
-        pb.sstore(sB(0), rb);
-        __syncthreads();
-        if (nstage > 1) {
-            pa.gload(BK, BK, K, nfull > 1, ra);
-            pb.gload(BK, BK, K, nfull > 1, rb);
+    auto issue = [&](int64_t st, float4 (&ra)[Panel<BM>::PER], float4 (&rb)[Panel<BNt>::PER]) {
+        if (st < nstage) {
+            pa.gload(st * BK, st * BK, K, st < nfull, ra);
+            pb.gload(st * BK, st * BK, K, st < nfull, rb);
         }
-    }
-    for (int64_t st = 0; st < nstage; ++st) {
+    };
+    auto stage = [&](int64_t st, float4 (&ra)[Panel<BM>::PER], float4 (&rb)[Panel<BNt>::PER]) {
+        // on entry LDS[st & 1] holds stage st and (ra, rb) hold stage st + 1
         const int cur = (int)(st & 1);
-        bf16x8 ah[2], al[2], b0h[2], b0l[2], b1h[2], b1l[2];
+        bf16x8 ah[2], al[2], bh[TNW][2], bl[TNW][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             read_frag(sA(cur), wave * 32, ks, ah[ks], al[ks]);
-            read_frag(sB(cur), 0, ks, b0h[ks], b0l[ks]);
-            read_frag(sB(cur), 32, ks, b1h[ks], b1l[ks]);
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) read_frag(sB(cur), 32 * t, ks, bh[t][ks], bl[t][ks]);
         }
         if (st + 1 < nstage) {
             pa.sstore(sA(cur ^ 1), ra);
             pb.sstore(sB(cur ^ 1), rb);
         }
-        if (st + 2 < nstage) {
-            pa.gload((st + 2) * BK, (st + 2) * BK, K, st + 2 < nfull, ra);
-            pb.gload((st + 2) * BK, (st + 2) * BK, K, st + 2 < nfull, rb);
-        }
-        if (live0) {
+        issue(st + 3, ra, rb);                        // this register set is free again
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b0h[ks], acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0l[ks], acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0h[ks], acc0, 0, 0, 0);
-            }
-        }
-        if (live1) {
+        for (int t = 0; t < TNW; ++t) {
+            if (live[t]) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b1h[ks], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1l[ks], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1h[ks], acc1, 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[t][ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[t][ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[t][ks], acc[t], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
+    };
+    if (nstage > 0) {
+        issue(0, ra0, rb0);
+        pa.sstore(sA(0), ra0);
+        pb.sstore(sB(0), rb0);
+        issue(1, ra0, rb0);
+        issue(2, ra1, rb1);
+        __syncthreads();
+    }
+    for (int64_t st = 0; st < nstage; st += 2) {
+        stage(st, ra0, rb0);
+        if (st + 1 < nstage) stage(st + 1, ra1, rb1);
     }
 
     // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int rl = lane & 31, kh = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TNW; ++t) {
         const int64_t col = bn + t * 32 + rl;
         if (col >= N) continue;
         const float bv = bias ? bias[col] : 0.f;
@@ -182,7 +192,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
         for (int r = 0; r < 16; ++r) {
             const int64_t row = bm + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (row >= M) continue;
-            float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+            float v = acc[t][r] + bv;
             float* p = C + row * ldc + col;
             if (accumulate) v += *p;
             if (relu) v = fmaxf(v, 0.f);
@@ -203,12 +213,17 @@ bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
                     hipStream_t s) {
     if (!(al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0)) return false;
     if (M < 1 || N < 1 || K < 8 || nbatch > 65535) return false;
-    const int64_t gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+    // column block 96 or 64: the smaller padded N wins (272 -> 288, 172 -> 192, 444 -> 480, 136 -> 192 either way), ties to 96
+    const int64_t pad3 = (N + 95) / 96 * 96, pad2 = (N + 63) / 64 * 64;
+    const int tnw = pad3 <= pad2 ? 3 : 2;
+    const int64_t gx = (N + 32 * tnw - 1) / (32 * tnw), gy = (M + BM - 1) / BM;
     if (gx * gy >= ((int64_t)1 << 30)) return false;
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     const dim3 grid((unsigned)(gx * gy), 1, (unsigned)nbatch);
-    gemm_bf16x3_nt_kernel<<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA,
-                                              strideB, strideC);
+    if (tnw == 3)
+        gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC);
+    else
+        gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC);
     return true;
 }
 

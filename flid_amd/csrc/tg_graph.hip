@@ -214,10 +214,29 @@ __device__ __forceinline__ uint32_t hash_pair(uint64_t k) {
 __global__ void __launch_bounds__(256) dedupe_insert_kernel(const int32_t* __restrict__ ids, const float* __restrict__ t, int64_t n,
         uint32_t mask, unsigned long long* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ pos,
         int32_t* __restrict__ out_ids, float* __restrict__ out_t, int32_t* __restrict__ count_pad) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t id = ids[i];
-        const float tt = t[i];
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool in = i < n;
+        const int32_t id = in ? ids[i] : -1;
+        const float tt = in ? t[i] : 0.f;
         const unsigned long long key = ((unsigned long long)(uint32_t)id << 32) | (unsigned long long)__float_as_uint(tt);
+        // The padding pair (0, +0.0f) is a fifth of all slots: it bypasses the table (thousands of CAS on one slot would
+        // serialise); one lane per wave claims its row through count_pad[1] (-1 = unclaimed, -2 = being claimed).
+        const bool is_pad = in && key == 0ULL;
+        const unsigned long long pad_lanes = __ballot(is_pad);
+        if (is_pad) {
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)pad_lanes) - 1) {
+                if (atomicCAS(&count_pad[1], -1, -2) == -1) {
+                    const int32_t idx = atomicAdd(&count_pad[0], 1);
+                    out_ids[idx] = 0;
+                    out_t[idx] = 0.f;
+                    atomicExch(&count_pad[1], idx);
+                }
+            }
+            pos[i] = -1;
+            continue;
+        }
+        if (!in) continue;
         uint32_t h = hash_pair(key) & mask;
         while (true) {
             const unsigned long long prev = atomicCAS(&keys[h], ~0ULL, key);
@@ -226,7 +245,6 @@ __global__ void __launch_bounds__(256) dedupe_insert_kernel(const int32_t* __res
                 vals[h] = idx;
                 out_ids[idx] = id;
                 out_t[idx] = tt;
-                if (key == 0ULL) count_pad[1] = idx;   // the padding pair (0, +0.0f)
                 break;
             }
             if (prev == key) break;
@@ -236,9 +254,10 @@ __global__ void __launch_bounds__(256) dedupe_insert_kernel(const int32_t* __res
     }
 }
 __global__ void __launch_bounds__(256) dedupe_lookup_kernel(const int32_t* __restrict__ pos, const int32_t* __restrict__ vals, int64_t n,
-                                                            int32_t offset, int32_t* __restrict__ inv) {
+                                                            int32_t offset, const int32_t* __restrict__ count_pad,
+                                                            int32_t* __restrict__ inv) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        inv[i] = vals[pos[i]] + offset;
+        inv[i] = (pos[i] < 0 ? count_pad[1] : vals[pos[i]]) + offset;
 }
 
 inline int grid_for(int64_t work_items, int64_t per_block) {
@@ -296,6 +315,6 @@ extern "C" int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n
     if (n == 0) return TG_OK;
     dedupe_insert_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_ids, d_t, n, (uint32_t)(capacity - 1), (unsigned long long*)d_keys_ws, d_vals_ws,
                                                           d_pos_ws, d_out_ids, d_out_t, d_count_pad);
-    dedupe_lookup_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_pos_ws, d_vals_ws, n, row_offset, d_out_row);
+    dedupe_lookup_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_pos_ws, d_vals_ws, n, row_offset, d_count_pad, d_out_row);
     return tg::launch_status("dedupe kernels");
 }

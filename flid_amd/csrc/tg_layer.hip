@@ -317,7 +317,7 @@ extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
 }
 
 extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
-    const int64_t a = ((rows + 63) / 64) * dn;                       // ReLU-mask slabs
+    const int64_t a = ((rows + 15) / 16) * dn;                       // ReLU-mask slabs
     const int64_t b = row_grid(rows) * 4 * dq;                       // LayerNorm slabs
     const int64_t c = (int64_t)tg_attn_bwd_parts(rows) * 2 * dt_dim; // time-encoder slabs
     return 16 + a + b + c;                                            // disjoint regions: they are consumed concurrently
@@ -339,7 +339,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     void* wstream = overlap ? (void*)g_side.side : stream;        // where everything that only feeds parameter gradients goes
     hipStream_t ws_ = (hipStream_t)wstream;
     // slab regions of `part` (each finished on the side stream while the main chain moves on)
-    const int64_t relu_blocks = (R + 63) / 64;
+    const int64_t relu_blocks = (R + 15) / 16;
     const unsigned ln_grid = (unsigned)row_grid(R);
     const int attn_parts = tg_attn_bwd_parts(R);
     float* part_relu = Bw->part;
@@ -354,8 +354,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     TG_TRY(tg_colsum(Bw->dout, dn, R, dn, G.b2, 0, wstream));
     TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
     TG_REQUIRE(dn <= 1024, "tg_tgat_layer_bwd: node dim > 1024 unsupported");
-    if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 64, part_relu);
-    else relu_bwd_colsum_kernel<4><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 64, part_relu);
+    if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
+    else relu_bwd_colsum_kernel<4><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
     TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
     if (overlap) TG_TRY(g_side.fork(s));                           // df1 and its slabs are final
     TG_TRY(tg_colsum(part_relu, dn, relu_blocks, dn, G.b1, 0, wstream));
