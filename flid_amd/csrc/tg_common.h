@@ -92,14 +92,21 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
     for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
 }
 
-// cos / sin of a float32 phase that may reach millions of radians (time deltas up to a month in seconds times w ~ 1):
-// the phase is reduced to [-0.5, 0.5] revolutions in float64 (exact for |phase| < 2^52 / 2 pi), then the hardware
-// v_cos_f32 / v_sin_f32 (argument in revolutions) finish.  Replaces the generic cosf() whose large-argument path costs
-// ~100 VGPRs; absolute error ~1e-6, far below the 0.06..0.25 rad fp32 ulp of the phase itself.
+// cos / sin of a float32 phase that may reach millions of radians (time deltas up to a month in seconds times w ~ 1).
+// The phase is turned into revolutions with a two-term constant 1/(2 pi) = C_HI + C_LO in float32 only:
+//   p = fl(phase * C_HI), e = fma(phase, C_HI, -p) (exact rounding error), q = fma(phase, C_LO, e)
+//   fraction = (p - rint(p)) + q          -- p - rint(p) is exact, |q| <= ulp(p)
+// (error ~1e-8 revolutions for |phase| < 2^22), then the hardware v_cos_f32 / v_sin_f32 (argument in revolutions) finish.
+// Replaces the generic cosf() whose large-argument path costs ~100 VGPRs, and an earlier float64 reduction whose five
+// double-rate instructions per element made the attention kernels VALU-bound; absolute error ~1e-6, far below the
+// 0.06..0.25 rad float32 ulp of the phase itself.
 __device__ __forceinline__ float phase_to_rev(float phase) {
-    double r = (double)phase * 0.15915494309189535;   // 1 / (2 pi)
-    r -= __builtin_rint(r);
-    return (float)r;
+    constexpr float C_HI = 0.15915494f;                 // fl32(1 / (2 pi))
+    constexpr float C_LO = 6.4206383e-9f;               // 1 / (2 pi) - C_HI   (C_HI = 0.159154936671257019...)
+    const float p = __fmul_rn(phase, C_HI);
+    const float e = fmaf(phase, C_HI, -p);
+    const float q = fmaf(phase, C_LO, e);
+    return (p - rintf(p)) + q;
 }
 __device__ __forceinline__ float cos_phase(float phase) { return __builtin_amdgcn_cosf(phase_to_rev(phase)); }
 __device__ __forceinline__ void sincos_phase(float phase, float* s, float* c) {

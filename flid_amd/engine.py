@@ -281,6 +281,7 @@ class _EmbedFn(torch.autograd.Function):
         return (None, None, d_table, d_tew.view_as(te_w), d_teb, *grads)
 
 
+_SCRATCH = {}
 NATIVE = True     # one native call per layer (tg_tgat_layer_fwd/bwd); False = the op-by-op Python composition below (same kernels)
 
 
@@ -321,9 +322,19 @@ class _NativeLayer:
         R, dev = self.R, dout.device
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         grads = [torch.empty_like(p) for p in params]
-        ws = dict(df1=e(R, Dn), dy=e(R, Dq), dsum=e(R, Dq), dres=e(R, Dq) if self.desc.res_dropout_p > 0 else None, dctx=e(R, Dq),
-                  dagg=e(R, H, Dk), du=e(R, H, Dk), dq=e(R, Dq),
-                  part=e(int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T))), vec=e(5 * Dq + 2 * T))
+        # scratch that lives only inside this call is kept across steps (grown on demand); saved activations are NOT cached:
+        # a caller may run several forwards before one backward (positive + negative edges of the reference's trainers)
+        sizes = dict(df1=R * Dn, dy=R * Dq, dsum=R * Dq, dres=R * Dq if self.desc.res_dropout_p > 0 else 0, dctx=R * Dq,
+                     dagg=R * H * Dk, du=R * H * Dk, dq=R * Dq, part=int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)),
+                     vec=5 * Dq + 2 * T)
+        ws = {}
+        for name, need in sizes.items():
+            key = (dev, name)
+            buf = _SCRATCH.get(key)
+            if need and (buf is None or buf.numel() < need):
+                buf = torch.empty(int(need * 1.25) + 16, dtype=torch.float32, device=dev)
+                _SCRATCH[key] = buf
+            ws[name] = buf if need else None
         d_raw = e(R, Dn) if want_d_raw else None
         b = LayerBwdDesc()
         b.grads = LayerParams(*[ops._p(t) for t in grads])
