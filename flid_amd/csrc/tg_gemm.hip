@@ -25,6 +25,8 @@ namespace tg {
 bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
                     hipStream_t s);
+bool gemm_bf16x3_tn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                    int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, int accumulate, hipStream_t s);
 }
 
 namespace {
@@ -286,9 +288,14 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
 
     // A panel: k-contiguous when A is M x K (not transposed).  B panel: k-contiguous when B is given as N x K (tb).
     const bool a_kc = !ta, b_kc = tb != 0;
-    if (g_gemm_mode == 1 && a_kc && b_kc && inner == 1 && alpha == 1.f &&
+    if (g_gemm_mode >= 1 && a_kc && b_kc && inner == 1 && alpha == 1.f &&
         tg::gemm_bf16x3_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s))
         return tg::launch_status("gemm_bf16x3_nt_kernel");
+    // mode 2 also sends the weight-gradient form (A^T B) to the split-bf16 kernel: measured no faster than the exact kernel on
+    // these shapes (both are bound by the split-K fill / atomics, tools/gemm_bench5.py), so it stays opt-in
+    if (g_gemm_mode == 2 && ta && !tb && inner == 1 && alpha == 1.f && !d_bias && !relu &&
+        tg::gemm_bf16x3_tn(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, accumulate, s))
+        return tg::launch_status("gemm_bf16x3_tn_kernel");
     bool vec = al16(d_A) && al16(d_B) && lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 &&
                innerA % 4 == 0 && innerB % 4 == 0;
     vec = vec && (a_kc ? K % 4 == 0 : M % 4 == 0) && (b_kc ? K % 4 == 0 : N % 4 == 0);

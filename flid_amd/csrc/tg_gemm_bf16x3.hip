@@ -201,6 +201,147 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight-gradient form  C[M,N] (+)= A^T B  with A stored (K x M) and B stored (K x N), both row-major (the contraction index is
+// the ROW index of both operands: dW = dY^T X).  Each thread loads a 4(k) x 4(row) micro-tile with four coalesced 16-byte loads,
+// transposes it in registers and writes 4 consecutive k per output row as one 8-byte word -- the LDS image is the same
+// [row][32 x bf16 hi | 32 x bf16 lo] as above, so the fragment reads and the MFMA schedule are shared.  The contraction is
+// split over blockIdx.z and folded with float atomics (C zeroed by the launcher).
+template <int R>
+struct PanelT {
+    static constexpr int TILES = (R / 4) * 8;               // 4x4 micro-tiles: R/4 row groups x 8 k groups
+    const float* src;          // micro-tile origin at k = 0
+    int lds_off;               // byte offset of (row group, k group)
+    int kcol;
+    bool active;
+
+    __device__ __forceinline__ void init(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows) {
+        const int t = threadIdx.x;
+        active = t < TILES;
+        const int rg = t % (R / 4), kg = t / (R / 4);          // consecutive threads -> consecutive rows: 16-B coalesced
+        int64_t row = row0 + rg * 4;
+        if (row > nrows - 4) row = nrows - 4;                   // nrows % 4 == 0 (checked by the launcher)
+        if (row < 0) row = 0;
+        src = X + (int64_t)(kg * 4) * ld + row;
+        lds_off = (rg * 4) * ROW_BYTES + kg * 8;
+        kcol = kg * 4;
+    }
+    __device__ __forceinline__ void gload(int64_t ld, int64_t k0, int64_t kend, float4 (&reg)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active && k0 + kcol + i < kend) v = *reinterpret_cast<const float4*>(src + (k0 + i) * ld);
+            reg[i] = v;
+        }
+    }
+    __device__ __forceinline__ void sstore(char* __restrict__ s, const float4 (&reg)[4]) const {
+        if (!active) return;
+        const float c0[4] = {reg[0].x, reg[1].x, reg[2].x, reg[3].x};   // row +0: k = 0..3
+        const float c1[4] = {reg[0].y, reg[1].y, reg[2].y, reg[3].y};
+        const float c2[4] = {reg[0].z, reg[1].z, reg[2].z, reg[3].z};
+        const float c3[4] = {reg[0].w, reg[1].w, reg[2].w, reg[3].w};
+        const float* cols[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint2 hi, lo;
+            split4(make_float4(cols[r][0], cols[r][1], cols[r][2], cols[r][3]), hi, lo);
+            *reinterpret_cast<uint2*>(s + lds_off + r * ROW_BYTES) = hi;
+            *reinterpret_cast<uint2*>(s + lds_off + r * ROW_BYTES + 64) = lo;
+        }
+    }
+};
+
+template <int TNW>
+__global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
+        const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, int gx, int64_t k_chunk, int nsplit,
+        int use_atomics, int64_t strideA, int64_t strideB, int64_t strideC) {
+    constexpr int BNt = 32 * TNW;
+    constexpr int FA = BM * ROW_BYTES, FB = BNt * ROW_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
+    auto sA = [&](int i) -> char* { return lds + i * (FA + FB); };
+    auto sB = [&](int i) -> char* { return lds + i * (FA + FB) + FA; };
+    const int by = blockIdx.x / gx, bx = blockIdx.x % gx;
+    const int batch = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
+    A += batch * strideA; B += batch * strideB; C += batch * strideC;
+    const int64_t bm = (int64_t)by * BM, bn = (int64_t)bx * BNt;
+    const int64_t kbeg = (int64_t)split * k_chunk, kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    bool live[TNW];
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) live[t] = (bm + wave * 32 < M) && (bn + 32 * t < N);
+    f32x16 acc[TNW];
+#pragma unroll
+    for (int t = 0; t < TNW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    PanelT<BM> pa;
+    PanelT<BNt> pb;
+    pa.init(A, lda, bm, M);
+    pb.init(B, ldb, bn, N);
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    const int64_t nstage = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    auto issue = [&](int64_t st, float4 (&ra)[4], float4 (&rb)[4]) {
+        if (st < nstage) {
+            pa.gload(lda, kbeg + st * BK, kend, ra);
+            pb.gload(ldb, kbeg + st * BK, kend, rb);
+        }
+    };
+    auto stage = [&](int64_t st, float4 (&ra)[4], float4 (&rb)[4]) {
+        const int cur = (int)(st & 1);
+        bf16x8 ah[2], al[2], bh[TNW][2], bl[TNW][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            read_frag(sA(cur), wave * 32, ks, ah[ks], al[ks]);
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) read_frag(sB(cur), 32 * t, ks, bh[t][ks], bl[t][ks]);
+        }
+        if (st + 1 < nstage) {
+            pa.sstore(sA(cur ^ 1), ra);
+            pb.sstore(sB(cur ^ 1), rb);
+        }
+        issue(st + 3, ra, rb);
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) {
+            if (live[t]) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[t][ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[t][ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[t][ks], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    if (nstage > 0) {
+        issue(0, ra0, rb0);
+        pa.sstore(sA(0), ra0);
+        pb.sstore(sB(0), rb0);
+        issue(1, ra0, rb0);
+        issue(2, ra1, rb1);
+        __syncthreads();
+    }
+    for (int64_t st = 0; st < nstage; st += 2) {
+        stage(st, ra0, rb0);
+        if (st + 1 < nstage) stage(st + 1, ra1, rb1);
+    }
+    const int rl = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) {
+        const int64_t col = bn + t * 32 + rl;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = bm + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row >= M) continue;
+            float* p = C + row * ldc + col;
+            if (use_atomics) atomicAdd(p, acc[t][r]);
+            else *p = acc[t][r];
+        }
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -224,6 +365,36 @@ bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
         gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC);
     else
         gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC);
+    return true;
+}
+
+// C[M,N] = A^T B (A: K x M, B: K x N, row-major).  false = shape not handled (fall back to the f32-input kernel).
+bool gemm_bf16x3_tn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                    int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, int accumulate, hipStream_t s) {
+    if (!(al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0)) return false;
+    if (M < 4 || N < 4 || K < 64) return false;
+    const int64_t pad3 = (N + 95) / 96 * 96, pad2 = (N + 63) / 64 * 64;
+    const int tnw = pad3 <= pad2 ? 3 : 2;
+    const int64_t gx = (N + 32 * tnw - 1) / (32 * tnw), gy = (M + BM - 1) / BM;
+    // ~2 workgroups per CU, at least 8 stages each
+    int64_t splits = (512 + gx * gy * nbatch - 1) / (gx * gy * nbatch);
+    const int64_t max_splits = (K + 8 * BK - 1) / (8 * BK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int64_t k_chunk = (K + splits - 1) / splits;
+    k_chunk = (k_chunk + BK - 1) / BK * BK;
+    splits = (K + k_chunk - 1) / k_chunk;
+    if (splits * nbatch > 65535) return false;
+    const int atomics = splits > 1 || accumulate;
+    if (atomics && !accumulate)
+        for (int b = 0; b < nbatch; ++b)
+            if (hipMemset2DAsync(C + b * strideC, ldc * sizeof(float), 0, N * sizeof(float), M, s) != hipSuccess) return false;
+    ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
+    const dim3 grid((unsigned)(gx * gy), 1, (unsigned)(nbatch * splits));
+    if (tnw == 3)
+        gemm_bf16x3_tn_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, (int)gx, k_chunk, (int)splits, atomics, strideA, strideB, strideC);
+    else
+        gemm_bf16x3_tn_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, (int)gx, k_chunk, (int)splits, atomics, strideA, strideB, strideC);
     return true;
 }
 

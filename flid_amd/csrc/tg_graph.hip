@@ -13,10 +13,11 @@ static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 
 struct ProfRec { std::string tag; double units; hipEvent_t a, b; };
-static bool g_prof_on = false;
+static int g_prof_mask = 0;   // bit 0 attn_fwd, bit 1 attn_bwd, bit 2 gemm
+static int prof_bit(const char* tag) { return tag[0] == 'g' ? 4 : (tag[5] == 'f' ? 1 : 2); }
 static std::vector<ProfRec> g_prof;
 ProfScope::ProfScope(const char* tag, double units, hipStream_t s) : slot(-1), stream(s) {
-    if (!g_prof_on) return;
+    if (!(g_prof_mask & prof_bit(tag))) return;
     ProfRec r{tag, units, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
@@ -28,7 +29,7 @@ ProfScope::~ProfScope() {
 }
 }  // namespace tg
 
-extern "C" void tg_profile_enable(int on) { tg::g_prof_on = on != 0; }
+extern "C" void tg_profile_enable(int mask) { tg::g_prof_mask = mask; }
 
 // Sum of elapsed ms / units / launches recorded under `tag` since the last reset.  Synchronises the device.
 extern "C" int tg_profile_collect(const char* tag, double* ms, double* units, int64_t* count, int reset) {

@@ -329,8 +329,15 @@ def time_encode_bwd(t, mask_ids, w, b, g):
     return s[:dim], s[dim:]
 
 
-def profile_enable(on: bool):
-    lib().tg_profile_enable(int(on))
+PROFILE_TAGS = {"attn_fwd": 1, "attn_bwd": 2, "gemm": 4}
+
+
+def profile_enable(on):
+    """on: False / True (all families) / a tag name / an iterable of tag names"""
+    if isinstance(on, str):
+        on = (on,)
+    mask = (7 if on else 0) if isinstance(on, (bool, int)) else sum(PROFILE_TAGS[t] for t in on)
+    lib().tg_profile_enable(int(mask))
 
 
 def profile_collect(tag: str, reset=True):

@@ -28,8 +28,9 @@ const char* tg_last_error(void);
 int tg_version(void);
 
 /* optional HIP-event timing of the kernel families "attn_fwd", "attn_bwd" (units = algorithmic bytes) and "gemm"
- * (units = flops), recorded on the launch stream; tg_profile_collect synchronises the device. */
-void tg_profile_enable(int on);
+ * (units = flops), recorded on the launch stream; tg_profile_collect synchronises the device.
+ * mask: bit 0 = attn_fwd, bit 1 = attn_bwd, bit 2 = gemm (7 = all, 0 = off). */
+void tg_profile_enable(int mask);
 int tg_profile_collect(const char* tag, double* ms, double* units, int64_t* count, int reset);
 
 /* ---- temporal adjacency ---------------------------------------------------------------------------
@@ -172,7 +173,8 @@ int tg_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, co
 
 /* Precision of the products whose operands are both k-contiguous (ta = 0, tb = 1: activations times a weight given as N x K):
  * mode 1 (default) = split-bf16, three bf16 MFMAs per product with fp32 accumulation, relative error ~4e-6 per product
- * (|emb - reference| 1.6e-5 on the full-dimension golden case); mode 0 = exact fp32 (f32-input MFMA) everywhere. */
+ * (|emb - reference| 1.6e-5 on the full-dimension golden case); mode 2 = additionally the weight-gradient form (ta = 1, tb = 0);
+ * mode 0 = exact fp32 (f32-input MFMA) everywhere. */
 void tg_set_gemm_mode(int mode);
 int tg_get_gemm_mode(void);
 

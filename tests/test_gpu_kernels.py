@@ -184,6 +184,25 @@ def test_gemm_exact_mode_matches_fp32_chain(dev):
     assert outs[0] < 1e-4 and outs[1] < 2e-3 and outs[0] < outs[1]
 
 
+def test_gemm_split_bf16_weight_gradient_form(dev):
+    """mode 2: A^T B on the split-bf16 kernel (register-transposed staging), vs fp64"""
+    from flid_amd import ops
+    from flid_amd._lib import lib
+    rs = np.random.RandomState(11)
+    lib().tg_set_gemm_mode(2)
+    try:
+        for (M, N, K) in ((272, 444, 5000), (172, 172, 1200), (136, 444, 12235), (272, 172, 333)):
+            a = torch.from_numpy(rs.standard_normal((K, M)).astype(np.float32)).to(dev)
+            b = torch.from_numpy(rs.standard_normal((K, N)).astype(np.float32)).to(dev)
+            out = torch.full((M, N), 3.0, device=dev)
+            ops.gemm(a, b, out, ta=True)
+            ref = a.double().cpu().T @ b.double().cpu()
+            mag = a.abs().double().cpu().T @ b.abs().double().cpu()
+            assert torch.all((out.cpu().double() - ref).abs() <= 2e-5 * mag + 1e-4), (M, N, K)
+    finally:
+        lib().tg_set_gemm_mode(1)
+
+
 def test_gemm_strided_views(dev):
     """column-sliced weights / per-head slices as the engine passes them (leading dimension != logical width)"""
     from flid_amd import ops
