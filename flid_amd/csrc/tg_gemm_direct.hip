@@ -1,0 +1,101 @@
+// Small-M products C = A B^T (+ bias, relu) for the root layer of the TGAT stack (M = 2 x batch = 1200 rows) and other short
+// operands.  With so few rows the LDS-tiled kernels run a handful of workgroups whose K loop is a chain of dependent
+// global -> LDS -> MFMA stages: 16..30 us for 0.3 GFLOP (rocprof, r01_v3).  Here the chain is cut instead of pipelined:
+//   * one workgroup per 32 x 32 tile of C, its 4 waves split the contraction 4 ways (fixed order, so results are reproducible);
+//   * no LDS staging: both operands are k-contiguous, so lane (i, h) loads float4s of row i at k = 8c + 4h straight into the
+//     A/B operand registers of v_mfma_f32_32x32x2_f32 -- the k order inside a product is free as long as A and B agree;
+//   * every load of a wave's slice is issued before its first MFMA (<= 8 chunks = 64 k per batch), the four partial tiles are
+//     folded through LDS.
+// Exact fp32 (f32-input MFMA).  Operands are L2 resident at these sizes, the kernel is latency-, not bandwidth-bound.
+#include "tg_common.h"
+
+namespace tg {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int U = 8;   // chunks (of 8 k) in flight per wave and operand: 16 float4 = 64 VGPRs
+
+__global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
+                                                             int64_t lda, int64_t sA, const float* __restrict__ B, int64_t ldb,
+                                                             int64_t sB, float* __restrict__ C, int64_t ldc, int64_t sC,
+                                                             const float* __restrict__ bias, int relu, int accumulate, int gx) {
+    __shared__ float red[3][32][33];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t tn = blockIdx.x % gx, tm = blockIdx.x / gx;
+    A += blockIdx.y * sA;
+    B += blockIdx.y * sB;
+    C += blockIdx.y * sC;
+    int64_t row = tm * 32 + i, col = tn * 32 + i;
+    row = row < M ? row : M - 1;                    // clamped rows are loaded but never stored
+    col = col < N ? col : N - 1;
+    const int64_t k8 = (K + 7) >> 3;                // chunks of 8 k; K % 4 == 0, so each half chunk is wholly in or out
+    const int64_t per = (k8 + 3) >> 2;
+    const int64_t c0 = w * per, c1 = (c0 + per < k8) ? c0 + per : k8;
+    const float* ap = A + row * lda + 4 * h;
+    const float* bp = B + col * ldb + 4 * h;
+
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t c = c0; c < c1; c += U) {
+        float4 av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = (c + u) * 8 + 4 * h;
+            const bool ok = (c + u < c1) && (k < K);
+            const int64_t off = ok ? (c + u) * 8 : 0;
+            av[u] = *reinterpret_cast<const float4*>(ap + off);
+            bv[u] = *reinterpret_cast<const float4*>(bp + off);
+            if (!ok) { av[u] = make_float4(0.f, 0.f, 0.f, 0.f); bv[u] = av[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+        }
+    }
+
+    // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (w > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w - 1][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
+    }
+    __syncthreads();
+    if (w > 0) return;
+    const int64_t ocol = tn * 32 + i;
+    if (ocol >= N) return;
+    const float bvv = bias ? bias[ocol] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int64_t orow = tm * 32 + rr;
+        if (orow >= M) continue;
+        float v = ((acc[r] + red[0][rr][i]) + red[1][rr][i]) + red[2][rr][i] + bvv;
+        float* p = C + orow * ldc + ocol;
+        if (accumulate) v += *p;
+        if (relu) v = fmaxf(v, 0.f);
+        *p = v;
+    }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// true = launched (or nothing to do); false = shape not handled here, the caller falls through to the tiled kernels
+bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                    int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
+                    hipStream_t s) {
+    if (K <= 0 || K % 4 || lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !al16(A) || !al16(B)) return false;
+    const int64_t gx = (N + 31) / 32, gy = (M + 31) / 32;
+    // the point of this kernel is a chip that would otherwise be mostly idle: beyond ~8 workgroups per CU the tiled kernels'
+    // operand reuse wins
+    if (gx * gy * nbatch > 2048 || nbatch > 65535 || K > 4096) return false;
+    ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
+    hipLaunchKernelGGL(gemm_direct_nt_kernel, dim3((unsigned)(gx * gy), (unsigned)nbatch), dim3(256), 0, s, M, N, K, A, lda, strideA,
+                       B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx);
+    return true;
+}
+
+}  // namespace tg

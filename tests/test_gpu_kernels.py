@@ -169,19 +169,48 @@ def test_gemm_exact_mode_matches_fp32_chain(dev):
     from flid_amd import ops
     from flid_amd._lib import lib
     rs = np.random.RandomState(5)
-    a = torch.from_numpy(rs.standard_normal((500, 272)).astype(np.float32)).to(dev)
+    a = torch.from_numpy(rs.standard_normal((20000, 272)).astype(np.float32)).to(dev)    # enough rows for the tiled kernels
     b = torch.from_numpy(rs.standard_normal((172, 272)).astype(np.float32)).to(dev)
     ref = a.double().cpu() @ b.double().cpu().T
     outs = {}
     for mode in (0, 1):
         lib().tg_set_gemm_mode(mode)
         try:
-            o = torch.empty((500, 172), device=dev)
+            o = torch.empty((20000, 172), device=dev)
             ops.gemm(a, b, o, tb=True)
             outs[mode] = (o.cpu().double() - ref).abs().max().item()
         finally:
             lib().tg_set_gemm_mode(1)
     assert outs[0] < 1e-4 and outs[1] < 2e-3 and outs[0] < outs[1]
+
+
+def test_gemm_direct_small_m(dev):
+    """few-row NT products take the direct kernel (tg_gemm_direct.hip): exact fp32, ragged tiles, bias/relu/accumulate, batches"""
+    from flid_amd import ops
+    rs = np.random.RandomState(12)
+    for (M, N, K) in ((1200, 272, 444), (1, 1, 4), (33, 65, 172), (600, 172, 136), (1200, 444, 8), (37, 31, 4092)):
+        a = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(dev)
+        b = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).to(dev)
+        bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(dev)
+        base = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(dev)
+        out = base.clone()
+        ops.gemm(a, b, out, tb=True, bias=bias, relu=True, accumulate=True)
+        ref = torch.relu(a.double().cpu() @ b.double().cpu().T + bias.double().cpu() + base.double().cpu())
+        mag = a.abs().double().cpu() @ b.abs().double().cpu().T
+        assert torch.all((out.cpu().double() - ref).abs() <= 4e-7 * mag + 1e-6), (M, N, K)
+        out2 = torch.empty_like(out)
+        ops.gemm(a, b, out2, tb=True)
+        out3 = torch.empty_like(out)
+        ops.gemm(a, b, out3, tb=True)
+        assert torch.equal(out2, out3)                                  # reproducible
+    # strided batch (two heads side by side in one buffer)
+    a = torch.from_numpy(rs.standard_normal((300, 2 * 136)).astype(np.float32)).to(dev)
+    w = torch.from_numpy(rs.standard_normal((2, 444, 136)).astype(np.float32)).to(dev)
+    out = torch.zeros(300, 2 * 444, device=dev)
+    ops.gemm_batched(a[:, :136], w[0], out[:, :444], 2, 136, 444 * 136, 444, tb=True)
+    for h in range(2):
+        ref = a[:, h * 136:(h + 1) * 136].double().cpu() @ w[h].double().cpu().T
+        assert torch.allclose(out[:, h * 444:(h + 1) * 444].cpu().double(), ref, atol=2e-4)
 
 
 def test_gemm_split_bf16_weight_gradient_form(dev):
