@@ -109,7 +109,7 @@ def main():
             prepared[s + 1] = model.prepare_batch(*dev_batches[s + 1], K)
         opt.zero_grad(set_to_none=True)
         se, de_ = model.compute_src_dst_node_temporal_embeddings(prepared.pop(s), None, None, K)
-        loss = (se * rw[0]).mean() + (de_ * rw[1]).mean()
+        loss = torch.addcmul(se * rw[0], de_, rw[1]).mean()          # scalar loss on both outputs, one reduction
         loss.backward()
         if reducer is not None:
             reducer.reduce()

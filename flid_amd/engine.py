@@ -390,7 +390,7 @@ class _EmbedFnNative(torch.autograd.Function):
         dev = dH.device
         Dn, T = table.shape[1], te_w.numel()
         grads = [None] * len(layer_params)
-        d_tew, d_teb, d_cosb = (torch.zeros(T, device=dev) for _ in range(3))
+        d_tew, d_teb, d_cosb = torch.zeros((3, T), device=dev).unbind(0)
         d_table = torch.zeros_like(table) if table_grad else None
         dH = dH.contiguous()
         for l in range(L, 0, -1):
@@ -413,9 +413,37 @@ class _EmbedFnNative(torch.autograd.Function):
                     ops.scatter_add_rows(d_own, fr.ids_all[:R], d_table)
             grads[(l - 1) * 11:(l - 1) * 11 + 11] = g
             dH = dH_prev
-        d_teb -= torch.sin(te_b) * d_cosb          # d cos(b) -> d b (zero interval: no weight gradient)
+        d_teb = torch.addcmul(d_teb, torch.sin(te_b), d_cosb, value=-1.0)    # d cos(b) -> d b (zero interval: no weight gradient)
         ctx.layers = None
-        return (None, None, d_table, d_tew.view_as(te_w), d_teb, *grads)
+        return (None, None, d_table, d_tew.reshape(te_w.shape), d_teb, *grads)
+
+
+class _SplitRows(torch.autograd.Function):
+    """(x[:n], x[n:]) whose backward is ONE concatenation (the stock slice backward is two zero fills, two copies and an add)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = n, x.shape
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        n, shape = ctx.n, ctx.shape
+        if g0 is None and g1 is None:
+            return None, None
+        ref = g0 if g0 is not None else g1
+        if g0 is None:
+            g0 = ref.new_zeros((n,) + tuple(shape[1:]))
+        if g1 is None:
+            g1 = ref.new_zeros((shape[0] - n,) + tuple(shape[1:]))
+        return torch.cat([g0, g1]), None
+
+
+def split_rows(x: torch.Tensor, n: int):
+    """the src / dst halves of a jointly computed embedding block"""
+    if not x.requires_grad:
+        return x[:n], x[n:]
+    return _SplitRows.apply(x, n)
 
 
 @dataclass

@@ -253,7 +253,7 @@ class MemoryModel(torch.nn.Module):
                            self.time_encoder.w.weight, self.time_encoder.w.bias, self.embedding_module.layer_params(),
                            emb_ids, emb_t, num_neighbors, self.num_layers,
                            self.num_heads, self.dropout, self.training, table_requires_grad=torch.is_grad_enabled())
-        src_emb, dst_emb = emb[:hi - lo], emb[hi - lo:]
+        src_emb, dst_emb = engine.split_rows(emb, hi - lo)
         if edges_are_positive:
             assert edge_ids is not None
             dev = self.node_raw_features.device

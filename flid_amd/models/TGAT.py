@@ -47,7 +47,7 @@ class TGAT(nn.Module):
         # both sides share one device pass: rows are independent (reference computes them one after the other, :61-65)
         if isinstance(src_node_ids, engine.PreparedFrontier):
             emb = self.compute_node_temporal_embeddings(src_node_ids, None, self.num_layers, num_neighbors)
-            return emb[:src_node_ids.nsrc], emb[src_node_ids.nsrc:]
+            return engine.split_rows(emb, src_node_ids.nsrc)
         nsrc = len(src_node_ids)
         if torch.is_tensor(src_node_ids):          # ids/times already in HBM (bench, fused trainers)
             ids = torch.cat([src_node_ids, dst_node_ids])
@@ -56,7 +56,7 @@ class TGAT(nn.Module):
             ids = np.concatenate([src_node_ids, dst_node_ids])
             times = np.concatenate([node_interact_times, node_interact_times])
         emb = self.compute_node_temporal_embeddings(ids, times, self.num_layers, num_neighbors)
-        return emb[:nsrc], emb[nsrc:]
+        return engine.split_rows(emb, nsrc)
 
     def prepare_batch(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20):
         """Optional prefetch (not in the reference): do the sampler work of a FUTURE batch now, on a side stream.  Takes
