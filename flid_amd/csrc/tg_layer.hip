@@ -168,19 +168,61 @@ __global__ void __launch_bounds__(256) add_cols_kernel(float* __restrict__ dst, 
     }
 }
 
-// out[i, j] = a[i] * b[j]      (the constant-column block of dWq)
-__global__ void __launch_bounds__(256) outer_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
-                                                    float* __restrict__ out, int64_t old) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na * nb; i += gridDim.x * blockDim.x) {
-        const int r = i / nb, c = i - r * nb;
-        out[(int64_t)r * old + c] = a[r] * b[c];
+
+// Column sums of a tall matrix added (float atomics) into up to 6 destination vectors: column c belongs to the first segment
+// with c < end[i] and lands at p[i][c - begin_i]; a null p[i] drops the segment.  One launch finishes a bias / LayerNorm /
+// time-encoder gradient that used to take two reduction passes plus copies.
+struct SegDst { float* p[6]; int end[6]; int n; };
+__global__ void __launch_bounds__(256) colsum_seg_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int cols, SegDst d) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < cols)
+        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < n; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0 || c >= cols) return;
+    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    int beg = 0;
+    for (int i = 0; i < d.n; ++i) {
+        if (c < d.end[i]) {
+            if (d.p[i]) atomicAdd(d.p[i] + (c - beg), t);
+            return;
+        }
+        beg = d.end[i];
     }
 }
+int colsum_seg(const float* x, int64_t ld, int64_t n, int cols, const SegDst& d, hipStream_t s) {
+    if (n == 0) return TG_OK;
+    const int slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, n / 32));
+    colsum_seg_kernel<<<dim3((cols + 63) / 64, slices), 256, 0, s>>>(x, ld, n, cols, d);
+    return tg::launch_status("colsum_seg_kernel");
+}
+SegDst seg1(float* p, int cols) { SegDst d{}; d.p[0] = p; d.end[0] = cols; d.n = 1; return d; }
 
-// dst[j] += src[j]   (tiny vectors: time-encoder gradient partials)
-__global__ void __launch_bounds__(256) vec_add_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += src[i];
+// The query projection sees [own | cos(b)]: with sq = sum_rows dq,
+//   dWq[:, dn:] += sq (x) cos(b)      and      d cos(b) += sq^T Wq[:, dn:].
+// Thread = one time column x 16 rows (independent loads), grid.y walks the rows.
+constexpr int WQT_ROWS = 16;
+__global__ void __launch_bounds__(64) wq_time_kernel(const float* __restrict__ sq, int dq, const float* __restrict__ cosb, int T,
+                                                     const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld,
+                                                     float* __restrict__ d_cosb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= T) return;
+    const float cb = cosb[c];
+    const int r0 = blockIdx.y * WQT_ROWS;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < WQT_ROWS; ++j) {
+        const int r = r0 + j;
+        if (r < dq) {
+            const float v = sq[r];
+            dWq_t[(int64_t)r * ld + c] += v * cb;
+            acc = fmaf(v, Wq_t[(int64_t)r * ld + c], acc);
+        }
+    }
+    atomicAdd(d_cosb + c, acc);
 }
 
 // up to 8 small matrix transposes in one launch (weights, once per step): dst[c * ldd + r] = src[r * lds + c]
@@ -333,7 +375,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const tg_layer_params& P = L->params;
     const tg_layer_grads& G = Bw->grads;
     const int64_t w1ld = dq + dn;
-    float* vec = Bw->vec;                                   // >= 4 * dq + 2 * T floats of scratch
+    float* vec = Bw->vec;
     const WT wt = wt_layout(L->wT, H, dn, dq, dk);                 // filled by the forward call of this step
     const bool overlap = g_overlap && g_side.init();
     void* wstream = overlap ? (void*)g_side.side : stream;        // where everything that only feeds parameter gradients goes
@@ -345,22 +387,20 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     float* part_relu = Bw->part;
     float* part_ln = part_relu + relu_blocks * dn;
     float* part_attn = part_ln + (int64_t)ln_grid * 4 * dq;
-    float* vec_ln = vec;                  // 4 dq
-    float* vec_te = vec + 4 * dq;         // 2 T
-    float* vec_dq = vec + 4 * dq + 2 * T; // dq
+    float* vec_dq = vec;                                    // dq floats, zero on entry like the gradients
     // ---- merge layer -------------------------------------------------------------------------------------------------------
     if (overlap) TG_TRY(g_side.fork(s));                           // dout is ready
-    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 0, wstream));
-    TG_TRY(tg_colsum(Bw->dout, dn, R, dn, G.b2, 0, wstream));
+    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 1, wstream));
+    TG_TRY(colsum_seg(Bw->dout, dn, R, dn, seg1(G.b2, dn), ws_));
     TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
     TG_REQUIRE(dn <= 1024, "tg_tgat_layer_bwd: node dim > 1024 unsupported");
     if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
     else relu_bwd_colsum_kernel<4><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
     TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
     if (overlap) TG_TRY(g_side.fork(s));                           // df1 and its slabs are final
-    TG_TRY(tg_colsum(part_relu, dn, relu_blocks, dn, G.b1, 0, wstream));
-    TG_TRY(tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 0, wstream));
-    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 0, wstream));
+    TG_TRY(colsum_seg(part_relu, dn, relu_blocks, dn, seg1(G.b1, dn), ws_));
+    TG_TRY(tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 1, wstream));
+    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 1, wstream));
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
     if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
@@ -373,35 +413,41 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
     }
     if (overlap) TG_TRY(g_side.fork(s));                           // dres / dsum and the LayerNorm slabs are final
-    TG_TRY(tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 0, wstream));
-    TG_TRY(tg_colsum(part_ln, 4 * dq, ln_grid, 4 * dq, vec_ln, 0, wstream));     // [dgamma | dbeta | sum dsum | sum dres]
-    TG_HIP_CHECK(hipMemcpyAsync(G.ln_g, vec_ln, sizeof(float) * dq, hipMemcpyDeviceToDevice, ws_));
-    TG_HIP_CHECK(hipMemcpyAsync(G.ln_b, vec_ln + dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, ws_));
-    TG_HIP_CHECK(hipMemcpyAsync(G.br, vec_ln + 3 * dq, sizeof(float) * dq, hipMemcpyDeviceToDevice, ws_));
-    vec_add_kernel<<<1, 256, 0, ws_>>>(Bw->d_cosb, vec_ln + 2 * dq + dn, T);   // d cos(b) from the residual's time half
-    TG_TRY(tg::launch_status("vec_add_kernel"));
+    TG_TRY(tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 1, wstream));
+    {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
+        SegDst d{};
+        d.n = 5;
+        d.p[0] = G.ln_g;     d.end[0] = dq;
+        d.p[1] = G.ln_b;     d.end[1] = 2 * dq;
+        d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
+        d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
+        d.p[4] = G.br;       d.end[4] = 4 * dq;
+        TG_TRY(colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_));
+    }
     // ---- output projection ------------------------------------------------------------------------------------------------------
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
     // ---- value path -------------------------------------------------------------------------------------------------------------
     if (overlap) TG_TRY(g_side.fork(s));                           // dctx is final
-    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 0, wstream));
+    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream));
     TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
     // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
     TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
     if (overlap) TG_TRY(g_side.fork(s));                           // du and the time-encoder slabs are final
-    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 0, wstream));
-    TG_TRY(tg_colsum(part_attn, 2 * T, attn_parts, 2 * T, vec_te, 0, wstream));
-    vec_add_kernel<<<1, 256, 0, ws_>>>(Bw->d_tew, vec_te, T);
-    vec_add_kernel<<<1, 256, 0, ws_>>>(Bw->d_teb, vec_te + T, T);
-    TG_TRY(tg::launch_status("vec_add_kernel"));
+    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream));
+    {
+        SegDst d{};
+        d.n = 2;
+        d.p[0] = Bw->d_tew; d.end[0] = T;
+        d.p[1] = Bw->d_teb; d.end[1] = 2 * T;
+        TG_TRY(colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, ws_));
+    }
     // ---- key / query path --------------------------------------------------------------------------------------------------------
     TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
     if (overlap) TG_TRY(g_side.fork(s));                           // dq is final
-    TG_TRY(tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 0, wstream));
-    TG_TRY(tg_colsum(Bw->dq, dq, R, dq, vec_dq, 0, wstream));                              // sum_rows dq
-    outer_kernel<<<ew_grid((int64_t)dq * T), 256, 0, ws_>>>(vec_dq, dq, L->cosb, T, G.Wq + dn, dq);
-    TG_TRY(tg::launch_status("outer_kernel"));
-    TG_TRY(tg_gemm_f32(0, 0, 1, T, dq, 1.f, vec_dq, dq, P.Wq + dn, dq, Bw->d_cosb, T, nullptr, 0, 1, wstream));   // += (sum dq) Wq[:, dn:]
+    TG_TRY(tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 1, wstream));
+    TG_TRY(colsum_seg(Bw->dq, dq, R, dq, seg1(vec_dq, dq), ws_));                           // sum_rows dq (vec is zero on entry)
+    wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, ws_>>>(vec_dq, dq, L->cosb, T, P.Wq + dn, G.Wq + dn, dq, Bw->d_cosb);
+    TG_TRY(tg::launch_status("wq_time_kernel"));
     if (Bw->d_own) {
         TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
         add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);

@@ -315,18 +315,26 @@ class _NativeLayer:
             check(lib().tg_tgat_layer_fwd(C.byref(self.desc), ops._stream()), "tg_tgat_layer_fwd")
         return self.buf["out"]
 
-    def backward(self, dout, params, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, d_own_accumulate, want_d_raw):
+    @staticmethod
+    def grad_floats(params, Dq):
+        """floats of the zeroed block one backward call accumulates into: every parameter gradient (16-B aligned) + vec"""
+        return sum((p.numel() + 3) // 4 * 4 for p in params) + (Dq + 3) // 4 * 4
+
+    def backward(self, dout, params, zeroed, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, d_own_accumulate, want_d_raw):
         import ctypes as C
         from ._lib import LayerBwdDesc, LayerParams, check, lib
         H, Dn, T, Dq, Dk = self.dims
         R, dev = self.R, dout.device
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        grads = [torch.empty_like(p) for p in params]
+        grads, off = [], 0                      # views of the caller's zeroed block (tg_tgat_layer_bwd accumulates)
+        for p in params:
+            grads.append(zeroed[off:off + p.numel()].view(p.shape))
+            off += (p.numel() + 3) // 4 * 4
+        vec = zeroed[off:off + Dq]
         # scratch that lives only inside this call is kept across steps (grown on demand); saved activations are NOT cached:
         # a caller may run several forwards before one backward (positive + negative edges of the reference's trainers)
         sizes = dict(df1=R * Dn, dy=R * Dq, dsum=R * Dq, dres=R * Dq if self.desc.res_dropout_p > 0 else 0, dctx=R * Dq,
-                     dagg=R * H * Dk, du=R * H * Dk, dq=R * Dq, part=int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)),
-                     vec=5 * Dq + 2 * T)
+                     dagg=R * H * Dk, du=R * H * Dk, dq=R * Dq, part=int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)))
         ws = {}
         for name, need in sizes.items():
             key = (dev, name)
@@ -341,6 +349,7 @@ class _NativeLayer:
         b.dout = ops._p(dout)
         for k_, v in ws.items():
             setattr(b, k_, ops._p(v))
+        b.vec = ops._p(vec)
         b.d_cosb, b.d_tew, b.d_teb = ops._p(d_cosb), ops._p(d_tew), ops._p(d_teb)
         b.dfeat, b.dfeat_ld, b.pad_row = ops._p(dfeat), (0 if dfeat is None else ops._rowmajor_ld(dfeat, "dfeat")), int(pad_row)
         b.d_own, b.d_own_ld, b.d_own_accumulate = ops._p(d_own), (0 if d_own is None else ops._rowmajor_ld(d_own, "d_own")), int(d_own_accumulate)
@@ -390,7 +399,13 @@ class _EmbedFnNative(torch.autograd.Function):
         dev = dH.device
         Dn, T = table.shape[1], te_w.numel()
         grads = [None] * len(layer_params)
-        d_tew, d_teb, d_cosb = torch.zeros((3, T), device=dev).unbind(0)
+        # one zero fill for everything the layer calls accumulate into
+        Dq = Dn + T
+        per_layer = [_NativeLayer.grad_floats(layer_params[(l - 1) * 11:(l - 1) * 11 + 11], Dq) for l in range(1, L + 1)]
+        head = (3 * T + 3) // 4 * 4
+        zeroed = torch.zeros(head + sum(per_layer), device=dev)
+        d_tew, d_teb, d_cosb = zeroed[:T], zeroed[T:2 * T], zeroed[2 * T:3 * T]
+        layer_off = [head + sum(per_layer[:l]) for l in range(L)]
         d_table = torch.zeros_like(table) if table_grad else None
         dH = dH.contiguous()
         for l in range(L, 0, -1):
@@ -404,7 +419,8 @@ class _EmbedFnNative(torch.autograd.Function):
             else:
                 dH_prev, dfeat, pad_row = None, d_table, 0
                 d_own, acc = (torch.empty((R, Dn), device=dev), False) if table_grad else (None, False)
-            g, d_raw = lay.backward(dH[:R], params, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, acc, table_grad)
+            g, d_raw = lay.backward(dH[:R], params, zeroed[layer_off[l - 1]:layer_off[l - 1] + per_layer[l - 1]], d_cosb, d_tew, d_teb,
+                                    dfeat, pad_row, d_own, acc, table_grad)
             if table_grad:
                 if l >= 2:
                     ops.scatter_add_rows(d_raw, fr.ids_all[:R], d_table)

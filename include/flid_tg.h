@@ -142,10 +142,11 @@ typedef struct tg_layer_desc {
     float *qbias, *q, *u, *agg, *prob, *ctx, *res, *y, *mean, *rstd, *f1, *out;
     float* wT;   /* tg_tgat_layer_wt_floats(dn, dq, dk) floats: transposed weights, written by fwd, read by bwd of the same step */
 } tg_layer_desc;
-/* backward: dout (R, dn) in; grads.* are OVERWRITTEN with this layer's parameter gradients; d_cosb / d_tew / d_teb (dt_dim)
- * are ACCUMULATED into (caller zeroes them once per call); dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional
- * gradient w.r.t. own (accumulated into if d_own_accumulate); d_raw (R, dn) optional gradient w.r.t. raw.
- * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats), vec (5 dq + 2 dt_dim). */
+/* backward: dout (R, dn) in; this layer's parameter gradients are ADDED into grads.* and into d_cosb / d_tew / d_teb (dt_dim)
+ * with float atomics: the caller zeroes them (one fill for the whole gradient block of a step) -- as torch accumulates into
+ * .grad.  vec (dq floats) must be zero on entry too.  dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional gradient
+ * w.r.t. own (accumulated into if d_own_accumulate); d_raw (R, dn) optional gradient w.r.t. raw.
+ * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats). */
 typedef struct tg_layer_bwd_desc {
     tg_layer_grads grads;
     const float* dout;
