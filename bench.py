@@ -50,8 +50,8 @@ def attn_bytes_per_instance(k=K, heads=H, dn=DN, de=DE, dt=DT, backward=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--roofline-kernel", default="attn_bwd", choices=["attn_fwd", "attn_bwd", "gemm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -152,7 +152,8 @@ template <bool A_KC, bool B_KC, bool VEC, int TM, int TN>
 __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64_t N, int64_t K, float alpha,
         const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
         const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics, int gx, int gy_in,
-        int64_t strideA, int64_t strideB, int64_t strideC, int nbatch, int inner, int64_t innerA, int64_t innerB, int64_t innerC) {
+        int64_t strideA, int64_t strideB, int64_t strideC, int nbatch, int inner, int64_t innerA, int64_t innerB, int64_t innerC,
+        float* __restrict__ ws, int nslice_x) {
     constexpr int NT = TM * TN * 64, RA = 32 * TM, RB_ = 32 * TN;
     constexpr int FA = PanelFloats<RA, A_KC>::value, FB = PanelFloats<RB_, B_KC>::value;
     using PA = Panel<RA, NT, A_KC, VEC>;
@@ -162,16 +163,29 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
     auto sB = [&](int i) -> float* { return lds + i * (FA + FB) + FA; };
 
     // workgroup id -> (row block, column block): XCD-aware bijective remap so that the column blocks of one row block (they
-    // share the A rows) run on the same XCD's L2.  blockIdx.z = batch * splits + split.
+    // share the A rows) run on the same XCD's L2.  Slice = batch * splits + split.
+    // Split contraction (nslice_x > 0, 1-D grid): every tile of one K slice shares that slice's rows of A and B, so a whole
+    // slice is pinned to one XCD (hardware deals workgroups to XCDs round-robin): each L2 then pulls 1/8 of the operands from
+    // memory once, instead of all 8 pulling nearly everything (the 272 x 444 x 12235 gradient moved ~280 MB, 60 us).
     int gy = gy_in;
     const int nwg = gx * (gy < 0 ? -gy : gy);
-    const int bid = blockIdx.x;
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
-    const int swz = gy < 0 ? bid : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    int swz, zidx, nz;
+    if (nslice_x > 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;          // nslice_x % 8 == 0 (host)
+        zidx = xcd + 8 * (j / nwg);
+        swz = j % nwg;
+        nz = nslice_x;
+    } else {
+        const int bid = blockIdx.x;
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+        swz = gy < 0 ? bid : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+        zidx = blockIdx.z;
+        nz = gridDim.z;
+    }
     if (gy < 0) gy = -gy;
     const int by = swz / gx, bx = swz % gx;
-    const int nsplit = gridDim.z / nbatch;
-    const int batch = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
+    const int nsplit = nz / nbatch;
+    const int batch = zidx / nsplit, split = zidx % nsplit;
     // two-level batch index: problem = (batch / inner, batch % inner), e.g. (sequence, head)
     const int bo = batch / inner, bi = batch % inner;
     A += bo * strideA + bi * innerA; B += bo * strideB + bi * innerB; C += bo * strideC + bi * innerC;
@@ -231,14 +245,17 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
     const int rl = lane & 31, kh = lane >> 5;
     const int64_t col = bn + tn * 32 + rl;
     if (col >= N) return;
-    const float bv = (bias && split == 0) ? bias[col] : 0.f;
+    const float bv = (bias && split == 0 && use_atomics != 2) ? bias[col] : 0.f;
+    if (use_atomics == 2) ws += (int64_t)zidx * M * N;          // this (batch, split)'s partial product, folded by splitk_reduce
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t row = bm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (row >= M) continue;
         float v = alpha * acc[r] + bv;
         float* p = C + row * ldc + col;
-        if (use_atomics) {
+        if (use_atomics == 2) {
+            ws[row * N + col] = v;
+        } else if (use_atomics) {
             atomicAdd(p, v);
         } else {
             if (accumulate) v += *p;
@@ -248,7 +265,52 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
     }
 }
 
+// C (+)= sum over the splits of the partial products a split-contraction launch left in ws[batch][split][M][N] (+ bias).
+// Fixed summation order: weight gradients come out reproducible, and the ~1e8/s float-atomic rate of the memory side no longer
+// bounds them (a 272 x 444 gradient split 48 ways was 5.8 M atomics = 60 us; the partials are 23 MB of plain stores).
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int64_t M, int64_t N, int nsplit, int nbatch,
+        float* __restrict__ C, int64_t ldc, int64_t strideC, int inner, int64_t innerC, const float* __restrict__ bias, int accumulate) {
+    const int64_t mn = M * N, total = mn * nbatch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / mn, rem = i - b * mn;
+        const int64_t row = rem / N, col = rem - row * N;
+        const float* p = ws + b * nsplit * mn + rem;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = 0;
+        for (; sp + 4 <= nsplit; sp += 4) {
+            s0 += p[(int64_t)sp * mn]; s1 += p[(int64_t)(sp + 1) * mn]; s2 += p[(int64_t)(sp + 2) * mn]; s3 += p[(int64_t)(sp + 3) * mn];
+        }
+        for (; sp < nsplit; ++sp) s0 += p[(int64_t)sp * mn];
+        float v = (s0 + s1) + (s2 + s3);
+        if (bias) v += bias[b * N + col];
+        float* c = C + (b / inner) * strideC + (b % inner) * innerC + row * ldc + col;
+        if (accumulate) v += *c;
+        *c = v;
+    }
+}
+
+// partial-product workspace, one per launch stream (main chain / weight-gradient side stream), grown on demand
+struct SplitWs { hipStream_t stream; float* p; size_t floats; };
+SplitWs g_split_ws[4] = {};
+constexpr size_t kSplitWsMaxFloats = (size_t)256 << 20;       // 1 GiB per stream; larger splits fall back to atomics
+
+float* split_workspace(size_t need, hipStream_t s) {
+    if (need > kSplitWsMaxFloats) return nullptr;
+    SplitWs* w = nullptr;
+    for (auto& c : g_split_ws) if (c.p && c.stream == s) { w = &c; break; }
+    if (!w) for (auto& c : g_split_ws) if (!c.p) { w = &c; w->stream = s; break; }
+    if (!w) return nullptr;
+    if (need > w->floats) {
+        if (w->p) { if (hipStreamSynchronize(s) != hipSuccess) return nullptr; (void)hipFree(w->p); w->p = nullptr; w->floats = 0; }
+        const size_t want = std::max<size_t>(need + need / 4, (size_t)8 << 20);
+        if (hipMalloc(&w->p, want * sizeof(float)) != hipSuccess) { w->p = nullptr; (void)hipGetLastError(); return nullptr; }
+        w->floats = want;
+    }
+    return w->p;
+}
+
 struct Args {
+    float* ws;
     int64_t M, N, K; float alpha; const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
     const float* bias; int relu, accumulate; int64_t k_chunk; int atomics, gx, gy; int64_t sA, sB, sC; int nbatch, splits;
     int inner; int64_t iA, iB, iC;
@@ -256,9 +318,12 @@ struct Args {
 
 template <bool A_KC, bool B_KC, bool VEC, int TM, int TN>
 void launch(const Args& a, hipStream_t s) {
-    const dim3 grid((unsigned)(a.gx * (a.gy < 0 ? -a.gy : a.gy)), 1, (unsigned)(a.nbatch * a.splits));
+    const unsigned tiles = (unsigned)(a.gx * (a.gy < 0 ? -a.gy : a.gy)), slices = (unsigned)(a.nbatch * a.splits);
+    static const bool nopin = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_GEMM_NOPIN") != nullptr;
+    const int nslice_x = (!nopin && a.splits > 1 && slices % 8 == 0) ? (int)slices : 0;
+    const dim3 grid(nslice_x ? tiles * slices : tiles, 1, nslice_x ? 1 : slices);
     gemm_tile_kernel<A_KC, B_KC, VEC, TM, TN><<<grid, TM * TN * 64, 0, s>>>(a.M, a.N, a.K, a.alpha, a.A, a.lda, a.B, a.ldb, a.C,
-        a.ldc, a.bias, a.relu, a.accumulate, a.k_chunk, a.atomics, a.gx, a.gy, a.sA, a.sB, a.sC, a.nbatch, a.inner, a.iA, a.iB, a.iC);
+        a.ldc, a.bias, a.relu, a.accumulate, a.k_chunk, a.atomics, a.gx, a.gy, a.sA, a.sB, a.sC, a.nbatch, a.inner, a.iA, a.iB, a.iC, a.ws, nslice_x);
 }
 
 template <bool A_KC, bool B_KC>
@@ -332,7 +397,9 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
         const char* e = tuning ? getenv("FLID_GEMM_SPLIT_BLOCKS") : nullptr;
         const int64_t target = e ? atoi(e) : 512;
         splits = (target + gx * gy * nbatch - 1) / (gx * gy * nbatch);
-        const int64_t max_splits = (K + 8 * BK - 1) / (8 * BK);
+        const char* e2 = tuning ? getenv("FLID_GEMM_MIN_STAGES") : nullptr;
+        const int64_t min_stages = e2 ? atoi(e2) : 8;
+        const int64_t max_splits = (K + min_stages * BK - 1) / (min_stages * BK);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
@@ -340,9 +407,19 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     k_chunk = (k_chunk + BK - 1) / BK * BK;
     if (k_chunk < BK) k_chunk = BK;
     splits = K == 0 ? 1 : (K + k_chunk - 1) / k_chunk;
+    // slices (batch x split) in multiples of 8 so that each can be pinned to an XCD; surplus splits past K are empty (zero partials)
+    if (splits > 1 && (splits * nbatch) % 8 != 0) {
+        int64_t up = splits;
+        while ((up * nbatch) % 8 != 0) ++up;
+        if (up - splits <= 3) splits = up;
+    }
     TG_REQUIRE(splits * nbatch <= 65535, "tg_gemm_f32: too many splits");
-    const int atomics = splits > 1;
-    if (atomics && !accumulate)
+    // split contraction: partial products into a workspace + one fixed-order fold; float atomics only if no workspace is to be had
+    int atomics = splits > 1;
+    float* ws = nullptr;
+    static const bool force_atomics = tuning && getenv("FLID_GEMM_ATOMICS") != nullptr;
+    if (atomics && !force_atomics && (ws = split_workspace((size_t)nbatch * splits * M * N, s)) != nullptr) atomics = 2;
+    if (atomics == 1 && !accumulate)
         for (int b = 0; b < nbatch; ++b)
             TG_HIP_CHECK(hipMemset2DAsync(d_C + (b / inner) * strideC + (b % inner) * innerC, ldc * sizeof(float), 0,
                                           N * sizeof(float), M, s));
@@ -351,12 +428,17 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     if (skip_launch) return TG_OK;
     tg::ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     const bool noswz = tuning && getenv("FLID_GEMM_NOSWZ") != nullptr;
-    const Args a{M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, noswz ? -(int)gy : (int)gy,
+    const Args a{ws, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, noswz ? -(int)gy : (int)gy,
                  strideA, strideB, strideC, nbatch, (int)splits, inner, innerA, innerB, innerC};
     if (a_kc && b_kc) dispatch<true, true>(vec, tm, tn, a, s);
     else if (a_kc && !b_kc) dispatch<true, false>(vec, tm, tn, a, s);
     else if (!a_kc && b_kc) dispatch<false, true>(vec, tm, tn, a, s);
     else dispatch<false, false>(vec, tm, tn, a, s);
+    if (atomics == 2) {
+        const int64_t total = (int64_t)nbatch * M * N;
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+        splitk_reduce_kernel<<<blocks, 256, 0, s>>>(ws, M, N, (int)splits, nbatch, d_C, ldc, strideC, inner, innerC, d_bias, accumulate);
+    }
     return tg::launch_status("gemm_tile_kernel");
 }
 
