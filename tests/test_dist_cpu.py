@@ -34,7 +34,9 @@ def _worker(rank, world, port, q):
     red = fdist.GradAllReducer(model.parameters())
     red.reduce(weight=(hi - lo) / len(x))              # mean loss over the GLOBAL batch
     rows = fdist.all_gather_rows(x[lo:hi], [fdist.shard_bounds(len(x), i, world)[1] - fdist.shard_bounds(len(x), i, world)[0] for i in range(world)])
-    q.put((rank, [p_.grad.clone() for p_ in model.parameters()], [p_.data.clone() for p_ in model.parameters()], rows))
+    # numpy, not tensors: a tensor travels through the queue as a shared-memory handle that dies with this process
+    q.put((rank, [p_.grad.numpy().copy() for p_ in model.parameters()], [p_.data.numpy().copy() for p_ in model.parameters()],
+           rows.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,9 +60,9 @@ def test_grad_allreduce_equals_single_process_full_batch():
     ((model(x) - y) ** 2).mean().backward()
     for rank, grads, weights, rows in out:
         for g_, w_, p_ in zip(grads, weights, model.parameters()):
-            assert torch.allclose(w_, p_.data), "broadcast_parameters did not install rank 0's weights"
-            assert torch.allclose(g_, p_.grad, atol=1e-6), "weighted all-reduce != full-batch gradient"
-        assert torch.equal(rows, x)
+            assert np.allclose(w_, p_.data.numpy()), "broadcast_parameters did not install rank 0's weights"
+            assert np.allclose(g_, p_.grad.numpy(), atol=1e-6), "weighted all-reduce != full-batch gradient"
+        assert np.array_equal(rows, x.numpy())
 
 
 def test_shard_bounds_partition():
