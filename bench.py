@@ -54,6 +54,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--roofline-kernel", default="attn_bwd", choices=["attn_fwd", "attn_bwd", "gemm"])
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"],
+                    help="train = fwd+bwd+Adam (the headline metric); fwd = eval-mode embedding regeneration sweep (M_step.py:456-509)")
+    ap.add_argument("--workload", default="wikipedia", choices=["wikipedia", "scale"],
+                    help="wikipedia = BASELINE configs[1] (the headline); scale = SURVEY 8d config 5 (10 M nodes / 100 M edges, tables "
+                         "hashed into HBM: 79 GB resident, the cache-defeating case)")
+    ap.add_argument("--scale-users", type=int, default=9_000_000)
+    ap.add_argument("--scale-items", type=int, default=1_000_000)
+    ap.add_argument("--scale-edges", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the untimed per-family profiling pass")
     ap.add_argument("--cpu-sample-edges", type=int, default=150)
@@ -62,20 +70,35 @@ def main():
     from flid_amd import dist as fdist
     from flid_amd import ops
     from flid_amd.models.TGAT import TGAT
-    from flid_amd.synth import wikipedia_like
+    from flid_amd.synth import scale_like, wikipedia_like
     from flid_amd.utils.utils import get_neighbor_sampler
 
     rank, world, local = fdist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product has no CPU path)"
+    if os.environ.get("FLID_BENCH_SHARE_GPU"):      # plumbing check of the N > 1 path on a 1-GPU box (with FLID_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    data = wikipedia_like(seed=0)
+    if args.workload == "scale":
+        t_gen = time.perf_counter()
+        data = scale_like(args.scale_users, args.scale_items, args.scale_edges, seed=0)
+        node_tab = ops.hash_features(args.scale_users + args.scale_items + 1, DN, 1, dev)
+        edge_tab = ops.hash_features(args.scale_edges + 1, DE, 2, dev)
+        args.no_cpu_baseline = True          # the oracle's python-list adjacency is infeasible at 2 x 10^8 entries
+        workload = (f"scale synthetic ({args.scale_users + args.scale_items} nodes, {args.scale_edges} edges, hashed {DN}-d node / "
+                    f"{DE}-d edge tables resident in HBM: {(node_tab.numel() + edge_tab.numel()) * 4 / 1e9:.1f} GB)")
+    else:
+        data = wikipedia_like(seed=0)
+        node_tab, edge_tab = data.node_raw_features, data.edge_raw_features
+        workload = "Wikipedia-shape synthetic (9227 nodes, 157474 edges, 172-d edge feats)"
     n_train = int(0.7 * data.num_interactions)
     sampler = get_neighbor_sampler(data.slice(0, n_train), "recent", seed=0)       # train graph, as EM_warmup.py:71-76
+    if args.workload == "scale" and rank == 0:
+        print(f"[bench] scale workload built in {time.perf_counter() - t_gen:.1f} s", file=sys.stderr, flush=True)
     torch.manual_seed(0)
-    model = TGAT(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=DT, num_layers=L, num_heads=H,
+    model = TGAT(node_tab, edge_tab, sampler, time_feat_dim=DT, num_layers=L, num_heads=H,
                  dropout=args.dropout, device=str(dev)).to(dev).train()
     fdist.broadcast_parameters(model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)                  # load_configs.py:119,123 (one fused update kernel)
@@ -101,12 +124,21 @@ def main():
 
     prepared = {}
 
+    if args.mode == "fwd":
+        model.eval()
+        args.no_cpu_baseline = True
+        args.roofline_kernel = "attn_fwd"
+
     def step(s):
         # sampler work of the NEXT batch is issued first, on a side stream (it depends on the graph only, not on the weights)
         if s not in prepared:
             prepared[s] = model.prepare_batch(*dev_batches[s], K)
         if s + 1 < len(dev_batches):
             prepared[s + 1] = model.prepare_batch(*dev_batches[s + 1], K)
+        if args.mode == "fwd":
+            with torch.no_grad():
+                model.compute_src_dst_node_temporal_embeddings(prepared.pop(s), None, None, K)
+            return
         opt.zero_grad(set_to_none=True)
         se, de_ = model.compute_src_dst_node_temporal_embeddings(prepared.pop(s), None, None, K)
         loss = torch.addcmul(se * rw[0], de_, rw[1]).mean()          # scalar loss on both outputs, one reduction
@@ -150,7 +182,7 @@ def main():
 
     edges = args.steps * BATCH * world
     value = edges / elapsed
-    bpe = tgat_bytes_per_edge()
+    bpe = tgat_bytes_per_edge() if args.mode == "train" else tgat_bytes_per_edge() // 2     # fwd = half of fwd+bwd
 
     # roofline of the selected kernel family: HIP events on its launch stream over the timed region
     ms, units, cnt = fam[args.roofline_kernel]
@@ -168,19 +200,21 @@ def main():
                 "avg_launch_ms": round(ms / max(1, cnt), 4), "bytes_per_instance": attn_bytes_per_instance(backward=bwd),
                 "bytes_per_launch_avg": round(units / max(1, cnt), 1)}
         tr = os.path.join(REPO, "profiles", "traffic_r01.json")
-        if os.path.exists(tr):
+        if os.path.exists(tr) and args.workload == "wikipedia" and args.mode == "train":
             try:
                 roof["traffic"] = json.load(open(tr)).get(args.roofline_kernel)
             except Exception:
                 pass
 
     out = {
-        "metric": "edges/sec (temporal-embedding fwd+bwd), TGAT Wikipedia, 1/2/4/8 MI355X",
+        "metric": ("edges/sec (temporal-embedding fwd+bwd), TGAT Wikipedia, 1/2/4/8 MI355X" if args.mode == "train" else
+                   "edges/sec (temporal-embedding fwd only, eval), TGAT Wikipedia") if args.workload == "wikipedia" else
+                  "edges/sec (temporal-embedding %s), TGAT 10M-node / 100M-edge scale graph" % ("fwd+bwd" if args.mode == "train" else "fwd only, eval"),
         "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Wikipedia-shape synthetic (9227 nodes, 157474 edges, 172-d edge feats) + TGAT L=2 H=2 T=100, "
-                               "batch 600 edges/GPU, 20 recent neighbors, dropout %.2f, fwd+bwd+Adam" % args.dropout,
+        "config": {"workload": workload + " + TGAT L=2 H=2 T=100, batch 600 edges/GPU, 20 recent neighbors, dropout %.2f, %s"
+                               % (args.dropout, "fwd+bwd+Adam" if args.mode == "train" else "fwd (eval)"),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world, "num_neighbors": K, "num_layers": L,
                    "parallelism": f"dp{world}"},
         "path_roofline": {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4),

@@ -47,6 +47,7 @@ SIGNATURES = {
     "tg_version": (C.c_int, []),
     "tg_profile_enable": (None, [C.c_int]),
     "tg_profile_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.c_int]),
+    "tg_hash_features": (C.c_int, [c_void, c_i64, c_i64, c_i64, C.c_int, C.c_uint64, c_void]),
     "tg_graph_create": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, C.POINTER(c_void)]),
     "tg_graph_destroy": (None, [c_void]),
     "tg_graph_num_rows": (c_i64, [c_void]),

@@ -222,6 +222,30 @@ ColsumWs g_colsum_ws[4] = {};
 
 }  // namespace
 
+// Synthetic feature tables for graphs too large to generate on the host: element (row, col) is a pure
+// function of (row, col, seed) -- uniform on [-sqrt(3), sqrt(3)) (unit variance), row 0 (the padding row) zero -- so that any row
+// can be recomputed on the host for spot parity (flid_amd/synth.py: hash_features_host).
+__global__ void __launch_bounds__(256) hash_features_kernel(float* __restrict__ out, int64_t ld, int64_t row0, int64_t nrows, int cols,
+                                                            uint64_t seed) {
+    const int64_t total = nrows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const int64_t row = row0 + r;
+        const uint64_t key = seed ^ ((uint64_t)(row * cols + c) * 0x9E3779B97F4A7C15ULL);
+        const float u = (float)(tg::mix32(key) & 0xFFFFFF) * (1.0f / 16777216.0f);
+        out[r * ld + c] = row == 0 ? 0.f : (u - 0.5f) * 3.4641016f;
+    }
+}
+
+extern "C" int tg_hash_features(float* d_out, int64_t ld, int64_t row0, int64_t nrows, int cols, uint64_t seed, void* stream) {
+    TG_REQUIRE(d_out && nrows >= 0 && cols > 0 && ld >= cols && row0 >= 0, "tg_hash_features: arguments");
+    if (nrows == 0) return TG_OK;
+    const int64_t blocks = std::min<int64_t>((nrows * cols + 255) / 256, tg::kMaxGridBlocks);
+    hash_features_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_out, ld, row0, nrows, cols, seed);
+    return tg::launch_status("hash_features_kernel");
+}
+
 extern "C" int tg_rowop_parts(int64_t n) { return (int)row_grid(n); }
 
 extern "C" int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols, float* d_out,

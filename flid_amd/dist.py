@@ -22,7 +22,7 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("FLID_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -52,23 +52,26 @@ class GradAllReducer:
             off += p.numel()
 
     def reduce(self, weight: float = None):
+        """Gather the gradients into the flat bucket (one multi-tensor copy), scale, ONE all-reduce, and hand the bucket's views
+        back as the .grad tensors (no copy back).  Call optimizer.zero_grad() between steps as usual."""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1:
             return
         w = (1.0 / world) if weight is None else float(weight)
+        dst, src = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
-            else:
-                v.copy_(p.grad)
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
         if w != 1.0:
             self.flat.mul_(w)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+            p.grad = v
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):

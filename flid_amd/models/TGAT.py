@@ -19,8 +19,11 @@ class TGAT(nn.Module):
         if torch.device(device).type != "cuda":
             raise RuntimeError("flid_amd.TGAT runs on a ROCm device only (device='cuda' / 'cuda:N'); there is no CPU path")
         # plain tensors, not parameters/buffers: not in state_dict, no grad (reference TGAT.py:26-29)
-        self.node_raw_features = torch.from_numpy(node_raw_features.astype(np.float32)).to(device).contiguous()
-        self.edge_raw_features = torch.from_numpy(edge_raw_features.astype(np.float32)).to(device).contiguous()
+        # (tables already resident in HBM -- flid_amd.ops.hash_features at SURVEY 8d config-5 sizes -- are taken as they are)
+        as_dev = lambda x: (x.to(device=device, dtype=torch.float32) if torch.is_tensor(x)
+                            else torch.from_numpy(x.astype(np.float32)).to(device)).contiguous()
+        self.node_raw_features = as_dev(node_raw_features)
+        self.edge_raw_features = as_dev(edge_raw_features)
         self.neighbor_sampler = neighbor_sampler
         self.node_feat_dim = self.node_raw_features.shape[1]
         self.edge_feat_dim = self.edge_raw_features.shape[1]

@@ -345,3 +345,13 @@ def profile_collect(tag: str, reset=True):
     ms, units, cnt = C.c_double(), C.c_double(), C.c_int64()
     check(lib().tg_profile_collect(tag.encode(), C.byref(ms), C.byref(units), C.byref(cnt), int(reset)), "tg_profile_collect")
     return ms.value, units.value, cnt.value
+
+
+def hash_features(nrows: int, cols: int, seed: int, device, chunk_rows: int = 1 << 22) -> torch.Tensor:
+    """(nrows, cols) fp32 table generated straight into HBM: element = f(row, col, seed), row 0 zero (synth.hash_features_host
+    recomputes any row on the host)"""
+    out = torch.empty((nrows, cols), dtype=torch.float32, device=device)
+    for r0 in range(0, nrows, chunk_rows):
+        n = min(chunk_rows, nrows - r0)
+        check(lib().tg_hash_features(_p(out[r0:]), cols, r0, n, cols, int(seed), _stream()), "tg_hash_features")
+    return out

@@ -163,6 +163,11 @@ int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, 
 /* weight-gradient products of tg_tgat_layer_bwd on an internal side stream (default on); they are joined before it returns */
 void tg_set_overlap(int on);
 
+/* ---- synthetic feature tables (measurement only) ---------------------------
+ * out[r, c] = f(row0 + r, c, seed), uniform with unit variance, row 0 = 0; the stand-in for the node / edge feature blobs
+ * utils/DataLoader.py:238-246 loads, at sizes (10 M x 172, 100 M x 172) that are generated straight into HBM. */
+int tg_hash_features(float* d_out, int64_t ld, int64_t row0, int64_t nrows, int cols, uint64_t seed, void* stream);
+
 /* ---- dense fp32 (MFMA 32x32x2 f32, exact fp32) -----------------------------------------------------
  * replaces the aten::mm / addmm calls behind nn.Linear in models/modules.py:54-69,152-163,235.
  * C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ C if accumulate), then optional ReLU.

@@ -186,3 +186,42 @@ def test_prepared_batch_equals_direct_call():
         s1, d1 = m.compute_src_dst_node_temporal_embeddings(pf, None, None, k)
         s2, d2 = m.compute_src_dst_node_temporal_embeddings(src, dst, t, k)
     assert torch.equal(s0, s1) and torch.equal(d0, d1) and torch.equal(s0, s2) and torch.equal(d0, d2)
+
+
+def test_scale_workload_small_hashed_tables_match_oracle():
+    """SURVEY 8d config 5 at toy size: interaction stream from synth.scale_like, feature tables hashed straight into HBM
+    (tg_hash_features); the host mirror of the hash reproduces the tables bit-exactly and the oracle, fed those, the embeddings."""
+    from flid_amd import ops
+    from flid_amd.synth import hash_features_host, scale_like
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = scale_like(num_users=3000, num_items=400, num_edges=40000, seed=3, chunk=7000)
+    assert np.all(np.diff(data.node_interact_times) >= 0) and data.dst_node_ids.max() == 3400
+    dev = torch.device("cuda:0")
+    node_tab = ops.hash_features(3401, 172, 1, dev, chunk_rows=1000)
+    edge_tab = ops.hash_features(40001, 172, 2, dev)
+    rows = np.array([0, 1, 2, 999, 1000, 1001, 3400])
+    assert np.array_equal(node_tab[rows].cpu().numpy(), hash_features_host(rows, 172, 1))
+    erows = np.array([0, 1, 39999, 40000])
+    assert np.array_equal(edge_tab[erows].cpu().numpy(), hash_features_host(erows, 172, 2))
+    assert float(node_tab[0].abs().max()) == 0.0 and abs(float(edge_tab[1:].var()) - 1.0) < 0.01
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    torch.manual_seed(0)
+    m = TGAT(node_tab, edge_tab, sampler, 100, 2, 2, 0.0, "cuda:0").to(dev).eval()
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.dim() > 1 and prm.shape[1] > 1:
+                prm.copy_(torch.randn_like(prm) * 0.05)
+    sl = slice(30000, 30016)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    with torch.no_grad():
+        s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 20)
+    p = {k_: v.detach().cpu() for k_, v in m.state_dict().items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    nt = torch.from_numpy(hash_features_host(np.arange(3401), 172, 1))
+    et = torch.from_numpy(hash_features_host(np.arange(40001), 172, 2))
+    orc = O.TGATOracle(nt, et, adj, p, 2, 2)
+    with torch.no_grad():
+        os_, od_ = orc.src_dst(bs, bd, bt, 20)
+    np.testing.assert_allclose(s.cpu().numpy(), os_.numpy(), atol=TOL)
+    np.testing.assert_allclose(d.cpu().numpy(), od_.numpy(), atol=TOL)
