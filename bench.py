@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--scale-edges", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the untimed per-family profiling pass")
-    ap.add_argument("--cpu-sample-edges", type=int, default=150)
+    ap.add_argument("--cpu-sample-edges", type=int, default=600)
     args = ap.parse_args()
 
     from flid_amd import dist as fdist
