@@ -195,7 +195,9 @@ __global__ void __launch_bounds__(256) colsum_seg_kernel(const float* __restrict
 }
 int colsum_seg(const float* x, int64_t ld, int64_t n, int cols, const SegDst& d, hipStream_t s) {
     if (n == 0) return TG_OK;
-    const int slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, n / 32));
+    const int col_groups = (cols + 63) / 64;
+    const int64_t max_slices = std::max<int64_t>(64, std::min<int64_t>(512, 2048 / col_groups));
+    const int slices = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, n / 32));
     colsum_seg_kernel<<<dim3((cols + 63) / 64, slices), 256, 0, s>>>(x, ld, n, cols, d);
     return tg::launch_status("colsum_seg_kernel");
 }

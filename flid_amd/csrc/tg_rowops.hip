@@ -296,7 +296,10 @@ extern "C" int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const fl
 extern "C" int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, float* d_out, int accumulate, void* stream) {
     TG_REQUIRE(d_x && d_out && cols > 0 && n >= 0 && ld >= cols, "tg_colsum: arguments");
     hipStream_t s = (hipStream_t)stream;
-    int slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, n / 32));
+    // enough row slices to cover the chip for tall inputs (38 400 token rows x 200..800 columns in DyGFormer: 64 slices = 25 us)
+    const int col_groups = (cols + 63) / 64;
+    const int64_t max_slices = std::max<int64_t>(64, std::min<int64_t>(512, 2048 / col_groups));
+    int slices = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, n / 32));
     const size_t need = (size_t)slices * cols;
     ColsumWs* w = nullptr;
     for (auto& c : g_colsum_ws) if (c.p && c.stream == s) { w = &c; break; }

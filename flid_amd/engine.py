@@ -527,9 +527,9 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
         if len(ids) and (int(ids.max()) >= graph.num_rows or int(ids.min()) < 0):
             raise IndexError("list index out of range")                      # what utils/utils.py:141 raises
         n = len(ids)
-        ids_dev = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(dev)
         tt = np.asarray(times)
-        times_dev = torch.from_numpy(np.ascontiguousarray(tt, dtype=np.float32 if tt.dtype == np.float32 else np.float64)).to(dev)
+        ids_dev, times_dev = ops.h2d([np.ascontiguousarray(ids, dtype=np.int32),
+                                      np.ascontiguousarray(tt, dtype=np.float32 if tt.dtype == np.float32 else np.float64)], dev)
     if n == 0:
         return torch.zeros((0, table.shape[1]), device=dev)
     if num_layers == 0:

@@ -95,11 +95,10 @@ class DyGFormer(nn.Module):
             if len(ids) and (int(ids.max()) >= g.num_rows or int(ids.min()) < 0):
                 raise IndexError("list index out of range")
         B, P = len(src_node_ids), self.patch_size
-        t_dev = torch.from_numpy(np.ascontiguousarray(node_interact_times, dtype=np.float64)).to(dev)
-        sides = []
-        for ids in (src_node_ids, dst_node_ids):
-            ids_dev = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(dev)
-            sides.append(self._windows(ids_dev, t_dev))
+        t_dev, src_dev, dst_dev = ops.h2d([np.ascontiguousarray(node_interact_times, dtype=np.float64),
+                                           np.ascontiguousarray(src_node_ids, dtype=np.int32),
+                                           np.ascontiguousarray(dst_node_ids, dtype=np.int32)], dev)
+        sides = [self._windows(ids_dev, t_dev) for ids_dev in (src_dev, dst_dev)]
         # the reference pads every side to ITS OWN longest sequence of the batch (+ the node itself, rounded up to a patch
         # multiple): the unmasked transformer sees the padded positions, so the width is part of the result.  One tiny readback.
         lens = torch.stack([sides[0][3].max(), sides[1][3].max()]).cpu().tolist() if B else [1, 1]

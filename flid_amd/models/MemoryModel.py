@@ -220,7 +220,7 @@ class MemoryModel(torch.nn.Module):
         new_rows = None
         if len(ids):
             dev = self.node_raw_features.device
-            idx = torch.from_numpy(ids.astype(np.int32)).to(dev)
+            idx, = ops.h2d([ids.astype(np.int32)], dev)
             new_rows = _GRURowsFn.apply(ops.gather_rows(bank._msg, idx), ops.gather_rows(bank.node_memories.detach(), idx),
                                         gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
             base = base.index_copy(0, idx.long(), new_rows + ops.gather_rows(self.node_raw_features, idx))
@@ -261,32 +261,32 @@ class MemoryModel(torch.nn.Module):
             #     Same inputs, same kernel as the view above: its rows are reused.
             uniq = np.unique(node_ids)
             upd = uniq[bank._has[uniq]]
+            n = len(src_node_ids)
+            rev_nodes = node_ids[::-1]
+            u, first_rev = np.unique(rev_nodes, return_index=True)
+            last_pos = (2 * n - 1 - first_rev).astype(np.int64)
             if len(upd):
                 self._check_not_in_the_past(upd)
-                ui = torch.from_numpy(upd).to(dev)
+            # every host array of the state update goes over in one pinned, asynchronous copy
+            ui, where, new_t, a, b, t32, e, u_dev, last_dev = ops.h2d(
+                [upd.astype(np.int64), np.searchsorted(pend_ids, upd).astype(np.int64), bank._msg_time[upd].astype(np.float32),
+                 np.concatenate([src_node_ids, dst_node_ids]).astype(np.int32), np.concatenate([dst_node_ids, src_node_ids]).astype(np.int32),
+                 np.concatenate([node_interact_times, node_interact_times]).astype(np.float32),
+                 np.concatenate([edge_ids, edge_ids]).astype(np.int32), u.astype(np.int64), last_pos], dev)
+            if len(upd):
                 with torch.no_grad():
-                    where = torch.from_numpy(np.searchsorted(pend_ids, upd)).to(dev)      # rows of the view's GRU output
-                    bank.node_memories.data.index_copy_(0, ui, new_rows.detach()[where])
-                    new_t = torch.from_numpy(bank._msg_time[upd].astype(np.float32)).to(dev)
+                    bank.node_memories.data.index_copy_(0, ui, new_rows.detach()[where])     # `where` = rows of the view's GRU output
                     bank.node_last_updated_times.data.index_copy_(0, ui, new_t)
                 bank._h_last[upd] = bank._msg_time[upd].astype(np.float32)
             # (2) clear the batch nodes' pending messages (:162)
             bank._has[uniq] = False
             # (3) new raw messages from the post-update state, source role then destination role (:165-180); per node the
             #     last one in that order is the one that will ever be read
-            n = len(src_node_ids)
-            a = torch.from_numpy(np.concatenate([src_node_ids, dst_node_ids]).astype(np.int32)).to(dev)
-            b = torch.from_numpy(np.concatenate([dst_node_ids, src_node_ids]).astype(np.int32)).to(dev)
-            t32 = torch.from_numpy(np.concatenate([node_interact_times, node_interact_times]).astype(np.float32)).to(dev)
-            e = torch.from_numpy(np.concatenate([edge_ids, edge_ids]).astype(np.int32)).to(dev)
             with torch.no_grad():
                 msgs = ops.build_messages(bank.node_memories.data, bank.node_last_updated_times.data, a, b, t32,
                                           self.edge_raw_features, e, self.time_encoder.w.weight.detach().reshape(-1),
                                           self.time_encoder.w.bias.detach())
-                rev_nodes = node_ids[::-1]
-                u, first_rev = np.unique(rev_nodes, return_index=True)
-                last_pos = (2 * n - 1 - first_rev).astype(np.int64)
-                bank._msg.index_copy_(0, torch.from_numpy(u).to(dev), msgs[torch.from_numpy(last_pos).to(dev)])
+                bank._msg.index_copy_(0, u_dev, msgs[last_dev])
             bank._has[u] = True
             bank._msg_time[u] = node_interact_times[last_pos % n]
         return src_emb, dst_emb

@@ -355,3 +355,28 @@ def hash_features(nrows: int, cols: int, seed: int, device, chunk_rows: int = 1 
         n = min(chunk_rows, nrows - r0)
         check(lib().tg_hash_features(_p(out[r0:]), cols, r0, n, cols, int(seed), _stream()), "tg_hash_features")
     return out
+
+
+_NP2T = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.float32): torch.float32,
+         np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8, np.dtype(np.bool_): torch.bool}
+
+
+def h2d(arrays, device):
+    """Several host numpy arrays -> device tensors with ONE asynchronous copy from a pinned staging block.
+    `torch.from_numpy(x).to(device)` on pageable memory blocks the host until the stream has drained up to the copy; a step that
+    hands over a dozen small id / time arrays that way serialises host and GPU a dozen times (TGN: 2.0 ms wall for 1.0 ms of
+    kernels).  The pinned block comes from torch's caching host allocator, which keeps it alive until the copy has run."""
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + 15) // 16 * 16
+    if total == 0:
+        return [torch.empty(a.shape, dtype=_NP2T[a.dtype], device=device) for a in arrays]
+    host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+    hv = host.numpy()
+    for a, o in zip(arrays, offs):
+        if a.nbytes:
+            hv[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    dev = host.to(device, non_blocking=True)
+    return [dev[o:o + a.nbytes].view(_NP2T[a.dtype]).reshape(a.shape) for a, o in zip(arrays, offs)]
