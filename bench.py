@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--scale-users", type=int, default=9_000_000)
     ap.add_argument("--scale-items", type=int, default=1_000_000)
     ap.add_argument("--scale-edges", type=int, default=100_000_000)
+    ap.add_argument("--no-flat", action="store_true", help="per-tensor parameters / gradients / Adam as in the reference's trainers")
+    ap.add_argument("--trace-steps", action="store_true", help="per-step GPU times (events) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the untimed per-family profiling pass")
     ap.add_argument("--cpu-sample-edges", type=int, default=1800)
@@ -101,8 +103,11 @@ def main():
     model = TGAT(node_tab, edge_tab, sampler, time_feat_dim=DT, num_layers=L, num_heads=H,
                  dropout=args.dropout, device=str(dev)).to(dev).train()
     fdist.broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)                  # load_configs.py:119,123 (one fused update kernel)
-    reducer = fdist.GradAllReducer(model.parameters()) if world > 1 else None
+    # all 24 parameter tensors live in one flat parameter (state_dict unchanged): one gradient tensor per step, one Adam kernel,
+    # one all-reduce operand.  --no-flat keeps the reference's per-tensor parameters.
+    train_params = [model.flatten_parameters()] if not args.no_flat else list(model.parameters())
+    opt = torch.optim.Adam(train_params, lr=1e-4, fused=True)                        # load_configs.py:119,123
+    reducer = fdist.GradAllReducer(train_params) if world > 1 else None
 
     total_steps = args.warmup + args.steps
     n_batches = n_train // BATCH
@@ -160,11 +165,21 @@ def main():
     ops.profile_enable(args.roofline_kernel)
     ops.profile_collect(args.roofline_kernel)
     barrier()
+    marks = []
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
         step(s)
+        if args.trace_steps:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((ev, time.perf_counter() - t0))
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.trace_steps and rank == 0:
+        gpu = [marks[i - 1][0].elapsed_time(marks[i][0]) for i in range(1, len(marks))]
+        host = [marks[i][1] - marks[i - 1][1] for i in range(1, len(marks))]
+        print("[bench] per-step GPU ms :", " ".join(f"{x:.2f}" for x in gpu), file=sys.stderr)
+        print("[bench] per-step host ms:", " ".join(f"{x * 1e3:.2f}" for x in host), file=sys.stderr)
     fam = {args.roofline_kernel: ops.profile_collect(args.roofline_kernel)}
     others = [t for t in ("attn_fwd", "attn_bwd", "gemm") if t != args.roofline_kernel]
     if not args.no_breakdown:

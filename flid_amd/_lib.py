@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libflid_tg.so")
+# FLID_TG_LIB: another build of the same library (A/B timing of kernel variants, tools/); never a different implementation
+LIB_PATH = os.environ.get("FLID_TG_LIB") or os.path.join(_HERE, "csrc", "libflid_tg.so")
 
 c_i64, c_i32, c_f32, c_void = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 

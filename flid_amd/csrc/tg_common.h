@@ -10,6 +10,7 @@
 namespace tg {
 
 void set_error(const std::string& s);
+std::string get_error();   // this thread's last error text (errors are thread-local: the side-stream issuing thread relays its own)
 
 #define TG_HIP_CHECK(expr)                                                                         \
     do {                                                                                           \
@@ -49,7 +50,9 @@ struct __attribute__((aligned(16))) Incidence {
 struct ProfScope {
     ProfScope(const char* tag, double units, hipStream_t s);
     ~ProfScope();
-    int slot;
+    const char* tag;
+    double units;
+    hipEvent_t a, b;     // null when the family is not being timed
     hipStream_t stream;
 };
 

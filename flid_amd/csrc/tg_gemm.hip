@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
         const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
         const float* __restrict__ bias, int relu, int accumulate, int64_t k_chunk, int use_atomics, int gx, int gy_in,
         int64_t strideA, int64_t strideB, int64_t strideC, int nbatch, int inner, int64_t innerA, int64_t innerB, int64_t innerC,
-        float* __restrict__ ws, int nslice_x) {
+        float* __restrict__ ws, int nslice_x, int vec_c) {
     constexpr int NT = TM * TN * 64, RA = 32 * TM, RB_ = 32 * TN;
     constexpr int FA = PanelFloats<RA, A_KC>::value, FB = PanelFloats<RB_, B_KC>::value;
     using PA = Panel<RA, NT, A_KC, VEC>;
@@ -243,10 +243,37 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
 
     // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int rl = lane & 31, kh = lane >> 5;
+    if (use_atomics == 2) ws += (int64_t)zidx * M * N;          // this (batch, split)'s partial product, folded by splitk_reduce
+    if (use_atomics != 1 && vec_c) {
+        // the block tile goes through LDS and leaves as whole 16-byte row chunks (plain result or split partial); the element-wise
+        // path below costs ~500 unrolled instructions and 128-byte store pieces per wave
+        constexpr int CS = RB_ + 8;                             // row stride in floats: 4 rows further = 32 banks further
+        static_assert(RA * CS <= 2 * (FA + FB), "C staging must fit the operand stages");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CS + tn * 32 + rl] = alpha * acc[r];
+        __syncthreads();
+        constexpr int C4 = RB_ / 4;
+        float* dst = use_atomics == 2 ? ws : C;
+        const int64_t dld = use_atomics == 2 ? N : ldc;
+        const bool plain = use_atomics == 0;
+        for (int idx = threadIdx.x; idx < RA * C4; idx += NT) {
+            const int r = idx / C4, c4 = idx - r * C4;
+            const int64_t row = bm + r, col = bn + c4 * 4;
+            if (row >= M || col >= N) continue;
+            float4 v = *reinterpret_cast<const float4*>(lds + r * CS + c4 * 4);
+            float* p = dst + row * dld + col;
+            if (plain) {
+                if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            *reinterpret_cast<float4*>(p) = v;
+        }
+        return;
+    }
     const int64_t col = bn + tn * 32 + rl;
     if (col >= N) return;
     const float bv = (bias && split == 0 && use_atomics != 2) ? bias[col] : 0.f;
-    if (use_atomics == 2) ws += (int64_t)zidx * M * N;          // this (batch, split)'s partial product, folded by splitk_reduce
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t row = bm + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -310,7 +337,7 @@ float* split_workspace(size_t need, hipStream_t s) {
 }
 
 struct Args {
-    float* ws;
+    float* ws; int vec_c;
     int64_t M, N, K; float alpha; const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
     const float* bias; int relu, accumulate; int64_t k_chunk; int atomics, gx, gy; int64_t sA, sB, sC; int nbatch, splits;
     int inner; int64_t iA, iB, iC;
@@ -323,7 +350,7 @@ void launch(const Args& a, hipStream_t s) {
     const int nslice_x = (!nopin && a.splits > 1 && slices % 8 == 0) ? (int)slices : 0;
     const dim3 grid(nslice_x ? tiles * slices : tiles, 1, nslice_x ? 1 : slices);
     gemm_tile_kernel<A_KC, B_KC, VEC, TM, TN><<<grid, TM * TN * 64, 0, s>>>(a.M, a.N, a.K, a.alpha, a.A, a.lda, a.B, a.ldb, a.C,
-        a.ldc, a.bias, a.relu, a.accumulate, a.k_chunk, a.atomics, a.gx, a.gy, a.sA, a.sB, a.sC, a.nbatch, a.inner, a.iA, a.iB, a.iC, a.ws, nslice_x);
+        a.ldc, a.bias, a.relu, a.accumulate, a.k_chunk, a.atomics, a.gx, a.gy, a.sA, a.sB, a.sC, a.nbatch, a.inner, a.iA, a.iB, a.iC, a.ws, nslice_x, a.vec_c);
 }
 
 template <bool A_KC, bool B_KC>
@@ -428,7 +455,9 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     if (skip_launch) return TG_OK;
     tg::ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     const bool noswz = tuning && getenv("FLID_GEMM_NOSWZ") != nullptr;
-    const Args a{ws, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, noswz ? -(int)gy : (int)gy,
+    // 16-byte row chunks of C (or of the split workspace) are stored whole when every chunk lies inside the matrix and is aligned
+    const int vec_c = N % 4 == 0 && (atomics == 2 || (ldc % 4 == 0 && strideC % 4 == 0 && innerC % 4 == 0 && al16(d_C) && (!d_bias || al16(d_bias))));
+    const Args a{ws, vec_c, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, noswz ? -(int)gy : (int)gy,
                  strideA, strideB, strideC, nbatch, (int)splits, inner, innerA, innerB, innerC};
     if (a_kc && b_kc) dispatch<true, true>(vec, tm, tn, a, s);
     else if (a_kc && !b_kc) dispatch<true, false>(vec, tm, tn, a, s);

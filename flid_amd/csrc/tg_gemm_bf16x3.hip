@@ -41,6 +41,11 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
     lo.y = pack_bf16(v.z - bf16_lo_to_f32(hi.y), v.w - bf16_hi_to_f32(hi.y));
 }
 
+// Loads past the end of K read this instead of being branched around: every issue() is then a fixed number of loads on every
+// path, so the compiler can wait with s_waitcnt vmcnt(N) for exactly the older register set.  With guarded loads it fell back to
+// vmcnt(0) before each LDS store, which also waited for the loads issued one stage ago -- the look-ahead was one stage, not two.
+// (a 16-byte zero block in global memory, handed to the kernel as an ordinary pointer so that the select stays a global load)
+
 // one panel of R rows x 32 k (k contiguous in memory); slot = (row, 4-float chunk)
 template <int R>
 struct Panel {
@@ -63,17 +68,13 @@ struct Panel {
             kcol[j] = c * 4;
         }
     }
-    __device__ __forceinline__ void gload(int64_t elems, int64_t k0, int64_t kend, bool full, float4 (&reg)[PER]) const {
-        if (full) {
+    // stage at float offset `elems` (= k0); `ok` = the stage exists at all (uniform)
+    __device__ __forceinline__ void gload(int64_t elems, int64_t k0, int64_t kend, bool ok, const float* __restrict__ zeros,
+                                          float4 (&reg)[PER]) const {
 #pragma unroll
-            for (int j = 0; j < PER; ++j) reg[j] = *reinterpret_cast<const float4*>(src[j] + elems);
-        } else {
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k0 + kcol[j] < kend) v = *reinterpret_cast<const float4*>(src[j] + elems);
-                reg[j] = v;
-            }
+        for (int j = 0; j < PER; ++j) {
+            const float* p = (ok && k0 + kcol[j] < kend) ? src[j] + elems : zeros;
+            reg[j] = *reinterpret_cast<const float4*>(p);
         }
     }
     __device__ __forceinline__ void sstore(char* __restrict__ s, const float4 (&reg)[PER]) const {
@@ -99,7 +100,7 @@ __device__ __forceinline__ void read_frag(const char* __restrict__ s, int tile_r
 template <int TNW>
 __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
         const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int relu,
-        int accumulate, int gx, int gy, int64_t strideA, int64_t strideB, int64_t strideC) {
+        int accumulate, int gx, int gy, int64_t strideA, int64_t strideB, int64_t strideC, const float* __restrict__ zeros, int vec_c) {
     constexpr int BNt = 32 * TNW;
     constexpr int FA = BM * ROW_BYTES, FB = BNt * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
@@ -133,12 +134,10 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
     // two register sets: the loads of stage s+2 and s+3 are in flight while stage s computes (the stages are short -- 12..18
     // bf16 MFMAs -- so one stage of look-ahead does not cover an L2 round trip)
     float4 ra0[Panel<BM>::PER], rb0[Panel<BNt>::PER], ra1[Panel<BM>::PER], rb1[Panel<BNt>::PER];
-    const int64_t nstage = (K + BK - 1) / BK, nfull = K / BK;
+    const int64_t nstage = (K + BK - 1) / BK;
     auto issue = [&](int64_t st, float4 (&ra)[Panel<BM>::PER], float4 (&rb)[Panel<BNt>::PER]) {
-        if (st < nstage) {
-            pa.gload(st * BK, st * BK, K, st < nfull, ra);
-            pb.gload(st * BK, st * BK, K, st < nfull, rb);
-        }
+        pa.gload(st * BK, st * BK, K, st < nstage, zeros, ra);   // unconditional: a stage past the end loads zeros
+        pb.gload(st * BK, st * BK, K, st < nstage, zeros, rb);
     };
     auto stage = [&](int64_t st, float4 (&ra)[Panel<BM>::PER], float4 (&rb)[Panel<BNt>::PER]) {
         // on entry LDS[st & 1] holds stage st and (ra, rb) hold stage st + 1
@@ -181,22 +180,46 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
         if (st + 1 < nstage) stage(st + 1, ra1, rb1);
     }
 
-    // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int rl = lane & 31, kh = lane >> 5;
+    // Epilogue through LDS: the MFMA C/D layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) would store
+    // 4-byte elements, two 128-byte pieces per instruction, from ~1000 unrolled instructions; a one-stage launch spent most of
+    // its 14 us there.  Each wave parks its 32 x BNt tile in its own LDS region and a short rolled loop writes whole
+    // 16-byte-aligned row segments (bias / accumulate / ReLU applied on the way).
+    __syncthreads();                                    // all waves are done reading the operand stages
+    constexpr int CS = BNt + 8;                         // row stride in floats: 4 rows further = 32 banks further
+    static_assert(4 * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
+    float* cs = reinterpret_cast<float*>(lds) + wave * 32 * CS;
+    {
+        const int rl = lane & 31, kh = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < TNW; ++t) {
-        const int64_t col = bn + t * 32 + rl;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        for (int t = 0; t < TNW; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = bm + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row >= M) continue;
-            float v = acc[t][r] + bv;
-            float* p = C + row * ldc + col;
-            if (accumulate) v += *p;
-            if (relu) v = fmaxf(v, 0.f);
-            *p = v;
+            for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * CS + t * 32 + rl] = acc[t][r];
+    }
+    __builtin_amdgcn_wave_barrier();                    // same wave reads back (LDS operations of a wave complete in order)
+    constexpr int C4 = BNt / 4;
+    const int64_t row0 = bm + wave * 32;
+#pragma unroll 2
+    for (int idx = lane; idx < 32 * C4; idx += 64) {
+        const int r = idx / C4, c4 = idx - r * C4;
+        const int64_t row = row0 + r, col = bn + c4 * 4;
+        if (row >= M || col >= N) continue;
+        float4 v = *reinterpret_cast<const float4*>(cs + r * CS + c4 * 4);
+        float* p = C + row * ldc + col;
+        if (vec_c) {                                    // N % 4 == 0, 16-byte aligned rows: the whole chunk is inside C
+            if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+            if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(p) = v;
+        } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (col + q >= N) break;
+                float x = e[q] + (bias ? bias[col + q] : 0.f);
+                if (accumulate) x += p[q];
+                if (relu) x = fmaxf(x, 0.f);
+                p[q] = x;
+            }
         }
     }
 }
@@ -359,12 +382,17 @@ bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     const int tnw = pad3 <= pad2 ? 3 : 2;
     const int64_t gx = (N + 32 * tnw - 1) / (32 * tnw), gy = (M + BM - 1) / BM;
     if (gx * gy >= ((int64_t)1 << 30)) return false;
+    static float* zeros = nullptr;          // 64 zero bytes the kernel's out-of-range loads are pointed at
+    if (!zeros) {
+        if (hipMalloc(&zeros, 64) != hipSuccess || hipMemset(zeros, 0, 64) != hipSuccess) { zeros = nullptr; (void)hipGetLastError(); return false; }
+    }
+    const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias));
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     const dim3 grid((unsigned)(gx * gy), 1, (unsigned)nbatch);
     if (tnw == 3)
-        gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC);
+        gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c);
     else
-        gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC);
+        gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c);
     return true;
 }
 

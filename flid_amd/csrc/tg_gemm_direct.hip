@@ -18,14 +18,15 @@ constexpr int U = 8;   // chunks (of 8 k) in flight per wave and operand: 16 flo
 __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
                                                              int64_t lda, int64_t sA, const float* __restrict__ B, int64_t ldb,
                                                              int64_t sB, float* __restrict__ C, int64_t ldc, int64_t sC,
-                                                             const float* __restrict__ bias, int relu, int accumulate, int gx) {
-    __shared__ float red[3][32][33];
+                                                             const float* __restrict__ bias, int relu, int accumulate, int gx, int vec_c) {
+    __shared__ float red[4][32][36];                // stride 36 floats: 16-byte aligned rows for the fold's float4 reads
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int64_t tn = blockIdx.x % gx, tm = blockIdx.x / gx;
     A += blockIdx.y * sA;
     B += blockIdx.y * sB;
     C += blockIdx.y * sC;
+    if (bias) bias += blockIdx.y * N;
     int64_t row = tm * 32 + i, col = tn * 32 + i;
     row = row < M ? row : M - 1;                    // clamped rows are loaded but never stored
     col = col < N ? col : N - 1;
@@ -56,26 +57,33 @@ __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t 
         }
     }
 
-    // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if (w > 0) {
+    // every wave parks its partial tile (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); then each of
+    // the 256 threads folds one 4-column chunk in fixed wave order and writes it as one 16-byte store
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[w - 1][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
-    }
+    for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
     __syncthreads();
-    if (w > 0) return;
-    const int64_t ocol = tn * 32 + i;
-    if (ocol >= N) return;
-    const float bvv = bias ? bias[ocol] : 0.f;
+    const int rr = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const int64_t orow = tm * 32 + rr, ocol = tn * 32 + c4;
+    if (orow >= M || ocol >= N) return;
+    float v[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int64_t orow = tm * 32 + rr;
-        if (orow >= M) continue;
-        float v = ((acc[r] + red[0][rr][i]) + red[1][rr][i]) + red[2][rr][i] + bvv;
-        float* p = C + orow * ldc + ocol;
-        if (accumulate) v += *p;
-        if (relu) v = fmaxf(v, 0.f);
-        *p = v;
+    for (int q = 0; q < 4; ++q) v[q] = ((red[0][rr][c4 + q] + red[1][rr][c4 + q]) + red[2][rr][c4 + q]) + red[3][rr][c4 + q];
+    float* p = C + orow * ldc + ocol;
+    if (vec_c) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + ocol); o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w; }
+        if (accumulate) { const float4 c = *reinterpret_cast<const float4*>(p); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(p) = o;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ocol + q >= N) break;
+            float x = v[q] + (bias ? bias[ocol + q] : 0.f);
+            if (accumulate) x += p[q];
+            if (relu) x = fmaxf(x, 0.f);
+            p[q] = x;
+        }
     }
 }
 
@@ -92,9 +100,10 @@ bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     // the point of this kernel is a chip that would otherwise be mostly idle: beyond ~8 workgroups per CU the tiled kernels'
     // operand reuse wins
     if (gx * gy * nbatch > 2048 || nbatch > 65535 || K > 4096) return false;
+    const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias));
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     hipLaunchKernelGGL(gemm_direct_nt_kernel, dim3((unsigned)(gx * gy), (unsigned)nbatch), dim3(256), 0, s, M, N, K, A, lda, strideA,
-                       B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx);
+                       B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx, vec_c);
     return true;
 }
 

@@ -6,26 +6,30 @@
 #include <numeric>
 #include <vector>
 
+#include <mutex>
+
 #include "tg_common.h"
 
 namespace tg {
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
+std::string get_error() { return g_err; }
 
 struct ProfRec { std::string tag; double units; hipEvent_t a, b; };
 static int g_prof_mask = 0;   // bit 0 attn_fwd, bit 1 attn_bwd, bit 2 gemm
 static int prof_bit(const char* tag) { return tag[0] == 'g' ? 4 : (tag[5] == 'f' ? 1 : 2); }
 static std::vector<ProfRec> g_prof;
-ProfScope::ProfScope(const char* tag, double units, hipStream_t s) : slot(-1), stream(s) {
+static std::mutex g_prof_mutex;          // launches come from two host threads (tg_layer.hip: SideIssuer)
+ProfScope::ProfScope(const char* tag_, double units_, hipStream_t s) : tag(tag_), units(units_), a(nullptr), b(nullptr), stream(s) {
     if (!(g_prof_mask & prof_bit(tag))) return;
-    ProfRec r{tag, units, nullptr, nullptr};
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    (void)hipEventRecord(r.a, s);
-    g_prof.push_back(r);
-    slot = (int)g_prof.size() - 1;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, s);
 }
 ProfScope::~ProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream);
+    if (!a) return;
+    (void)hipEventRecord(b, stream);
+    std::lock_guard<std::mutex> g(g_prof_mutex);
+    g_prof.push_back(ProfRec{tag, units, a, b});
 }
 }  // namespace tg
 

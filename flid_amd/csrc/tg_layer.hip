@@ -7,6 +7,12 @@
 //                     models/TGAT.py:132-142 / models/MemoryModel.py:703-713, and their autograd.
 #include <math.h>
 
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 #include "tg_common.h"
 
 namespace {
@@ -273,7 +279,7 @@ inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::
 // cores are free for them.  fork(): side waits for everything issued on main so far; join(): main waits for side.
 struct SideStream {
     hipStream_t side = nullptr;
-    hipEvent_t ev[8];
+    hipEvent_t ev[16];
     int next = 0;
     bool ok = false;
     bool init() {
@@ -283,19 +289,69 @@ struct SideStream {
         ok = true;
         return true;
     }
-    int fork(hipStream_t main) {
-        hipEvent_t e = ev[next++ & 7];
-        TG_HIP_CHECK(hipEventRecord(e, main));
-        TG_HIP_CHECK(hipStreamWaitEvent(side, e, 0));
-        return TG_OK;
-    }
-    int join(hipStream_t main) {
-        hipEvent_t e = ev[next++ & 7];
-        TG_HIP_CHECK(hipEventRecord(e, side));
-        TG_HIP_CHECK(hipStreamWaitEvent(main, e, 0));
-        return TG_OK;
+    hipEvent_t mark(hipStream_t on, int* rc) {           // record "everything issued on `on` so far"
+        hipEvent_t e = ev[next++ & 15];
+        *rc = hipEventRecord(e, on) == hipSuccess ? TG_OK : TG_EHIP;
+        return e;
     }
 };
+
+// The side stream's launches are ISSUED by a helper thread: a backward call is ~35 launches per layer, two thirds of them on
+// the side stream, and at ~6 us of host time per launch the step had become bound by the issuing thread (host 1.4 ms vs GPU
+// 1.5 ms per step, any host jitter showed in the headline).  Jobs run strictly in push order; drain() returns after the last
+// one has been issued (not executed) so that the caller can join the streams.
+class SideIssuer {
+public:
+    void push(std::function<int()> f) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (!started_) { started_ = true; int dev = 0; (void)hipGetDevice(&dev); th_ = std::thread([this, dev] { run(dev); }); }
+            q_.push_back(std::move(f));
+        }
+        cv_.notify_one();
+    }
+    int drain() {
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return q_.empty() && !busy_; });
+        const int rc = err_;
+        err_ = TG_OK;
+        if (rc != TG_OK) tg::set_error(msg_);          // errors are thread-local: relay the issuing thread's text
+        return rc;
+    }
+    ~SideIssuer() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_one();
+        if (th_.joinable()) th_.join();
+    }
+private:
+    void run(int dev) {
+        (void)hipSetDevice(dev);
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return stop_ || !q_.empty(); });
+            if (stop_ && q_.empty()) return;
+            std::function<int()> f = std::move(q_.front());
+            q_.pop_front();
+            busy_ = true;
+            g.unlock();
+            const int rc = f();
+            std::string msg = rc != TG_OK ? tg::get_error() : std::string();
+            g.lock();
+            busy_ = false;
+            if (rc != TG_OK && err_ == TG_OK) { err_ = rc; msg_ = std::move(msg); }
+            if (q_.empty()) done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::deque<std::function<int()>> q_;
+    std::thread th_;
+    bool started_ = false, stop_ = false, busy_ = false;
+    int err_ = TG_OK;
+    std::string msg_;
+};
+SideIssuer g_issuer;
+bool g_issue_thread = true;
 SideStream g_side;
 bool g_overlap = true;
 
@@ -382,6 +438,23 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const bool overlap = g_overlap && g_side.init();
     void* wstream = overlap ? (void*)g_side.side : stream;        // where everything that only feeds parameter gradients goes
     hipStream_t ws_ = (hipStream_t)wstream;
+    // side(f): issue f's launches now, or hand them to the issuing thread (then every exit path drains it: the closures
+    // refer to this call's descriptors)
+    const bool threaded = overlap && g_issue_thread;
+    struct Drain { bool on; ~Drain() { if (on) (void)g_issuer.drain(); } } drain_guard{threaded};
+    auto side = [&](std::function<int()> f) -> int {
+        if (!threaded) return f();
+        g_issuer.push(std::move(f));
+        return TG_OK;
+    };
+    auto fork = [&]() -> int {                                     // side stream waits for everything issued on main so far
+        if (!overlap) return TG_OK;
+        int rc = TG_OK;
+        hipEvent_t e = g_side.mark(s, &rc);
+        if (rc != TG_OK) return rc;
+        hipStream_t sd = g_side.side;
+        return side([e, sd] { return hipStreamWaitEvent(sd, e, 0) == hipSuccess ? TG_OK : TG_EHIP; });
+    };
     // slab regions of `part` (each finished on the side stream while the main chain moves on)
     const int64_t relu_blocks = (R + 15) / 16;
     const unsigned ln_grid = (unsigned)row_grid(R);
@@ -391,18 +464,18 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     float* part_attn = part_ln + (int64_t)ln_grid * 4 * dq;
     float* vec_dq = vec;                                    // dq floats, zero on entry like the gradients
     // ---- merge layer -------------------------------------------------------------------------------------------------------
-    if (overlap) TG_TRY(g_side.fork(s));                           // dout is ready
-    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 1, wstream));
-    TG_TRY(colsum_seg(Bw->dout, dn, R, dn, seg1(G.b2, dn), ws_));
+    TG_TRY(fork());                           // dout is ready
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return colsum_seg(Bw->dout, dn, R, dn, seg1(G.b2, dn), ws_); }));
     TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
     TG_REQUIRE(dn <= 1024, "tg_tgat_layer_bwd: node dim > 1024 unsupported");
     if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
     else relu_bwd_colsum_kernel<4><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
     TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
-    if (overlap) TG_TRY(g_side.fork(s));                           // df1 and its slabs are final
-    TG_TRY(colsum_seg(part_relu, dn, relu_blocks, dn, seg1(G.b1, dn), ws_));
-    TG_TRY(tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 1, wstream));
-    TG_TRY(tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 1, wstream));
+    TG_TRY(fork());                           // df1 and its slabs are final
+    TG_TRY(side([=] { return colsum_seg(part_relu, dn, relu_blocks, dn, seg1(G.b1, dn), ws_); }));
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 1, wstream); }));
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
     if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
@@ -414,8 +487,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         else ln_res_bwd_kernel<16><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
     }
-    if (overlap) TG_TRY(g_side.fork(s));                           // dres / dsum and the LayerNorm slabs are final
-    TG_TRY(tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 1, wstream));
+    TG_TRY(fork());                           // dres / dsum and the LayerNorm slabs are final
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 1, wstream); }));
     {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
         SegDst d{};
         d.n = 5;
@@ -424,39 +497,47 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
         d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
         d.p[4] = G.br;       d.end[4] = 4 * dq;
-        TG_TRY(colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_));
+        TG_TRY(side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_); }));
     }
     // ---- output projection ------------------------------------------------------------------------------------------------------
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
     // ---- value path -------------------------------------------------------------------------------------------------------------
-    if (overlap) TG_TRY(g_side.fork(s));                           // dctx is final
-    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream));
+    TG_TRY(fork());                           // dctx is final
+    TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
     TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
     // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
     TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
-    if (overlap) TG_TRY(g_side.fork(s));                           // du and the time-encoder slabs are final
-    TG_TRY(tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream));
+    TG_TRY(fork());                           // du and the time-encoder slabs are final
+    TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
     {
         SegDst d{};
         d.n = 2;
         d.p[0] = Bw->d_tew; d.end[0] = T;
         d.p[1] = Bw->d_teb; d.end[1] = 2 * T;
-        TG_TRY(colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, ws_));
+        TG_TRY(side([=] { return colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, ws_); }));
     }
     // ---- key / query path --------------------------------------------------------------------------------------------------------
     TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
-    if (overlap) TG_TRY(g_side.fork(s));                           // dq is final
-    TG_TRY(tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 1, wstream));
-    TG_TRY(colsum_seg(Bw->dq, dq, R, dq, seg1(vec_dq, dq), ws_));                           // sum_rows dq (vec is zero on entry)
-    wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, ws_>>>(vec_dq, dq, L->cosb, T, P.Wq + dn, G.Wq + dn, dq, Bw->d_cosb);
-    TG_TRY(tg::launch_status("wq_time_kernel"));
+    TG_TRY(fork());                           // dq is final
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return colsum_seg(Bw->dq, dq, R, dq, seg1(vec_dq, dq), ws_); }));                           // sum_rows dq (vec is zero on entry)
+    TG_TRY(side([=] {
+        wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, ws_>>>(vec_dq, dq, L->cosb, T, P.Wq + dn, G.Wq + dn, dq, Bw->d_cosb);
+        return tg::launch_status("wq_time_kernel");
+    }));
     if (Bw->d_own) {
         TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
         add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
         TG_TRY(tg::launch_status("add_cols_kernel"));
     }
-    if (overlap) TG_TRY(g_side.join(s));
+    if (overlap) {                                                 // main waits for everything issued on the side stream
+        if (threaded) { drain_guard.on = false; TG_TRY(g_issuer.drain()); }
+        int rc = TG_OK;
+        hipEvent_t e = g_side.mark(g_side.side, &rc);
+        TG_TRY(rc);
+        TG_HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+    }
     return TG_OK;
 }
 
-extern "C" void tg_set_overlap(int on) { g_overlap = on != 0; }
+extern "C" void tg_set_overlap(int on) { g_overlap = (on & 1) != 0; g_issue_thread = (on & 2) == 0; }

@@ -285,8 +285,18 @@ _SCRATCH = {}
 NATIVE = True     # one native call per layer (tg_tgat_layer_fwd/bwd); False = the op-by-op Python composition below (same kernels)
 
 
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+_FWD_FIELDS = ("qbias", "q", "u", "agg", "prob", "ctx", "res", "y", "mean", "rstd", "f1", "wT")
+_BWD_FIELDS = ("df1", "dy", "dsum", "dres", "dctx", "dagg", "du", "dq", "part")
+
+
 class _NativeLayer:
-    """buffers + C descriptors of one tg_tgat_layer_fwd/bwd call pair"""
+    """buffers + C descriptors of one tg_tgat_layer_fwd/bwd call pair.  Host cost matters here (the step is ~150 launches and
+    the Python around them was as long as the GPU work): the saved activations of a layer are ONE allocation addressed by
+    offset, the backward scratch is one cached allocation, and only tensors that leave this class are torch views."""
 
     def __init__(self, attn: ops.AttnArgs, params, own, raw, cosb, p_res, seed_res):
         from ._lib import LayerDesc, LayerParams, lib
@@ -294,18 +304,25 @@ class _NativeLayer:
         R, H, Dn, T, Dk = attn.m, attn.heads, attn.dn, attn.dt_dim, attn.dk
         Dq = Dn + T
         self.attn, self.R, self.dims = attn, R, (H, Dn, T, Dq, Dk)
-        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        self.buf = dict(qbias=e(Dq), q=e(R, Dq), u=e(R, H, Dk), agg=e(R, H, Dk), prob=e(R, H, attn.k), ctx=e(R, Dq), res=e(R, Dq),
-                        y=e(R, Dq), mean=e(R), rstd=e(R), f1=e(R, Dn), out=e(R, Dn),
-                        wT=e(int(lib().tg_tgat_layer_wt_floats(Dn, Dq, Dk))))
+        sizes = (Dq, R * Dq, R * H * Dk, R * H * Dk, R * H * attn.k, R * Dq, R * Dq, R * Dq, R, R, R * Dn,
+                 int(lib().tg_tgat_layer_wt_floats(Dn, Dq, Dk)))
+        total = 0
+        offs = []
+        for n in sizes:
+            offs.append(total)
+            total += _r4(n)
+        self.act = torch.empty(total, dtype=torch.float32, device=dev)          # saved for backward as a whole
+        self.out = torch.empty((R, Dn), dtype=torch.float32, device=dev)
         self.keep = (params, own, raw, cosb)
+        base = self.act.data_ptr()
         d = LayerDesc()
         d.attn = attn.desc
-        d.params = LayerParams(*[ops._p(t) for t in params])
-        d.own, d.own_ld, d.raw, d.raw_ld, d.cosb = ops._p(own), ops._rowmajor_ld(own, "own"), ops._p(raw), ops._rowmajor_ld(raw, "raw"), ops._p(cosb)
+        d.params = LayerParams(*[t.data_ptr() for t in params])
+        d.own, d.own_ld, d.raw, d.raw_ld, d.cosb = own.data_ptr(), ops._rowmajor_ld(own, "own"), raw.data_ptr(), ops._rowmajor_ld(raw, "raw"), cosb.data_ptr()
         d.res_dropout_p, d.res_seed = float(p_res), int(seed_res)
-        for k_, v in self.buf.items():
-            setattr(d, k_, ops._p(v))
+        for name, o in zip(_FWD_FIELDS, offs):
+            setattr(d, name, base + 4 * o)
+        d.out = self.out.data_ptr()
         self.desc = d
 
     def forward(self):
@@ -313,57 +330,71 @@ class _NativeLayer:
         from ._lib import check, lib
         with ops._timed("layer_fwd", self.R):
             check(lib().tg_tgat_layer_fwd(C.byref(self.desc), ops._stream()), "tg_tgat_layer_fwd")
-        return self.buf["out"]
+        return self.out
 
     @staticmethod
-    def grad_floats(params, Dq):
-        """floats of the zeroed block one backward call accumulates into: every parameter gradient (16-B aligned) + vec"""
-        return sum((p.numel() + 3) // 4 * 4 for p in params) + (Dq + 3) // 4 * 4
+    def grad_layout(params):
+        """[(offset, numel, shape)] of every parameter gradient inside a layer's block (16-byte aligned) and the block size"""
+        lay, off = [], 0
+        for p in params:
+            lay.append((off, p.numel(), p.shape))
+            off += _r4(p.numel())
+        return lay, off
 
-    def backward(self, dout, params, zeroed, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, d_own_accumulate, want_d_raw):
+    def backward(self, dout, params, gblock, vec, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, d_own_accumulate, want_d_raw):
+        """gblock: this layer's zero-filled gradient block (layout = grad_layout(params)); vec: dq zero floats of scratch"""
         import ctypes as C
         from ._lib import LayerBwdDesc, LayerParams, check, lib
         H, Dn, T, Dq, Dk = self.dims
         R, dev = self.R, dout.device
-        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        grads, off = [], 0                      # views of the caller's zeroed block (tg_tgat_layer_bwd accumulates)
-        for p in params:
-            grads.append(zeroed[off:off + p.numel()].view(p.shape))
-            off += (p.numel() + 3) // 4 * 4
-        vec = zeroed[off:off + Dq]
         # scratch that lives only inside this call is kept across steps (grown on demand); saved activations are NOT cached:
         # a caller may run several forwards before one backward (positive + negative edges of the reference's trainers)
-        sizes = dict(df1=R * Dn, dy=R * Dq, dsum=R * Dq, dres=R * Dq if self.desc.res_dropout_p > 0 else 0, dctx=R * Dq,
-                     dagg=R * H * Dk, du=R * H * Dk, dq=R * Dq, part=int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)))
-        ws = {}
-        for name, need in sizes.items():
-            key = (dev, name)
-            buf = _SCRATCH.get(key)
-            if need and (buf is None or buf.numel() < need):
-                buf = torch.empty(int(need * 1.25) + 16, dtype=torch.float32, device=dev)
-                _SCRATCH[key] = buf
-            ws[name] = buf if need else None
-        d_raw = e(R, Dn) if want_d_raw else None
+        sizes = (R * Dn, R * Dq, R * Dq, R * Dq if self.desc.res_dropout_p > 0 else 0, R * Dq, R * H * Dk, R * H * Dk, R * Dq,
+                 int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)))
+        total, offs = 0, []
+        for n in sizes:
+            offs.append(total)
+            total += _r4(n)
+        buf = _SCRATCH.get(dev)
+        if buf is None or buf.numel() < total:
+            buf = torch.empty(int(total * 1.25) + 16, dtype=torch.float32, device=dev)
+            _SCRATCH[dev] = buf
+        base = buf.data_ptr()
+        d_raw = torch.empty((R, Dn), dtype=torch.float32, device=dev) if want_d_raw else None
         b = LayerBwdDesc()
-        b.grads = LayerParams(*[ops._p(t) for t in grads])
-        b.dout = ops._p(dout)
-        for k_, v in ws.items():
-            setattr(b, k_, ops._p(v))
-        b.vec = ops._p(vec)
-        b.d_cosb, b.d_tew, b.d_teb = ops._p(d_cosb), ops._p(d_tew), ops._p(d_teb)
+        gb = gblock.data_ptr()
+        b.grads = LayerParams(*[gb + 4 * o for o, _, _ in self.grad_layout(params)[0]])
+        b.dout = dout.data_ptr()
+        for name, o, n in zip(_BWD_FIELDS, offs, sizes):
+            setattr(b, name, base + 4 * o if n else None)
+        b.vec = vec.data_ptr()
+        b.d_cosb, b.d_tew, b.d_teb = d_cosb.data_ptr(), d_tew.data_ptr(), d_teb.data_ptr()
         b.dfeat, b.dfeat_ld, b.pad_row = ops._p(dfeat), (0 if dfeat is None else ops._rowmajor_ld(dfeat, "dfeat")), int(pad_row)
         b.d_own, b.d_own_ld, b.d_own_accumulate = ops._p(d_own), (0 if d_own is None else ops._rowmajor_ld(d_own, "d_own")), int(d_own_accumulate)
         b.d_raw = ops._p(d_raw)
         with ops._timed("layer_bwd", self.R):
             check(lib().tg_tgat_layer_bwd(C.byref(self.desc), C.byref(b), ops._stream()), "tg_tgat_layer_bwd")
-        return grads, d_raw
+        return d_raw
+
+
+def block_layout(tensors):
+    """offsets (in floats, 16-byte aligned) of `tensors` laid end to end, and the total length: the layout of the gradient block
+    one backward pass accumulates into -- and of TGAT.flatten_parameters()' flat parameter, so that the block IS its gradient"""
+    offs, total = [], 0
+    for t in tensors:
+        offs.append(total)
+        total += _r4(t.numel())
+    return offs, total
 
 
 class _EmbedFnNative(torch.autograd.Function):
-    """Same contract as _EmbedFn; every layer is one native forward call and one native backward call."""
+    """Same contract as _EmbedFn; every layer is one native forward call and one native backward call.
+    Differentiable inputs: (te_w, te_b, *layer_params), or -- cfg["flat_views"] set -- the single flat parameter those are views of."""
 
     @staticmethod
-    def forward(ctx, cfg, fr, table, te_w, te_b, *layer_params):
+    def forward(ctx, cfg, fr, table, *tensors):
+        views = cfg.get("flat_views")
+        te_w, te_b, *layer_params = views if views is not None else tensors
         n, k, L, H = cfg["n"], cfg["k"], cfg["num_layers"], cfg["num_heads"]
         edge, p_drop, training = cfg["edge_table"], cfg["dropout"], cfg["training"]
         dev = table.device
@@ -371,7 +402,7 @@ class _EmbedFnNative(torch.autograd.Function):
         hd = (Dn + T) // H
         S_nbr, S_eid, S_t, S_dt = fr.S
         te_w_flat = te_w.reshape(-1)
-        cosb = ops.time_encode(torch.zeros(1, device=dev), te_w_flat, te_b).reshape(-1)
+        cosb = ops.time_encode(_zero1(dev), te_w_flat, te_b).reshape(-1)
         p_eff = p_drop if training else 0.0
         layers, H_prev = [], None
         for l in range(1, L + 1):
@@ -387,25 +418,23 @@ class _EmbedFnNative(torch.autograd.Function):
             H_prev = lay.forward()
             layers.append(lay)
         ctx.layers, ctx.cfg, ctx.fr, ctx.table, ctx.cosb = layers, cfg, fr, table, cosb
-        ctx.save_for_backward(te_w, te_b, *layer_params)
+        ctx.params = (te_w, te_b, layer_params)        # parameters (or views of the flat parameter): not outputs, no cycle
         return H_prev
 
     @staticmethod
     def backward(ctx, dH):
         cfg, fr, table, cosb = ctx.cfg, ctx.fr, ctx.table, ctx.cosb
-        te_w, te_b, *layer_params = ctx.saved_tensors
+        te_w, te_b, layer_params = ctx.params
         n, k, L = cfg["n"], cfg["k"], cfg["num_layers"]
         table_grad = cfg["table_grad"]
         dev = dH.device
         Dn, T = table.shape[1], te_w.numel()
-        grads = [None] * len(layer_params)
-        # one zero fill for everything the layer calls accumulate into
         Dq = Dn + T
-        per_layer = [_NativeLayer.grad_floats(layer_params[(l - 1) * 11:(l - 1) * 11 + 11], Dq) for l in range(1, L + 1)]
-        head = (3 * T + 3) // 4 * 4
-        zeroed = torch.zeros(head + sum(per_layer), device=dev)
-        d_tew, d_teb, d_cosb = zeroed[:T], zeroed[T:2 * T], zeroed[2 * T:3 * T]
-        layer_off = [head + sum(per_layer[:l]) for l in range(L)]
+        # ONE zero fill: [gradient of te_w | te_b | every layer parameter (block_layout)] + scratch [d cos(b) | dq floats per layer]
+        every = [te_w, te_b, *layer_params]
+        offs, npar = block_layout(every)
+        zeroed = torch.zeros(npar + _r4(T) + L * _r4(Dq), device=dev)
+        d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar:npar + T]
         d_table = torch.zeros_like(table) if table_grad else None
         dH = dH.contiguous()
         for l in range(L, 0, -1):
@@ -419,19 +448,32 @@ class _EmbedFnNative(torch.autograd.Function):
             else:
                 dH_prev, dfeat, pad_row = None, d_table, 0
                 d_own, acc = (torch.empty((R, Dn), device=dev), False) if table_grad else (None, False)
-            g, d_raw = lay.backward(dH[:R], params, zeroed[layer_off[l - 1]:layer_off[l - 1] + per_layer[l - 1]], d_cosb, d_tew, d_teb,
-                                    dfeat, pad_row, d_own, acc, table_grad)
+            v0 = npar + _r4(T) + (l - 1) * _r4(Dq)
+            d_raw = lay.backward(dH[:R], params, zeroed[offs[2 + (l - 1) * 11]:], zeroed[v0:v0 + Dq], d_cosb, d_tew, d_teb,
+                                 dfeat, pad_row, d_own, acc, table_grad)
             if table_grad:
                 if l >= 2:
                     ops.scatter_add_rows(d_raw, fr.ids_all[:R], d_table)
                 else:
                     d_own += d_raw
                     ops.scatter_add_rows(d_own, fr.ids_all[:R], d_table)
-            grads[(l - 1) * 11:(l - 1) * 11 + 11] = g
             dH = dH_prev
-        d_teb = torch.addcmul(d_teb, torch.sin(te_b), d_cosb, value=-1.0)    # d cos(b) -> d b (zero interval: no weight gradient)
-        ctx.layers = None
-        return (None, None, d_table, d_tew.reshape(te_w.shape), d_teb, *grads)
+        d_teb.addcmul_(torch.sin(te_b), d_cosb, value=-1.0)    # d cos(b) -> d b (zero interval: no weight gradient)
+        ctx.layers = ctx.params = None
+        if cfg.get("flat_views") is not None:
+            return (None, None, d_table, zeroed[:npar])       # the block is laid out like the flat parameter: it IS its gradient
+        grads = [zeroed[o:o + t.numel()].view(t.shape) for o, t in zip(offs, every)]
+        return (None, None, d_table, *grads)
+
+
+_ZERO1 = {}
+
+
+def _zero1(dev):
+    z = _ZERO1.get(dev)
+    if z is None:
+        z = _ZERO1[dev] = torch.zeros(1, device=dev)
+    return z
 
 
 class _SplitRows(torch.autograd.Function):
@@ -505,7 +547,7 @@ def prepare_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: tor
 
 def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, te_w, te_b, layer_params, ids: np.ndarray,
           times: np.ndarray, k: int, num_layers: int, num_heads: int, dropout: float, training: bool,
-          table_requires_grad: bool = False):
+          table_requires_grad: bool = False, flat=None):
     """H^L for `ids` at `times` (host numpy in, device tensor out, autograd-connected to the parameters).
     `ids` may also be a PreparedFrontier (prepare_frontier): the neighbor lookups of that batch were already done."""
     dev = table.device
@@ -516,8 +558,7 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
         torch.cuda.current_stream().wait_event(pf.ready)
         cfg = dict(n=pf.n, k=k, num_layers=num_layers, num_heads=num_heads, dropout=float(dropout), training=bool(training),
                    edge_table=edge_table, table_grad=bool(table_requires_grad))
-        fn = _EmbedFnNative if NATIVE else _EmbedFn
-        return fn.apply(cfg, pf.frontier, table, te_w, te_b, *layer_params)
+        return _apply(cfg, pf.frontier, table, te_w, te_b, layer_params, flat)
     if torch.is_tensor(ids):
         # already resident in HBM (int32 ids, float64/float32 times): the caller vouches for the id range
         ids_dev, times_dev = ids.to(device=dev, dtype=torch.int32).contiguous(), times.to(dev).contiguous()
@@ -537,5 +578,13 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
     fr = sample_frontier(graph, ids_dev, times_dev, k, num_layers, dedupe=DEDUPE)
     cfg = dict(n=n, k=k, num_layers=num_layers, num_heads=num_heads, dropout=float(dropout), training=bool(training),
                edge_table=edge_table, table_grad=bool(table_requires_grad))
+    return _apply(cfg, fr, table, te_w, te_b, layer_params, flat)
+
+
+def _apply(cfg, fr, table, te_w, te_b, layer_params, flat):
+    """flat = (flat parameter, [views of it: te_w, te_b, *layer_params]) from TGAT.flatten_parameters(), or None"""
+    if flat is not None and NATIVE:
+        cfg["flat_views"] = flat[1]
+        return _EmbedFnNative.apply(cfg, fr, table, flat[0])
     fn = _EmbedFnNative if NATIVE else _EmbedFn
     return fn.apply(cfg, fr, table, te_w, te_b, *layer_params)

@@ -45,6 +45,28 @@ class TGAT(nn.Module):
             out += conv.fused_params() + [merge.fc1.weight, merge.fc1.bias, merge.fc2.weight, merge.fc2.bias]
         return out
 
+    def flatten_parameters(self) -> nn.Parameter:
+        """Opt-in (not in the reference): re-home every parameter of the backbone in ONE flat nn.Parameter and return it.
+        The named parameters stay where they are -- same state_dict keys, load_state_dict keeps working -- but become views of
+        the flat buffer with requires_grad off; the trainer hands the returned parameter to its optimizer instead of
+        model.parameters().  The backward pass then delivers one gradient tensor (its gradient block already has this layout,
+        engine.block_layout): one AccumulateGrad, one optimizer kernel, one all-reduce operand instead of 24.  Call after the
+        module is on its device."""
+        params = [self.time_encoder.w.weight, self.time_encoder.w.bias] + self._layer_params()
+        offs, total = engine.block_layout(params)
+        flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        views = []
+        with torch.no_grad():
+            for o, p in zip(offs, params):
+                v = flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                p.requires_grad_(False)
+                views.append(v)
+        flat_param = nn.Parameter(flat)
+        self._flat_pack = [flat_param, views]          # a list: nn.Module must not register it (state_dict stays the reference's)
+        return flat_param
+
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray,
                                                  node_interact_times: np.ndarray, num_neighbors: int = 20):
         # both sides share one device pass: rows are independent (reference computes them one after the other, :61-65)
@@ -76,6 +98,12 @@ class TGAT(nn.Module):
         if self.neighbor_sampler.sample_neighbor_strategy != "recent":
             raise NotImplementedError("the device path samples 'recent' neighbors (the FLiD default, load_configs.py:115); "
                                       "uniform / time_interval_aware are host-RNG strategies")
+        flat = getattr(self, "_flat_pack", None)
+        if flat is not None and current_layer_num == self.num_layers and torch.is_grad_enabled():
+            views = flat[1]
+            return engine.embed(self.neighbor_sampler.graph, self.node_raw_features, self.edge_raw_features, views[0], views[1],
+                                views[2:], node_ids, node_interact_times, num_neighbors, current_layer_num, self.num_heads,
+                                self.dropout, self.training, flat=flat)
         params = self._layer_params()[:11 * current_layer_num]
         return engine.embed(self.neighbor_sampler.graph, self.node_raw_features, self.edge_raw_features,
                             self.time_encoder.w.weight, self.time_encoder.w.bias, params, node_ids, node_interact_times,

@@ -160,7 +160,9 @@ int tg_tgat_layer_fwd(const tg_layer_desc* layer, void* stream);
 int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk);
 int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim);
 int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, void* stream);
-/* weight-gradient products of tg_tgat_layer_bwd on an internal side stream (default on); they are joined before it returns */
+/* weight-gradient products of tg_tgat_layer_bwd go to an internal side stream and are issued by an internal helper thread
+ * (default, on = 1); both are joined before the call returns.  on = 3: side stream, launches issued by the calling thread;
+ * on = 0: everything on the caller's stream. */
 void tg_set_overlap(int on);
 
 /* ---- synthetic feature tables (measurement only) ---------------------------

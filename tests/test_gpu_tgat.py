@@ -225,3 +225,44 @@ def test_scale_workload_small_hashed_tables_match_oracle():
         os_, od_ = orc.src_dst(bs, bd, bt, 20)
     np.testing.assert_allclose(s.cpu().numpy(), os_.numpy(), atol=TOL)
     np.testing.assert_allclose(d.cpu().numpy(), od_.numpy(), atol=TOL)
+
+
+def test_tgat_flat_parameter_mode_matches_per_tensor_mode():
+    """TGAT.flatten_parameters(): same state_dict, same embeddings; the ONE gradient tensor holds every per-tensor gradient at
+    engine.block_layout offsets; load_state_dict still lands in the flat buffer; one Adam step moves both models alike."""
+    from flid_amd import engine
+    g = load_golden("tgat_L2_K20")
+    m0, p, k = _model(g)
+    m1, _, _ = _model(g)
+    keys = sorted(m0.state_dict().keys())
+    flat = m1.flatten_parameters()
+    assert sorted(m1.state_dict().keys()) == keys and all(not q.requires_grad for q in m1.parameters())
+    for a, b in zip(m0.state_dict().values(), m1.state_dict().values()):
+        assert torch.equal(a, b)
+    m0.train(); m1.train()
+    rs = np.random.RandomState(0)
+    r = torch.from_numpy(rs.standard_normal((2, len(g["bs"]), g["node_feat"].shape[1])).astype(np.float32)).cuda()
+    outs = []
+    for m in (m0, m1):
+        s, d = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+        ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+        outs.append((s.detach(), d.detach()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    named = [m0.time_encoder.w.weight, m0.time_encoder.w.bias] + m0._layer_params()
+    offs, total = engine.block_layout(named)
+    assert flat.grad is not None and flat.grad.shape == (total,) and flat.numel() == total
+    for o, q in zip(offs, named):
+        got = flat.grad[o:o + q.numel()].view(q.shape)
+        scale = float(q.grad.abs().max()) + 1e-12
+        assert float((got - q.grad).abs().max()) <= 1e-5 * scale + 1e-9          # column sums fold with float atomics
+    # optimizer step on the flat parameter == per-tensor step
+    o0 = torch.optim.Adam(m0.parameters(), lr=1e-3)
+    o1 = torch.optim.Adam([flat], lr=1e-3)
+    o0.step(); o1.step()
+    for a, b in zip(m0.state_dict().values(), m1.state_dict().values()):
+        assert torch.allclose(a, b, atol=2e-6)
+    # checkpoints still load into the views
+    m1.load_state_dict(p)
+    assert torch.equal(m1.state_dict()["merge_layers.1.fc2.weight"], p["merge_layers.1.fc2.weight"].cuda())
+    o, t = offs[-2], named[-2]
+    assert torch.equal(flat.data[o:o + t.numel()].view(t.shape), p["merge_layers.1.fc2.weight"].cuda())
