@@ -10,6 +10,7 @@
 namespace tg {
 
 void set_error(const std::string& s);
+const float* zero_block();  // 256 zero bytes in device memory (out-of-range operand loads of the product kernels point here)
 std::string get_error();   // this thread's last error text (errors are thread-local: the side-stream issuing thread relays its own)
 
 #define TG_HIP_CHECK(expr)                                                                         \

@@ -196,7 +196,6 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
     const int64_t kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tm = wave / TN, tn = wave % TN;
-    const bool tile_live = (bm + tm * 32 < M) && (bn + tn * 32 < N);
 
     f32x16 acc;
 #pragma unroll
@@ -234,10 +233,10 @@ __global__ void __launch_bounds__(TM* TN * 64) gemm_tile_kernel(int64_t M, int64
             pa.gload(lda, (st + 2) * stepA, kbeg + (st + 2) * BK, kend, st + 2 < nfull, ra);
             pb.gload(ldb, (st + 2) * stepB, kbeg + (st + 2) * BK, kend, st + 2 < nfull, rb);
         }
-        if (tile_live) {                             // wave-uniform: tiles wholly outside C only help with the staging
+        // (tiles wholly outside C multiply clamped rows too: a branch around the MFMAs made the compiler shuttle the accumulator
+        // between AGPRs and VGPRs every stage -- 48 moves -- and those waves wait at the barrier either way)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
-        }
+        for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
         __syncthreads();
     }
 

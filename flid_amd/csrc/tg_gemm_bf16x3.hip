@@ -382,10 +382,8 @@ bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     const int tnw = pad3 <= pad2 ? 3 : 2;
     const int64_t gx = (N + 32 * tnw - 1) / (32 * tnw), gy = (M + BM - 1) / BM;
     if (gx * gy >= ((int64_t)1 << 30)) return false;
-    static float* zeros = nullptr;          // 64 zero bytes the kernel's out-of-range loads are pointed at
-    if (!zeros) {
-        if (hipMalloc(&zeros, 64) != hipSuccess || hipMemset(zeros, 0, 64) != hipSuccess) { zeros = nullptr; (void)hipGetLastError(); return false; }
-    }
+    const float* zeros = zero_block();      // the kernel's out-of-range loads are pointed at it
+    if (!zeros) return false;
     const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias));
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     const dim3 grid((unsigned)(gx * gy), 1, (unsigned)nbatch);

@@ -14,6 +14,14 @@ namespace tg {
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 std::string get_error() { return g_err; }
+const float* zero_block() {
+    static float* z = [] {
+        float* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) { (void)hipGetLastError(); return (float*)nullptr; }
+        return p;
+    }();
+    return z;
+}
 
 struct ProfRec { std::string tag; double units; hipEvent_t a, b; };
 static int g_prof_mask = 0;   // bit 0 attn_fwd, bit 1 attn_bwd, bit 2 gemm
