@@ -106,7 +106,11 @@ def main():
     # all 24 parameter tensors live in one flat parameter (state_dict unchanged): one gradient tensor per step, one Adam kernel,
     # one all-reduce operand.  --no-flat keeps the reference's per-tensor parameters.
     train_params = [model.flatten_parameters()] if not args.no_flat else list(model.parameters())
-    opt = torch.optim.Adam(train_params, lr=1e-4, fused=True)                        # load_configs.py:119,123
+    if args.no_flat:
+        opt = torch.optim.Adam(train_params, lr=1e-4, fused=True)                    # load_configs.py:119,123
+    else:
+        from flid_amd.optim import FlatAdam
+        opt = FlatAdam(train_params, lr=1e-4)                                        # same update rule, one kernel (tg_adam_f32)
     reducer = fdist.GradAllReducer(train_params) if world > 1 else None
 
     total_steps = args.warmup + args.steps

@@ -48,6 +48,7 @@ SIGNATURES = {
     "tg_version": (C.c_int, []),
     "tg_profile_enable": (None, [C.c_int]),
     "tg_profile_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.c_int]),
+    "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),
     "tg_hash_features": (C.c_int, [c_void, c_i64, c_i64, c_i64, C.c_int, C.c_uint64, c_void]),
     "tg_graph_create": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, C.POINTER(c_void)]),
     "tg_graph_destroy": (None, [c_void]),

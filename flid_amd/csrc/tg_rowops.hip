@@ -246,6 +246,39 @@ extern "C" int tg_hash_features(float* d_out, int64_t ld, int64_t row0, int64_t 
     return tg::launch_status("hash_features_kernel");
 }
 
+// Adam update of ONE flat fp32 parameter (TGAT.flatten_parameters): the arithmetic of torch.optim.Adam (no amsgrad, L2 weight
+// decay folded into the gradient, bias-corrected step) in a single element-wise pass -- torch's multi-tensor kernel spends 46 us
+// on a single 1 M-element tensor (16 workgroups), this one ~5 us.
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float step_size, float omb1, float b2, float omb2,
+                                                   float eps, float wd, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = m[i] + omb1 * (gi - m[i]);                     // lerp, as torch's fused kernel
+        const float vi = b2 * v[i] + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+extern "C" int tg_adam_f32(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1,
+                double beta2, double eps, double weight_decay, int64_t step, void* stream) {
+    TG_REQUIRE(d_param && d_grad && d_exp_avg && d_exp_avg_sq && n >= 0 && step >= 1, "tg_adam_f32: arguments");
+    if (n == 0) return TG_OK;
+    // scalars in double, as torch's host side computes them
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    const int64_t blocks = std::min<int64_t>((n + 255) / 256, tg::kMaxGridBlocks);
+    adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_param, d_grad, d_exp_avg, d_exp_avg_sq, n, step_size, omb1, (float)beta2, omb2,
+                                                                    (float)eps, (float)weight_decay, bc2_sqrt);
+    return tg::launch_status("adam_kernel");
+}
+
 extern "C" int tg_rowop_parts(int64_t n) { return (int)row_grid(n); }
 
 extern "C" int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols, float* d_out,

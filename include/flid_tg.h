@@ -165,6 +165,12 @@ int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, 
  * on = 0: everything on the caller's stream. */
 void tg_set_overlap(int on);
 
+/* ---- optimizer step for the flat-parameter mode (the trainers' torch.optim.Adam, utils/utils.py:40-60 create_optimizer) ----
+ * one element-wise pass over a flat fp32 parameter: exp_avg / exp_avg_sq updated in place, bias-corrected step `step` (>= 1),
+ * L2 weight decay folded into the gradient.  No amsgrad. */
+int tg_adam_f32(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1,
+                double beta2, double eps, double weight_decay, int64_t step, void* stream);
+
 /* ---- synthetic feature tables (measurement only) ---------------------------
  * out[r, c] = f(row0 + r, c, seed), uniform with unit variance, row 0 = 0; the stand-in for the node / edge feature blobs
  * utils/DataLoader.py:238-246 loads, at sizes (10 M x 172, 100 M x 172) that are generated straight into HBM. */

@@ -415,3 +415,21 @@ def test_gemm_random_shapes_and_views(dev):
         mask = np.ones_like(c_full, dtype=bool)
         mask[:, off_c:off_c + N] = False
         assert np.array_equal(got[mask], c_full[mask]), f"it={it}: wrote outside the C view"
+
+
+def test_flat_adam_matches_torch_adam(dev):
+    """tg_adam_f32 / flid_amd.optim.FlatAdam: torch.optim.Adam's update (bias correction, L2 weight decay) over several steps"""
+    from flid_amd.optim import FlatAdam
+    rs = np.random.RandomState(21)
+    for wd in (0.0, 0.01):
+        w0 = torch.from_numpy(rs.standard_normal(100003).astype(np.float32)).to(dev)
+        a, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+        oa = torch.optim.Adam([a], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        ob = FlatAdam([b], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        for it in range(5):
+            g = torch.from_numpy(rs.standard_normal(100003).astype(np.float32)).to(dev) * (10.0 ** (it - 2))
+            a.grad, b.grad = g.clone(), g.clone()
+            oa.step(); ob.step()
+            assert torch.allclose(a.data, b.data, rtol=2e-6, atol=2e-7), (wd, it, float((a.data - b.data).abs().max()))
+        assert ob.state[b]["step"] == 5
+        assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
