@@ -58,6 +58,12 @@ class GradAllReducer:
         if world == 1:
             return
         w = (1.0 / world) if weight is None else float(weight)
+        if len(self.params) == 1 and self.params[0].grad is not None and self.params[0].grad.is_contiguous():
+            g = self.params[0].grad                 # flat-parameter mode: the gradient block is the bucket, reduced in place
+            if w != 1.0:
+                g.mul_(w)
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            return
         dst, src = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
