@@ -17,12 +17,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, single=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, w, _ = fdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
     torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    model = _net(single)
     for p_ in model.parameters():                      # ranks start from different weights; rank 0's must win
         p_.data.add_(rank * 0.5)
     fdist.broadcast_parameters(model)
@@ -41,11 +41,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_grad_allreduce_equals_single_process_full_batch():
+def _net(single):
+    # single = one parameter tensor: the in-place path of GradAllReducer (flat-parameter mode)
+    return torch.nn.Sequential(torch.nn.Linear(6, 3, bias=False)) if single else \
+        torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_grad_allreduce_equals_single_process_full_batch(single):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, single)) for r in range(world)]
     for p_ in procs:
         p_.start()
     out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
@@ -54,7 +61,7 @@ def test_grad_allreduce_equals_single_process_full_batch():
         assert p_.exitcode == 0
     # single-process reference on the full batch with rank 0's weights
     torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    model = _net(single)
     x = torch.from_numpy(np.random.RandomState(1).standard_normal((11, 6)).astype(np.float32))
     y = torch.from_numpy(np.random.RandomState(2).standard_normal((11, 3)).astype(np.float32))
     ((model(x) - y) ** 2).mean().backward()
