@@ -304,7 +304,10 @@ class _NativeLayer:
         R, H, Dn, T, Dk = attn.m, attn.heads, attn.dn, attn.dt_dim, attn.dk
         Dq = Dn + T
         self.attn, self.R, self.dims = attn, R, (H, Dn, T, Dq, Dk)
-        sizes = (Dq, R * Dq, R * H * Dk, R * H * Dk, R * H * attn.k, R * Dq, R * Dq, R * Dq, R, R, R * Dn,
+        # sized for the row count rounded up to a multiple of 1024: the number of distinct rows changes every step, and a fresh
+        # 160 MB request that no cached block fits costs the caching allocator a hipMalloc (4-6 ms stalls, seen in step traces)
+        Rc = (R + 1023) // 1024 * 1024
+        sizes = (Dq, Rc * Dq, Rc * H * Dk, Rc * H * Dk, Rc * H * attn.k, Rc * Dq, Rc * Dq, Rc * Dq, Rc, Rc, Rc * Dn,
                  int(lib().tg_tgat_layer_wt_floats(Dn, Dq, Dk)))
         total = 0
         offs = []
