@@ -39,7 +39,7 @@ class LayerBwdDesc(C.Structure):
     _fields_ = [("grads", LayerParams), ("dout", c_void)] + \
                [(n, c_void) for n in ("df1", "dy", "dsum", "dres", "dctx", "dagg", "du", "dq", "part", "vec", "d_cosb", "d_tew", "d_teb")] + \
                [("dfeat", c_void), ("dfeat_ld", c_i64), ("pad_row", c_i64), ("d_own", c_void), ("d_own_ld", c_i64),
-                ("d_own_accumulate", C.c_int), ("d_raw", c_void)]
+                ("d_own_accumulate", C.c_int), ("d_raw", c_void), ("defer_join", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/flid_tg.h
@@ -67,6 +67,7 @@ SIGNATURES = {
     "tg_tgat_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), c_void]),
     "tg_tgat_layer_wt_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
     "tg_tgat_layer_part_floats": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
+    "tg_side_join": (C.c_int, [c_void]),
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),
     "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
                               c_void, C.c_int, C.c_int, c_void]),

@@ -278,19 +278,21 @@ inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::
 // main chain is alternately HBM-bound (fused attention backward) and latency-bound (one GEMM after another), so the matrix
 // cores are free for them.  fork(): side waits for everything issued on main so far; join(): main waits for side.
 struct SideStream {
-    hipStream_t side = nullptr;
-    hipEvent_t ev[16];
-    int next = 0;
+    static constexpr int NS = 2;        // the fork groups alternate between two streams: each weight-gradient product is a few
+                                        // hundred latency-bound workgroups, two of them side by side fill the chip better
+    hipStream_t side[NS] = {nullptr, nullptr};
+    hipEvent_t ev[32];
+    int next = 0, cur = 0;
     bool ok = false;
     bool init() {
         if (ok) return true;
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+        for (auto& st : side) if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
         for (auto& e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
         ok = true;
         return true;
     }
     hipEvent_t mark(hipStream_t on, int* rc) {           // record "everything issued on `on` so far"
-        hipEvent_t e = ev[next++ & 15];
+        hipEvent_t e = ev[next++ & 31];
         *rc = hipEventRecord(e, on) == hipSuccess ? TG_OK : TG_EHIP;
         return e;
     }
@@ -356,6 +358,23 @@ SideStream g_side;
 bool g_overlap = true;
 
 }  // namespace
+
+namespace {
+// main waits for everything issued (also by the helper thread) on the side streams
+int side_join(hipStream_t s) {
+    if (!g_side.ok) return TG_OK;
+    if (g_issue_thread) TG_TRY(g_issuer.drain());
+    for (hipStream_t sd : g_side.side) {
+        int rc = TG_OK;
+        hipEvent_t e = g_side.mark(sd, &rc);
+        TG_TRY(rc);
+        TG_HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+    }
+    return TG_OK;
+}
+}  // namespace
+
+extern "C" int tg_side_join(void* stream) { return side_join((hipStream_t)stream); }
 
 extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     TG_REQUIRE(L, "tg_tgat_layer_fwd: null descriptor");
@@ -432,16 +451,20 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     hipStream_t s = (hipStream_t)stream;
     const tg_layer_params& P = L->params;
     const tg_layer_grads& G = Bw->grads;
+    const tg_layer_desc Lc = *L;                 // by-value copies for the closures the helper thread runs: with a deferred
+    const tg_layer_bwd_desc Bc = *Bw;            // join they outlive this call (and the caller's descriptor structs)
     const int64_t w1ld = dq + dn;
     float* vec = Bw->vec;
     const WT wt = wt_layout(L->wT, H, dn, dq, dk);                 // filled by the forward call of this step
     const bool overlap = g_overlap && g_side.init();
-    void* wstream = overlap ? (void*)g_side.side : stream;        // where everything that only feeds parameter gradients goes
-    hipStream_t ws_ = (hipStream_t)wstream;
+    // where everything that only feeds parameter gradients goes: re-pointed by every fork()
+    void* wstream = stream;
+    hipStream_t ws_ = s;
     // side(f): issue f's launches now, or hand them to the issuing thread (then every exit path drains it: the closures
     // refer to this call's descriptors)
     const bool threaded = overlap && g_issue_thread;
-    struct Drain { bool on; ~Drain() { if (on) (void)g_issuer.drain(); } } drain_guard{threaded};
+    const bool defer = overlap && Bw->defer_join != 0;             // the caller joins once, after its last layer (tg_side_join)
+    struct Drain { bool on; ~Drain() { if (on) (void)g_issuer.drain(); } } drain_guard{threaded && !defer};
     auto side = [&](std::function<int()> f) -> int {
         if (!threaded) return f();
         g_issuer.push(std::move(f));
@@ -452,7 +475,10 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         int rc = TG_OK;
         hipEvent_t e = g_side.mark(s, &rc);
         if (rc != TG_OK) return rc;
-        hipStream_t sd = g_side.side;
+        g_side.cur = (g_side.cur + 1) % SideStream::NS;
+        hipStream_t sd = g_side.side[g_side.cur];
+        wstream = (void*)sd;
+        ws_ = sd;
         return side([e, sd] { return hipStreamWaitEvent(sd, e, 0) == hipSuccess ? TG_OK : TG_EHIP; });
     };
     // slab regions of `part` (each finished on the side stream while the main chain moves on)
@@ -465,8 +491,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     float* vec_dq = vec;                                    // dq floats, zero on entry like the gradients
     // ---- merge layer -------------------------------------------------------------------------------------------------------
     TG_TRY(fork());                           // dout is ready
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->dout, dn, L->f1, dn, G.W2, dn, nullptr, 0, 1, wstream); }));
-    TG_TRY(side([=] { return colsum_seg(Bw->dout, dn, R, dn, seg1(G.b2, dn), ws_); }));
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bc.dout, dn, Lc.f1, dn, G.W2, dn, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return colsum_seg(Bc.dout, dn, R, dn, seg1(G.b2, dn), ws_); }));
     TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
     TG_REQUIRE(dn <= 1024, "tg_tgat_layer_bwd: node dim > 1024 unsupported");
     if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
@@ -474,8 +500,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
     TG_TRY(fork());                           // df1 and its slabs are final
     TG_TRY(side([=] { return colsum_seg(part_relu, dn, relu_blocks, dn, seg1(G.b1, dn), ws_); }));
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bw->df1, dn, L->y, dq, G.W1, w1ld, nullptr, 0, 1, wstream); }));
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bw->df1, dn, L->raw, L->raw_ld, G.W1 + dq, w1ld, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bc.df1, dn, Lc.y, dq, G.W1, w1ld, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bc.df1, dn, Lc.raw, Lc.raw_ld, G.W1 + dq, w1ld, nullptr, 0, 1, wstream); }));
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
     if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
@@ -488,7 +514,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
     }
     TG_TRY(fork());                           // dres / dsum and the LayerNorm slabs are final
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, L->ctx, dq, G.Wr, dq, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, Lc.ctx, dq, G.Wr, dq, nullptr, 0, 1, wstream); }));
     {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
         SegDst d{};
         d.n = 5;
@@ -503,12 +529,12 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
     // ---- value path -------------------------------------------------------------------------------------------------------------
     TG_TRY(fork());                           // dctx is final
-    TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bw->dctx, dq, hd, L->agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bc.dctx, dq, hd, Lc.agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
     TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
     // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
     TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
     TG_TRY(fork());                           // du and the time-encoder slabs are final
-    TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, L->q, dq, hd, Bw->du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Lc.q, dq, hd, Bc.du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
     {
         SegDst d{};
         d.n = 2;
@@ -519,10 +545,10 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // ---- key / query path --------------------------------------------------------------------------------------------------------
     TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
     TG_TRY(fork());                           // dq is final
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bw->dq, dq, L->own, L->own_ld, G.Wq, dq, nullptr, 0, 1, wstream); }));
-    TG_TRY(side([=] { return colsum_seg(Bw->dq, dq, R, dq, seg1(vec_dq, dq), ws_); }));                           // sum_rows dq (vec is zero on entry)
+    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bc.dq, dq, Lc.own, Lc.own_ld, G.Wq, dq, nullptr, 0, 1, wstream); }));
+    TG_TRY(side([=] { return colsum_seg(Bc.dq, dq, R, dq, seg1(vec_dq, dq), ws_); }));                           // sum_rows dq (vec is zero on entry)
     TG_TRY(side([=] {
-        wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, ws_>>>(vec_dq, dq, L->cosb, T, P.Wq + dn, G.Wq + dn, dq, Bw->d_cosb);
+        wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, ws_>>>(vec_dq, dq, Lc.cosb, T, P.Wq + dn, G.Wq + dn, dq, Bc.d_cosb);
         return tg::launch_status("wq_time_kernel");
     }));
     if (Bw->d_own) {
@@ -530,12 +556,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
         TG_TRY(tg::launch_status("add_cols_kernel"));
     }
-    if (overlap) {                                                 // main waits for everything issued on the side stream
-        if (threaded) { drain_guard.on = false; TG_TRY(g_issuer.drain()); }
-        int rc = TG_OK;
-        hipEvent_t e = g_side.mark(g_side.side, &rc);
-        TG_TRY(rc);
-        TG_HIP_CHECK(hipStreamWaitEvent(s, e, 0));
+    if (overlap && !defer) {
+        drain_guard.on = false;
+        TG_TRY(side_join(s));
     }
     return TG_OK;
 }

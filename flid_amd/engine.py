@@ -344,7 +344,8 @@ class _NativeLayer:
             off += _r4(p.numel())
         return lay, off
 
-    def backward(self, dout, params, gblock, vec, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, d_own_accumulate, want_d_raw):
+    def backward(self, dout, params, gblock, vec, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, d_own_accumulate, want_d_raw,
+                 slot=0, defer_join=False):
         """gblock: this layer's zero-filled gradient block (layout = grad_layout(params)); vec: dq zero floats of scratch"""
         import ctypes as C
         from ._lib import LayerBwdDesc, LayerParams, check, lib
@@ -358,10 +359,11 @@ class _NativeLayer:
         for n in sizes:
             offs.append(total)
             total += _r4(n)
-        buf = _SCRATCH.get(dev)
+        # one scratch block per layer slot: with a deferred join the side streams still read layer l's block while layer l-1 runs
+        buf = _SCRATCH.get((dev, slot))
         if buf is None or buf.numel() < total:
             buf = torch.empty(int(total * 1.25) + 16, dtype=torch.float32, device=dev)
-            _SCRATCH[dev] = buf
+            _SCRATCH[(dev, slot)] = buf
         base = buf.data_ptr()
         d_raw = torch.empty((R, Dn), dtype=torch.float32, device=dev) if want_d_raw else None
         b = LayerBwdDesc()
@@ -375,6 +377,7 @@ class _NativeLayer:
         b.dfeat, b.dfeat_ld, b.pad_row = ops._p(dfeat), (0 if dfeat is None else ops._rowmajor_ld(dfeat, "dfeat")), int(pad_row)
         b.d_own, b.d_own_ld, b.d_own_accumulate = ops._p(d_own), (0 if d_own is None else ops._rowmajor_ld(d_own, "d_own")), int(d_own_accumulate)
         b.d_raw = ops._p(d_raw)
+        b.defer_join = int(defer_join)
         with ops._timed("layer_bwd", self.R):
             check(lib().tg_tgat_layer_bwd(C.byref(self.desc), C.byref(b), ops._stream()), "tg_tgat_layer_bwd")
         return d_raw
@@ -440,6 +443,9 @@ class _EmbedFnNative(torch.autograd.Function):
         d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar:npar + T]
         d_table = torch.zeros_like(table) if table_grad else None
         dH = dH.contiguous()
+        # The side streams (weight gradients) are joined ONCE, after the last layer: until then everything they read stays alive
+        # (`alive`) and untouched (per-layer scratch), and nothing that lives on them is consumed.
+        alive = [dH]
         for l in range(L, 0, -1):
             lay = ctx.layers[l - 1]
             R = lay.R
@@ -453,7 +459,8 @@ class _EmbedFnNative(torch.autograd.Function):
                 d_own, acc = (torch.empty((R, Dn), device=dev), False) if table_grad else (None, False)
             v0 = npar + _r4(T) + (l - 1) * _r4(Dq)
             d_raw = lay.backward(dH[:R], params, zeroed[offs[2 + (l - 1) * 11]:], zeroed[v0:v0 + Dq], d_cosb, d_tew, d_teb,
-                                 dfeat, pad_row, d_own, acc, table_grad)
+                                 dfeat, pad_row, d_own, acc, table_grad, slot=l, defer_join=True)
+            alive += [dH_prev, d_own, d_raw]
             if table_grad:
                 if l >= 2:
                     ops.scatter_add_rows(d_raw, fr.ids_all[:R], d_table)
@@ -461,6 +468,9 @@ class _EmbedFnNative(torch.autograd.Function):
                     d_own += d_raw
                     ops.scatter_add_rows(d_own, fr.ids_all[:R], d_table)
             dH = dH_prev
+        from ._lib import check, lib
+        check(lib().tg_side_join(ops._stream()), "tg_side_join")
+        del alive
         d_teb.addcmul_(torch.sin(te_b), d_cosb, value=-1.0)    # d cos(b) -> d b (zero interval: no weight gradient)
         ctx.layers = ctx.params = None
         if cfg.get("flat_views") is not None:

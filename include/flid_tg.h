@@ -155,6 +155,8 @@ typedef struct tg_layer_bwd_desc {
     float* dfeat; int64_t dfeat_ld; int64_t pad_row;
     float* d_own; int64_t d_own_ld; int d_own_accumulate;
     float* d_raw;
+    int defer_join;   /* 1: do not wait for the side streams before returning; the caller calls tg_side_join() after its last
+                       * layer and must keep every buffer named here untouched (and alive) until then */
 } tg_layer_bwd_desc;
 int tg_tgat_layer_fwd(const tg_layer_desc* layer, void* stream);
 int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk);
@@ -164,6 +166,8 @@ int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, 
  * (default, on = 1); both are joined before the call returns.  on = 3: side stream, launches issued by the calling thread;
  * on = 0: everything on the caller's stream. */
 void tg_set_overlap(int on);
+/* `stream` waits for everything tg_tgat_layer_bwd(defer_join = 1) put on the side streams (drains the helper thread first) */
+int tg_side_join(void* stream);
 
 /* ---- optimizer step for the flat-parameter mode (the trainers' torch.optim.Adam, utils/utils.py:40-60 create_optimizer) ----
  * one element-wise pass over a flat fp32 parameter: exp_avg / exp_avg_sq updated in place, bias-corrected step `step` (>= 1),
