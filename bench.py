@@ -54,8 +54,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--roofline-kernel", default="attn_bwd", choices=["attn_fwd", "attn_bwd", "gemm"])
-    ap.add_argument("--mode", default="train", choices=["train", "fwd"],
-                    help="train = fwd+bwd+Adam (the headline metric); fwd = eval-mode embedding regeneration sweep (M_step.py:456-509)")
+    ap.add_argument("--mode", default="train", choices=["train", "fwd", "lp"],
+                    help="train = fwd+bwd+Adam (the headline metric); fwd = eval-mode embedding regeneration sweep (M_step.py:456-509); "
+                         "lp = link-prediction train step of EM_warmup.py:126-231: src, dst and a random negative dst embedded in ONE "
+                         "call (3 roots per edge), MergeLayer head, BCE loss, Adam on backbone + head")
     ap.add_argument("--workload", default="wikipedia", choices=["wikipedia", "scale"],
                     help="wikipedia = BASELINE configs[1] (the headline); scale = SURVEY 8d config 5 (10 M nodes / 100 M edges, tables "
                          "hashed into HBM: 79 GB resident, the cache-defeating case)")
@@ -132,13 +134,53 @@ def main():
     rw = torch.randn(2, BATCH, DN, device=dev)
 
     prepared = {}
+    if args.mode == "lp":
+        from flid_amd import engine
+        from flid_amd.models.modules import MergeLayer
+        torch.manual_seed(1)
+        head = MergeLayer(DN, DN, DN, 1).to(dev)                                     # the reference's link predictor (EM_init.py)
+        fdist.broadcast_parameters(head)
+        head_opt = torch.optim.Adam(head.parameters(), lr=1e-4, fused=True)
+        head_reducer = fdist.GradAllReducer(head.parameters()) if world > 1 else None
+        n_items = 1000 if args.workload == "wikipedia" else args.scale_items
+        first_item = int(data.dst_node_ids.min())
+        rs_neg = np.random.RandomState(7 + rank)
+        neg_batches = [torch.from_numpy(rs_neg.randint(first_item, first_item + n_items, BATCH).astype(np.int32)).to(dev)
+                       for _ in range(total_steps)]
+        labels = torch.cat([torch.ones(BATCH, device=dev), torch.zeros(BATCH, device=dev)])
+        bce = torch.nn.BCELoss()
+        args.no_cpu_baseline = True
+
+        def prepare_lp(s_):
+            src, dst, t = dev_batches[s_]
+            return engine.prepare_frontier(sampler.graph, [src, dst, neg_batches[s_]], [t, t, t], K, L)
 
     if args.mode == "fwd":
         model.eval()
         args.no_cpu_baseline = True
         args.roofline_kernel = "attn_fwd"
 
+    def step_lp(s):
+        if s not in prepared:
+            prepared[s] = prepare_lp(s)
+        if s + 1 < len(dev_batches):
+            prepared[s + 1] = prepare_lp(s + 1)
+        opt.zero_grad(set_to_none=True)
+        head_opt.zero_grad(set_to_none=True)
+        emb = model.compute_node_temporal_embeddings(prepared.pop(s), None, L, K)    # (3 B, Dn): src | dst | negative dst
+        se, de_, ne = emb[:BATCH], emb[BATCH:2 * BATCH], emb[2 * BATCH:]
+        prob = torch.cat([head(se, de_), head(se, ne)]).squeeze(1).sigmoid()         # EM_warmup.py:178-186
+        loss = bce(prob, labels)
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce()
+            head_reducer.reduce()
+        opt.step()
+        head_opt.step()
+
     def step(s):
+        if args.mode == "lp":
+            return step_lp(s)
         # sampler work of the NEXT batch is issued first, on a side stream (it depends on the graph only, not on the weights)
         if s not in prepared:
             prepared[s] = model.prepare_batch(*dev_batches[s], K)
@@ -201,7 +243,8 @@ def main():
 
     edges = args.steps * BATCH * world
     value = edges / elapsed
-    bpe = tgat_bytes_per_edge() if args.mode == "train" else tgat_bytes_per_edge() // 2     # fwd = half of fwd+bwd
+    # fwd = half of fwd+bwd; the link-prediction step embeds 3 roots per edge instead of 2
+    bpe = {"train": tgat_bytes_per_edge(), "fwd": tgat_bytes_per_edge() // 2, "lp": tgat_bytes_per_edge() * 3 // 2}[args.mode]
 
     # roofline of the selected kernel family: HIP events on its launch stream over the timed region
     ms, units, cnt = fam[args.roofline_kernel]
@@ -226,14 +269,15 @@ def main():
                 pass
 
     out = {
-        "metric": ("edges/sec (temporal-embedding fwd+bwd), TGAT Wikipedia, 1/2/4/8 MI355X" if args.mode == "train" else
+        "metric": "edges/sec (link-prediction train step: 3 roots/edge + MergeLayer head + BCE), TGAT" if args.mode == "lp" else
+                  ("edges/sec (temporal-embedding fwd+bwd), TGAT Wikipedia, 1/2/4/8 MI355X" if args.mode == "train" else
                    "edges/sec (temporal-embedding fwd only, eval), TGAT Wikipedia") if args.workload == "wikipedia" else
                   "edges/sec (temporal-embedding %s), TGAT 10M-node / 100M-edge scale graph" % ("fwd+bwd" if args.mode == "train" else "fwd only, eval"),
         "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload + " + TGAT L=2 H=2 T=100, batch 600 edges/GPU, 20 recent neighbors, dropout %.2f, %s"
-                               % (args.dropout, "fwd+bwd+Adam" if args.mode == "train" else "fwd (eval)"),
+                               % (args.dropout, {"train": "fwd+bwd+Adam", "fwd": "fwd (eval)", "lp": "link-prediction step"}[args.mode]),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world, "num_neighbors": K, "num_layers": L,
                    "parallelism": f"dp{world}"},
         "path_roofline": {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4),
