@@ -22,6 +22,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BK = 32;
 constexpr int ROW_BYTES = 144;                 // 64 B hi + 64 B lo + 16 B pad
 constexpr int BM = 128, NT = 256;
+#ifndef FLID_NT_SCHED
+#define FLID_NT_SCHED 1
+#endif
+constexpr bool SCHED = FLID_NT_SCHED != 0;
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -71,9 +75,10 @@ struct Panel {
     // stage at float offset `elems` (= k0); `ok` = the stage exists at all (uniform)
     __device__ __forceinline__ void gload(int64_t elems, int64_t k0, int64_t kend, bool ok, const float* __restrict__ zeros,
                                           float4 (&reg)[PER]) const {
+        const int64_t lim = ok ? kend : 0;           // (a scalar select, not a branch: the stage body must stay one basic block)
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const float* p = (ok && k0 + kcol[j] < kend) ? src[j] + elems : zeros;
+            const float* p = (k0 + kcol[j] < lim) ? src[j] + elems : zeros;
             reg[j] = *reinterpret_cast<const float4*>(p);
         }
     }
@@ -149,20 +154,29 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
 #pragma unroll
             for (int t = 0; t < TNW; ++t) read_frag(sB(cur), 32 * t, ks, bh[t][ks], bl[t][ks]);
         }
-        if (st + 1 < nstage) {
-            pa.sstore(sA(cur ^ 1), ra);
-            pb.sstore(sB(cur ^ 1), rb);
-        }
+        // One basic block per stage (no branches: the store after the last stage writes zeros into the idle buffer, tiles wholly
+        // outside C multiply clamped rows), so that the scheduler can be told to run the next stage's split (VALU) and LDS
+        // stores in the shadow of this stage's MFMAs instead of before them: a wave per SIMD has nobody else to overlap with.
+        pa.sstore(sA(cur ^ 1), ra);
+        pb.sstore(sB(cur ^ 1), rb);
         issue(st + 3, ra, rb);                        // this register set is free again
 #pragma unroll
-        for (int t = 0; t < TNW; ++t) {
-            if (live[t]) {
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[t][ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[t][ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[t][ks], acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < TNW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[t][ks], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[t][ks], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[t][ks], acc[t], 0, 0, 0);
+        }
+        if (SCHED) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8 + 4 * TNW - 4, 0);      // the fragment reads first
+#pragma unroll
+            for (int i = 0; i < 6 * TNW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // one MFMA ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                // ... six split / address instructions under it
+                if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // an LDS store
+                if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // a global load
             }
         }
         __syncthreads();
