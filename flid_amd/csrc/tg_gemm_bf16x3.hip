@@ -26,6 +26,12 @@ constexpr int BM = 128, NT = 256;
 #define FLID_NT_SCHED 1
 #endif
 constexpr bool SCHED = FLID_NT_SCHED != 0;
+#ifndef FLID_NT_EXP
+#define FLID_NT_EXP 0   // timing experiments only (results wrong): 1 no steady-state global loads, 2 no MFMAs, 3 no split VALU
+#endif
+#ifndef FLID_NT_VPM
+#define FLID_NT_VPM 6
+#endif
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -86,7 +92,12 @@ struct Panel {
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             uint2 hi, lo;
-            split4(reg[j], hi, lo);
+            if (FLID_NT_EXP == 3) {
+                hi = make_uint2(__builtin_bit_cast(uint32_t, reg[j].x), __builtin_bit_cast(uint32_t, reg[j].y));
+                lo = make_uint2(__builtin_bit_cast(uint32_t, reg[j].z), __builtin_bit_cast(uint32_t, reg[j].w));
+            } else {
+                split4(reg[j], hi, lo);
+            }
             *reinterpret_cast<uint2*>(s + lds_off[j]) = hi;
             *reinterpret_cast<uint2*>(s + lds_off[j] + 64) = lo;
         }
@@ -159,9 +170,9 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
         // stores in the shadow of this stage's MFMAs instead of before them: a wave per SIMD has nobody else to overlap with.
         pa.sstore(sA(cur ^ 1), ra);
         pb.sstore(sB(cur ^ 1), rb);
-        issue(st + 3, ra, rb);                        // this register set is free again
+        if (FLID_NT_EXP != 1) issue(st + 3, ra, rb);  // this register set is free again
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < (FLID_NT_EXP == 2 ? 0 : 2); ++ks) {
 #pragma unroll
             for (int t = 0; t < TNW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[t][ks], acc[t], 0, 0, 0);
 #pragma unroll
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
 #pragma unroll
             for (int i = 0; i < 6 * TNW; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // one MFMA ...
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                // ... six split / address instructions under it
+                __builtin_amdgcn_sched_group_barrier(0x002, FLID_NT_VPM, 0);      // ... six split / address instructions under it
                 if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // an LDS store
                 if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // a global load
             }
