@@ -256,7 +256,97 @@ __global__ void __launch_bounds__(256) transpose_many_kernel(TrJobs jobs) {
     }
 }
 
-struct WT { float *Wk, *Wv, *W2, *W1a, *W1b, *Wr, *WqL; };
+// Merged projections of one attention layer, weights only (once per step and layer, ~0.1 GFLOP):
+//   P_h = Wk_h^T Wq_h[:, :dn]   (dk x dn)    u_h = own P_h^T + ub_h      replaces  q = [own | cos b] Wq^T ; u_h = Wk_h^T q_h
+//   V_h = Wr[:, h] Wv_h         (dq x dk)    res = agg V^T + br          replaces  ctx_h = Wv_h agg_h ; res = Wr ctx + br
+// Two products per direction leave the main chain; each output element is one hd-deep dot product, written in both layouts.
+struct MergeJob {            // C[m, n] = sum_k A(m, k) B(k, n), written as C (ldc) and as its transpose CT (ldct)
+    const float *A, *B;
+    float *C, *CT;
+    int M, N, sAm, sAk, sBk, ldc, ldct, tiles_n, tile0;
+};
+struct MergeJobs { MergeJob j[4]; int n, K, total_tiles; };
+
+// 32 x 32 output tile per workgroup, K (= head dim) in LDS chunks of 32; thread (ty, tx) owns rows ty, ty+8, ty+16, ty+24 of
+// column tx.  Operand tiles are loaded along whichever index is contiguous in memory.
+__global__ void __launch_bounds__(256) merge_weights_kernel(MergeJobs jobs, const float* __restrict__ Wk, const float* __restrict__ qb,
+                                                            int H, int hd, int dk, float* __restrict__ ub) {
+    __shared__ float As[32][33], Bs[32][33], Cs[32][33];
+    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+    if ((int)blockIdx.x >= jobs.total_tiles) {           // ub[h dk + j] = sum_k Wk[h hd + k, j] qb[h hd + k]
+        const int64_t hj = (int64_t)(blockIdx.x - jobs.total_tiles) * 256 + t;
+        if (hj < (int64_t)H * dk) {
+            const int h = (int)(hj / dk), jj = (int)(hj % dk);
+            float acc = 0.f;
+            for (int k = 0; k < hd; ++k) acc = fmaf(Wk[((int64_t)h * hd + k) * dk + jj], qb[h * hd + k], acc);
+            ub[hj] = acc;
+        }
+        return;
+    }
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].tile0) ++ji;
+    const MergeJob J = jobs.j[ji];
+    const int tile = blockIdx.x - J.tile0, m0 = (tile / J.tiles_n) * 32, n0 = (tile % J.tiles_n) * 32;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < jobs.K; k0 += 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + 256 * q;                                   // 1024 elements of each operand tile
+            // A: fastest index = the contiguous one
+            const int am = J.sAm == 1 ? (e & 31) : (e >> 5), ak = J.sAm == 1 ? (e >> 5) : (e & 31);
+            As[ak][am] = (m0 + am < J.M && k0 + ak < jobs.K) ? J.A[(int64_t)(m0 + am) * J.sAm + (int64_t)(k0 + ak) * J.sAk] : 0.f;
+            const int bn = e & 31, bk = e >> 5;                          // B(k, n): n is contiguous in both uses
+            Bs[bk][bn] = (n0 + bn < J.N && k0 + bk < jobs.K) ? J.B[(int64_t)(k0 + bk) * J.sBk + (n0 + bn)] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float b = Bs[k][tx];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fmaf(As[k][ty + 8 * q], b, acc[q]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + ty + 8 * q, n = n0 + tx;
+        Cs[ty + 8 * q][tx] = acc[q];
+        if (m < J.M && n < J.N) J.C[(int64_t)m * J.ldc + n] = acc[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                        // transposed copy: consecutive threads walk m
+        const int n = n0 + ty + 8 * q, m = m0 + tx;
+        if (m < J.M && n < J.N) J.CT[(int64_t)n * J.ldct + m] = Cs[tx][ty + 8 * q];
+    }
+}
+
+// Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), one workgroup per query row i = h hd + k:
+//   dqb_i = Wk[i, :] . dub_h ;  dWk[i, :] += qb_i dub_h ;  dWq[i, dn:] += dqb_i cos b ;  d cos b += Wq[i, dn:] dqb_i
+__global__ void __launch_bounds__(256) ub_bwd_kernel(const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
+        const float* __restrict__ Wq, const float* __restrict__ cosb, int hd, int dn, int dq, int dk, int T, float* __restrict__ dWk,
+        float* __restrict__ dWq, float* __restrict__ d_cosb) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, h = i / hd;
+    const float* du = dub + (int64_t)h * dk;
+    const float qbi = qb[i];
+    float part = 0.f;
+    for (int j = threadIdx.x; j < dk; j += blockDim.x) {
+        const float d = du[j];
+        part = fmaf(Wk[(int64_t)i * dk + j], d, part);
+        dWk[(int64_t)i * dk + j] += qbi * d;
+    }
+    part = tg::wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float dqb = red[0] + red[1] + red[2] + red[3];
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        dWq[(int64_t)i * dq + dn + t] += dqb * cosb[t];
+        atomicAdd(d_cosb + t, Wq[(int64_t)i * dq + dn + t] * dqb);
+    }
+}
+
+struct WT { float *Wk, *Wv, *W2, *W1a, *W1b, *Wr, *WqL, *P, *PT, *V, *VT, *ub; };
 inline WT wt_layout(float* base, int H, int dn, int dq, int dk) {
     WT w;
     float* p = base;
@@ -266,7 +356,14 @@ inline WT wt_layout(float* base, int H, int dn, int dq, int dk) {
     w.W1a = p; p += (int64_t)dq * dn;     // (dq, dn)
     w.W1b = p; p += (int64_t)dn * dn;
     w.Wr = p; p += (int64_t)dq * dq;
-    w.WqL = p;                             // (dn, dq)
+    w.WqL = p; p += (int64_t)dn * dq;      // (dn, dq)
+    // merged projections (g_merged): P = [Wk_h^T Wq_h[:, :dn]]_h (H dk, dn), V = [Wr[:, h] Wv_h]_h (dq, H dk), their transposes,
+    // and the constant part of u: ub_h = Wk_h^T (Wq_h[:, dn:] cos b)
+    w.P = p; p += (int64_t)H * dk * dn;
+    w.PT = p; p += (int64_t)H * dk * dn;
+    w.V = p; p += (int64_t)H * dk * dq;
+    w.VT = p; p += (int64_t)H * dk * dq;
+    w.ub = p;
     return w;
 }
 
@@ -354,6 +451,7 @@ private:
 };
 SideIssuer g_issuer;
 bool g_issue_thread = true;
+bool g_merged = true;      // merged projections (merge_weights_kernel); false = the reference's four separate products per layer
 SideStream g_side;
 bool g_overlap = true;
 
@@ -389,13 +487,53 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     // Transposed copies of the weights that the chain multiplies "from the right" (u = q Wk, and every dX = dY W of the
     // backward): with them EVERY product of the main chain has two k-contiguous operands and runs on the split-bf16 kernel.
     const WT wt = wt_layout(L->wT, H, dn, dq, dk);
-    {
+    TG_REQUIRE(H <= 2, "tg_tgat_layer_fwd: the native layer path supports 1 or 2 heads");
+    // the constant half of the query, qb = Wq[:, dn:] cos b
+    TG_TRY(tg_gemm_f32(0, 1, 1, dq, T, 1.f, L->cosb, T, P.Wq + dn, dq, L->qbias, dq, nullptr, 0, 0, stream));
+    if (g_merged) {
+        TrJobs jobs;
+        int n = 0;
+        jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
+        jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
+        jobs.j[n++] = TrJob{P.W1 + dq, wt.W1b, dn, dn, (int64_t)dq + dn, dn};
+        jobs.n = n;
+        transpose_many_kernel<<<dim3(64, n), 256, 0, s>>>(jobs);
+        TG_TRY(tg::launch_status("transpose_many_kernel"));
+        {
+            MergeJobs mj;
+            mj.n = 0;
+            mj.K = hd;
+            int tile0 = 0;
+            for (int h = 0; h < H; ++h) {       // P_h (dk x dn): A(m = j, k) = Wk[h hd + k, j], B(k, n = i) = Wq[h hd + k, i]
+                MergeJob& J = mj.j[mj.n++];
+                J = MergeJob{P.Wk + (int64_t)h * hd * dk, P.Wq + (int64_t)h * hd * dq, wt.P + (int64_t)h * dk * dn, wt.PT + (int64_t)h * dk,
+                             dk, dn, 1, dk, dq, dn, H * dk, (dn + 31) / 32, tile0};
+                tile0 += ((dk + 31) / 32) * J.tiles_n;
+            }
+            for (int h = 0; h < H; ++h) {       // V_h (dq x dk): A(m = r, k) = Wr[r, h hd + k], B(k, n = j) = Wv[h hd + k, j]
+                MergeJob& J = mj.j[mj.n++];
+                J = MergeJob{P.Wr + (int64_t)h * hd, P.Wv + (int64_t)h * hd * dk, wt.V + (int64_t)h * dk, wt.VT + (int64_t)h * dk * dq,
+                             dq, dk, dq, 1, dk, H * dk, dq, (dk + 31) / 32, tile0};
+                tile0 += ((dq + 31) / 32) * J.tiles_n;
+            }
+            mj.total_tiles = tile0;
+            const unsigned blocks = (unsigned)(tile0 + ((int64_t)H * dk + 255) / 256);
+            merge_weights_kernel<<<blocks, 256, 0, s>>>(mj, P.Wk, L->qbias, H, hd, dk, wt.ub);
+            TG_TRY(tg::launch_status("merge_weights_kernel"));
+        }
+        // u = own P^T + ub   (all heads in one product, K = dn)
+        TG_TRY(tg_gemm_f32(0, 1, R, H * dk, dn, 1.f, L->own, L->own_ld, wt.P, dn, L->u, (int64_t)H * dk, wt.ub, 0, 0, stream));
+        TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
+        // res = agg V^T + br   (K = H dk)
+        TG_TRY(tg_gemm_f32(0, 1, R, dq, H * dk, 1.f, L->agg, (int64_t)H * dk, wt.V, (int64_t)H * dk, L->res, dq, P.br, 0, 0, stream));
+    } else {
+        // Transposed copies of the weights that the chain multiplies "from the right" (u = q Wk, and every dX = dY W of the
+        // backward): with them EVERY product of the main chain has two k-contiguous operands and runs on the split-bf16 kernel.
         TrJobs jobs;
         int n = 0;
         for (int h = 0; h < H && n < 4; ++h) {
             jobs.j[n++] = TrJob{P.Wk + (int64_t)h * hd * dk, wt.Wk + (int64_t)h * dk * hd, hd, dk, dk, hd};
         }
-        TG_REQUIRE(H <= 2, "tg_tgat_layer_fwd: the native layer path supports 1 or 2 heads");
         for (int h = 0; h < H; ++h) jobs.j[n++] = TrJob{P.Wv + (int64_t)h * hd * dk, wt.Wv + (int64_t)h * dk * hd, hd, dk, dk, hd};
         jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
         jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
@@ -408,16 +546,15 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         j2.n = 1;
         transpose_many_kernel<<<dim3(64, 1), 256, 0, s>>>(j2);
         TG_TRY(tg::launch_status("transpose_many_kernel"));
+        // q = [own | cos b] Wq^T : the constant half is a bias row
+        TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
+        // u_h = Wk_h^T q_h
+        TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, L->q, dq, hd, wt.Wk, hd, (int64_t)dk * hd, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
+        TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
+        // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
+        TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
+        TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
     }
-    // q = [own | cos b] Wq^T : the constant half is a bias row
-    TG_TRY(tg_gemm_f32(0, 1, 1, dq, T, 1.f, L->cosb, T, P.Wq + dn, dq, L->qbias, dq, nullptr, 0, 0, stream));
-    TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
-    // u_h = Wk_h^T q_h
-    TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, L->q, dq, hd, wt.Wk, hd, (int64_t)dk * hd, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
-    TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
-    // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
-    TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
-    TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
     const unsigned g = (unsigned)row_grid(R);
     if (dq <= 64) ln_res_fwd_kernel<1><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
     else if (dq <= 320) ln_res_fwd_kernel<5><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
@@ -432,7 +569,9 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
 }
 
 extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
-    return 2 * (int64_t)dk * dq + 2 * (int64_t)dn * dn + 2 * (int64_t)dq * dn + (int64_t)dq * dq;
+    const int64_t H = 2;                                              // the native layer path supports 1 or 2 heads
+    return 2 * (int64_t)dk * dq + 2 * (int64_t)dn * dn + 2 * (int64_t)dq * dn + (int64_t)dq * dq +
+           2 * H * dk * dn + 2 * H * dk * dq + H * dk + 16;
 }
 
 extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
@@ -440,6 +579,7 @@ extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int d
     const int64_t b = row_grid(rows) * 4 * dq;                       // LayerNorm slabs
     const int64_t c = (int64_t)tg_attn_bwd_parts(rows) * 2 * dt_dim; // time-encoder slabs
     return 16 + a + b + c;                                            // disjoint regions: they are consumed concurrently
+    // (with merged projections the caller appends dq * heads * dk + heads * dk * dn + 32 floats: dV and dP)
 }
 
 extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, void* stream) {
@@ -513,8 +653,17 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         else ln_res_bwd_kernel<16><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
     }
-    TG_TRY(fork());                           // dres / dsum and the LayerNorm slabs are final
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, Lc.ctx, dq, G.Wr, dq, nullptr, 0, 1, wstream); }));
+    if (g_merged) {
+        // gradients of the merged projections land in scratch and are chained back to Wq / Wk / Wv / Wr in weight space
+        const int64_t hk = (int64_t)H * dk;
+        float* dVm = part_attn + ((int64_t)attn_parts * 2 * T + 3) / 4 * 4;      // (dq, H dk)
+        float* dPm = dVm + ((int64_t)dq * hk + 3) / 4 * 4;                        // (H dk, dn)
+        float* dub = vec;                                                         // H dk floats, zero on entry
+        TG_TRY(fork());                       // dres / dsum and the LayerNorm slabs are final
+        TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, hk, R, 1.f, dres, dq, Lc.agg, hk, dVm, hk, nullptr, 0, 0, wstream); }));          // dV = dres^T agg
+        // V_h = Wr[:, h] Wv_h :  dWr[:, h] += dV_h Wv_h^T ;  dWv_h += Wr[:, h]^T dV_h
+        TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, dq, hd, dk, 1.f, dVm, hk, dk, P.Wv, dk, (int64_t)hd * dk, G.Wr, dq, hd, H, nullptr, 0, 1, wstream); }));
+        TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, dq, 1.f, P.Wr, dq, hd, dVm, hk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
     {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
         SegDst d{};
         d.n = 5;
@@ -525,16 +674,20 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         d.p[4] = G.br;       d.end[4] = 4 * dq;
         TG_TRY(side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_); }));
     }
-    // ---- output projection ------------------------------------------------------------------------------------------------------
-    TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
-    // ---- value path -------------------------------------------------------------------------------------------------------------
-    TG_TRY(fork());                           // dctx is final
-    TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bc.dctx, dq, hd, Lc.agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
-    TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
-    // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
-    TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
-    TG_TRY(fork());                           // du and the time-encoder slabs are final
-    TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Lc.q, dq, hd, Bc.du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
+        // ---- value path: dagg = dres V ----------------------------------------------------------------------------------------------
+        TG_TRY(tg_gemm_f32(0, 1, R, hk, dq, 1.f, dres, dq, wt.VT, dq, Bw->dagg, hk, nullptr, 0, 0, stream));
+        // ---- fused attention backward (HBM-bound: the side streams' products run under it) ----------------------------------------
+        TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
+        TG_TRY(fork());                       // du and the time-encoder slabs are final
+        TG_TRY(side([=] { return tg_gemm_f32(1, 0, hk, dn, R, 1.f, Bc.du, hk, Lc.own, Lc.own_ld, dPm, dn, nullptr, 0, 0, wstream); }));  // dP = du^T own
+        TG_TRY(side([=] { return colsum_seg(Bc.du, hk, R, (int)hk, seg1(dub, (int)hk), ws_); }));                                  // dub = sum_rows du
+        // P_h = Wk_h^T Wq_h[:, :dn] :  dWk_h += Wq_h[:, :dn] dP_h^T ;  dWq_h[:, :dn] += Wk_h dP_h ;  then the constant part (ub)
+        TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, hd, dk, dn, 1.f, P.Wq, dq, (int64_t)hd * dq, dPm, dn, (int64_t)dk * dn, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
+        TG_TRY(side([=] { return tg_gemm_f32_batched(0, 0, hd, dn, dk, 1.f, P.Wk, dk, (int64_t)hd * dk, dPm, dn, (int64_t)dk * dn, G.Wq, dq, (int64_t)hd * dq, H, nullptr, 0, 1, wstream); }));
+        TG_TRY(side([=] {
+            ub_bwd_kernel<<<dq, 256, 0, ws_>>>(dub, Lc.qbias, P.Wk, P.Wq, Lc.cosb, hd, dn, dq, dk, T, G.Wk, G.Wq, Bc.d_cosb);
+            return tg::launch_status("ub_bwd_kernel");
+        }));
     {
         SegDst d{};
         d.n = 2;
@@ -542,19 +695,56 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         d.p[1] = Bw->d_teb; d.end[1] = 2 * T;
         TG_TRY(side([=] { return colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, ws_); }));
     }
-    // ---- key / query path --------------------------------------------------------------------------------------------------------
-    TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
-    TG_TRY(fork());                           // dq is final
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bc.dq, dq, Lc.own, Lc.own_ld, G.Wq, dq, nullptr, 0, 1, wstream); }));
-    TG_TRY(side([=] { return colsum_seg(Bc.dq, dq, R, dq, seg1(vec_dq, dq), ws_); }));                           // sum_rows dq (vec is zero on entry)
-    TG_TRY(side([=] {
-        wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, ws_>>>(vec_dq, dq, Lc.cosb, T, P.Wq + dn, G.Wq + dn, dq, Bc.d_cosb);
-        return tg::launch_status("wq_time_kernel");
-    }));
-    if (Bw->d_own) {
-        TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
-        add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
-        TG_TRY(tg::launch_status("add_cols_kernel"));
+        // ---- key / query path: d own = du P (+ the residual's share) ------------------------------------------------------------------
+        if (Bw->d_own) {
+            TG_TRY(tg_gemm_f32(0, 1, R, dn, hk, 1.f, Bw->du, hk, wt.PT, hk, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
+            add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
+            TG_TRY(tg::launch_status("add_cols_kernel"));
+        }
+    } else {
+        TG_TRY(fork());                           // dres / dsum and the LayerNorm slabs are final
+        TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, Lc.ctx, dq, G.Wr, dq, nullptr, 0, 1, wstream); }));
+        {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
+            SegDst d{};
+            d.n = 5;
+            d.p[0] = G.ln_g;     d.end[0] = dq;
+            d.p[1] = G.ln_b;     d.end[1] = 2 * dq;
+            d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
+            d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
+            d.p[4] = G.br;       d.end[4] = 4 * dq;
+            TG_TRY(side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_); }));
+        }
+        // ---- output projection ------------------------------------------------------------------------------------------------------
+        TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
+        // ---- value path -------------------------------------------------------------------------------------------------------------
+        TG_TRY(fork());                           // dctx is final
+        TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bc.dctx, dq, hd, Lc.agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
+        TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
+        // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
+        TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
+        TG_TRY(fork());                           // du and the time-encoder slabs are final
+        TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Lc.q, dq, hd, Bc.du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
+        {
+            SegDst d{};
+            d.n = 2;
+            d.p[0] = Bw->d_tew; d.end[0] = T;
+            d.p[1] = Bw->d_teb; d.end[1] = 2 * T;
+            TG_TRY(side([=] { return colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, ws_); }));
+        }
+        // ---- key / query path --------------------------------------------------------------------------------------------------------
+        TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
+        TG_TRY(fork());                           // dq is final
+        TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bc.dq, dq, Lc.own, Lc.own_ld, G.Wq, dq, nullptr, 0, 1, wstream); }));
+        TG_TRY(side([=] { return colsum_seg(Bc.dq, dq, R, dq, seg1(vec_dq, dq), ws_); }));                           // sum_rows dq (vec is zero on entry)
+        TG_TRY(side([=] {
+            wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, ws_>>>(vec_dq, dq, Lc.cosb, T, P.Wq + dn, G.Wq + dn, dq, Bc.d_cosb);
+            return tg::launch_status("wq_time_kernel");
+        }));
+        if (Bw->d_own) {
+            TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
+            add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
+            TG_TRY(tg::launch_status("add_cols_kernel"));
+        }
     }
     if (overlap && !defer) {
         drain_guard.on = false;
@@ -564,3 +754,4 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
 }
 
 extern "C" void tg_set_overlap(int on) { g_overlap = (on & 1) != 0; g_issue_thread = (on & 2) == 0; }
+extern "C" void tg_set_layer_merged(int on) { g_merged = on != 0; }

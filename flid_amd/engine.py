@@ -354,7 +354,7 @@ class _NativeLayer:
         # scratch that lives only inside this call is kept across steps (grown on demand); saved activations are NOT cached:
         # a caller may run several forwards before one backward (positive + negative edges of the reference's trainers)
         sizes = (R * Dn, R * Dq, R * Dq, R * Dq if self.desc.res_dropout_p > 0 else 0, R * Dq, R * H * Dk, R * H * Dk, R * Dq,
-                 int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)))
+                 int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)) + Dq * H * Dk + H * Dk * Dn + 32)
         total, offs = 0, []
         for n in sizes:
             offs.append(total)
@@ -439,7 +439,9 @@ class _EmbedFnNative(torch.autograd.Function):
         # ONE zero fill: [gradient of te_w | te_b | every layer parameter (block_layout)] + scratch [d cos(b) | dq floats per layer]
         every = [te_w, te_b, *layer_params]
         offs, npar = block_layout(every)
-        zeroed = torch.zeros(npar + _r4(T) + L * _r4(Dq), device=dev)
+        H, Dk = cfg["num_heads"], Dn + cfg["edge_table"].shape[1] + T
+        vlen = _r4(Dq + H * Dk)                       # per layer: zero scratch of tg_tgat_layer_bwd (`vec`)
+        zeroed = torch.zeros(npar + _r4(T) + L * vlen, device=dev)
         d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar:npar + T]
         d_table = torch.zeros_like(table) if table_grad else None
         dH = dH.contiguous()
@@ -457,8 +459,8 @@ class _EmbedFnNative(torch.autograd.Function):
             else:
                 dH_prev, dfeat, pad_row = None, d_table, 0
                 d_own, acc = (torch.empty((R, Dn), device=dev), False) if table_grad else (None, False)
-            v0 = npar + _r4(T) + (l - 1) * _r4(Dq)
-            d_raw = lay.backward(dH[:R], params, zeroed[offs[2 + (l - 1) * 11]:], zeroed[v0:v0 + Dq], d_cosb, d_tew, d_teb,
+            v0 = npar + _r4(T) + (l - 1) * vlen
+            d_raw = lay.backward(dH[:R], params, zeroed[offs[2 + (l - 1) * 11]:], zeroed[v0:v0 + vlen], d_cosb, d_tew, d_teb,
                                  dfeat, pad_row, d_own, acc, table_grad, slot=l, defer_join=True)
             alive += [dH_prev, d_own, d_raw]
             if table_grad:

@@ -144,9 +144,10 @@ typedef struct tg_layer_desc {
 } tg_layer_desc;
 /* backward: dout (R, dn) in; this layer's parameter gradients are ADDED into grads.* and into d_cosb / d_tew / d_teb (dt_dim)
  * with float atomics: the caller zeroes them (one fill for the whole gradient block of a step) -- as torch accumulates into
- * .grad.  vec (dq floats) must be zero on entry too.  dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional gradient
+ * .grad.  vec (dq + heads * dk floats) must be zero on entry too.  dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional gradient
  * w.r.t. own (accumulated into if d_own_accumulate); d_raw (R, dn) optional gradient w.r.t. raw.
- * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats). */
+ * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats + dq*heads*dk +
+ * heads*dk*dn + 32 floats for the merged projections' gradients). */
 typedef struct tg_layer_bwd_desc {
     tg_layer_grads grads;
     const float* dout;
@@ -166,6 +167,10 @@ int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, 
  * (default, on = 1); both are joined before the call returns.  on = 3: side stream, launches issued by the calling thread;
  * on = 0: everything on the caller's stream. */
 void tg_set_overlap(int on);
+/* 1 (default): the layer multiplies with merged projections computed once per call from the weights --
+ * u_h = own (Wk_h^T Wq_h[:, :dn])^T + ub_h and res = agg (Wr[:, h] Wv_h)^T + br -- two products fewer per direction on the main
+ * chain, same function up to fp32 reassociation; 0: the reference's q / u / ctx / res products.  Set before forward, keep for its backward. */
+void tg_set_layer_merged(int on);
 /* `stream` waits for everything tg_tgat_layer_bwd(defer_join = 1) put on the side streams (drains the helper thread first) */
 int tg_side_join(void* stream);
 
