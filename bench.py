@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--scale-items", type=int, default=1_000_000)
     ap.add_argument("--scale-edges", type=int, default=100_000_000)
     ap.add_argument("--no-flat", action="store_true", help="per-tensor parameters / gradients / Adam as in the reference's trainers")
+    ap.add_argument("--gemm-mode", type=int, default=None, help="tg_set_gemm_mode override (experiments)")
     ap.add_argument("--trace-steps", action="store_true", help="per-step GPU times (events) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the untimed per-family profiling pass")
@@ -77,6 +78,9 @@ def main():
     from flid_amd.synth import scale_like, wikipedia_like
     from flid_amd.utils.utils import get_neighbor_sampler
 
+    if args.gemm_mode is not None:
+        from flid_amd._lib import lib as _l
+        _l().tg_set_gemm_mode(args.gemm_mode)
     rank, world, local = fdist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product has no CPU path)"

@@ -383,7 +383,13 @@ struct SideStream {
     bool ok = false;
     bool init() {
         if (ok) return true;
-        for (auto& st : side) if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+        // lowest priority: the side streams' products should fill what the main chain leaves idle, not share the CUs with it
+        // evenly (three concurrent products each ran 2-3x slower, and the main-chain one is on the critical path)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        static const bool flat_prio = getenv("FLID_SIDE_PRIO_DEFAULT") != nullptr;
+        for (auto& st : side)
+            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, flat_prio ? 0 : lo) != hipSuccess) return false;
         for (auto& e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
         ok = true;
         return true;
