@@ -458,6 +458,9 @@ private:
 SideIssuer g_issuer;
 bool g_issue_thread = true;
 bool g_merged = true;      // merged projections (merge_weights_kernel); false = the reference's four separate products per layer
+// the weight-space work of the merged form (one merge kernel forward, ~6 small launches backward) is a fixed cost per layer call:
+// it pays from a few thousand rows on (TGAT layer 1: 12 k rows), not for the 1 200-row root layer or a TGN batch
+constexpr int64_t kMergedMinRows = 4096;
 SideStream g_side;
 bool g_overlap = true;
 
@@ -496,7 +499,7 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     TG_REQUIRE(H <= 2, "tg_tgat_layer_fwd: the native layer path supports 1 or 2 heads");
     // the constant half of the query, qb = Wq[:, dn:] cos b
     TG_TRY(tg_gemm_f32(0, 1, 1, dq, T, 1.f, L->cosb, T, P.Wq + dn, dq, L->qbias, dq, nullptr, 0, 0, stream));
-    if (g_merged) {
+    if (g_merged && R >= kMergedMinRows) {
         TrJobs jobs;
         int n = 0;
         jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
@@ -659,7 +662,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         else ln_res_bwd_kernel<16><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
     }
-    if (g_merged) {
+    if (g_merged && R >= kMergedMinRows) {
         // gradients of the merged projections land in scratch and are chained back to Wq / Wk / Wv / Wr in weight space
         const int64_t hk = (int64_t)H * dk;
         float* dVm = part_attn + ((int64_t)attn_parts * 2 * T + 3) / 4 * 4;      // (dq, H dk)
