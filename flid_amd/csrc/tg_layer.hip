@@ -668,23 +668,24 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         float* dVm = part_attn + ((int64_t)attn_parts * 2 * T + 3) / 4 * 4;      // (dq, H dk)
         float* dPm = dVm + ((int64_t)dq * hk + 3) / 4 * 4;                        // (H dk, dn)
         float* dub = vec;                                                         // H dk floats, zero on entry
+        // ---- value path: dagg = dres V ----------------------------------------------------------------------------------------------
+        TG_TRY(tg_gemm_f32(0, 1, R, hk, dq, 1.f, dres, dq, wt.VT, dq, Bw->dagg, hk, nullptr, 0, 0, stream));
+        // (issued after the main-chain product above: dV then runs under the attention backward instead of competing with dagg)
         TG_TRY(fork());                       // dres / dsum and the LayerNorm slabs are final
         TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, hk, R, 1.f, dres, dq, Lc.agg, hk, dVm, hk, nullptr, 0, 0, wstream); }));          // dV = dres^T agg
         // V_h = Wr[:, h] Wv_h :  dWr[:, h] += dV_h Wv_h^T ;  dWv_h += Wr[:, h]^T dV_h
         TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, dq, hd, dk, 1.f, dVm, hk, dk, P.Wv, dk, (int64_t)hd * dk, G.Wr, dq, hd, H, nullptr, 0, 1, wstream); }));
         TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, dq, 1.f, P.Wr, dq, hd, dVm, hk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
-    {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
-        SegDst d{};
-        d.n = 5;
-        d.p[0] = G.ln_g;     d.end[0] = dq;
-        d.p[1] = G.ln_b;     d.end[1] = 2 * dq;
-        d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
-        d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
-        d.p[4] = G.br;       d.end[4] = 4 * dq;
-        TG_TRY(side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_); }));
-    }
-        // ---- value path: dagg = dres V ----------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32(0, 1, R, hk, dq, 1.f, dres, dq, wt.VT, dq, Bw->dagg, hk, nullptr, 0, 0, stream));
+        {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
+            SegDst d{};
+            d.n = 5;
+            d.p[0] = G.ln_g;     d.end[0] = dq;
+            d.p[1] = G.ln_b;     d.end[1] = 2 * dq;
+            d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
+            d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
+            d.p[4] = G.br;       d.end[4] = 4 * dq;
+            TG_TRY(side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_); }));
+        }
         // ---- fused attention backward (HBM-bound: the side streams' products run under it) ----------------------------------------
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
         TG_TRY(fork());                       // du and the time-encoder slabs are final
