@@ -260,15 +260,16 @@ __global__ void __launch_bounds__(256) transpose_many_kernel(TrJobs jobs) {
 //   P_h = Wk_h^T Wq_h[:, :dn]   (dk x dn)    u_h = own P_h^T + ub_h      replaces  q = [own | cos b] Wq^T ; u_h = Wk_h^T q_h
 //   V_h = Wr[:, h] Wv_h         (dq x dk)    res = agg V^T + br          replaces  ctx_h = Wv_h agg_h ; res = Wr ctx + br
 // Two products per direction leave the main chain; each output element is one hd-deep dot product, written in both layouts.
-struct MergeJob {            // C[m, n] = sum_k A(m, k) B(k, n), written as C (ldc) and as its transpose CT (ldct)
+struct MergeJob {            // C[m, n] (+)= sum_k A(m, k) B(k, n); optionally also written transposed to CT (ldct)
     const float *A, *B;
     float *C, *CT;
-    int M, N, sAm, sAk, sBk, ldc, ldct, tiles_n, tile0;
+    int M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, tiles_n, tile0, accumulate;
 };
-struct MergeJobs { MergeJob j[4]; int n, K, total_tiles; };
+struct MergeJobs { MergeJob j[4]; int n, total_tiles; };
 
-// 32 x 32 output tile per workgroup, K (= head dim) in LDS chunks of 32; thread (ty, tx) owns rows ty, ty+8, ty+16, ty+24 of
-// column tx.  Operand tiles are loaded along whichever index is contiguous in memory.
+// Small weight-space products, up to 4 jobs per launch (the merged projections forward, their gradient chains backward):
+// 32 x 32 output tile per workgroup, K in LDS chunks of 32; thread (ty, tx) owns rows ty, ty+8, ty+16, ty+24 of column tx.
+// Operand tiles are loaded along whichever index is contiguous in memory.  Blocks past the tiles compute ub (forward only).
 __global__ void __launch_bounds__(256) merge_weights_kernel(MergeJobs jobs, const float* __restrict__ Wk, const float* __restrict__ qb,
                                                             int H, int hd, int dk, float* __restrict__ ub) {
     __shared__ float As[32][33], Bs[32][33], Cs[32][33];
@@ -288,15 +289,14 @@ __global__ void __launch_bounds__(256) merge_weights_kernel(MergeJobs jobs, cons
     const MergeJob J = jobs.j[ji];
     const int tile = blockIdx.x - J.tile0, m0 = (tile / J.tiles_n) * 32, n0 = (tile % J.tiles_n) * 32;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < jobs.K; k0 += 32) {
+    for (int k0 = 0; k0 < J.K; k0 += 32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = t + 256 * q;                                   // 1024 elements of each operand tile
-            // A: fastest index = the contiguous one
             const int am = J.sAm == 1 ? (e & 31) : (e >> 5), ak = J.sAm == 1 ? (e >> 5) : (e & 31);
-            As[ak][am] = (m0 + am < J.M && k0 + ak < jobs.K) ? J.A[(int64_t)(m0 + am) * J.sAm + (int64_t)(k0 + ak) * J.sAk] : 0.f;
-            const int bn = e & 31, bk = e >> 5;                          // B(k, n): n is contiguous in both uses
-            Bs[bk][bn] = (n0 + bn < J.N && k0 + bk < jobs.K) ? J.B[(int64_t)(k0 + bk) * J.sBk + (n0 + bn)] : 0.f;
+            As[ak][am] = (m0 + am < J.M && k0 + ak < J.K) ? J.A[(int64_t)(m0 + am) * J.sAm + (int64_t)(k0 + ak) * J.sAk] : 0.f;
+            const int bn = J.sBn == 1 ? (e & 31) : (e >> 5), bk = J.sBn == 1 ? (e >> 5) : (e & 31);
+            Bs[bk][bn] = (n0 + bn < J.N && k0 + bk < J.K) ? J.B[(int64_t)(k0 + bk) * J.sBk + (int64_t)(n0 + bn) * J.sBn] : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -311,14 +311,26 @@ __global__ void __launch_bounds__(256) merge_weights_kernel(MergeJobs jobs, cons
     for (int q = 0; q < 4; ++q) {
         const int m = m0 + ty + 8 * q, n = n0 + tx;
         Cs[ty + 8 * q][tx] = acc[q];
-        if (m < J.M && n < J.N) J.C[(int64_t)m * J.ldc + n] = acc[q];
+        if (m < J.M && n < J.N) {
+            float* c = J.C + (int64_t)m * J.ldc + n;
+            *c = J.accumulate ? *c + acc[q] : acc[q];
+        }
     }
+    if (!J.CT) return;                                                   // (uniform per workgroup)
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                                        // transposed copy: consecutive threads walk m
         const int n = n0 + ty + 8 * q, m = m0 + tx;
         if (m < J.M && n < J.N) J.CT[(int64_t)n * J.ldct + m] = Cs[tx][ty + 8 * q];
     }
+}
+
+// job table helper: appends a job and advances the running tile count
+inline void add_job(MergeJobs& mj, const float* A, const float* B, float* C, float* CT, int M, int N, int K, int sAm, int sAk, int sBk,
+                    int sBn, int ldc, int ldct, int accumulate) {
+    MergeJob& J = mj.j[mj.n++];
+    J = MergeJob{A, B, C, CT, M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, (N + 31) / 32, mj.total_tiles, accumulate};
+    mj.total_tiles += ((M + 31) / 32) * J.tiles_n;
 }
 
 // Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), one workgroup per query row i = h hd + k:
@@ -511,22 +523,14 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         {
             MergeJobs mj;
             mj.n = 0;
-            mj.K = hd;
-            int tile0 = 0;
-            for (int h = 0; h < H; ++h) {       // P_h (dk x dn): A(m = j, k) = Wk[h hd + k, j], B(k, n = i) = Wq[h hd + k, i]
-                MergeJob& J = mj.j[mj.n++];
-                J = MergeJob{P.Wk + (int64_t)h * hd * dk, P.Wq + (int64_t)h * hd * dq, wt.P + (int64_t)h * dk * dn, wt.PT + (int64_t)h * dk,
-                             dk, dn, 1, dk, dq, dn, H * dk, (dn + 31) / 32, tile0};
-                tile0 += ((dk + 31) / 32) * J.tiles_n;
-            }
-            for (int h = 0; h < H; ++h) {       // V_h (dq x dk): A(m = r, k) = Wr[r, h hd + k], B(k, n = j) = Wv[h hd + k, j]
-                MergeJob& J = mj.j[mj.n++];
-                J = MergeJob{P.Wr + (int64_t)h * hd, P.Wv + (int64_t)h * hd * dk, wt.V + (int64_t)h * dk, wt.VT + (int64_t)h * dk * dq,
-                             dq, dk, dq, 1, dk, H * dk, dq, (dk + 31) / 32, tile0};
-                tile0 += ((dq + 31) / 32) * J.tiles_n;
-            }
-            mj.total_tiles = tile0;
-            const unsigned blocks = (unsigned)(tile0 + ((int64_t)H * dk + 255) / 256);
+            mj.total_tiles = 0;
+            for (int h = 0; h < H; ++h)         // P_h (dk x dn): A(m = j, k) = Wk[h hd + k, j], B(k, n = i) = Wq[h hd + k, i]
+                add_job(mj, P.Wk + (int64_t)h * hd * dk, P.Wq + (int64_t)h * hd * dq, wt.P + (int64_t)h * dk * dn, wt.PT + (int64_t)h * dk,
+                        dk, dn, hd, 1, dk, dq, 1, dn, H * dk, 0);
+            for (int h = 0; h < H; ++h)         // V_h (dq x dk): A(m = r, k) = Wr[r, h hd + k], B(k, n = j) = Wv[h hd + k, j]
+                add_job(mj, P.Wr + (int64_t)h * hd, P.Wv + (int64_t)h * hd * dk, wt.V + (int64_t)h * dk, wt.VT + (int64_t)h * dk * dq,
+                        dq, dk, hd, dq, 1, dk, 1, H * dk, dq, 0);
+            const unsigned blocks = (unsigned)(mj.total_tiles + ((int64_t)H * dk + 255) / 256);
             merge_weights_kernel<<<blocks, 256, 0, s>>>(mj, P.Wk, L->qbias, H, hd, dk, wt.ub);
             TG_TRY(tg::launch_status("merge_weights_kernel"));
         }
@@ -674,6 +678,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(fork());                       // dres / dsum and the LayerNorm slabs are final
         TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, hk, R, 1.f, dres, dq, Lc.agg, hk, dVm, hk, nullptr, 0, 0, wstream); }));          // dV = dres^T agg
         // V_h = Wr[:, h] Wv_h :  dWr[:, h] += dV_h Wv_h^T ;  dWv_h += Wr[:, h]^T dV_h
+        // (as MFMA products: one launch of merge_weights_kernel for all four chain products was tried and is slower, 433 k vs 447 k)
         TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, dq, hd, dk, 1.f, dVm, hk, dk, P.Wv, dk, (int64_t)hd * dk, G.Wr, dq, hd, H, nullptr, 0, 1, wstream); }));
         TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, dq, 1.f, P.Wr, dq, hd, dVm, hk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
         {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
