@@ -16,7 +16,7 @@ class AttnDesc(C.Structure):
                 ("d_edge", c_void), ("edge_ld", c_i64), ("d_edge_idx", c_void),
                 ("d_nbr", c_void), ("d_dt", c_void), ("d_te_w", c_void), ("d_te_b", c_void),
                 ("m", c_i64), ("k", C.c_int), ("heads", C.c_int), ("dn", C.c_int), ("de", C.c_int), ("dt_dim", C.c_int),
-                ("scale", c_f32), ("dropout_p", c_f32), ("seed", C.c_uint64)]
+                ("scale", c_f32), ("dropout_p", c_f32), ("seed", C.c_uint64), ("row0", c_i64)]
 
 
 _PARAM_NAMES = ("Wq", "Wk", "Wv", "ln_g", "ln_b", "Wr", "br", "W1", "b1", "W2", "b2")

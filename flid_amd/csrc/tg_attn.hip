@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
                         const float corr = __expf(mx[h] - mnew);
                         const float pe = __expf(sc - mnew);
                         den[h] = den[h] * corr + pe;
-                        const float wgt = pe * tg::dropout_keep_scale(a.seed, row, h, s0 + s, a.dropout_p);
+                        const float wgt = pe * tg::dropout_keep_scale(a.seed, a.row0 + row, h, s0 + s, a.dropout_p);
 #pragma unroll
                         for (int i = 0; i < CPL; ++i)
 #pragma unroll
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
                     for (int h = 0; h < H; ++h) {
                         const float da = part[r * H + h];
                         const float pr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_p[h]), s));
-                        const float pd = pr * tg::dropout_keep_scale(a.seed, row, h, s0 + s, a.dropout_p);
+                        const float pd = pr * tg::dropout_keep_scale(a.seed, a.row0 + row, h, s0 + s, a.dropout_p);
                         const float dsc = nb[r] == 0 ? 0.f : (pd * da - pr * cterm[h]) * a.scale;
 #pragma unroll
                         for (int i = 0; i < CPL; ++i)

@@ -587,10 +587,18 @@ extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
            2 * H * dk * dn + 2 * H * dk * dq + H * dk + 16;
 }
 
+// rows of the first chunk when the attention backward of a large layer is split in two (the weight gradient of the first
+// chunk's du then runs under the second chunk instead of after the whole kernel); 0 = not split
+inline int64_t attn_split_rows(int64_t rows) { (void)rows; return 0; }     // (the split is not used: see tg_tgat_layer_bwd)
+inline int64_t attn_slab_parts(int64_t rows) {
+    const int64_t ra = attn_split_rows(rows);
+    return ra ? (int64_t)tg_attn_bwd_parts(ra) + tg_attn_bwd_parts(rows - ra) : (int64_t)tg_attn_bwd_parts(rows);
+}
+
 extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
     const int64_t a = ((rows + 15) / 16) * dn;                       // ReLU-mask slabs
     const int64_t b = row_grid(rows) * 4 * dq;                       // LayerNorm slabs
-    const int64_t c = (int64_t)tg_attn_bwd_parts(rows) * 2 * dt_dim; // time-encoder slabs
+    const int64_t c = std::max<int64_t>(attn_slab_parts(rows), 2 * (int64_t)tg_attn_bwd_parts(rows / 2 + 8)) * 2 * dt_dim; // time-encoder slabs
     return 16 + a + b + c;                                            // disjoint regions: they are consumed concurrently
     // (with merged projections the caller appends dq * heads * dk + heads * dk * dn + 32 floats: dV and dP)
 }
@@ -623,12 +631,12 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         g_issuer.push(std::move(f));
         return TG_OK;
     };
-    auto fork = [&]() -> int {                                     // side stream waits for everything issued on main so far
+    auto fork = [&](bool same_stream = false) -> int {             // side stream waits for everything issued on main so far
         if (!overlap) return TG_OK;
         int rc = TG_OK;
         hipEvent_t e = g_side.mark(s, &rc);
         if (rc != TG_OK) return rc;
-        g_side.cur = (g_side.cur + 1) % SideStream::NS;
+        if (!same_stream) g_side.cur = (g_side.cur + 1) % SideStream::NS;
         hipStream_t sd = g_side.side[g_side.cur];
         wstream = (void*)sd;
         ws_ = sd;
@@ -637,7 +645,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // slab regions of `part` (each finished on the side stream while the main chain moves on)
     const int64_t relu_blocks = (R + 15) / 16;
     const unsigned ln_grid = (unsigned)row_grid(R);
-    const int attn_parts = tg_attn_bwd_parts(R);
+    const int attn_parts = (int)attn_slab_parts(R);
     float* part_relu = Bw->part;
     float* part_ln = part_relu + relu_blocks * dn;
     float* part_attn = part_ln + (int64_t)ln_grid * 4 * dq;
@@ -692,6 +700,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             TG_TRY(side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_); }));
         }
         // ---- fused attention backward (HBM-bound: the side streams' products run under it) ----------------------------------------
+        // (splitting this launch into two row chunks so that the first chunk's dP = du^T own runs under the second chunk was tried:
+        // 431 k vs 445 k edges/s -- two smaller launches plus the product competing with the second one cost more than the shorter tail)
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
         TG_TRY(fork());                       // du and the time-encoder slabs are final
         TG_TRY(side([=] { return tg_gemm_f32(1, 0, hk, dn, R, 1.f, Bc.du, hk, Lc.own, Lc.own_ld, dPm, dn, nullptr, 0, 0, wstream); }));  // dP = du^T own

@@ -108,6 +108,7 @@ typedef struct tg_attn_desc {
     const float* d_te_w;   const float* d_te_b;
     int64_t m; int k; int heads; int dn; int de; int dt_dim;
     float scale; float dropout_p; uint64_t seed;
+    int64_t row0;          /* instance index of row 0 in the dropout stream (non-zero when one call is split into row chunks) */
 } tg_attn_desc;
 
 int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg, float* d_prob, void* stream);
