@@ -266,3 +266,41 @@ def test_tgat_flat_parameter_mode_matches_per_tensor_mode():
     assert torch.equal(m1.state_dict()["merge_layers.1.fc2.weight"], p["merge_layers.1.fc2.weight"].cuda())
     o, t = offs[-2], named[-2]
     assert torch.equal(flat.data[o:o + t.numel()].view(t.shape), p["merge_layers.1.fc2.weight"].cuda())
+
+
+def test_merged_projections_match_separate_products():
+    """tg_set_layer_merged: the merged form (P = Wk^T Wq', V = Wr Wv per head, layers with >= 4096 rows) and the reference's four
+    separate products are the same function: embeddings and every parameter gradient on a BASELINE-shape batch."""
+    from flid_amd._lib import lib
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = wikipedia_like(num_edges=30000, seed=0)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    sl = slice(20000, 20600)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    rs = np.random.RandomState(3)
+    r = torch.from_numpy(rs.standard_normal((2, 600, 172)).astype(np.float32)).cuda()
+    res = []
+    for merged in (1, 0):
+        lib().tg_set_layer_merged(merged)
+        try:
+            torch.manual_seed(0)
+            m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 100, 2, 2, 0.0, "cuda:0").to("cuda:0").train()
+            with torch.no_grad():
+                for prm in m.parameters():
+                    if prm.dim() > 1 and prm.shape[1] > 1:
+                        prm.copy_(torch.randn_like(prm) * 0.05)
+            s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 20)
+            ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+            res.append((s.detach(), d.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+        finally:
+            lib().tg_set_layer_merged(1)
+    (s1, d1, g1), (s0, d0, g0) = res
+    assert float((s1 - s0).abs().max()) < 2e-5 and float((d1 - d0).abs().max()) < 2e-5
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-12
+        diff = (g1[n] - g0[n]).abs()
+        # a ReLU unit within rounding of zero may flip between the two evaluations: allow a few entries to move a little
+        bad = (diff > 1e-4 * scale).float().mean().item()
+        assert bad <= 0.005 and float(diff.max()) <= 0.02 * scale, (n, bad, float(diff.max()) / scale)
