@@ -335,6 +335,39 @@ float* split_workspace(size_t need, hipStream_t s) {
     return w->p;
 }
 
+// B (K x N, row-major) -> Bt (N x K): 32 x 32 tiles through LDS.  Lets an `X W` product (input gradient of a Linear whose caller
+// did not keep a transposed weight) run on the k-contiguous kernels.
+__global__ void __launch_bounds__(256) transpose_kn_kernel(const float* __restrict__ B, int64_t ldb, int64_t K, int64_t N, float* __restrict__ Bt) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t k0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t k = k0 + ty + 8 * q, n = n0 + tx;
+        tile[ty + 8 * q][tx] = (k < K && n < N) ? B[k * ldb + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t n = n0 + ty + 8 * q, k = k0 + tx;
+        if (n < N && k < K) Bt[n * K + k] = tile[tx][ty + 8 * q];
+    }
+}
+SplitWs g_tr_ws[4] = {};
+float* transpose_workspace(size_t need, hipStream_t s) {
+    SplitWs* w = nullptr;
+    for (auto& c : g_tr_ws) if (c.p && c.stream == s) { w = &c; break; }
+    if (!w) for (auto& c : g_tr_ws) if (!c.p) { w = &c; w->stream = s; break; }
+    if (!w) return nullptr;
+    if (need > w->floats) {
+        if (w->p) { if (hipStreamSynchronize(s) != hipSuccess) return nullptr; (void)hipFree(w->p); w->p = nullptr; w->floats = 0; }
+        const size_t want = std::max<size_t>(need, (size_t)1 << 20);
+        if (hipMalloc(&w->p, want * sizeof(float)) != hipSuccess) { w->p = nullptr; (void)hipGetLastError(); return nullptr; }
+        w->floats = want;
+    }
+    return w->p;
+}
+
 struct Args {
     float* ws; int vec_c;
     int64_t M, N, K; float alpha; const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
@@ -382,6 +415,15 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
 
     // A panel: k-contiguous when A is M x K (not transposed).  B panel: k-contiguous when B is given as N x K (tb).
     const bool a_kc = !ta, b_kc = tb != 0;
+    // X W with a small W (K x N): transpose W once into a per-stream scratch and take the k-contiguous kernels (direct / split-bf16):
+    // the f32-input tile kernel runs such products at 131 TFLOP/s at best, the split-bf16 one at 230 (DyGFormer's 38 400-row
+    // input gradients, TGN's GRU).  Not for batched calls, nor when W is as large as the activations.
+    if (g_gemm_mode >= 1 && a_kc && !b_kc && inner == 1 && nbatch == 1 && alpha == 1.f && K % 4 == 0 && M >= 4 * N && K * N <= ((int64_t)4 << 20)) {
+        if (float* bt = transpose_workspace((size_t)K * N, s)) {
+            transpose_kn_kernel<<<dim3((unsigned)((N + 31) / 32), (unsigned)((K + 31) / 32)), 256, 0, s>>>(d_B, ldb, K, N, bt);
+            return gemm_impl(0, 1, M, N, K, alpha, d_A, lda, 0, bt, K, 0, d_C, ldc, 0, 1, d_bias, relu, accumulate, s);
+        }
+    }
     static const bool no_direct = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_GEMM_NODIRECT") != nullptr;
     // few rows (the root layer's 2 x batch): exact fp32, contraction split over the 4 waves of a workgroup (tg_gemm_direct.hip)
     if (!no_direct && a_kc && b_kc && inner == 1 && alpha == 1.f &&

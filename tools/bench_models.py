@@ -20,7 +20,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=600)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--gemm-mode", type=int, default=None)
     args = ap.parse_args()
+    if args.gemm_mode is not None:
+        from flid_amd._lib import lib
+        lib().tg_set_gemm_mode(args.gemm_mode)
     from flid_amd.synth import reddit_like
     from flid_amd.utils.utils import get_neighbor_sampler
     dev = torch.device("cuda:0")
