@@ -125,36 +125,6 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
     }
 }
 
-// column sums: grid.x blocks over column groups of 64, grid.y row slices; second pass folds the slices.
-__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int cols,
-                                                             float* __restrict__ part) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < cols)
-        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < n; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
-    red[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-}
-// fold the slices: block = 64 columns x 4 waves, wave w takes slices w, w+4, ...
-__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int slices, int cols,
-                                                           float* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < cols)
-        for (int i = wave; i < slices; i += 4) s += part[(int64_t)i * cols + c];
-    red[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && c < cols) {
-        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        out[c] = accumulate ? out[c] + t : t;
-    }
-}
-
 __global__ void __launch_bounds__(256) relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, int64_t numel) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
         if (!(y[i] > 0.f)) dy[i] = 0.f;
@@ -217,8 +187,6 @@ __global__ void __launch_bounds__(256) time_encode_bwd_kernel(const float* __res
 }
 
 // scratch for the two-pass column sums, one per stream that uses them (the layer backward runs them on two streams)
-struct ColsumWs { hipStream_t stream; float* p; size_t floats; };
-ColsumWs g_colsum_ws[4] = {};
 
 }  // namespace
 
@@ -326,27 +294,30 @@ extern "C" int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const fl
     return tg::launch_status("add_ln_bwd_kernel");
 }
 
+// column sums folded with float atomics (one pass; the two-pass form spent as long in its fold kernel as in the sums for the
+// 38 400-row inputs of DyGFormer)
+__global__ void __launch_bounds__(256) colsum_atomic_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int cols, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < cols)
+        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < n; r += (int64_t)gridDim.y * 4) s += x[r * ld + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
 extern "C" int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, float* d_out, int accumulate, void* stream) {
     TG_REQUIRE(d_x && d_out && cols > 0 && n >= 0 && ld >= cols, "tg_colsum: arguments");
     hipStream_t s = (hipStream_t)stream;
-    // enough row slices to cover the chip for tall inputs (38 400 token rows x 200..800 columns in DyGFormer: 64 slices = 25 us)
+    if (!accumulate) TG_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(float) * cols, s));
+    if (n == 0) return TG_OK;
     const int col_groups = (cols + 63) / 64;
     const int64_t max_slices = std::max<int64_t>(64, std::min<int64_t>(512, 2048 / col_groups));
-    int slices = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, n / 32));
-    const size_t need = (size_t)slices * cols;
-    ColsumWs* w = nullptr;
-    for (auto& c : g_colsum_ws) if (c.p && c.stream == s) { w = &c; break; }
-    if (!w) for (auto& c : g_colsum_ws) if (!c.p) { w = &c; w->stream = s; break; }
-    TG_REQUIRE(w, "tg_colsum: called from more than 4 distinct streams");
-    if (need > w->floats) {   // grows rarely; never inside a captured region after warm-up
-        if (w->p) { TG_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(w->p); }
-        w->floats = std::max<size_t>(need, 512 * 1024);
-        TG_HIP_CHECK(hipMalloc(&w->p, w->floats * sizeof(float)));
-    }
-    float* g_ws = w->p;
-    colsum_partial_kernel<<<dim3((cols + 63) / 64, slices), 256, 0, s>>>(d_x, ld, n, cols, g_ws);
-    colsum_final_kernel<<<(cols + 63) / 64, 256, 0, s>>>(g_ws, slices, cols, d_out, accumulate);
-    return tg::launch_status("colsum kernels");
+    const int slices = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, n / 32));
+    colsum_atomic_kernel<<<dim3(col_groups, slices), 256, 0, s>>>(d_x, ld, n, cols, d_out);
+    return tg::launch_status("colsum_atomic_kernel");
 }
 
 extern "C" int tg_relu_bwd_inplace(float* d_dy, const float* d_y, int64_t numel, void* stream) {
