@@ -587,18 +587,10 @@ extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
            2 * H * dk * dn + 2 * H * dk * dq + H * dk + 16;
 }
 
-// rows of the first chunk when the attention backward of a large layer is split in two (the weight gradient of the first
-// chunk's du then runs under the second chunk instead of after the whole kernel); 0 = not split
-inline int64_t attn_split_rows(int64_t rows) { (void)rows; return 0; }     // (the split is not used: see tg_tgat_layer_bwd)
-inline int64_t attn_slab_parts(int64_t rows) {
-    const int64_t ra = attn_split_rows(rows);
-    return ra ? (int64_t)tg_attn_bwd_parts(ra) + tg_attn_bwd_parts(rows - ra) : (int64_t)tg_attn_bwd_parts(rows);
-}
-
 extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
     const int64_t a = ((rows + 15) / 16) * dn;                       // ReLU-mask slabs
     const int64_t b = row_grid(rows) * 4 * dq;                       // LayerNorm slabs
-    const int64_t c = std::max<int64_t>(attn_slab_parts(rows), 2 * (int64_t)tg_attn_bwd_parts(rows / 2 + 8)) * 2 * dt_dim; // time-encoder slabs
+    const int64_t c = (int64_t)tg_attn_bwd_parts(rows) * 2 * dt_dim; // time-encoder slabs
     return 16 + a + b + c;                                            // disjoint regions: they are consumed concurrently
     // (with merged projections the caller appends dq * heads * dk + heads * dk * dn + 32 floats: dV and dP)
 }
@@ -645,7 +637,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // slab regions of `part` (each finished on the side stream while the main chain moves on)
     const int64_t relu_blocks = (R + 15) / 16;
     const unsigned ln_grid = (unsigned)row_grid(R);
-    const int attn_parts = (int)attn_slab_parts(R);
+    const int attn_parts = tg_attn_bwd_parts(R);
     float* part_relu = Bw->part;
     float* part_ln = part_relu + relu_blocks * dn;
     float* part_attn = part_ln + (int64_t)ln_grid * 4 * dq;
