@@ -617,7 +617,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // refer to this call's descriptors)
     const bool threaded = overlap && g_issue_thread;
     const bool defer = overlap && Bw->defer_join != 0;             // the caller joins once, after its last layer (tg_side_join)
-    struct Drain { bool on; ~Drain() { if (on) (void)g_issuer.drain(); } } drain_guard{threaded && !defer};
+    struct Drain { bool on; ~Drain() { if (on) (void)g_issuer.drain(); } } drain_guard{threaded};    // disarmed on the success paths below
     auto side = [&](std::function<int()> f) -> int {
         if (!threaded) return f();
         g_issuer.push(std::move(f));
@@ -767,6 +767,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         drain_guard.on = false;
         TG_TRY(side_join(s));
     }
+    drain_guard.on = false;                   // deferred join: the closures own copies of the descriptors (Lc, Bc)
     return TG_OK;
 }
 
