@@ -298,7 +298,7 @@ def main():
                                 "unit": "TFLOP/s", "frac": round(g_fl / (g_ms * 1e-3) / MFMA_F32_PEAK, 4), "launches": g_cnt,
                                 "gflop_per_step": round(g_fl / args.steps / 1e9, 2)}
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:        # reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(data, n_train, model, batch_slice(args.warmup), args.cpu_sample_edges)
     if rank == 0:
         print(json.dumps(out), flush=True)
