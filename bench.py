@@ -122,10 +122,11 @@ def main():
     total_steps = args.warmup + args.steps
     n_batches = n_train // BATCH
     first = n_batches // 2                                                           # mid-stream: histories are populated
-    assert first + total_steps * world <= n_batches, "not enough batches for this many steps"
+    span = n_batches - first            # rank r takes batches r, r + N, ... of the second half of the train stream, cyclically:
+                                        # long runs / many ranks re-visit batches (same shapes, same graph; synthetic input)
 
     def batch_slice(step):
-        b = first + step * world + rank
+        b = first + (step * world + rank) % span
         return slice(b * BATCH, (b + 1) * BATCH)
 
     # inputs resident in HBM before the timed region
