@@ -28,8 +28,8 @@ bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
 bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
                     hipStream_t s);
-bool gemm_bf16x3_tn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
-                    int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, int accumulate, hipStream_t s);
+bool gemm_bf16x3_tn_partials(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                             int64_t strideB, float* ws, int nbatch, int nsplit, int64_t k_chunk, hipStream_t s);
 }
 
 namespace {
@@ -432,11 +432,6 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     if (g_gemm_mode >= 1 && a_kc && b_kc && inner == 1 && alpha == 1.f &&
         tg::gemm_bf16x3_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s))
         return tg::launch_status("gemm_bf16x3_nt_kernel");
-    // mode 2 also sends the weight-gradient form (A^T B) to the split-bf16 kernel: measured no faster than the exact kernel on
-    // these shapes (both are bound by the split-K fill / atomics, tools/gemm_bench5.py), so it stays opt-in
-    if (g_gemm_mode == 2 && ta && !tb && inner == 1 && alpha == 1.f && !d_bias && !relu &&
-        tg::gemm_bf16x3_tn(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, accumulate, s))
-        return tg::launch_status("gemm_bf16x3_tn_kernel");
     bool vec = al16(d_A) && al16(d_B) && lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 &&
                innerA % 4 == 0 && innerB % 4 == 0;
     vec = vec && (a_kc ? K % 4 == 0 : M % 4 == 0) && (b_kc ? K % 4 == 0 : N % 4 == 0);
@@ -459,12 +454,15 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     // Split the contraction only for weight-gradient shapes (A^T: K = number of rows, small output) so that forward products
     // stay bitwise reproducible; the partial products are folded with float atomics.
     int64_t splits = 1;
-    if (!relu && ta && gx * gy * nbatch < 512 && K >= 2 * BK) {
+    // tiles the split is sized for: the split-bf16 weight-gradient kernel (mode 2) works on 128 x 96 / 128 x 64 tiles
+    const bool tn_bf16 = g_gemm_mode == 2 && ta && !tb && inner == 1 && alpha == 1.f && !d_bias && !relu && M % 4 == 0 && N % 4 == 0;
+    const int64_t tiles_for_split = tn_bf16 ? ((M + 127) / 128) * std::min((N + 95) / 96, (N + 63) / 64) : gx * gy;
+    if (!relu && ta && tiles_for_split * nbatch < 512 && K >= 2 * BK) {
         // ~2 workgroups per CU, each with at least 8 K-stages: many short slices would only multiply the atomic traffic onto
         // a small output (a 172 x 172 gradient split 131 ways spent 48 us; 57 ways ...)
         const char* e = tuning ? getenv("FLID_GEMM_SPLIT_BLOCKS") : nullptr;
         const int64_t target = e ? atoi(e) : 512;
-        splits = (target + gx * gy * nbatch - 1) / (gx * gy * nbatch);
+        splits = (target + tiles_for_split * nbatch - 1) / (tiles_for_split * nbatch);
         const char* e2 = tuning ? getenv("FLID_GEMM_MIN_STAGES") : nullptr;
         const int64_t min_stages = e2 ? atoi(e2) : 8;
         const int64_t max_splits = (K + min_stages * BK - 1) / (min_stages * BK);
@@ -500,6 +498,11 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     const int vec_c = N % 4 == 0 && (atomics == 2 || (ldc % 4 == 0 && strideC % 4 == 0 && innerC % 4 == 0 && al16(d_C) && (!d_bias || al16(d_bias))));
     const Args a{ws, vec_c, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, noswz ? -(int)gy : (int)gy,
                  strideA, strideB, strideC, nbatch, (int)splits, inner, innerA, innerB, innerC};
+    // mode 2: the weight-gradient form (A^T B, split contraction) on the split-bf16 kernel, same workspace and fold
+    if (g_gemm_mode == 2 && atomics == 2 && ta && !tb && inner == 1 && alpha == 1.f &&
+        tg::gemm_bf16x3_tn_partials(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, ws, nbatch, (int)splits, k_chunk, s)) {
+        // (partials are in place)
+    } else
     if (a_kc && b_kc) dispatch<true, true>(vec, tm, tn, a, s);
     else if (a_kc && !b_kc) dispatch<true, false>(vec, tm, tn, a, s);
     else if (!a_kc && b_kc) dispatch<false, true>(vec, tm, tn, a, s);

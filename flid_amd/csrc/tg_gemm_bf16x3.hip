@@ -261,11 +261,10 @@ struct PanelT {
     const float* src;          // micro-tile origin at k = 0
     int lds_off;               // byte offset of (row group, k group)
     int kcol;
-    bool active;
 
+    // threads beyond TILES redo slot (t mod TILES): same loads, same bytes into LDS -- no inactive-thread branches in the stage
     __device__ __forceinline__ void init(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows) {
-        const int t = threadIdx.x;
-        active = t < TILES;
+        const int t = threadIdx.x % TILES;
         const int rg = t % (R / 4), kg = t / (R / 4);          // consecutive threads -> consecutive rows: 16-B coalesced
         int64_t row = row0 + rg * 4;
         if (row > nrows - 4) row = nrows - 4;                   // nrows % 4 == 0 (checked by the launcher)
@@ -274,16 +273,16 @@ struct PanelT {
         lds_off = (rg * 4) * ROW_BYTES + kg * 8;
         kcol = kg * 4;
     }
-    __device__ __forceinline__ void gload(int64_t ld, int64_t k0, int64_t kend, float4 (&reg)[4]) const {
+    // the four k rows of the micro-tile at stage offset k0; rows past kend (or a stage that does not exist) read the zero block
+    __device__ __forceinline__ void gload(int64_t ld, int64_t k0, int64_t kend, bool ok, const float* __restrict__ zeros, float4 (&reg)[4]) const {
+        const int64_t lim = ok ? kend : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active && k0 + kcol + i < kend) v = *reinterpret_cast<const float4*>(src + (k0 + i) * ld);
-            reg[i] = v;
+            const float* p = (k0 + kcol + i < lim) ? src + (k0 + i) * ld : zeros;
+            reg[i] = *reinterpret_cast<const float4*>(p);
         }
     }
     __device__ __forceinline__ void sstore(char* __restrict__ s, const float4 (&reg)[4]) const {
-        if (!active) return;
         const float c0[4] = {reg[0].x, reg[1].x, reg[2].x, reg[3].x};   // row +0: k = 0..3
         const float c1[4] = {reg[0].y, reg[1].y, reg[2].y, reg[3].y};
         const float c2[4] = {reg[0].z, reg[1].z, reg[2].z, reg[3].z};
@@ -299,24 +298,26 @@ struct PanelT {
     }
 };
 
+// 1-D grid of tiles x slices (slice = batch * nsplit + split, a multiple of 8 of them): every tile of one K slice runs on the same
+// XCD (hardware deals workgroups round-robin), as in the f32-input kernel.  Each workgroup leaves its partial tile in
+// ws[slice][M][N] as whole 16-byte chunks; tg_gemm.hip folds the slices in fixed order.
 template <int TNW>
 __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
-        const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, int gx, int64_t k_chunk, int nsplit,
-        int use_atomics, int64_t strideA, int64_t strideB, int64_t strideC) {
+        const float* __restrict__ B, int64_t ldb, float* __restrict__ ws, int gx, int ntiles, int64_t k_chunk, int nsplit,
+        int64_t strideA, int64_t strideB, const float* __restrict__ zeros) {
     constexpr int BNt = 32 * TNW;
     constexpr int FA = BM * ROW_BYTES, FB = BNt * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
     auto sA = [&](int i) -> char* { return lds + i * (FA + FB); };
     auto sB = [&](int i) -> char* { return lds + i * (FA + FB) + FA; };
-    const int by = blockIdx.x / gx, bx = blockIdx.x % gx;
-    const int batch = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
-    A += batch * strideA; B += batch * strideB; C += batch * strideC;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int slice = xcd + 8 * (jj / ntiles), tile = jj % ntiles;
+    const int by = tile / gx, bx = tile % gx;
+    const int batch = slice / nsplit, split = slice % nsplit;
+    A += batch * strideA; B += batch * strideB;
     const int64_t bm = (int64_t)by * BM, bn = (int64_t)bx * BNt;
     const int64_t kbeg = (int64_t)split * k_chunk, kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    bool live[TNW];
-#pragma unroll
-    for (int t = 0; t < TNW; ++t) live[t] = (bm + wave * 32 < M) && (bn + 32 * t < N);
     f32x16 acc[TNW];
 #pragma unroll
     for (int t = 0; t < TNW; ++t)
@@ -330,10 +331,8 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N
     float4 ra0[4], rb0[4], ra1[4], rb1[4];
     const int64_t nstage = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
     auto issue = [&](int64_t st, float4 (&ra)[4], float4 (&rb)[4]) {
-        if (st < nstage) {
-            pa.gload(lda, kbeg + st * BK, kend, ra);
-            pb.gload(ldb, kbeg + st * BK, kend, rb);
-        }
+        pa.gload(lda, kbeg + st * BK, kend, st < nstage, zeros, ra);
+        pb.gload(ldb, kbeg + st * BK, kend, st < nstage, zeros, rb);
     };
     auto stage = [&](int64_t st, float4 (&ra)[4], float4 (&rb)[4]) {
         const int cur = (int)(st & 1);
@@ -344,20 +343,26 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N
 #pragma unroll
             for (int t = 0; t < TNW; ++t) read_frag(sB(cur), 32 * t, ks, bh[t][ks], bl[t][ks]);
         }
-        if (st + 1 < nstage) {
-            pa.sstore(sA(cur ^ 1), ra);
-            pb.sstore(sB(cur ^ 1), rb);
-        }
+        pa.sstore(sA(cur ^ 1), ra);                   // one basic block per stage, as in the NT kernel
+        pb.sstore(sB(cur ^ 1), rb);
         issue(st + 3, ra, rb);
 #pragma unroll
-        for (int t = 0; t < TNW; ++t) {
-            if (live[t]) {
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[t][ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[t][ks], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[t][ks], acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < TNW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[t][ks], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[t][ks], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[t][ks], acc[t], 0, 0, 0);
+        }
+        if (SCHED) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 4 * TNW, 0);
+#pragma unroll
+            for (int i = 0; i < 6 * TNW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
         __syncthreads();
@@ -374,19 +379,28 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N
         stage(st, ra0, rb0);
         if (st + 1 < nstage) stage(st + 1, ra1, rb1);
     }
-    const int rl = lane & 31, kh = lane >> 5;
+    // partial tile -> LDS -> whole 16-byte chunks of ws[slice] (N % 4 == 0, checked by the launcher)
+    __syncthreads();
+    constexpr int CS = BNt + 8;
+    static_assert(4 * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
+    float* cs = reinterpret_cast<float*>(lds) + wave * 32 * CS;
+    {
+        const int rl = lane & 31, kh = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < TNW; ++t) {
-        const int64_t col = bn + t * 32 + rl;
-        if (col >= N) continue;
+        for (int t = 0; t < TNW; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = bm + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row >= M) continue;
-            float* p = C + row * ldc + col;
-            if (use_atomics) atomicAdd(p, acc[t][r]);
-            else *p = acc[t][r];
-        }
+            for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * CS + t * 32 + rl] = acc[t][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int C4 = BNt / 4;
+    float* dst = ws + (int64_t)slice * M * N;
+    const int64_t row0 = bm + wave * 32;
+#pragma unroll 2
+    for (int idx = lane; idx < 32 * C4; idx += 64) {
+        const int r = idx / C4, c4 = idx - r * C4;
+        const int64_t row = row0 + r, col = bn + c4 * 4;
+        if (row >= M || col >= N) continue;
+        *reinterpret_cast<float4*>(dst + row * N + col) = *reinterpret_cast<const float4*>(cs + r * CS + c4 * 4);
     }
 }
 
@@ -419,33 +433,23 @@ bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     return true;
 }
 
-// C[M,N] = A^T B (A: K x M, B: K x N, row-major).  false = shape not handled (fall back to the f32-input kernel).
-bool gemm_bf16x3_tn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
-                    int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, int accumulate, hipStream_t s) {
+// Partial products of C = A^T B (A: K x M, B: K x N, row-major) for nbatch x nsplit K slices into ws[slice][M][N]; the caller
+// (tg_gemm.hip) chose the split, owns the workspace and folds it.  false = shape not handled (use the f32-input kernel).
+bool gemm_bf16x3_tn_partials(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                             int64_t strideB, float* ws, int nbatch, int nsplit, int64_t k_chunk, hipStream_t s) {
     if (!(al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0)) return false;
-    if (M < 4 || N < 4 || K < 64) return false;
+    if (M < 4 || N < 4 || K < 64 || !ws || (nbatch * nsplit) % 8 != 0 || k_chunk % BK != 0) return false;
+    const float* zeros = zero_block();
+    if (!zeros) return false;
     const int64_t pad3 = (N + 95) / 96 * 96, pad2 = (N + 63) / 64 * 64;
     const int tnw = pad3 <= pad2 ? 3 : 2;
     const int64_t gx = (N + 32 * tnw - 1) / (32 * tnw), gy = (M + BM - 1) / BM;
-    // ~2 workgroups per CU, at least 8 stages each
-    int64_t splits = (512 + gx * gy * nbatch - 1) / (gx * gy * nbatch);
-    const int64_t max_splits = (K + 8 * BK - 1) / (8 * BK);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int64_t k_chunk = (K + splits - 1) / splits;
-    k_chunk = (k_chunk + BK - 1) / BK * BK;
-    splits = (K + k_chunk - 1) / k_chunk;
-    if (splits * nbatch > 65535) return false;
-    const int atomics = splits > 1 || accumulate;
-    if (atomics && !accumulate)
-        for (int b = 0; b < nbatch; ++b)
-            if (hipMemset2DAsync(C + b * strideC, ldc * sizeof(float), 0, N * sizeof(float), M, s) != hipSuccess) return false;
-    ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
-    const dim3 grid((unsigned)(gx * gy), 1, (unsigned)(nbatch * splits));
+    const int64_t blocks = gx * gy * nbatch * nsplit;
+    if (blocks >= ((int64_t)1 << 31)) return false;
     if (tnw == 3)
-        gemm_bf16x3_tn_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, (int)gx, k_chunk, (int)splits, atomics, strideA, strideB, strideC);
+        gemm_bf16x3_tn_kernel<3><<<(unsigned)blocks, NT, 0, s>>>(M, N, K, A, lda, B, ldb, ws, (int)gx, (int)(gx * gy), k_chunk, nsplit, strideA, strideB, zeros);
     else
-        gemm_bf16x3_tn_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, (int)gx, k_chunk, (int)splits, atomics, strideA, strideB, strideC);
+        gemm_bf16x3_tn_kernel<2><<<(unsigned)blocks, NT, 0, s>>>(M, N, K, A, lda, B, ldb, ws, (int)gx, (int)(gx * gy), k_chunk, nsplit, strideA, strideB, zeros);
     return true;
 }
 
