@@ -433,3 +433,38 @@ def test_flat_adam_matches_torch_adam(dev):
             assert torch.allclose(a.data, b.data, rtol=2e-6, atol=2e-7), (wd, it, float((a.data - b.data).abs().max()))
         assert ob.state[b]["step"] == 5
         assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+
+
+def test_sample_recent_full_size_properties(dev):
+    """BASELINE-size graph (157 474 edges) and frontier (24 000 hop-2 queries with float32 times): properties that need no oracle --
+    right-aligned zero padding, strictly-earlier and ascending times, every returned (neighbor, edge id, time) is an incidence of
+    the queried node, and the row holds the NEWEST min(k, history) of them; calling twice gives identical bits."""
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.graph import TemporalGraph
+    data = wikipedia_like(seed=0)
+    g = TemporalGraph(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    rp, nb, ei, tt = g.host_csr()
+    rs = np.random.RandomState(5)
+    k, n = 20, 24000
+    ids = rs.randint(0, g.num_rows, n).astype(np.int32)
+    t32 = rs.uniform(0, 2.678e6, n).astype(np.float32)                       # hop-2 style queries
+    out = [g.sample_recent(torch.from_numpy(ids).to(dev), torch.from_numpy(t32).to(dev), k, want_dt=False) for _ in range(2)]
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert torch.equal(a, b)
+    nbr, eid, ts = (x.cpu().numpy() for x in out[0][:3])
+    valid = nbr != 0
+    # right alignment: once a slot is valid every later slot is
+    assert np.all(valid[:, 1:] >= valid[:, :-1])
+    assert np.all(ts[valid] < np.repeat(t32[:, None], k, 1)[valid].astype(np.float64))
+    assert np.all(np.diff(ts, axis=1)[valid[:, :-1]] >= 0)                    # ascending inside the valid (right-aligned) part
+    assert np.all(eid[~valid] == 0) and np.all(ts[~valid] == 0)
+    # counts and membership on a sample of rows (host CSR walk)
+    for r in rs.choice(n, 400, replace=False):
+        lo, hi = rp[ids[r]], rp[ids[r] + 1]
+        i = int(np.searchsorted(tt[lo:hi], np.float64(t32[r]), side="left"))
+        take = min(k, i)
+        assert int(valid[r].sum()) == take
+        if take:
+            sl = slice(lo + i - take, lo + i)
+            assert np.array_equal(nbr[r, k - take:], nb[sl]) and np.array_equal(eid[r, k - take:], ei[sl])
+            assert np.array_equal(ts[r, k - take:], tt[sl].astype(np.float32))

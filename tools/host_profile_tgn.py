@@ -38,4 +38,4 @@ pr = cProfile.Profile(); pr.enable()
 for s in range(5, 25): step(s)
 torch.cuda.synchronize()
 pr.disable()
-st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45); print(st.getvalue()[:9000])
+st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(32); print(st.getvalue()[:7000])
