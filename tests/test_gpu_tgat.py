@@ -304,3 +304,35 @@ def test_merged_projections_match_separate_products():
         # a ReLU unit within rounding of zero may flip between the two evaluations: allow a few entries to move a little
         bad = (diff > 1e-4 * scale).float().mean().item()
         assert bad <= 0.005 and float(diff.max()) <= 0.02 * scale, (n, bad, float(diff.max()) / scale)
+
+
+def test_tgat_full_size_equivariance_and_linearity():
+    """BASELINE-size batch (600 edges, K=20, L=2, full dims), properties that need no oracle: permuting the batch permutes the
+    embeddings (each root is a function of its own (node, time) only), and the backward pass is linear in the upstream gradient."""
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = wikipedia_like(seed=0)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    torch.manual_seed(0)
+    m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 100, 2, 2, 0.0, "cuda:0").to("cuda:0").train()
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.dim() > 1 and prm.shape[1] > 1:
+                prm.copy_(torch.randn_like(prm) * 0.05)
+    sl = slice(100000, 100600)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    perm = np.random.RandomState(1).permutation(600)
+    with torch.no_grad():
+        s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 20)
+        sp, dp = m.compute_src_dst_node_temporal_embeddings(bs[perm], bd[perm], bt[perm], 20)
+    assert float((sp - s[perm]).abs().max()) < 2e-5 and float((dp - d[perm]).abs().max()) < 2e-5
+    r = torch.from_numpy(np.random.RandomState(2).standard_normal((2, 600, 172)).astype(np.float32)).cuda()
+    grads = []
+    for scale in (1.0, 2.0):
+        m.zero_grad(set_to_none=True)
+        s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 20)
+        torch.autograd.backward([s, d], [scale * r[0], scale * r[1]])
+        grads.append([p.grad.clone() for p in m.parameters()])
+    for g1, g2 in zip(*grads):
+        assert float((g2 - 2.0 * g1).abs().max()) <= 2e-5 * float(g2.abs().max()) + 1e-9
