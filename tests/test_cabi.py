@@ -45,3 +45,18 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle|oracle/", open(os.path.join(root, f)).read(), flags=re.M):
                     bad.append(f)
     assert not bad, f"product files reference the oracle: {bad}"
+
+
+def test_missing_library_and_cpu_device_fail_loudly(tmp_path):
+    """no CPU fallback: a missing libflid_tg.so raises at first use, and the model classes refuse a CPU device"""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['FLID_TG_LIB'] = %r\n"
+            "from flid_amd import _lib\n"
+            "try:\n    _lib.lib()\nexcept Exception as e:\n    print('RAISED', type(e).__name__)\n" % (REPO, str(tmp_path / "nope.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED" in out.stdout, out.stdout + out.stderr
+    import numpy as np
+    from flid_amd.models.TGAT import TGAT
+    with pytest.raises(RuntimeError):
+        TGAT(np.zeros((3, 4), np.float32), np.zeros((3, 4), np.float32), None, 4, 1, 2, 0.0, device="cpu")
