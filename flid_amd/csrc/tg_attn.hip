@@ -56,6 +56,10 @@ __host__ __device__ inline int64_t attn_grid(int64_t m) {
 // Slots are processed RB at a time: all RB rows' loads are issued first (memory-level parallelism: RB x CPL 16-byte loads
 // per lane in flight), then the RB x H partial dot products are folded across the wave together.
 constexpr int RB = 5;
+// SPLIT = one attention instance per WORKGROUP: wave w takes the row batches w, w+4, ... and the four online-softmax states are
+// merged through LDS.  For launches of a few thousand instances or fewer (the 1 200-row root layer, a TGN batch) there is about one
+// wave per SIMD, so an instance's 20 rows are pure serial latency for that wave (28 / 68 us per launch forward / backward).
+constexpr int64_t kSplitMaxRows = 4096;
 
 template <int VEC, int CPL>
 __device__ __forceinline__ void load_row(const tg_attn_desc& a, const Seg (&seg)[CPL], const float (&tw)[CPL][VEC],
@@ -75,9 +79,12 @@ __device__ __forceinline__ void load_row(const tg_attn_desc& a, const Seg (&seg)
     }
 }
 
-template <int VEC, int CPL, int H>
+template <int VEC, int CPL, int H, bool SPLIT = false>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_attn_desc a, const float* __restrict__ u,
                                                                          float* __restrict__ agg, float* __restrict__ prob) {
+    // merge area of the SPLIT form: per wave the running max / denominator of every head and the un-normalised aggregate
+    __shared__ float s_md[SPLIT ? WAVES_PER_BLOCK : 1][2 * H];
+    __shared__ float s_acc[SPLIT ? WAVES_PER_BLOCK : 1][SPLIT ? H * CPL * VEC * kWave : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int dk = a.dn + a.de + a.dt_dim;
@@ -95,7 +102,9 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
         }
     }
 
-    for (int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; row < a.m; row += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+    const int64_t row_first = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int64_t row_step = SPLIT ? (int64_t)gridDim.x : (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (int64_t row = row_first; row < a.m; row += row_step) {
         float uh[H][CPL][VEC], acc[H][CPL][VEC];
         float mx[H], den[H], keep_score[H];
 #pragma unroll
@@ -118,7 +127,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
             const int my_n = sl < k ? a.d_nbr[mo] : 0;
             const float my_dt = sl < k ? a.d_dt[mo] : 0.f;
             const int cnt = (k - s0) < kWave ? (k - s0) : kWave;
-            for (int sb = 0; sb < cnt; sb += RB) {
+            for (int sb = SPLIT ? wave * RB : 0; sb < cnt; sb += SPLIT ? WAVES_PER_BLOCK * RB : RB) {
                 float z[RB][CPL][VEC];
                 int nb[RB];
 #pragma unroll
@@ -167,6 +176,59 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
                     }
                 }
             }
+            if constexpr (SPLIT) {
+                // k <= 64 (launcher): one metadata tile.  Merge the four waves' states, then every wave writes the probabilities
+                // of the slots it owns and wave 0 the aggregate.
+                if (lane == 0) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) { s_md[wave][2 * h] = mx[h]; s_md[wave][2 * h + 1] = den[h]; }
+                }
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) s_acc[wave][((h * CPL + i) * VEC + e) * kWave + lane] = acc[h][i][e];
+                __syncthreads();
+                float M[H], D[H], wsc[H][WAVES_PER_BLOCK];
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    M[h] = -INFINITY;
+#pragma unroll
+                    for (int w = 0; w < WAVES_PER_BLOCK; ++w) M[h] = fmaxf(M[h], s_md[w][2 * h]);
+                    D[h] = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+                        wsc[h][w] = s_md[w][2 * h + 1] > 0.f ? __expf(s_md[w][2 * h] - M[h]) : 0.f;      // a wave without rows: den = 0
+                        D[h] += s_md[w][2 * h + 1] * wsc[h][w];
+                    }
+                }
+                const bool mine = lane < cnt && (lane / RB) % WAVES_PER_BLOCK == wave;
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+                    if (mine) prob[(row * H + h) * k + lane] = __expf(keep_score[h] - M[h]) / D[h];
+                if (wave == 0) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const float inv = 1.f / D[h];
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i) {
+                            if (seg[i].kind == 3) continue;
+                            float o[VEC];
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) {
+                                float t = 0.f;
+#pragma unroll
+                                for (int w = 0; w < WAVES_PER_BLOCK; ++w) t = fmaf(s_acc[w][((h * CPL + i) * VEC + e) * kWave + lane], wsc[h][w], t);
+                                o[e] = t * inv;
+                            }
+                            store_chunk<VEC>(agg + (row * H + h) * dk + (lane + kWave * i) * VEC, o);
+                        }
+                    }
+                }
+                __syncthreads();                       // the merge area is reused by the next instance of this workgroup
+                continue;                              // (SPLIT: the s0 loop has a single iteration)
+            }
             // probabilities need the final max/denominator: exact here when k <= 64 (one tile); for longer rows the raw
             // scores are parked in `prob` and normalised after the loop.
             if (k <= kWave) {
@@ -179,6 +241,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
                     if (sl < k) prob[(row * H + h) * k + sl] = keep_score[h];
             }
         }
+        if constexpr (SPLIT) continue;
         if (k > kWave) {
 #pragma unroll
             for (int h = 0; h < H; ++h)
@@ -205,9 +268,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
 // ------------------------------------------------------------------------------------------------ backward
 // d score_{h,n} = a'_{h,n} (dagg_h . z_n) - a_{h,n} (dagg_h . agg_h)      a' = dropped/scaled prob, a = softmax prob
 // masked slots get no score gradient (masked_fill), but still pass d z through a'.
-constexpr int RBB = 4;
-
-template <int VEC, int CPL, int H>
+template <int VEC, int CPL, int H, bool SPLIT = false, int RBB = 4>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_attn_desc a, const float* __restrict__ u,
         const float* __restrict__ agg, const float* __restrict__ prob, const float* __restrict__ dagg,
         float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld, float* __restrict__ dte_part, int64_t pad_row) {
@@ -215,7 +276,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
     const int wave = threadIdx.x / kWave;
     const int dk = a.dn + a.de + a.dt_dim;
     const int k = a.k;
-    extern __shared__ float red[];   // WAVES_PER_BLOCK * (2 * dt_dim + dn)
+    extern __shared__ float red[];   // WAVES_PER_BLOCK * (2 * dt_dim + dn)  [+ WAVES_PER_BLOCK * H * CPL * VEC * 64 when SPLIT]
     // every padded slot gathers the SAME row (pad_row): its gradient is summed in registers and leaves the workgroup as one
     // row of atomics instead of thousands of adds onto one address (14x slower per the float-atomic contention rule)
     float dpad[CPL][VEC];
@@ -237,7 +298,9 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
         }
     }
 
-    for (int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; row < a.m; row += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+    const int64_t row_first = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int64_t row_step = SPLIT ? (int64_t)gridDim.x : (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (int64_t row = row_first; row < a.m; row += row_step) {
         float uh[H][CPL][VEC], dg[H][CPL][VEC], dacc[H][CPL][VEC];
         float cterm[H];
 #pragma unroll
@@ -272,7 +335,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
 #pragma unroll
             for (int h = 0; h < H; ++h) my_p[h] = sl < k ? prob[(row * H + h) * k + sl] : 0.f;
             const int cnt = (k - s0) < kWave ? (k - s0) : kWave;
-            for (int sb = 0; sb < cnt; sb += RBB) {
+            for (int sb = SPLIT ? wave * RBB : 0; sb < cnt; sb += SPLIT ? WAVES_PER_BLOCK * RBB : RBB) {
                 float z[RBB][CPL][VEC];
                 int nb[RBB];
                 int64_t fis[RBB];
@@ -348,11 +411,41 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
                 }
             }
         }
+        if constexpr (SPLIT) {
+            // the four waves hold the du contributions of their own rows: fold through LDS, wave 0 stores
+            float* racc = red + WAVES_PER_BLOCK * (2 * a.dt_dim + a.dn);
 #pragma unroll
-        for (int h = 0; h < H; ++h)
+            for (int h = 0; h < H; ++h)
 #pragma unroll
-            for (int i = 0; i < CPL; ++i)
-                if (seg[i].kind != 3) store_chunk<VEC>(du + (row * H + h) * dk + (lane + kWave * i) * VEC, dacc[h][i]);
+                for (int i = 0; i < CPL; ++i)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) racc[(wave * H * CPL * VEC + (h * CPL + i) * VEC + e) * kWave + lane] = dacc[h][i][e];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) {
+                        if (seg[i].kind == 3) continue;
+                        float o[VEC];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            float t = 0.f;
+#pragma unroll
+                            for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += racc[(w * H * CPL * VEC + (h * CPL + i) * VEC + e) * kWave + lane];
+                            o[e] = t;
+                        }
+                        store_chunk<VEC>(du + (row * H + h) * dk + (lane + kWave * i) * VEC, o);
+                    }
+            }
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+                for (int i = 0; i < CPL; ++i)
+                    if (seg[i].kind != 3) store_chunk<VEC>(du + (row * H + h) * dk + (lane + kWave * i) * VEC, dacc[h][i]);
+        }
     }
 
     // block partial of (dw | db): waves -> LDS -> one slab row per workgroup (no atomics, deterministic)
@@ -390,9 +483,21 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
     }
 }
 
+// one instance per workgroup (SPLIT) pays for launches that leave most SIMDs with a single wave
+inline bool use_split(const tg_attn_desc& a, int vec, int cpl) {
+    return vec == 4 && cpl == 2 && a.heads == 2 && a.m <= kSplitMaxRows && a.k <= kWave && a.k > RB;
+}
+inline int64_t split_grid(int64_t m) { return m < 1 ? 1 : (m > tg::kMaxGridBlocks ? tg::kMaxGridBlocks : m); }
+
 template <int VEC, int CPL>
 int launch_fwd(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s) {
     const dim3 grid((unsigned)attn_grid(a.m)), block(WAVES_PER_BLOCK * kWave);
+    if constexpr (VEC == 4 && CPL == 2) {
+        if (use_split(a, VEC, CPL)) {
+            attn_fwd_kernel<4, 2, 2, true><<<dim3((unsigned)split_grid(a.m)), block, 0, s>>>(a, u, agg, prob);
+            return tg::launch_status("attn_fwd_kernel");
+        }
+    }
     switch (a.heads) {
         case 1: attn_fwd_kernel<VEC, CPL, 1><<<grid, block, 0, s>>>(a, u, agg, prob); break;
         case 2: attn_fwd_kernel<VEC, CPL, 2><<<grid, block, 0, s>>>(a, u, agg, prob); break;
@@ -407,6 +512,8 @@ int launch_bwd(const tg_attn_desc& a, const float* u, const float* agg, const fl
                float* dfeat, int64_t dfeat_ld, float* dte, int64_t pad_row, hipStream_t s) {
     const dim3 grid((unsigned)attn_grid(a.m)), block(WAVES_PER_BLOCK * kWave);
     const size_t lds = sizeof(float) * WAVES_PER_BLOCK * (2 * a.dt_dim + a.dn);
+    // (the SPLIT form of the backward kernel is not launched: 68 -> 65 us on the root layer, whose time is the 4 M float atomics of
+    // the neighbor-feature gradient, not row latency)
     switch (a.heads) {
         case 1: attn_bwd_kernel<VEC, CPL, 1><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row); break;
         case 2: attn_bwd_kernel<VEC, CPL, 2><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row); break;
