@@ -261,7 +261,7 @@ def main():
                 "avg_launch_ms": round(ms / max(1, cnt), 4), "flops_per_step": units / args.steps}
     else:
         bwd = args.roofline_kernel == "attn_bwd"
-        roof = {"bound": "hbm", "kernel": "attn_bwd_kernel<4,2,2>" if bwd else "attn_fwd_kernel<4,2,2>",
+        roof = {"bound": "hbm", "kernel": "attn_bwd_kernel<4,2,2,false,4>" if bwd else "attn_fwd_kernel<4,2,2,false>",
                 "achieved": round(units / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(units / secs / HBM_PEAK, 4), "traffic": None, "launches": cnt,
                 "avg_launch_ms": round(ms / max(1, cnt), 4), "bytes_per_instance": attn_bytes_per_instance(backward=bwd),
