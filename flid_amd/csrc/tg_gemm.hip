@@ -455,7 +455,9 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     // stay bitwise reproducible; the partial products are folded with float atomics.
     int64_t splits = 1;
     // tiles the split is sized for: the split-bf16 weight-gradient kernel (mode 2) works on 128 x 96 / 128 x 64 tiles
-    const bool tn_bf16 = g_gemm_mode == 2 && ta && !tb && inner == 1 && alpha == 1.f && !d_bias && !relu && M % 4 == 0 && N % 4 == 0;
+    // mode 1 takes it for the larger outputs only (dP 888 x 172: 71 -> 57 us, dV 272 x 888: 102 -> 84 us; 172 x 272 and smaller lose)
+    const bool tn_bf16 = (g_gemm_mode == 2 || (g_gemm_mode == 1 && M * N >= 65536)) && ta && !tb && inner == 1 && alpha == 1.f && !d_bias &&
+                         !relu && M % 4 == 0 && N % 4 == 0;
     const int64_t tiles_for_split = tn_bf16 ? ((M + 127) / 128) * std::min((N + 95) / 96, (N + 63) / 64) : gx * gy;
     if (!relu && ta && tiles_for_split * nbatch < 512 && K >= 2 * BK) {
         // ~2 workgroups per CU, each with at least 8 K-stages: many short slices would only multiply the atomic traffic onto
@@ -499,7 +501,7 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     const Args a{ws, vec_c, M, N, K, alpha, d_A, lda, d_B, ldb, d_C, ldc, d_bias, relu, accumulate, k_chunk, atomics, (int)gx, noswz ? -(int)gy : (int)gy,
                  strideA, strideB, strideC, nbatch, (int)splits, inner, innerA, innerB, innerC};
     // mode 2: the weight-gradient form (A^T B, split contraction) on the split-bf16 kernel, same workspace and fold
-    if (g_gemm_mode == 2 && atomics == 2 && ta && !tb && inner == 1 && alpha == 1.f &&
+    if (tn_bf16 && atomics == 2 &&
         tg::gemm_bf16x3_tn_partials(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, ws, nbatch, (int)splits, k_chunk, s)) {
         // (partials are in place)
     } else

@@ -195,9 +195,12 @@ int tg_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, co
                 const float* d_B, int64_t ldb, float* d_C, int64_t ldc, const float* d_bias, int relu, int accumulate,
                 void* stream);
 
-/* Precision of the products whose operands are both k-contiguous (ta = 0, tb = 1: activations times a weight given as N x K):
- * mode 1 (default) = split-bf16, three bf16 MFMAs per product with fp32 accumulation, relative error ~4e-6 per product
- * (|emb - reference| 1.6e-5 on the full-dimension golden case); mode 2 = additionally the weight-gradient form (ta = 1, tb = 0);
+/* Precision of the products:
+ * mode 1 (default) = split-bf16 (three bf16 MFMAs per product term, fp32 accumulation, relative error ~4e-6 per product;
+ *   |emb - reference| 1.6e-5 on the full-dimension golden case) for products whose operands are both k-contiguous (ta = 0, tb = 1:
+ *   activations times a weight given as N x K) and for weight-gradient products (ta = 1, tb = 0) with M * N >= 65536; exact
+ *   f32-input MFMA for everything else (few-row products, small weight gradients);
+ * mode 2 = split-bf16 for every weight-gradient product as well;
  * mode 0 = exact fp32 (f32-input MFMA) everywhere. */
 void tg_set_gemm_mode(int mode);
 int tg_get_gemm_mode(void);
