@@ -618,7 +618,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const bool threaded = overlap && g_issue_thread;
     const bool defer = overlap && Bw->defer_join != 0;             // the caller joins once, after its last layer (tg_side_join)
     struct Drain { bool on; ~Drain() { if (on) (void)g_issuer.drain(); } } drain_guard{threaded};    // disarmed on the success paths below
+    static const bool exp_skip_side = getenv("FLID_EXP_SKIP_SIDE") != nullptr;   // timing experiment (wrong gradients): the main chain alone
     auto side = [&](std::function<int()> f) -> int {
+        if (exp_skip_side) return TG_OK;
         if (!threaded) return f();
         g_issuer.push(std::move(f));
         return TG_OK;
