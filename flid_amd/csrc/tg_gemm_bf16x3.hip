@@ -265,7 +265,10 @@ struct PanelT {
     // threads beyond TILES redo slot (t mod TILES): same loads, same bytes into LDS -- no inactive-thread branches in the stage
     __device__ __forceinline__ void init(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows) {
         const int t = threadIdx.x % TILES;
-        const int rg = t % (R / 4), kg = t / (R / 4);          // consecutive threads -> consecutive rows: 16-B coalesced
+        // consecutive threads -> consecutive k groups: their LDS stores (8 B each, same rows) fall into consecutive banks; with
+        // consecutive ROWS per lane the 576-byte row-group stride put 8 lanes on every bank pair.  Global side: 8 k rows x 128 B
+        // contiguous per instruction (whole cache lines either way).
+        const int kg = t % 8, rg = t / 8;
         int64_t row = row0 + rg * 4;
         if (row > nrows - 4) row = nrows - 4;                   // nrows % 4 == 0 (checked by the launcher)
         if (row < 0) row = 0;
