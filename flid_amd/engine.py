@@ -598,8 +598,13 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
 
 def _apply(cfg, fr, table, te_w, te_b, layer_params, flat):
     """flat = (flat parameter, [views of it: te_w, te_b, *layer_params]) from TGAT.flatten_parameters(), or None"""
-    if flat is not None and NATIVE:
+    native = NATIVE and cfg["num_heads"] <= 2          # the one-call-per-layer path covers 1 or 2 heads (the reference default: 2);
+                                                       # more heads take the op-by-op composition of the same HIP kernels
+    if flat is not None and native:
         cfg["flat_views"] = flat[1]
         return _EmbedFnNative.apply(cfg, fr, table, flat[0])
-    fn = _EmbedFnNative if NATIVE else _EmbedFn
+    if flat is not None:                                # flat parameter + op-by-op path: differentiate through its views
+        views = [flat[0][o:o + v.numel()].view(v.shape) for o, v in zip(block_layout(flat[1])[0], flat[1])]
+        te_w, te_b, layer_params = views[0], views[1], views[2:]
+    fn = _EmbedFnNative if native else _EmbedFn
     return fn.apply(cfg, fr, table, te_w, te_b, *layer_params)

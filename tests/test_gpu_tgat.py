@@ -336,3 +336,31 @@ def test_tgat_full_size_equivariance_and_linearity():
         grads.append([p.grad.clone() for p in m.parameters()])
     for g1, g2 in zip(*grads):
         assert float((g2 - 2.0 * g1).abs().max()) <= 2e-5 * float(g2.abs().max()) + 1e-9
+
+
+def test_tgat_four_heads_takes_the_op_by_op_path():
+    """num_heads = 4 (not the reference default): the per-layer native call covers 1-2 heads, more heads run the op-by-op
+    composition of the same kernels -- still against the oracle, forward and gradients"""
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = wikipedia_like(num_edges=4000, num_users=300, num_items=60, feat_dim=12, seed=5, zero_node_feat=False)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    torch.manual_seed(0)
+    m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 4, 2, 4, 0.0, "cuda:0").to("cuda:0").train()
+    with torch.no_grad():
+        m.time_encoder.w.bias.zero_()
+    sl = slice(3000, 3040)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 5)
+    (s.sum() + 2.0 * d.sum()).backward()
+    p = {k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in m.state_dict().items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    orc = O.TGATOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 2, 4)
+    os_, od_ = orc.src_dst(bs, bd, bt, 5)
+    (os_.sum() + 2.0 * od_.sum()).backward()
+    np.testing.assert_allclose(s.detach().cpu().numpy(), os_.detach().numpy(), atol=TOL)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), od_.detach().numpy(), atol=TOL)
+    for name, prm in m.named_parameters():
+        g, go = prm.grad.cpu().numpy(), p[name].grad.numpy()
+        assert np.abs(g - go).max() <= 1e-4 * max(1.0, np.abs(go).max()), name
