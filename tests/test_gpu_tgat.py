@@ -364,3 +364,41 @@ def test_tgat_four_heads_takes_the_op_by_op_path():
     for name, prm in m.named_parameters():
         g, go = prm.grad.cpu().numpy(), p[name].grad.numpy()
         assert np.abs(g - go).max() <= 1e-4 * max(1.0, np.abs(go).max()), name
+
+
+@pytest.mark.parametrize("dims", [(10, 6, 6), (9, 5, 7)])
+def test_tgat_unaligned_feature_dims(dims):
+    """feature widths that are not multiples of 4 (and a node width != edge width): the scalar-load / unaligned fall-backs of every
+    kernel, forward and gradients against the oracle"""
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    dn, de, dt = dims
+    rs = np.random.RandomState(11)
+    E, nu, ni = 3000, 200, 50
+    src = rs.randint(1, nu + 1, E).astype(np.int64)
+    dst = rs.randint(nu + 1, nu + ni + 1, E).astype(np.int64)
+    dst[-1] = nu + ni
+    t = np.sort(rs.uniform(0, 1e5, E)).round(0)
+    eid = np.arange(1, E + 1, dtype=np.int64)
+    node = np.zeros((nu + ni + 1, dn), np.float32); node[1:] = rs.standard_normal((nu + ni, dn)).astype(np.float32)
+    edge = np.zeros((E + 1, de), np.float32); edge[1:] = rs.standard_normal((E, de)).astype(np.float32)
+
+    class D:
+        src_node_ids, dst_node_ids, edge_ids, node_interact_times = src, dst, eid, t
+    sampler = get_neighbor_sampler(D, "recent", seed=0)
+    torch.manual_seed(0)
+    m = TGAT(node, edge, sampler, dt, 2, 2, 0.0, "cuda:0").to("cuda:0").train()
+    with torch.no_grad():
+        m.time_encoder.w.bias.zero_()
+    sl = slice(2500, 2532)
+    s, d = m.compute_src_dst_node_temporal_embeddings(src[sl], dst[sl], t[sl], 7)
+    (s.sum() - d.sum()).backward()
+    p = {k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in m.state_dict().items()}
+    orc = O.TGATOracle(torch.from_numpy(node), torch.from_numpy(edge), O.build_adjacency(src, dst, eid, t), p, 2, 2)
+    os_, od_ = orc.src_dst(src[sl], dst[sl], t[sl], 7)
+    (os_.sum() - od_.sum()).backward()
+    np.testing.assert_allclose(s.detach().cpu().numpy(), os_.detach().numpy(), atol=TOL)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), od_.detach().numpy(), atol=TOL)
+    for name, prm in m.named_parameters():
+        g, go = prm.grad.cpu().numpy(), p[name].grad.numpy()
+        assert np.abs(g - go).max() <= 1e-4 * max(1.0, np.abs(go).max()), name
