@@ -402,3 +402,31 @@ def test_tgat_unaligned_feature_dims(dims):
     for name, prm in m.named_parameters():
         g, go = prm.grad.cpu().numpy(), p[name].grad.numpy()
         assert np.abs(g - go).max() <= 1e-4 * max(1.0, np.abs(go).max()), name
+
+
+@pytest.mark.parametrize("k", [1, 3, 70])
+def test_tgat_neighbor_count_extremes(k):
+    """num_neighbors 1, 3 and 70 (> one wave of slots: the multi-tile path of the attention kernels), odd batch size"""
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = wikipedia_like(num_edges=6000, num_users=150, num_items=30, feat_dim=8, seed=9, zero_node_feat=False)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    torch.manual_seed(0)
+    m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 4, 2, 2, 0.0, "cuda:0").to("cuda:0").train()
+    with torch.no_grad():
+        m.time_encoder.w.bias.zero_()
+    sl = slice(5000, 5007)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, k)
+    (s.sum() + d.sum()).backward()
+    p = {k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in m.state_dict().items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    orc = O.TGATOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 2, 2)
+    os_, od_ = orc.src_dst(bs, bd, bt, k)
+    (os_.sum() + od_.sum()).backward()
+    np.testing.assert_allclose(s.detach().cpu().numpy(), os_.detach().numpy(), atol=TOL)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), od_.detach().numpy(), atol=TOL)
+    for name, prm in m.named_parameters():
+        g, go = prm.grad.cpu().numpy(), p[name].grad.numpy()
+        assert np.abs(g - go).max() <= 1e-4 * max(1.0, np.abs(go).max()), name
