@@ -60,3 +60,21 @@ def test_missing_library_and_cpu_device_fail_loudly(tmp_path):
     from flid_amd.models.TGAT import TGAT
     with pytest.raises(RuntimeError):
         TGAT(np.zeros((3, 4), np.float32), np.zeros((3, 4), np.float32), None, 4, 1, 2, 0.0, device="cpu")
+
+
+def test_install_aliases_the_reference_import_names():
+    """flid_amd.install(): `from models.TGAT import TGAT`, `from utils.utils import get_neighbor_sampler` ... resolve to the mirrors
+    (run in a fresh interpreter so that this process's module table stays clean)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import flid_amd; flid_amd.install()\n"
+            "from models.TGAT import TGAT\nfrom models.MemoryModel import MemoryModel, compute_src_dst_node_time_shifts\n"
+            "from models.DyGFormer import DyGFormer\nfrom models.modules import TimeEncoder, MergeLayer, MultiHeadAttention, MLPClassifier\n"
+            "from utils.utils import NeighborSampler, get_neighbor_sampler\n"
+            "import flid_amd.models.TGAT as T\nassert TGAT is T.TGAT\n"
+            "m = MemoryModel.__init__.__code__.co_varnames\n"
+            "assert 'src_node_mean_time_shift' in m and 'model_name' in m\n"
+            "print('ALIASED')\n" % REPO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "ALIASED" in out.stdout, out.stdout + out.stderr
