@@ -36,10 +36,12 @@ def grads_compact_np(named):
     return out
 
 
-def assert_grads_match(gold, named, atol=1e-4, rtol=1e-4, kink_frac=0.005):
+def assert_grads_match(gold, named, atol=1e-4, rtol=1e-4, kink_frac=0.005, strict=False):
     """Gradients are long cancelling sums: the absolute tolerance scales with the tensor's largest entry.  A ReLU unit whose
     pre-activation is within rounding of zero may switch between two correct fp32 evaluations and move a handful of entries
     by a visible amount; at most `kink_frac` of a tensor's entries may do so, and only by < 2 % of the largest entry."""
+    if strict:          # kink-free fixtures (oracle.kink_free_): every sampled entry within atol * max|g|, no allowance
+        rtol, kink_frac = 0.0, 0.0
     mine = grads_compact_np(named)
     keys = [k for k in gold if k.startswith("g:")]
     assert keys, "fixture holds no gradients"
@@ -48,7 +50,9 @@ def assert_grads_match(gold, named, atol=1e-4, rtol=1e-4, kink_frac=0.005):
         big = max(1.0, float(np.abs(gold[k]).max()))
         err = np.abs(mine[k].astype(np.float64) - gold[k])
         bad = err > atol * big + rtol * np.abs(gold[k])
-        assert bad.mean() <= kink_frac, (k, int(bad.sum()), bad.size, float(err.max()))
+        # (a tensor of <= 200 entries -- the time encoder's 100 -- may still have ONE such entry: its gradient entries are scaled by
+        # time intervals of up to 2.7e6, so a single flipped unit is visible in one of them)
+        assert bad.sum() <= (0 if strict else max(1.0, kink_frac * bad.size)), (k, int(bad.sum()), bad.size, float(err.max()), big)
         assert float(err.max()) <= 0.02 * big, (k, float(err.max()), big)
         s = "gs:" + k[2:]
         scale = max(1.0, np.sqrt(gold[s][1]))

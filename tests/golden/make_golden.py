@@ -335,7 +335,144 @@ def gold_state_dict_keys():
     save("state_dict_keys", **out)
 
 
+# ------------------------------------------------------------------------------------------------- full size (B = 600)
+# BASELINE batch size on Wikipedia / Reddit-shape graphs of reduced edge count: the row counts at which the product takes its
+# production dispatch (split-bf16 products, merged projections, row sharing).  The graph is rebuilt in the tests from
+# flid_amd.synth with the recorded arguments (a checksum of the arrays is stored); weights and upstream gradients are seeds.
+def _crc(*arrs):
+    import zlib
+    c = 0
+    for a in arrs:
+        c = zlib.crc32(np.ascontiguousarray(a).view(np.uint8), c)
+    return np.int64(c)
+
+
+def _rows(x, step):
+    return x.detach().numpy()[::step].copy()
+
+
+def run_tgat_b600(tag, seed, lo, zero_node_feat, bias_te, num_edges=30000, scale=0.05, kink_free=False):
+    from flid_amd.synth import wikipedia_like
+    data = wikipedia_like(num_edges=num_edges, seed=0, zero_node_feat=zero_node_feat)
+    ns = get_neighbor_sampler(Data(data.src_node_ids, data.dst_node_ids, data.node_interact_times, data.edge_ids), "recent", seed=0)
+    model = TGAT(data.node_raw_features, data.edge_raw_features, ns, time_feat_dim=100, num_layers=2, num_heads=2, dropout=0.0)
+    shapes = {k_: tuple(v.shape) for k_, v in model.state_dict().items()}
+    params = O.seeded_like(shapes, seed=seed, scale=scale)
+    if not bias_te:
+        params["time_encoder.w.bias"].zero_()
+    if kink_free:
+        O.kink_free_(params)
+    model.load_state_dict(params)
+    model.train()
+    sl = slice(lo, lo + 600)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    s_emb, d_emb = model.compute_src_dst_node_temporal_embeddings(bs, bd, bt, num_neighbors=20)
+    r = np.random.RandomState(seed + 1000).standard_normal((2, 600, 172)).astype(np.float32)
+    (s_emb * torch.from_numpy(r[0])).sum().add((d_emb * torch.from_numpy(r[1])).sum()).backward()
+    save(tag, num_edges=np.int64(num_edges), zero_node_feat=np.bool_(zero_node_feat), lo=np.int64(lo), seed=np.int64(seed),
+         scale=np.float64(scale), bias_te=np.bool_(bias_te), r_seed=np.int64(seed + 1000), kink_free=np.bool_(kink_free),
+         crc=_crc(data.src_node_ids, data.dst_node_ids, data.node_interact_times, data.edge_raw_features[:64]),
+         s_emb=s_emb.detach().numpy(), d_emb=d_emb.detach().numpy(),
+         **grads_compact({k_: p.grad for k_, p in model.named_parameters()}))
+
+
+def gold_tgn_b600(num_edges=24000, warm=30, rec=3, seed=61, scale=0.05, step=4):
+    from flid_amd.synth import reddit_like
+    data = reddit_like(num_edges=num_edges, seed=3)
+    src, dst, t, eid = data.src_node_ids, data.dst_node_ids, data.node_interact_times, data.edge_ids
+    ns = get_neighbor_sampler(Data(src, dst, t, eid), "recent", seed=0)
+    model = MemoryModel(data.node_raw_features, data.edge_raw_features, ns, time_feat_dim=100, model_name="TGN", num_layers=1,
+                        num_heads=2, dropout=0.0)
+    params = O.seeded_like(O.tgn_shapes(172, 172, 100, 1), seed=seed, scale=scale)
+    params["time_encoder.w.bias"].zero_()
+    O.kink_free_(params)
+    sd = dict(params)
+    sd["embedding_module.time_encoder.w.weight"] = params["time_encoder.w.weight"]
+    sd["embedding_module.time_encoder.w.bias"] = params["time_encoder.w.bias"]
+    missing = model.load_state_dict(sd, strict=False)
+    assert all("memory_bank" in m for m in missing.missing_keys), missing
+    model.train()
+    B = 600
+    out = dict(num_edges=np.int64(num_edges), warm=np.int64(warm), rec=np.int64(rec), seed=np.int64(seed), scale=np.float64(scale),
+               step=np.int64(step), crc=_crc(src, dst, t, data.edge_raw_features[:64]))
+    model.memory_bank.__init_memory_bank__()
+    rs = np.random.RandomState(seed + 1)
+    first_item, n_items = int(dst.min()), int(dst.max() - dst.min() + 1)
+    for b in range(warm):                       # state warm-up: positives only, no autograd (negatives never change the state)
+        sl = slice(b * B, (b + 1) * B)
+        with torch.no_grad():
+            model.compute_src_dst_node_temporal_embeddings(src[sl], dst[sl], t[sl], eid[sl], True, 20)
+    for j in range(rec):
+        b = warm + j
+        sl = slice(b * B, (b + 1) * B)
+        bs, bd, bt, be = src[sl], dst[sl], t[sl], eid[sl]
+        neg = rs.randint(first_item, first_item + n_items, size=B).astype(np.int64)
+        out[f"neg{j}"] = neg
+        model.zero_grad()
+        ns_emb, nd_emb = model.compute_src_dst_node_temporal_embeddings(bs, neg, bt, None, False, 20)
+        ps_emb, pd_emb = model.compute_src_dst_node_temporal_embeddings(bs, bd, bt, be, True, 20)
+        r = np.random.RandomState(seed + 100 + j).standard_normal((4, B, 172)).astype(np.float32)
+        sum((e * torch.from_numpy(r[i])).sum() for i, e in enumerate((ns_emb, nd_emb, ps_emb, pd_emb))).backward()
+        g = grads_compact({k_: p.grad for k_, p in model.named_parameters() if p.grad is not None})
+        out.update({f"b{j}:" + k_: v for k_, v in g.items()})
+        model.memory_bank.detach_memory_bank()
+        for key, e in (("ns", ns_emb), ("nd", nd_emb), ("ps", ps_emb), ("pd", pd_emb)):
+            out[f"{key}{j}"] = _rows(e, step)
+        mem = model.memory_bank.node_memories.detach()
+        touched = np.unique(np.concatenate([bs, bd]))[::3]
+        out[f"touched{j}"] = touched
+        out[f"mem{j}"] = mem.numpy()[touched].copy()
+        out[f"memsum{j}"] = np.array([mem.double().sum().item(), (mem.double() ** 2).sum().item()])
+        out[f"lu{j}"] = model.memory_bank.node_last_updated_times.detach().numpy().copy()
+        has = np.zeros(mem.shape[0], dtype=bool)
+        msum = np.zeros(mem.shape[0], dtype=np.float64)
+        pt = np.zeros(mem.shape[0], dtype=np.float64)
+        for nid, lst in model.memory_bank.node_raw_messages.items():
+            if len(lst):
+                has[nid], msum[nid], pt[nid] = True, lst[-1][0].detach().double().sum().item(), lst[-1][1]
+        out[f"has{j}"], out[f"pmsum{j}"], out[f"pt{j}"] = has, msum, pt
+    save("tgn_B600x3", **out)
+
+
+def gold_dyg_b600(num_edges=24000, lo=20000, seed=71, scale=0.04):
+    from flid_amd.synth import reddit_like
+    data = reddit_like(num_edges=num_edges, seed=4)
+    src, dst, t, eid = data.src_node_ids, data.dst_node_ids, data.node_interact_times, data.edge_ids
+    ns = get_neighbor_sampler(Data(src, dst, t, eid), "recent", seed=0)
+    model = DyGFormer(data.node_raw_features, data.edge_raw_features, ns, time_feat_dim=100, channel_embedding_dim=50, patch_size=1,
+                      num_layers=2, num_heads=2, dropout=0.0, max_input_sequence_length=32)
+    shapes = {k_: tuple(v.shape) for k_, v in model.state_dict().items()}
+    assert shapes == O.dyg_shapes(172, 172, 100, 50, 1, 2)
+    params = O.seeded_like(shapes, seed=seed, scale=scale)
+    params["time_encoder.w.bias"].zero_()
+    model.load_state_dict(params)
+    model.train()
+    sl = slice(lo, lo + 600)
+    s_emb, d_emb = model.compute_src_dst_node_temporal_embeddings(src[sl], dst[sl], t[sl])
+    r = np.random.RandomState(seed + 1000).standard_normal((2, 600, 172)).astype(np.float32)
+    (s_emb * torch.from_numpy(r[0])).sum().add((d_emb * torch.from_numpy(r[1])).sum()).backward()
+    save("dyg_B600", num_edges=np.int64(num_edges), lo=np.int64(lo), seed=np.int64(seed), scale=np.float64(scale),
+         r_seed=np.int64(seed + 1000), crc=_crc(src, dst, t, data.edge_raw_features[:64]),
+         s_emb=s_emb.detach().numpy(), d_emb=d_emb.detach().numpy(),
+         **grads_compact({k_: p.grad for k_, p in model.named_parameters()}))
+
+
+FULL = {
+    "tgat_B600_full": lambda: run_tgat_b600("tgat_B600_full", seed=46, lo=20000, zero_node_feat=True, bias_te=False),
+    # non-zero node features, trained-like time-encoder bias, ReLU units away from their kink: gradients comparable at 1e-4 max|g|
+    "tgat_B600_kinkfree": lambda: run_tgat_b600("tgat_B600_kinkfree", seed=47, lo=25000, zero_node_feat=False, bias_te=True,
+                                                kink_free=True),
+    "tgn_B600x3": gold_tgn_b600,
+    "dyg_B600": gold_dyg_b600,
+}
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:                                   # regenerate selected full-size fixtures only
+        for name in only:
+            FULL[name]()
+        sys.exit(0)
     gold_sampler()
     gold_time_encoder()
     gold_attention()
@@ -349,3 +486,5 @@ if __name__ == "__main__":
     run_dyg("dyg_p1", 1, 8, seed=51, graph_seed=7)
     run_dyg("dyg_p2", 2, 9, seed=52, graph_seed=7)
     gold_state_dict_keys()
+    for fn in FULL.values():
+        fn()

@@ -1,0 +1,117 @@
+"""GPU parity AT THE BASELINE BATCH SIZE against vectors the reference itself produced (tests/golden/make_golden.py::FULL):
+B = 600, 172 / 172 / 100 dims, K = 20 -- the row counts at which the product takes its PRODUCTION dispatch (split-bf16 products,
+merged projections from 4 096 rows on, row sharing at ~12 k rows, the weight-gradient kernels), in the default mode and in the
+flat-parameter mode.  Tolerances: embeddings 1e-4 absolute (north_star); gradients 1e-4 max|g| per tensor, with no kink allowance
+on the kink-free fixtures (oracle.kink_free_)."""
+import numpy as np
+import pytest
+import torch
+
+import fullsize
+from conftest import assert_grads_match, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _tgat(data, p, dropout=0.0):
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, num_layers=2, num_heads=2, dropout=dropout,
+             device="cuda:0")
+    m.load_state_dict(p)
+    return m.to("cuda:0").train()
+
+
+@pytest.mark.parametrize("name", ["tgat_B600_full", "tgat_B600_kinkfree"])
+@pytest.mark.parametrize("flat", [False, True], ids=["per_tensor", "flat"])
+def test_tgat_b600_matches_reference(name, flat):
+    from flid_amd import engine
+    from flid_amd._lib import lib
+    g = load_golden(name)
+    data, p, (bs, bd, bt), r = fullsize.tgat_case(g)
+    m = _tgat(data, p)
+    flat_param = m.flatten_parameters() if flat else None
+    assert engine.DEDUPE and engine.NATIVE                      # the default dispatch is what is being pinned
+    s, d = m.compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=bd, node_interact_times=bt, num_neighbors=20)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), g["d_emb"], atol=TOL)
+    rr = torch.from_numpy(r).cuda()
+    ((s * rr[0]).sum() + (d * rr[1]).sum()).backward()
+    if flat:
+        named = [m.time_encoder.w.weight, m.time_encoder.w.bias] + m._layer_params()
+        offs, _ = engine.block_layout(named)
+        by_id = {id(q): flat_param.grad[o:o + q.numel()].view(q.shape) for o, q in zip(offs, named)}
+        grads = {k_: by_id[id(v)].cpu().numpy() for k_, v in m.named_parameters()}
+    else:
+        grads = {k_: v.grad.cpu().numpy() for k_, v in m.named_parameters()}
+    assert_grads_match(g, grads, atol=1e-4, rtol=1e-3, strict=bool(g["kink_free"]))
+    assert lib().tg_version() >= 1
+
+
+def test_tgn_b600_sequence_matches_reference():
+    """30 warm-up batches + 3 recorded batches of 600 at the Reddit shape, train() with gradients, neg-then-pos order"""
+    from flid_amd.models.MemoryModel import MemoryModel
+    from flid_amd.utils.utils import get_neighbor_sampler
+    g = load_golden("tgn_B600x3")
+    data, p = fullsize.tgn_case(g)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = MemoryModel(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, model_name="TGN", num_layers=1,
+                    num_heads=2, dropout=0.0, device="cuda:0")
+    sd = dict(p)
+    sd["embedding_module.time_encoder.w.weight"], sd["embedding_module.time_encoder.w.bias"] = p["time_encoder.w.weight"], p["time_encoder.w.bias"]
+    missing = m.load_state_dict(sd, strict=False)
+    assert all("memory_bank" in x for x in missing.missing_keys)
+    m.train()
+    bank = m.memory_bank
+    bank.__init_memory_bank__()
+    step = int(g["step"])
+    for j, (bs, bd, bt, be), neg, r in fullsize.tgn_batches(g, data):
+        if j is None:
+            with torch.no_grad():
+                m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, be, True, 20)
+            continue
+        m.zero_grad(set_to_none=True)
+        ns_, nd_ = m.compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=neg, node_interact_times=bt, edge_ids=None,
+                                                              edges_are_positive=False, num_neighbors=20)
+        ps_, pd_ = m.compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=bd, node_interact_times=bt, edge_ids=be,
+                                                              edges_are_positive=True, num_neighbors=20)
+        rr = torch.from_numpy(r).cuda()
+        sum((e * rr[i]).sum() for i, e in enumerate((ns_, nd_, ps_, pd_))).backward()
+        grads = {k_: v.grad.cpu().numpy() for k_, v in m.named_parameters() if v.grad is not None}
+        assert "memory_updater.memory_updater.weight_ih" in grads
+        assert_grads_match(fullsize.tgn_grads_view(g, j), grads, atol=1e-4, strict=True)
+        bank.detach_memory_bank()
+        for mine, key in ((ns_, "ns"), (nd_, "nd"), (ps_, "ps"), (pd_, "pd")):
+            np.testing.assert_allclose(mine.detach().cpu().numpy()[::step], g[f"{key}{j}"], atol=TOL, err_msg=f"{key}{j}")
+        mem = bank.node_memories.detach().cpu()
+        np.testing.assert_allclose(mem.numpy()[g[f"touched{j}"]], g[f"mem{j}"], atol=TOL)
+        assert abs(mem.double().sum().item() - g[f"memsum{j}"][0]) < 5e-2
+        assert np.array_equal(bank.node_last_updated_times.detach().cpu().numpy(), g[f"lu{j}"])
+        raw = bank.node_raw_messages
+        has = np.zeros(mem.shape[0], dtype=bool)
+        has[[nid for nid, lst in raw.items() if len(lst)]] = True
+        assert np.array_equal(has, g[f"has{j}"])
+        ids = np.nonzero(has)[0]
+        sums = torch.stack([raw[int(i)][-1][0] for i in ids]).double().sum(1).cpu().numpy()
+        np.testing.assert_allclose(sums, g[f"pmsum{j}"][ids], atol=2e-3)
+        assert all(raw[int(i)][-1][1] == g[f"pt{j}"][i] for i in ids)
+
+
+def test_dygformer_b600_matches_reference():
+    from flid_amd.models.DyGFormer import DyGFormer
+    from flid_amd.utils.utils import get_neighbor_sampler
+    g = load_golden("dyg_B600")
+    data, p, (bs, bd, bt), r = fullsize.dyg_case(g)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, channel_embedding_dim=50, patch_size=1,
+                  num_layers=2, num_heads=2, dropout=0.0, max_input_sequence_length=32, device="cuda:0")
+    m.load_state_dict(p)
+    m = m.to("cuda:0").train()
+    s, d = m.compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=bd, node_interact_times=bt)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), g["d_emb"], atol=TOL)
+    rr = torch.from_numpy(r).cuda()
+    ((s * rr[0]).sum() + (d * rr[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.cpu().numpy() for k_, v in m.named_parameters()}, atol=1e-4, rtol=1e-3)

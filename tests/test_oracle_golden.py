@@ -175,3 +175,70 @@ def test_state_dict_contract():
     tn = dict(zip(g["tgn_keys"], g["tgn_shapes"]))
     for k, v in O.tgn_shapes(172, 172, 100, 1).items():
         assert ",".join(map(str, v)) == tn[k], k
+
+
+# ---- full size (B = 600, BASELINE dims): the oracle against what the reference produced on the same batches -----------------------
+import fullsize  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["tgat_B600_full", "tgat_B600_kinkfree"])
+def test_tgat_full_size(name):
+    g = load_golden(name)
+    data, p, (bs, bd, bt), r = fullsize.tgat_case(g)
+    p = {k_: v.requires_grad_(True) for k_, v in p.items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    m = O.TGATOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 2, 2)
+    s, d = m.src_dst(bs, bd, bt, 20)
+    np.testing.assert_allclose(s.detach().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().numpy(), g["d_emb"], atol=TOL)
+    rr = torch.from_numpy(r)
+    ((s * rr[0]).sum() + (d * rr[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.numpy() for k_, v in p.items()}, atol=1e-4, rtol=1e-3, strict=bool(g["kink_free"]))
+
+
+def test_tgn_full_size_sequence():
+    g = load_golden("tgn_B600x3")
+    data, p = fullsize.tgn_case(g)
+    p = {k_: v.requires_grad_(True) for k_, v in p.items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    m = O.TGNOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 1, 2)
+    step = int(g["step"])
+    for j, (bs, bd, bt, be), neg, r in fullsize.tgn_batches(g, data):
+        if j is None:
+            with torch.no_grad():
+                m.src_dst(bs, bd, bt, be, True, 20)
+            continue
+        for v in p.values():
+            v.grad = None
+        ns_, nd_ = m.src_dst(bs, neg, bt, None, False, 20)
+        ps_, pd_ = m.src_dst(bs, bd, bt, be, True, 20)
+        rr = torch.from_numpy(r)
+        sum((e * rr[i]).sum() for i, e in enumerate((ns_, nd_, ps_, pd_))).backward()
+        assert_grads_match(fullsize.tgn_grads_view(g, j), {k_: v.grad.numpy() for k_, v in p.items() if v.grad is not None},
+                           atol=1e-4, strict=True)
+        m.detach()
+        for mine, key in ((ns_, "ns"), (nd_, "nd"), (ps_, "ps"), (pd_, "pd")):
+            np.testing.assert_allclose(mine.detach().numpy()[::step], g[f"{key}{j}"], atol=TOL, err_msg=f"{key}{j}")
+        np.testing.assert_allclose(m.memory.numpy()[g[f"touched{j}"]], g[f"mem{j}"], atol=TOL)
+        assert abs(m.memory.double().sum().item() - g[f"memsum{j}"][0]) < 1e-2
+        assert np.array_equal(m.last_update.numpy(), g[f"lu{j}"])
+        has = np.zeros(m.num_rows, dtype=bool)
+        has[list(m.pending)] = True
+        assert np.array_equal(has, g[f"has{j}"])
+        for nid, (msg, ts) in m.pending.items():
+            assert ts == g[f"pt{j}"][nid]
+            assert abs(msg.double().sum().item() - g[f"pmsum{j}"][nid]) < 1e-3
+
+
+def test_dygformer_full_size():
+    g = load_golden("dyg_B600")
+    data, p, (bs, bd, bt), r = fullsize.dyg_case(g)
+    p = {k_: v.requires_grad_(True) for k_, v in p.items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    m = O.DyGFormerOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 50, 1, 2, 2, 32)
+    s, d = m.src_dst(bs, bd, bt)
+    np.testing.assert_allclose(s.detach().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().numpy(), g["d_emb"], atol=TOL)
+    rr = torch.from_numpy(r)
+    ((s * rr[0]).sum() + (d * rr[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.numpy() for k_, v in p.items()}, atol=1e-4, rtol=1e-3)
