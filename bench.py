@@ -70,7 +70,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the untimed per-family profiling pass")
     ap.add_argument("--cpu-sample-edges", type=int, default=1800)
+    ap.add_argument("--autograd", action="store_true",
+                    help="train mode: loss and backward through torch autograd (loss.backward()) instead of the fused step "
+                         "TGAT.train_step (same kernels, no autograd graph, loss scalar from one HIP reduction)")
+    ap.add_argument("--master-port", type=int, default=29533)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched plainly with --gpus N: become the launcher.  The ranks are CHILD processes started before this process has
+        # touched the GPU (nothing above imports torch.cuda state); their exit code is ours.
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     from flid_amd import dist as fdist
     from flid_amd import ops
@@ -120,6 +133,7 @@ def main():
     reducer = fdist.GradAllReducer(train_params) if world > 1 else None
 
     total_steps = args.warmup + args.steps
+    n_prefetch = 2                      # batches prepared ahead of the one being computed (two-stage sampler prefetch)
     n_batches = n_train // BATCH
     first = n_batches // 2                                                           # mid-stream: histories are populated
     span = n_batches - first            # rank r takes batches r, r + N, ... of the second half of the train stream, cyclically:
@@ -131,14 +145,22 @@ def main():
 
     # inputs resident in HBM before the timed region
     dev_batches = []
-    for s in range(total_steps):
+    for s in range(total_steps + n_prefetch):          # the last timed step still prefetches like every other
         sl = batch_slice(s)
         dev_batches.append((torch.from_numpy(data.src_node_ids[sl].astype(np.int32)).to(dev),
                             torch.from_numpy(data.dst_node_ids[sl].astype(np.int32)).to(dev),
                             torch.from_numpy(data.node_interact_times[sl]).to(dev)))
     rw = torch.randn(2, BATCH, DN, device=dev)
+    # the scalar loss of a step: mean over the batch of (src_emb . rw[0] + dst_emb . rw[1]) -- as a fused-step loss function
+    # (value from one HIP reduction, gradient w.r.t. the embedding block = rw / (B Dn), a constant)
+    rw_flat = rw.reshape(2 * BATCH, DN).contiguous()
+    rw_grad = rw_flat / float(BATCH * DN)
+    loss_out = torch.zeros(1, device=dev)
 
-    prepared = {}
+    def mean_loss(emb):
+        return ops.weighted_sum(emb, rw_flat, 1.0 / (BATCH * DN), out=loss_out), rw_grad
+
+    prepared, jobs = {}, {}
     if args.mode == "lp":
         from flid_amd import engine
         from flid_amd.models.modules import MergeLayer
@@ -151,25 +173,39 @@ def main():
         first_item = int(data.dst_node_ids.min())
         rs_neg = np.random.RandomState(7 + rank)
         neg_batches = [torch.from_numpy(rs_neg.randint(first_item, first_item + n_items, BATCH).astype(np.int32)).to(dev)
-                       for _ in range(total_steps)]
+                       for _ in range(total_steps + n_prefetch)]
         labels = torch.cat([torch.ones(BATCH, device=dev), torch.zeros(BATCH, device=dev)])
         bce = torch.nn.BCELoss()
         args.no_cpu_baseline = True
 
-        def prepare_lp(s_):
+        def begin_lp(s_):
             src, dst, t = dev_batches[s_]
-            return engine.prepare_frontier(sampler.graph, [src, dst, neg_batches[s_]], [t, t, t], K, L)
+            return engine.prepare_begin(sampler.graph, [src, dst, neg_batches[s_]], [t, t, t], K, L)
 
     if args.mode == "fwd":
         model.eval()
         args.no_cpu_baseline = True
         args.roofline_kernel = "attn_fwd"
 
+    def begin(s_):
+        return begin_lp(s_) if args.mode == "lp" else model.prepare_batch_begin(*dev_batches[s_], K)
+
+    def finish(job):
+        from flid_amd import engine as _e
+        return _e.prepare_finish(job) if args.mode == "lp" else model.prepare_batch_finish(job)
+
+    def prefetch(s):
+        """sampler work of FUTURE batches on the side stream (graph only, weight-independent -- the data-loader style prefetch):
+        batch s+1's second half (its distinct-row count was copied to pinned memory a step ago: no wait), batch s+2's first half"""
+        if s not in prepared:                                      # cold start
+            prepared[s] = finish(jobs.pop(s) if s in jobs else begin(s))
+        if s + 1 < len(dev_batches) and s + 1 not in prepared:
+            prepared[s + 1] = finish(jobs.pop(s + 1) if s + 1 in jobs else begin(s + 1))
+        if s + 2 < len(dev_batches) and s + 2 not in jobs:
+            jobs[s + 2] = begin(s + 2)
+
     def step_lp(s):
-        if s not in prepared:
-            prepared[s] = prepare_lp(s)
-        if s + 1 < len(dev_batches):
-            prepared[s + 1] = prepare_lp(s + 1)
+        prefetch(s)
         opt.zero_grad(set_to_none=True)
         head_opt.zero_grad(set_to_none=True)
         emb = model.compute_node_temporal_embeddings(prepared.pop(s), None, L, K)    # (3 B, Dn): src | dst | negative dst
@@ -183,22 +219,23 @@ def main():
         opt.step()
         head_opt.step()
 
+    fused = args.mode == "train" and not args.autograd and not args.no_flat
+
     def step(s):
         if args.mode == "lp":
             return step_lp(s)
-        # sampler work of the NEXT batch is issued first, on a side stream (it depends on the graph only, not on the weights)
-        if s not in prepared:
-            prepared[s] = model.prepare_batch(*dev_batches[s], K)
-        if s + 1 < len(dev_batches):
-            prepared[s + 1] = model.prepare_batch(*dev_batches[s + 1], K)
+        prefetch(s)
         if args.mode == "fwd":
             with torch.no_grad():
                 model.compute_src_dst_node_temporal_embeddings(prepared.pop(s), None, None, K)
             return
         opt.zero_grad(set_to_none=True)
-        se, de_ = model.compute_src_dst_node_temporal_embeddings(prepared.pop(s), None, None, K)
-        loss = torch.addcmul(se * rw[0], de_, rw[1]).mean()          # scalar loss on both outputs, one reduction
-        loss.backward()
+        if fused:
+            model.train_step(prepared.pop(s), mean_loss, K)          # forward, loss, backward: no autograd graph
+        else:
+            se, de_ = model.compute_src_dst_node_temporal_embeddings(prepared.pop(s), None, None, K)
+            loss = torch.addcmul(se * rw[0], de_, rw[1]).mean()      # the same scalar through torch autograd
+            loss.backward()
         if reducer is not None:
             reducer.reduce()
         opt.step()
@@ -236,6 +273,7 @@ def main():
     if not args.no_breakdown:
         ops.profile_enable(others)
         prepared.clear()
+        jobs.clear()
         for s in range(args.warmup, total_steps):          # same batches again (weights have moved on; shapes are identical)
             step(s)
         fam.update({tag: ops.profile_collect(tag) for tag in others})
@@ -282,7 +320,8 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload + " + TGAT L=2 H=2 T=100, batch 600 edges/GPU, 20 recent neighbors, dropout %.2f, %s"
-                               % (args.dropout, {"train": "fwd+bwd+Adam", "fwd": "fwd (eval)", "lp": "link-prediction step"}[args.mode]),
+                               % (args.dropout, {"train": "fwd+bwd+Adam (%s)" % ("fused step" if fused else "autograd"), "fwd": "fwd (eval)",
+                                                 "lp": "link-prediction step"}[args.mode]),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world, "num_neighbors": K, "num_layers": L,
                    "parallelism": f"dp{world}"},
         "path_roofline": {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4),

@@ -49,6 +49,8 @@ SIGNATURES = {
     "tg_profile_enable": (None, [C.c_int]),
     "tg_profile_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.c_int]),
     "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),
+    "tg_time_bias_finish": (C.c_int, [c_void, c_void, c_void, C.c_int, c_void]),
+    "tg_weighted_sum": (C.c_int, [c_void, c_void, c_i64, c_f32, c_void, c_void]),
     "tg_hash_features": (C.c_int, [c_void, c_i64, c_i64, c_i64, C.c_int, C.c_uint64, c_void]),
     "tg_graph_create": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, C.POINTER(c_void)]),
     "tg_graph_destroy": (None, [c_void]),
@@ -62,7 +64,8 @@ SIGNATURES = {
     "tg_time_encode": (C.c_int, [c_void, c_i64, c_void, c_void, C.c_int, C.c_int, c_void, c_void]),
     "tg_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void]),
     "tg_attn_bwd_parts": (C.c_int, [c_i64]),
-    "tg_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_void, c_void]),
+    "tg_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_void, c_i64, c_void, c_void]),
+    "tg_set_attn_fast": (None, [C.c_int]),
     "tg_set_overlap": (None, [C.c_int]),
     "tg_tgat_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), c_void]),
     "tg_tgat_layer_wt_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),

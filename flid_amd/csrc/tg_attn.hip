@@ -47,10 +47,8 @@ __device__ __forceinline__ Seg classify(int col, int dn, int de, int dk) {
 
 constexpr int WAVES_PER_BLOCK = 4;
 
-__host__ __device__ inline int64_t attn_grid(int64_t m) {
-    int64_t b = (m + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    return b < 1 ? 1 : (b > tg::kMaxGridBlocks ? tg::kMaxGridBlocks : b);
-}
+static_assert(WAVES_PER_BLOCK == 4, "tg::attn_grid_blocks assumes 4 instances per workgroup");
+inline int64_t attn_grid(int64_t m) { return tg::attn_grid_blocks(m); }
 
 // ------------------------------------------------------------------------------------------------ forward
 // Slots are processed RB at a time: all RB rows' loads are issued first (memory-level parallelism: RB x CPL 16-byte loads
@@ -271,7 +269,8 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
 template <int VEC, int CPL, int H, bool SPLIT = false, int RBB = 4>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_attn_desc a, const float* __restrict__ u,
         const float* __restrict__ agg, const float* __restrict__ prob, const float* __restrict__ dagg,
-        float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld, float* __restrict__ dte_part, int64_t pad_row) {
+        float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld, float* __restrict__ dte_part, int64_t pad_row,
+        float* __restrict__ dedge, int64_t dedge_ld) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int dk = a.dn + a.de + a.dt_dim;
@@ -338,7 +337,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
             for (int sb = SPLIT ? wave * RBB : 0; sb < cnt; sb += SPLIT ? WAVES_PER_BLOCK * RBB : RBB) {
                 float z[RBB][CPL][VEC];
                 int nb[RBB];
-                int64_t fis[RBB];
+                int64_t fis[RBB], eis[RBB];
                 float dts[RBB];
 #pragma unroll
                 for (int r = 0; r < RBB; ++r) {
@@ -346,10 +345,10 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
                     const bool live = s < cnt;
                     const int ss = live ? s : 0;
                     fis[r] = __builtin_amdgcn_readlane(my_f, ss);
-                    const int64_t ei = __builtin_amdgcn_readlane(my_e, ss);
+                    eis[r] = __builtin_amdgcn_readlane(my_e, ss);
                     nb[r] = __builtin_amdgcn_readlane(my_n, ss);
                     dts[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), ss));
-                    load_row<VEC, CPL>(a, seg, tw, tb, fis[r], ei, dts[r], live, z[r]);
+                    load_row<VEC, CPL>(a, seg, tw, tb, fis[r], eis[r], dts[r], live, z[r]);
                 }
                 float part[RBB * H];
 #pragma unroll
@@ -397,6 +396,9 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
 #pragma unroll
                                 for (int e = 0; e < VEC; ++e) atomicAdd(dfeat + fis[r] * dfeat_ld + seg[i].col + e, dz[i][e]);
                             }
+                        } else if (seg[i].kind == 1 && dedge) {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) atomicAdd(dedge + eis[r] * dedge_ld + seg[i].col + e, dz[i][e]);
                         } else if (seg[i].kind == 2) {
 #pragma unroll
                             for (int e = 0; e < VEC; ++e) {
@@ -509,15 +511,15 @@ int launch_fwd(const tg_attn_desc& a, const float* u, float* agg, float* prob, h
 
 template <int VEC, int CPL>
 int launch_bwd(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
-               float* dfeat, int64_t dfeat_ld, float* dte, int64_t pad_row, hipStream_t s) {
+               float* dfeat, int64_t dfeat_ld, float* dte, int64_t pad_row, float* dedge, int64_t dedge_ld, hipStream_t s) {
     const dim3 grid((unsigned)attn_grid(a.m)), block(WAVES_PER_BLOCK * kWave);
     const size_t lds = sizeof(float) * WAVES_PER_BLOCK * (2 * a.dt_dim + a.dn);
     // (the SPLIT form of the backward kernel is not launched: 68 -> 65 us on the root layer, whose time is the 4 M float atomics of
     // the neighbor-feature gradient, not row latency)
     switch (a.heads) {
-        case 1: attn_bwd_kernel<VEC, CPL, 1><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row); break;
-        case 2: attn_bwd_kernel<VEC, CPL, 2><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row); break;
-        case 4: attn_bwd_kernel<VEC, CPL, 4><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row); break;
+        case 1: attn_bwd_kernel<VEC, CPL, 1><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row, dedge, dedge_ld); break;
+        case 2: attn_bwd_kernel<VEC, CPL, 2><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row, dedge, dedge_ld); break;
+        case 4: attn_bwd_kernel<VEC, CPL, 4><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row, dedge, dedge_ld); break;
         default: tg::set_error("tg_attn: heads must be 1, 2 or 4"); return TG_EINVAL;
     }
     return tg::launch_status("attn_bwd_kernel");
@@ -525,11 +527,15 @@ int launch_bwd(const tg_attn_desc& a, const float* u, const float* agg, const fl
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// bit 0: forward on tg_attn_fast.hip, bit 1: backward, bit 2: the fast forward also where the one-instance-per-workgroup (SPLIT)
+// form of the generic kernel would run (launches of <= 4096 instances).  tg_set_attn_fast() is for A/B tests and timing.
+int g_fast = 3;
+
 int check_desc(const tg_attn_desc* a) {
     TG_REQUIRE(a, "tg_attn: null descriptor");
-    TG_REQUIRE(a->d_feat && a->d_feat_idx && a->d_edge && a->d_edge_idx && a->d_nbr && a->d_dt && a->d_te_w && a->d_te_b,
-               "tg_attn: null pointer in descriptor");
-    TG_REQUIRE(a->m >= 0 && a->k > 0 && a->dn > 0 && a->de >= 0 && a->dt_dim > 0, "tg_attn: sizes");
+    TG_REQUIRE(a->d_feat && a->d_feat_idx && a->d_edge && a->d_edge_idx && a->d_nbr && a->d_dt, "tg_attn: null pointer in descriptor");
+    TG_REQUIRE(a->dt_dim == 0 || (a->d_te_w && a->d_te_b), "tg_attn: null time-encoder pointer");
+    TG_REQUIRE(a->m >= 0 && a->k > 0 && a->dn > 0 && a->de >= 0 && a->dt_dim >= 0, "tg_attn: sizes");
     TG_REQUIRE(a->dn + a->de + a->dt_dim <= 1024, "tg_attn: key dimension > 1024 unsupported");
     TG_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "tg_attn: dropout_p");
     return TG_OK;
@@ -551,6 +557,10 @@ extern "C" int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg
     const int dk = a->dn + a->de + a->dt_dim;
     // algorithmic bytes: k neighbor rows (node + edge) + 16 B slot metadata each, u in, agg out, prob out
     tg::ProfScope prof("attn_fwd", (double)a->m * (a->k * 4.0 * (a->dn + a->de) + a->k * 16.0 + 2.0 * a->heads * dk * 4 + a->heads * a->k * 4.0), s);
+    if ((g_fast & 1) && ((g_fast & 4) || !use_split(*a, 4, 2))) {
+        const int rc = tg::attn_fwd_fast(*a, d_u, d_agg, d_prob, s);
+        if (rc != 1) return rc;
+    }
     if (vec4_ok(a, d_u, d_agg, nullptr, nullptr, nullptr)) {
         const int c = (dk / 4 + 63) / 64;
         if (c <= 1) return launch_fwd<4, 1>(*a, d_u, d_agg, d_prob, s);
@@ -565,9 +575,11 @@ extern "C" int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg
 
 extern "C" int tg_attn_bwd_parts(int64_t m) { return (int)attn_grid(m); }
 
+extern "C" void tg_set_attn_fast(int mask) { g_fast = mask; }
+
 extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
                            const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, int64_t pad_feat_row,
-                           float* d_dte_part, void* stream) {
+                           float* d_dedge, int64_t dedge_ld, float* d_dte_part, void* stream) {
     if (int rc = check_desc(a)) return rc;
     TG_REQUIRE(d_u && d_agg && d_prob && d_dagg && d_du && d_dte_part, "tg_attn_bwd: null pointer");
     if (a->m == 0) return TG_OK;
@@ -575,14 +587,18 @@ extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float*
     const int dk = a->dn + a->de + a->dt_dim;
     // as forward, plus dagg and agg in, du out
     tg::ProfScope prof("attn_bwd", (double)a->m * (a->k * 4.0 * (a->dn + a->de) + a->k * 16.0 + 4.0 * a->heads * dk * 4 + a->heads * a->k * 4.0), s);
+    if (g_fast & 2) {
+        const int rc = tg::attn_bwd_fast(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, pad_feat_row, d_dedge, dedge_ld, d_dte_part, s);
+        if (rc != 1) return rc;
+    }
     if (vec4_ok(a, d_u, d_agg, d_dagg, d_du, nullptr)) {
         const int c = (dk / 4 + 63) / 64;
-        if (c <= 1) return launch_bwd<4, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
-        if (c <= 2) return launch_bwd<4, 2>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
-        return launch_bwd<4, 4>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
+        if (c <= 1) return launch_bwd<4, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, d_dedge, dedge_ld, s);
+        if (c <= 2) return launch_bwd<4, 2>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, d_dedge, dedge_ld, s);
+        return launch_bwd<4, 4>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, d_dedge, dedge_ld, s);
     }
     const int c = (dk + 63) / 64;
-    if (c <= 1) return launch_bwd<1, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
+    if (c <= 1) return launch_bwd<1, 1>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, d_dedge, dedge_ld, s);
     TG_REQUIRE(c <= 8, "tg_attn_bwd: unaligned rows wider than 512 floats unsupported");
-    return launch_bwd<1, 8>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, s);
+    return launch_bwd<1, 8>(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, d_dte_part, pad_feat_row, d_dedge, dedge_ld, s);
 }

@@ -1,0 +1,467 @@
+// Production form of the gather-fused single-query temporal attention (tg_attn_fwd / tg_attn_bwd): same math and the same C entry
+// points as tg_attn.hip, whose generic kernels stay as the fall-back for odd shapes.  Taken when
+//     dn % 4 == de % 4 == 0, (dn + de) / 4 <= 128 chunks, dt_dim <= 128, k <= 64, heads <= 2, 16-byte aligned operands.
+//
+// replaces: models/modules.py:190-228 (neighbor side of MultiHeadAttention.forward) + the gathers of models/TGAT.py:110-129 /
+//           models/MemoryModel.py:679-700, and their autograd.
+//
+// What bounds these kernels is bytes in flight, not arithmetic: one wave owns one attention instance and streams its k
+// neighbor rows (node row + edge row, 2 x 688 B at the reference's 172-d features) from HBM / Infinity Cache.  The first
+// version loaded a batch of rows, waited, computed, and only then loaded the next batch -- with 2 waves per SIMD that kept
+// ~5 KB per SIMD in flight on average and ran at the latency-bound 2.0 (bwd) / 3.2 (fwd) TB/s.  Here
+//   * the rows are SOFTWARE-PIPELINED through two register sets: the loads of batch i+1 are issued before batch i is used, so a
+//     wave always has RB..2RB rows (5..11 KB) outstanding;
+//   * the time encoding lives on its own lane mapping (column j on lane j mod 64, not in 25 of the 64 float4 slots), so a row
+//     costs 2 phase evaluations per lane instead of 4, and the backward takes sin and cos from ONE reduction of the phase
+//     (it used to re-evaluate the cosine and then sincos: 3 transcendental passes);
+//   * the online-softmax rescale of the aggregate is skipped unless the running maximum actually moves (wave-uniform branch;
+//     a new maximum appears ~3.6 times in 20 slots);
+//   * neighbor-feature gradients leave the wave as contiguous 256-byte atomic instructions (transposed through LDS) instead of
+//     four 16-byte-strided ones: a float-atomic request is 64 B at the memory side, the strided form issued 4x as many.
+#include <math.h>
+
+#include "tg_common.h"
+
+#ifndef FLID_ATTN_RBF
+#define FLID_ATTN_RBF 2
+#endif
+#ifndef FLID_ATTN_RBB
+#define FLID_ATTN_RBB 2
+#endif
+#ifndef FLID_ATTN_OCC
+#define FLID_ATTN_OCC 1
+#endif
+namespace {
+
+using tg::kWave;
+constexpr int WPB = 4;                 // waves (= instances in flight) per workgroup
+
+__device__ __forceinline__ void ld4(const float* __restrict__ p, float (&v)[4]) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void zero4(float (&v)[4]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+
+// which 16-byte chunks of a neighbor row z = [node row | edge row] this lane owns, and where they come from
+struct LaneMap {
+    bool has[2];        // chunk slot i (chunk index lane + 64 i) exists
+    bool node[2];       // ... and lies in the node row (else the edge row)
+    int col[2];         // first column inside its table row
+    int ucol[2];        // first column inside u / agg / du (feature part)
+};
+__device__ __forceinline__ LaneMap lane_map(const tg_attn_desc& a, int lane) {
+    LaneMap m;
+    const int nch = (a.dn + a.de) >> 2, ndn = a.dn >> 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane + kWave * i;
+        m.has[i] = c < nch;
+        m.node[i] = c < ndn;
+        m.col[i] = (m.node[i] ? c : c - ndn) * 4;
+        m.ucol[i] = c * 4;
+    }
+    return m;
+}
+
+__device__ __forceinline__ void issue_row(const tg_attn_desc& a, const LaneMap& m, bool live, int64_t fi, int64_t ei, float (&z)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (live && m.has[i]) {
+            const float* p = m.node[i] ? a.d_feat + fi * a.feat_ld + m.col[i] : a.d_edge + ei * a.edge_ld + m.col[i];
+            ld4(p, z[i]);
+        } else {
+            zero4(z[i]);
+        }
+    }
+}
+
+inline int64_t fast_grid(int64_t m) { return tg::attn_grid_blocks(m); }
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int H, int RB>
+__global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_fwd_fast_kernel(tg_attn_desc a, const float* __restrict__ u, float* __restrict__ agg,
+                                                                  float* __restrict__ prob) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int nfe = a.dn + a.de, dk = nfe + a.dt_dim, k = a.k, T = a.dt_dim;
+    const LaneMap m = lane_map(a, lane);
+    const bool ht0 = lane < T, ht1 = lane + kWave < T;
+    const float w0 = ht0 ? a.d_te_w[lane] : 0.f, b0 = ht0 ? a.d_te_b[lane] : 0.f;
+    const float w1 = ht1 ? a.d_te_w[lane + kWave] : 0.f, b1 = ht1 ? a.d_te_b[lane + kWave] : 0.f;
+    const bool two_t = T > kWave;
+
+    for (int64_t row = (int64_t)blockIdx.x * WPB + wave; row < a.m; row += (int64_t)gridDim.x * WPB) {
+        const int64_t mo = row * k + lane;
+        const bool sl = lane < k;
+        const int my_f = sl ? a.d_feat_idx[mo] : 0, my_e = sl ? a.d_edge_idx[mo] : 0, my_n = sl ? a.d_nbr[mo] : 0;
+        const float my_dt = sl ? a.d_dt[mo] : 0.f;
+        float zA[RB][2][4], zB[RB][2][4];
+        auto issue = [&](float (&zb)[RB][2][4], int sb) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int s = sb + r;
+                const bool live = s < k;
+                const int ss = live ? s : 0;
+                issue_row(a, m, live, __builtin_amdgcn_readlane(my_f, ss), __builtin_amdgcn_readlane(my_e, ss), zb[r]);
+            }
+        };
+        issue(zA, 0);
+        float uh[H][2][4], ut[H][2], acc[H][2][4], at[H][2], mx[H], den[H], keep_score[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float* ur = u + (row * H + h) * dk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (m.has[i]) ld4(ur + m.ucol[i], uh[h][i]); else zero4(uh[h][i]);
+                zero4(acc[h][i]);
+            }
+            ut[h][0] = ht0 ? ur[nfe + lane] : 0.f;
+            ut[h][1] = ht1 ? ur[nfe + lane + kWave] : 0.f;
+            at[h][0] = at[h][1] = 0.f;
+            mx[h] = -INFINITY; den[h] = 0.f; keep_score[h] = 0.f;
+        }
+        auto compute = [&](float (&zb)[RB][2][4], int sb) {
+            float zt[RB][2], part[RB * H];
+            int nb[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int s = sb + r;
+                const bool live = s < k;
+                const int ss = live ? s : 0;
+                nb[r] = __builtin_amdgcn_readlane(my_n, ss);
+                const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), ss));
+                zt[r][0] = (live && ht0) ? tg::cos_phase(fmaf(dt, w0, b0)) : 0.f;
+                zt[r][1] = 0.f;
+                if (two_t) zt[r][1] = (live && ht1) ? tg::cos_phase(fmaf(dt, w1, b1)) : 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    float p = ut[h][0] * zt[r][0];
+                    p = fmaf(ut[h][1], zt[r][1], p);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p = fmaf(uh[h][i][e], zb[r][i][e], p);
+                    part[r * H + h] = p;
+                }
+            }
+            tg::wave_sum_n<RB * H>(part);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int s = sb + r;
+                if (s >= k) break;                     // wave-uniform
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    float sc = part[r * H + h] * a.scale;
+                    if (nb[r] == 0) sc = -1e10f;                                        // modules.py:221
+                    if (lane == s) keep_score[h] = sc;
+                    if (sc > mx[h]) {                  // wave-uniform: the running maximum moves, rescale what was gathered so far
+                        const float corr = __expf(mx[h] - sc);
+                        den[h] *= corr;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[h][i][e] *= corr;
+                        at[h][0] *= corr; at[h][1] *= corr;
+                        mx[h] = sc;
+                    }
+                    const float pe = __expf(sc - mx[h]);
+                    den[h] += pe;
+                    const float wgt = pe * tg::dropout_keep_scale(a.seed, a.row0 + row, h, s, a.dropout_p);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[h][i][e] = fmaf(wgt, zb[r][i][e], acc[h][i][e]);
+                    at[h][0] = fmaf(wgt, zt[r][0], at[h][0]);
+                    at[h][1] = fmaf(wgt, zt[r][1], at[h][1]);
+                }
+            }
+        };
+        for (int sb = 0; sb < k; sb += 2 * RB) {
+            if (sb + RB < k) issue(zB, sb + RB);
+            compute(zA, sb);
+            if (sb + RB >= k) break;
+            if (sb + 2 * RB < k) issue(zA, sb + 2 * RB);
+            compute(zB, sb + RB);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float inv = 1.f / den[h];
+            if (sl) prob[(row * H + h) * k + lane] = __expf(keep_score[h] - mx[h]) * inv;
+            float* ar = agg + (row * H + h) * dk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!m.has[i]) continue;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[h][i][e] * inv;
+                st4(ar + m.ucol[i], o);
+            }
+            if (ht0) ar[nfe + lane] = at[h][0] * inv;
+            if (ht1) ar[nfe + lane + kWave] = at[h][1] * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// d score_{h,n} = a'_{h,n} (dagg_h . z_n) - a_{h,n} (dagg_h . agg_h)      a' = dropped/scaled prob, a = softmax prob
+// masked slots get no score gradient (masked_fill), but still pass d z through a'.
+// DF: a gradient w.r.t. the gathered node rows is wanted (dfeat); DE: w.r.t. the gathered edge rows (dedge; stand-alone
+// MultiHeadAttention.forward only -- the backbones' edge table carries no gradient, models/TGAT.py:26-29).
+template <int H, int RB, bool DF, bool DE>
+__global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kernel(tg_attn_desc a, const float* __restrict__ u, const float* __restrict__ agg,
+        const float* __restrict__ prob, const float* __restrict__ dagg, float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld,
+        int64_t pad_row, float* __restrict__ dedge, int64_t dedge_ld, float* __restrict__ dte_part) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int nfe = a.dn + a.de, dk = nfe + a.dt_dim, k = a.k, T = a.dt_dim;
+    const LaneMap m = lane_map(a, lane);
+    const bool ht0 = lane < T, ht1 = lane + kWave < T;
+    const float w0 = ht0 ? a.d_te_w[lane] : 0.f, b0 = ht0 ? a.d_te_b[lane] : 0.f;
+    const float w1 = ht1 ? a.d_te_w[lane + kWave] : 0.f, b1 = ht1 ? a.d_te_b[lane + kWave] : 0.f;
+    const bool two_t = T > kWave;
+    // LDS: [WPB][2 T] time-encoder partials | [WPB][dn] padded-slot feature gradient | [WPB][max(dn, de)] transpose scratch
+    extern __shared__ __align__(16) float red[];
+    const int wmax = a.dn > a.de ? a.dn : a.de;
+    float* tr = red + WPB * (2 * T + a.dn) + wave * wmax;
+    float gw[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f};
+    float dpad[2][4];
+    zero4(dpad[0]); zero4(dpad[1]);
+
+    for (int64_t row = (int64_t)blockIdx.x * WPB + wave; row < a.m; row += (int64_t)gridDim.x * WPB) {
+        const int64_t mo = row * k + lane;
+        const bool sl = lane < k;
+        const int my_f = sl ? a.d_feat_idx[mo] : 0, my_e = sl ? a.d_edge_idx[mo] : 0, my_n = sl ? a.d_nbr[mo] : 0;
+        const float my_dt = sl ? a.d_dt[mo] : 0.f;
+        float zA[RB][2][4], zB[RB][2][4];
+        auto issue = [&](float (&zb)[RB][2][4], int sb) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int s = sb + r;
+                const bool live = s < k;
+                const int ss = live ? s : 0;
+                issue_row(a, m, live, __builtin_amdgcn_readlane(my_f, ss), __builtin_amdgcn_readlane(my_e, ss), zb[r]);
+            }
+        };
+        issue(zA, 0);
+        float my_p[H];
+        float uh[H][2][4], ut[H][2], dg[H][2][4], dgt[H][2], dacc[H][2][4], dat[H][2], cterm[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            my_p[h] = sl ? prob[(row * H + h) * k + lane] : 0.f;
+            const int64_t o = (row * H + h) * dk;
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float ag[4];
+                if (m.has[i]) {
+                    ld4(u + o + m.ucol[i], uh[h][i]);
+                    ld4(dagg + o + m.ucol[i], dg[h][i]);
+                    ld4(agg + o + m.ucol[i], ag);
+                } else {
+                    zero4(uh[h][i]); zero4(dg[h][i]); zero4(ag);
+                }
+                zero4(dacc[h][i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p = fmaf(dg[h][i][e], ag[e], p);
+            }
+            ut[h][0] = ht0 ? u[o + nfe + lane] : 0.f;
+            ut[h][1] = ht1 ? u[o + nfe + lane + kWave] : 0.f;
+            dgt[h][0] = ht0 ? dagg[o + nfe + lane] : 0.f;
+            dgt[h][1] = ht1 ? dagg[o + nfe + lane + kWave] : 0.f;
+            p = fmaf(dgt[h][0], ht0 ? agg[o + nfe + lane] : 0.f, p);
+            p = fmaf(dgt[h][1], ht1 ? agg[o + nfe + lane + kWave] : 0.f, p);
+            dat[h][0] = dat[h][1] = 0.f;
+            cterm[h] = p;
+        }
+        tg::wave_sum_n<H>(cterm);
+        auto compute = [&](float (&zb)[RB][2][4], int sb) {
+            float zt[RB][2], sn[RB][2], dts[RB], part[RB * H];
+            int nb[RB];
+            int64_t fis[RB], eis[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int s = sb + r;
+                const bool live = s < k;
+                const int ss = live ? s : 0;
+                nb[r] = __builtin_amdgcn_readlane(my_n, ss);
+                fis[r] = __builtin_amdgcn_readlane(my_f, ss);
+                eis[r] = __builtin_amdgcn_readlane(my_e, ss);
+                dts[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), ss));
+                float s0, c0, s1 = 0.f, c1 = 0.f;
+                tg::sincos_phase(fmaf(dts[r], w0, b0), &s0, &c0);
+                if (two_t) tg::sincos_phase(fmaf(dts[r], w1, b1), &s1, &c1);
+                zt[r][0] = (live && ht0) ? c0 : 0.f;  sn[r][0] = (live && ht0) ? s0 : 0.f;
+                zt[r][1] = (live && ht1) ? c1 : 0.f;  sn[r][1] = (live && ht1) ? s1 : 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    float p = dgt[h][0] * zt[r][0];
+                    p = fmaf(dgt[h][1], zt[r][1], p);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p = fmaf(dg[h][i][e], zb[r][i][e], p);
+                    part[r * H + h] = p;
+                }
+            }
+            tg::wave_sum_n<RB * H>(part);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int s = sb + r;
+                if (s >= k) break;                     // wave-uniform
+                float pd[H], dsc[H];
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const float pr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_p[h]), s));
+                    pd[h] = pr * tg::dropout_keep_scale(a.seed, a.row0 + row, h, s, a.dropout_p);
+                    dsc[h] = nb[r] == 0 ? 0.f : (pd[h] * part[r * H + h] - pr * cterm[h]) * a.scale;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dacc[h][i][e] = fmaf(dsc[h], zb[r][i][e], dacc[h][i][e]);
+                    dat[h][0] = fmaf(dsc[h], zt[r][0], dat[h][0]);
+                    dat[h][1] = fmaf(dsc[h], zt[r][1], dat[h][1]);
+                }
+                // time encoder: d phase = -sin(phase) dz_time
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float dz = 0.f;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) dz = fmaf(pd[h], dgt[h][j], fmaf(dsc[h], ut[h][j], dz));
+                    const float dph = -sn[r][j] * dz;
+                    gw[j] = fmaf(dts[r], dph, gw[j]);
+                    gb[j] += dph;
+                }
+                if constexpr (DF || DE) {
+                    float dz[2][4];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int h = 0; h < H; ++h) v = fmaf(pd[h], dg[h][i][e], fmaf(dsc[h], uh[h][i][e], v));
+                            dz[i][e] = v;
+                        }
+                    if (DF && nb[r] == 0 && pad_row >= 0) {         // wave-uniform: every padded slot gathers the same row
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (m.has[i] && m.node[i])
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) dpad[i][e] += dz[i][e];
+                    } else if (DF) {
+                        // transpose through LDS: lane l then owns columns l, l+64, ... and one atomic instruction covers 256
+                        // contiguous bytes of the destination row
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (m.has[i] && m.node[i]) st4(tr + m.col[i], dz[i]);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        float* dst = dfeat + fis[r] * dfeat_ld;
+                        for (int c = lane; c < a.dn; c += kWave) atomicAdd(dst + c, tr[c]);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                    if constexpr (DE) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (m.has[i] && !m.node[i]) st4(tr + m.col[i], dz[i]);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        float* dst = dedge + eis[r] * dedge_ld;
+                        for (int c = lane; c < a.de; c += kWave) atomicAdd(dst + c, tr[c]);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                }
+            }
+        };
+        for (int sb = 0; sb < k; sb += 2 * RB) {
+            if (sb + RB < k) issue(zB, sb + RB);
+            compute(zA, sb);
+            if (sb + RB >= k) break;
+            if (sb + 2 * RB < k) issue(zA, sb + 2 * RB);
+            compute(zB, sb + RB);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float* dr = du + (row * H + h) * dk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (m.has[i]) st4(dr + m.ucol[i], dacc[h][i]);
+            if (ht0) dr[nfe + lane] = dat[h][0];
+            if (ht1) dr[nfe + lane + kWave] = dat[h][1];
+        }
+    }
+
+    // block partial of (dw | db): waves -> LDS -> one slab row per workgroup (no atomics, deterministic)
+    if (ht0) { red[wave * 2 * T + lane] = gw[0]; red[wave * 2 * T + T + lane] = gb[0]; }
+    if (ht1) { red[wave * 2 * T + lane + kWave] = gw[1]; red[wave * 2 * T + T + lane + kWave] = gb[1]; }
+    float* redp = red + WPB * 2 * T;
+    if (DF && pad_row >= 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (m.has[i] && m.node[i]) st4(redp + wave * a.dn + m.col[i], dpad[i]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * T; j += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) s += red[w * 2 * T + j];
+        dte_part[(int64_t)blockIdx.x * 2 * T + j] = s;
+    }
+    if (DF && pad_row >= 0) {
+        for (int j = threadIdx.x; j < a.dn; j += blockDim.x) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) s += redp[w * a.dn + j];
+            if (s != 0.f) atomicAdd(dfeat + pad_row * dfeat_ld + j, s);
+        }
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool shape_ok(const tg_attn_desc& a) {
+    return a.dn % 4 == 0 && a.de % 4 == 0 && (a.dn + a.de) / 4 <= 2 * kWave && a.dt_dim <= 2 * kWave && a.dt_dim % 4 == 0 &&
+           a.k <= kWave && (a.heads == 1 || a.heads == 2) && a.feat_ld % 4 == 0 && a.edge_ld % 4 == 0 && aligned16(a.d_feat) &&
+           aligned16(a.d_edge);
+}
+
+constexpr int kRBF = FLID_ATTN_RBF, kRBB = FLID_ATTN_RBB;
+
+}  // namespace
+
+namespace tg {
+
+// returns TG_OK when launched, 1 when the shape is not covered (the caller falls back to the generic kernel)
+int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s) {
+    if (!shape_ok(a) || !aligned16(u) || !aligned16(agg)) return 1;
+    const dim3 grid((unsigned)fast_grid(a.m)), block(WPB * kWave);
+    if (a.heads == 1) attn_fwd_fast_kernel<1, kRBF><<<grid, block, 0, s>>>(a, u, agg, prob);
+    else attn_fwd_fast_kernel<2, kRBF><<<grid, block, 0, s>>>(a, u, agg, prob);
+    return launch_status("attn_fwd_fast_kernel");
+}
+
+int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
+                  float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s) {
+    if (!shape_ok(a) || !aligned16(u) || !aligned16(agg) || !aligned16(dagg) || !aligned16(du)) return 1;
+    if (dedge && !dfeat) return 1;
+    const dim3 grid((unsigned)fast_grid(a.m)), block(WPB * kWave);
+    const int wmax = a.dn > a.de ? a.dn : a.de;
+    const size_t lds = sizeof(float) * WPB * (2 * a.dt_dim + a.dn + wmax);
+#define FLID_LAUNCH(HH, DFF, DEE) attn_bwd_fast_kernel<HH, kRBB, DFF, DEE><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, pad_row, dedge, dedge_ld, dte)
+    if (a.heads == 1) {
+        if (dedge) FLID_LAUNCH(1, true, true); else if (dfeat) FLID_LAUNCH(1, true, false); else FLID_LAUNCH(1, false, false);
+    } else {
+        if (dedge) FLID_LAUNCH(2, true, true); else if (dfeat) FLID_LAUNCH(2, true, false); else FLID_LAUNCH(2, false, false);
+    }
+#undef FLID_LAUNCH
+    return launch_status("attn_bwd_fast_kernel");
+}
+
+}  // namespace tg

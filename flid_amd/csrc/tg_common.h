@@ -60,6 +60,17 @@ struct ProfScope {
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kMaxGridBlocks = 2048; // 256 CUs x 8 resident blocks: grid-stride beyond this
 
+// attention kernels (tg_attn.hip, tg_attn_fast.hip): 4 instances per workgroup; the grid is also the number of time-encoder
+// gradient slabs (tg_attn_bwd_parts), so the generic and the fast kernels share it
+constexpr int kAttnMaxBlocks = 4096;
+inline int64_t attn_grid_blocks(int64_t m) {
+    const int64_t b = (m + 3) / 4;
+    return b < 1 ? 1 : (b > kAttnMaxBlocks ? kAttnMaxBlocks : b);
+}
+int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
+int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
+                  float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s);
+
 // ---- wave64 helpers -------------------------------------------------------------------------------
 // DPP lane exchange inside the VALU (no LDS crossbar): quad swaps, 8- and 16-lane mirrors, then the two row broadcasts
 // of the GFX9 wave64 reduction; the total lands in lane 63 and is read back as a wave-uniform scalar.

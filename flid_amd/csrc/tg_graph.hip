@@ -273,6 +273,12 @@ __global__ void __launch_bounds__(256) dedupe_lookup_kernel(const int32_t* __res
         inv[i] = (pos[i] < 0 ? count_pad[1] : vals[pos[i]]) + offset;
 }
 
+// empty hash set + (count, pad row) = (0, -1): one launch instead of three memsets
+__global__ void __launch_bounds__(256) dedupe_init_kernel(unsigned long long* __restrict__ keys, int64_t capacity, int32_t* __restrict__ count_pad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x) keys[i] = ~0ULL;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { count_pad[0] = 0; count_pad[1] = -1; }
+}
+
 inline int grid_for(int64_t work_items, int64_t per_block) {
     int64_t b = (work_items + per_block - 1) / per_block;
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, 8 * tg::kMaxGridBlocks));
@@ -322,10 +328,8 @@ extern "C" int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n
     TG_REQUIRE(d_ids && d_t && d_keys_ws && d_vals_ws && d_pos_ws && d_out_ids && d_out_t && d_out_row && d_count_pad, "tg_dedupe_pairs: null pointer");
     TG_REQUIRE(n >= 0 && capacity >= 2 * n && (capacity & (capacity - 1)) == 0 && capacity <= ((int64_t)1 << 31), "tg_dedupe_pairs: capacity must be a power of two >= 2n");
     hipStream_t s = (hipStream_t)stream;
-    TG_HIP_CHECK(hipMemsetAsync(d_keys_ws, 0xFF, sizeof(unsigned long long) * capacity, s));
-    TG_HIP_CHECK(hipMemsetAsync(d_count_pad, 0, sizeof(int32_t), s));
-    TG_HIP_CHECK(hipMemsetAsync(d_count_pad + 1, 0xFF, sizeof(int32_t), s));      // pad row = -1 until seen
-    if (n == 0) return TG_OK;
+    dedupe_init_kernel<<<grid_for(capacity, 1024), 256, 0, s>>>((unsigned long long*)d_keys_ws, capacity, d_count_pad);   // pad row = -1 until seen
+    if (n == 0) return tg::launch_status("dedupe_init_kernel");
     dedupe_insert_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_ids, d_t, n, (uint32_t)(capacity - 1), (unsigned long long*)d_keys_ws, d_vals_ws,
                                                           d_pos_ws, d_out_ids, d_out_t, d_count_pad);
     dedupe_lookup_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_pos_ws, d_vals_ws, n, row_offset, d_count_pad, d_out_row);

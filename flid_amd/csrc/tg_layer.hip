@@ -696,7 +696,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         // ---- fused attention backward (HBM-bound: the side streams' products run under it) ----------------------------------------
         // (splitting this launch into two row chunks so that the first chunk's dP = du^T own runs under the second chunk was tried:
         // 431 k vs 445 k edges/s -- two smaller launches plus the product competing with the second one cost more than the shorter tail)
-        TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
+        TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         TG_TRY(fork());                       // du and the time-encoder slabs are final
         TG_TRY(side([=] { return tg_gemm_f32(1, 0, hk, dn, R, 1.f, Bc.du, hk, Lc.own, Lc.own_ld, dPm, dn, nullptr, 0, 0, wstream); }));  // dP = du^T own
         TG_TRY(side([=] { return colsum_seg(Bc.du, hk, R, (int)hk, seg1(dub, (int)hk), ws_); }));                                  // dub = sum_rows du
@@ -740,7 +740,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bc.dctx, dq, hd, Lc.agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
         TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
         // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
-        TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, part_attn, stream));
+        TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         TG_TRY(fork());                           // du and the time-encoder slabs are final
         TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Lc.q, dq, hd, Bc.du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
         {

@@ -247,6 +247,49 @@ extern "C" int tg_adam_f32(float* d_param, const float* d_grad, float* d_exp_avg
     return tg::launch_status("adam_kernel");
 }
 
+// d_teb[j] -= sin(b[j]) * d_cosb[j]: the gradient that reached cos(b) (the time encoding of a zero interval, models/TGAT.py:84-85)
+// handed on to b; one launch at the end of a backward pass instead of two element-wise torch kernels.
+__global__ void time_bias_finish_kernel(float* __restrict__ d_teb, const float* __restrict__ b, const float* __restrict__ d_cosb, int T) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < T) d_teb[j] -= sinf(b[j]) * d_cosb[j];
+}
+extern "C" int tg_time_bias_finish(float* d_teb, const float* d_b, const float* d_cosb, int dim, void* stream) {
+    TG_REQUIRE(d_teb && d_b && d_cosb && dim >= 0, "tg_time_bias_finish: arguments");
+    if (dim == 0) return TG_OK;
+    time_bias_finish_kernel<<<(dim + 127) / 128, 128, 0, (hipStream_t)stream>>>(d_teb, d_b, d_cosb, dim);
+    return tg::launch_status("time_bias_finish_kernel");
+}
+
+// out[0] = scale * sum_i a[i] * w[i]: the scalar of a weighted-mean loss over an embedding block, ONE workgroup (the block is a few
+// hundred thousand elements; a second launch to fold partials would cost more than the serial tail)
+__global__ void __launch_bounds__(1024) weighted_sum_kernel(const float* __restrict__ a, const float* __restrict__ w, int64_t n, float scale,
+                                                            float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 x = a4[i], y = w4[i];
+        s = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, s))));
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s = fmaf(a[i], w[i], s);
+    s = tg::wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+        out[0] = t * scale;
+    }
+}
+extern "C" int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, float scale, float* d_out, void* stream) {
+    TG_REQUIRE(d_a && d_w && d_out && n >= 0, "tg_weighted_sum: arguments");
+    TG_REQUIRE(((reinterpret_cast<uintptr_t>(d_a) | reinterpret_cast<uintptr_t>(d_w)) & 15) == 0, "tg_weighted_sum: operands must be 16-byte aligned");
+    weighted_sum_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(d_a, d_w, n, scale, d_out);
+    return tg::launch_status("weighted_sum_kernel");
+}
+
 extern "C" int tg_rowop_parts(int64_t n) { return (int)row_grid(n); }
 
 extern "C" int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols, float* d_out,

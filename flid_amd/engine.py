@@ -72,7 +72,9 @@ class Frontier:
     level 0 = the n roots; level d+1 = the distinct (neighbor id, float32 neighbor time) pairs sampled from level d.
     The embedding of a node at a time is a pure function of that pair, so rows that recur inside a batch (the same user a
     few edges later shares 19 of its 20 most recent neighbors; every padded slot is the pair (0, 0.0)) are computed once
-    and shared: `child[r*k + j]` is the row that holds slot j of row r.  Exact -- no result changes."""
+    and shared: `child[r*k + j]` is the row that holds slot j of row r.  Exact in eval mode and with dropout 0.  In train mode
+    with dropout > 0 a shared row also shares ONE dropout mask, where the reference draws an independent mask for every
+    occurrence: same expectation, slightly more correlated noise (engine.DEDUPE = False restores the reference's behaviour)."""
     counts: List[int]                 # rows per level, len L+... (levels 0..L-1 are sampled; level L is never materialised)
     ids_all: torch.Tensor             # int32 (sum(counts),)   node id of every row
     S: tuple                          # (nbr i32, eid i32, t f32, dt f32) each (R_1, k): slot lists of levels 0..L-1
@@ -157,7 +159,7 @@ class _EmbedFn(torch.autograd.Function):
                 feat, feat_idx = table, S_nbr[:R].reshape(-1)
             else:
                 feat, feat_idx = H_prev, fr.child[:R * k]
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (training and p_drop > 0) else 0
+            seed = _next_seeds(1)[0] if (training and p_drop > 0) else 0
             lc.attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
                                    te_w_flat, te_b, k, H, hd ** -0.5, p_drop if training else 0.0, seed)
             lc.agg, lc.prob = ops.attn_fwd(lc.attn, lc.u)
@@ -393,63 +395,60 @@ def block_layout(tensors):
     return offs, total
 
 
-class _EmbedFnNative(torch.autograd.Function):
-    """Same contract as _EmbedFn; every layer is one native forward call and one native backward call.
-    Differentiable inputs: (te_w, te_b, *layer_params), or -- cfg["flat_views"] set -- the single flat parameter those are views of."""
+def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
+    """every layer = one native forward call (tg_tgat_layer_fwd); returns H^L and what the backward needs"""
+    n, k, L, H = cfg["n"], cfg["k"], cfg["num_layers"], cfg["num_heads"]
+    edge, p_drop, training = cfg["edge_table"], cfg["dropout"], cfg["training"]
+    dev = table.device
+    Dn, T = table.shape[1], te_w.numel()
+    hd = (Dn + T) // H
+    S_nbr, S_eid, S_t, S_dt = fr.S
+    te_w_flat = te_w.reshape(-1)
+    cosb = ops.time_encode(_zero1(dev), te_w_flat, te_b).reshape(-1)
+    p_eff = p_drop if training else 0.0
+    layers, H_prev = [], None
+    for l in range(1, L + 1):
+        params = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
+        R = fr.rows(L - l)
+        raw = ops.gather_rows(table, fr.ids_all[:R])
+        own = raw if l == 1 else H_prev[:R]
+        feat, feat_idx = (table, S_nbr[:R].reshape(-1)) if l == 1 else (H_prev, fr.child[:R * k])
+        seeds = _next_seeds(2) if p_eff > 0 else [0, 0]
+        attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
+                            te_w_flat, te_b, k, H, hd ** -0.5, p_eff, seeds[0])
+        lay = _NativeLayer(attn, params, own, raw, cosb, p_eff, seeds[1])
+        H_prev = lay.forward()
+        layers.append(lay)
+    return H_prev, (layers, cosb)
 
-    @staticmethod
-    def forward(ctx, cfg, fr, table, *tensors):
-        views = cfg.get("flat_views")
-        te_w, te_b, *layer_params = views if views is not None else tensors
-        n, k, L, H = cfg["n"], cfg["k"], cfg["num_layers"], cfg["num_heads"]
-        edge, p_drop, training = cfg["edge_table"], cfg["dropout"], cfg["training"]
-        dev = table.device
-        Dn, T = table.shape[1], te_w.numel()
-        hd = (Dn + T) // H
-        S_nbr, S_eid, S_t, S_dt = fr.S
-        te_w_flat = te_w.reshape(-1)
-        cosb = ops.time_encode(_zero1(dev), te_w_flat, te_b).reshape(-1)
-        p_eff = p_drop if training else 0.0
-        layers, H_prev = [], None
-        for l in range(1, L + 1):
-            params = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
-            R = fr.rows(L - l)
-            raw = ops.gather_rows(table, fr.ids_all[:R])
-            own = raw if l == 1 else H_prev[:R]
-            feat, feat_idx = (table, S_nbr[:R].reshape(-1)) if l == 1 else (H_prev, fr.child[:R * k])
-            seeds = torch.randint(0, 2 ** 62, (2,)).tolist() if p_eff > 0 else [0, 0]
-            attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
-                                te_w_flat, te_b, k, H, hd ** -0.5, p_eff, seeds[0])
-            lay = _NativeLayer(attn, params, own, raw, cosb, p_eff, seeds[1])
-            H_prev = lay.forward()
-            layers.append(lay)
-        ctx.layers, ctx.cfg, ctx.fr, ctx.table, ctx.cosb = layers, cfg, fr, table, cosb
-        ctx.params = (te_w, te_b, layer_params)        # parameters (or views of the flat parameter): not outputs, no cycle
-        return H_prev
 
-    @staticmethod
-    def backward(ctx, dH):
-        cfg, fr, table, cosb = ctx.cfg, ctx.fr, ctx.table, ctx.cosb
-        te_w, te_b, layer_params = ctx.params
-        n, k, L = cfg["n"], cfg["k"], cfg["num_layers"]
-        table_grad = cfg["table_grad"]
-        dev = dH.device
-        Dn, T = table.shape[1], te_w.numel()
-        Dq = Dn + T
-        # ONE zero fill: [gradient of te_w | te_b | every layer parameter (block_layout)] + scratch [d cos(b) | dq floats per layer]
-        every = [te_w, te_b, *layer_params]
-        offs, npar = block_layout(every)
-        H, Dk = cfg["num_heads"], Dn + cfg["edge_table"].shape[1] + T
-        vlen = _r4(Dq + H * Dk)                       # per layer: zero scratch of tg_tgat_layer_bwd (`vec`)
-        zeroed = torch.zeros(npar + _r4(T) + L * vlen, device=dev)
-        d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar:npar + T]
-        d_table = torch.zeros_like(table) if table_grad else None
-        dH = dH.contiguous()
-        # The side streams (weight gradients) are joined ONCE, after the last layer: until then everything they read stays alive
-        # (`alive`) and untouched (per-layer scratch), and nothing that lives on them is consumed.
-        alive = [dH]
+def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH):
+    """every layer = one native backward call; returns (d_table or None, gradient block, offsets of [te_w, te_b, *layer_params]
+    inside it, number of gradient floats).  The block is laid out like TGAT.flatten_parameters()' flat parameter."""
+    layers, cosb = saved
+    n, k, L = cfg["n"], cfg["k"], cfg["num_layers"]
+    table_grad = cfg["table_grad"]
+    dev = dH.device
+    Dn, T = table.shape[1], te_w.numel()
+    Dq = Dn + T
+    # ONE zero fill: [gradient of te_w | te_b | every layer parameter (block_layout)] + scratch [d cos(b) | dq floats per layer]
+    every = [te_w, te_b, *layer_params]
+    offs, npar = block_layout(every)
+    H, Dk = cfg["num_heads"], Dn + cfg["edge_table"].shape[1] + T
+    vlen = _r4(Dq + H * Dk)                       # per layer: zero scratch of tg_tgat_layer_bwd (`vec`)
+    zeroed = torch.zeros(npar + _r4(T) + L * vlen, device=dev)
+    d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar:npar + T]
+    d_table = torch.zeros_like(table) if table_grad else None
+    dH = dH.contiguous()
+    from ._lib import check, lib
+    # The side streams (weight gradients) are joined ONCE, after the last layer: until then everything they read stays alive
+    # (`alive`) and untouched (per-layer scratch), and nothing that lives on them is consumed.  Whatever happens in between
+    # (an allocation failure, a TgError from a layer), the join runs before `alive` is released: queued side-stream products
+    # must not outlive their operands.
+    alive = [dH]
+    try:
         for l in range(L, 0, -1):
-            lay = ctx.layers[l - 1]
+            lay = layers[l - 1]
             R = lay.R
             params = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
             if l >= 2:
@@ -470,15 +469,82 @@ class _EmbedFnNative(torch.autograd.Function):
                     d_own += d_raw
                     ops.scatter_add_rows(d_own, fr.ids_all[:R], d_table)
             dH = dH_prev
-        from ._lib import check, lib
+    finally:
         check(lib().tg_side_join(ops._stream()), "tg_side_join")
-        del alive
-        d_teb.addcmul_(torch.sin(te_b), d_cosb, value=-1.0)    # d cos(b) -> d b (zero interval: no weight gradient)
-        ctx.layers = ctx.params = None
+    del alive
+    # d cos(b) -> d b (zero interval: no weight gradient): d_teb -= sin(b) * d_cosb
+    check(lib().tg_time_bias_finish(ops._p(d_teb), ops._p(te_b), ops._p(d_cosb), T, ops._stream()), "tg_time_bias_finish")
+    return d_table, zeroed, offs, npar
+
+
+_SEED_GEN = None
+
+
+def seed_dropout(seed: int, rank: int = 0):
+    """(re)seed the dropout stream of the native layers; `rank` decorrelates data-parallel replicas that share `seed`"""
+    global _SEED_GEN
+    _SEED_GEN = np.random.Generator(np.random.Philox(key=[int(seed) & 0xFFFFFFFFFFFFFFFF, int(rank)]))
+
+
+def _next_seeds(n):
+    """n 62-bit seeds.  Default stream: torch's CPU generator mixed with the distributed rank (every data-parallel rank usually
+    seeds torch identically, and identical mask streams on different data would correlate the replicas' noise)."""
+    if _SEED_GEN is not None:
+        return [int(v) for v in _SEED_GEN.integers(0, 2 ** 62, size=n)]
+    vals = torch.randint(0, 2 ** 62, (n,)).tolist()
+    rank = _rank()
+    return [(v ^ (rank * 0x9E3779B97F4A7C15)) & (2 ** 62 - 1) for v in vals] if rank else vals
+
+
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class _EmbedFnNative(torch.autograd.Function):
+    """Same contract as _EmbedFn; every layer is one native forward call and one native backward call.
+    Differentiable inputs: (te_w, te_b, *layer_params), or -- cfg["flat_views"] set -- the single flat parameter those are views of."""
+
+    @staticmethod
+    def forward(ctx, cfg, fr, table, *tensors):
+        views = cfg.get("flat_views")
+        te_w, te_b, *layer_params = views if views is not None else tensors
+        out, saved = _native_forward(cfg, fr, table, te_w, te_b, layer_params)
+        ctx.saved, ctx.cfg, ctx.fr, ctx.table = saved, cfg, fr, table
+        ctx.params = (te_w, te_b, layer_params)        # parameters (or views of the flat parameter): not outputs, no cycle
+        return out
+
+    @staticmethod
+    def backward(ctx, dH):
+        cfg, fr, table = ctx.cfg, ctx.fr, ctx.table
+        te_w, te_b, layer_params = ctx.params
+        d_table, zeroed, offs, npar = _native_backward(cfg, fr, table, te_w, te_b, layer_params, ctx.saved, dH)
+        ctx.saved = ctx.params = None
         if cfg.get("flat_views") is not None:
             return (None, None, d_table, zeroed[:npar])       # the block is laid out like the flat parameter: it IS its gradient
+        every = [te_w, te_b, *layer_params]
         grads = [zeroed[o:o + t.numel()].view(t.shape) for o, t in zip(offs, every)]
         return (None, None, d_table, *grads)
+
+
+def forward_backward(cfg, fr, table, flat, loss_fn):
+    """Fused-trainer form of one step: forward, the caller's loss on the embeddings, backward -- with no autograd
+    graph in between.  flat = (flat parameter, views) of TGAT.flatten_parameters(); loss_fn(emb) -> (loss, d loss / d emb) sees the
+    (n, Dn) embeddings detached.  Returns (embeddings, loss); the gradient is ADDED to flat[0].grad (set if None), exactly what
+    loss.backward() through embed() would have left there."""
+    views = flat[1]
+    te_w, te_b, layer_params = views[0], views[1], views[2:]
+    with torch.no_grad():
+        out, saved = _native_forward(cfg, fr, table, te_w, te_b, layer_params)
+    loss, d_out = loss_fn(out)
+    with torch.no_grad():
+        _, zeroed, _, npar = _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, d_out)
+        g = zeroed[:npar]
+        if flat[0].grad is None:
+            flat[0].grad = g
+        else:
+            flat[0].grad.add_(g)
+    return out, loss
 
 
 _ZERO1 = {}
@@ -535,29 +601,94 @@ class PreparedFrontier:
 _prefetch_stream = None
 
 
-def prepare_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torch.Tensor, k: int, num_layers: int,
-                     inputs_ready: bool = True) -> PreparedFrontier:
-    """ids int32 / times float64 already on the device.  Runs on an internal side stream; embed() waits for it.
-    inputs_ready=False makes the side stream first wait for everything queued on the current stream (needed only when the
-    ids were produced by kernels still in flight there -- it also drags the step's readback behind that work)."""
+def _side_stream():
     global _prefetch_stream
     if _prefetch_stream is None:
         _prefetch_stream = torch.cuda.Stream()
-    main = torch.cuda.current_stream()
+    return _prefetch_stream
+
+
+@dataclass
+class FrontierJob:
+    """first half of a prepared frontier: level-0 lookups + row sharing are in flight on the side stream, the count of distinct
+    rows is on its way to a pinned host word; prepare_finish() reads it (no wait if a step has passed) and issues the rest"""
+    graph: TemporalGraph
+    n: int
+    k: int
+    num_layers: int
+    main: "torch.cuda.Stream"
+    done: Optional[Frontier] = None            # already complete (depth 1, or the synchronous fall-back)
+    S: tuple = None
+    ids_all: torch.Tensor = None
+    uniq_t: torch.Tensor = None
+    child: torch.Tensor = None
+    count_host: torch.Tensor = None
+    count_ready: "torch.cuda.Event" = None
+
+
+def prepare_begin(graph: TemporalGraph, ids_dev, times_dev, k: int, num_layers: int, inputs_ready: bool = True) -> FrontierJob:
+    """Stage 1 of the prefetch (all on the side stream, nothing blocks the host): concatenate the ids, level-0 lookups, row
+    sharing, and an asynchronous copy of the distinct-row count into pinned memory.  ids int32 / times float64 on the device
+    (or lists of such tensors).  inputs_ready=False makes the side stream first wait for everything queued on the current stream
+    (only needed when the ids were produced by kernels still in flight there)."""
+    side, main = _side_stream(), torch.cuda.current_stream()
     if not inputs_ready:
-        _prefetch_stream.wait_stream(main)
-    with torch.cuda.stream(_prefetch_stream):
+        side.wait_stream(main)
+    with torch.cuda.stream(side):
         # lists of tensors are concatenated HERE, on the side stream: a cat issued on the busy main stream would not have
         # run yet when the side stream reads its result
         if isinstance(ids_dev, (list, tuple)):
             ids_dev, times_dev = torch.cat(list(ids_dev)), torch.cat(list(times_dev))
-        fr = sample_frontier(graph, ids_dev.to(torch.int32).contiguous(), times_dev.contiguous(), k, num_layers, dedupe=DEDUPE)
+        ids_dev, times_dev = ids_dev.to(torch.int32).contiguous(), times_dev.contiguous()
+        n, dev = ids_dev.numel(), ids_dev.device
+        job = FrontierJob(graph, n, k, num_layers, main)
+        if num_layers != 2 or not DEDUPE or n == 0:
+            job.done = sample_frontier(graph, ids_dev, times_dev, k, num_layers, dedupe=DEDUPE)      # (reads counts back at once)
+            return job
+        cap = n + n * k                       # rows of levels 0 and 1 if no pair repeated
+        S = (torch.empty((cap, k), dtype=torch.int32, device=dev), torch.empty((cap, k), dtype=torch.int32, device=dev),
+             torch.empty((cap, k), dtype=torch.float32, device=dev), torch.empty((cap, k), dtype=torch.float32, device=dev))
+        graph.sample_recent(ids_dev, times_dev, k, out=tuple(x[:n] for x in S))
+        ids_all = torch.empty(cap, dtype=torch.int32, device=dev)
+        ids_all[:n].copy_(ids_dev)
+        uniq_t = torch.empty(n * k, dtype=torch.float32, device=dev)
+        child = torch.empty(n * k, dtype=torch.int32, device=dev)
+        cp = graph.dedupe_pairs_async(S[0][:n].reshape(-1), S[2][:n].reshape(-1), n, ids_all[n:], uniq_t, child)
+        job.count_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        job.count_host.copy_(cp, non_blocking=True)
+        job.count_ready = torch.cuda.Event()
+        job.count_ready.record()
+        job.S, job.ids_all, job.uniq_t, job.child = S, ids_all, uniq_t, child
+    return job
+
+
+def prepare_finish(job: FrontierJob) -> PreparedFrontier:
+    """Stage 2: read the distinct-row count (pinned word, copied by stage 1) and issue the level-1 lookups on the side stream."""
+    side = _side_stream()
+    if job.done is not None:
+        fr = job.done
+    else:
+        job.count_ready.synchronize()
+        count, pad = job.count_host.tolist()
+        n, k = job.n, job.k
+        with torch.cuda.stream(side):
+            job.graph.sample_recent(job.ids_all[n:n + count], job.uniq_t[:count], k, out=tuple(x[n:n + count] for x in job.S))
+        fr = Frontier(counts=[n, count], ids_all=job.ids_all[:n + count], S=tuple(x[:n + count] for x in job.S), child=job.child,
+                      pad_rows=[pad + n if pad >= 0 else -1])
+    with torch.cuda.stream(side):
         ev = torch.cuda.Event()
         ev.record()
     for t in (fr.ids_all, fr.child) + tuple(fr.S):            # allocated on the side stream, consumed on the main stream
         if t is not None:
-            t.record_stream(main)
-    return PreparedFrontier(fr, ev, graph, ids_dev.numel(), k, num_layers)
+            t.record_stream(job.main)
+    return PreparedFrontier(fr, ev, job.graph, job.n, job.k, job.num_layers)
+
+
+def prepare_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torch.Tensor, k: int, num_layers: int,
+                     inputs_ready: bool = True) -> PreparedFrontier:
+    """both stages at once (the host waits for the distinct-row count of THIS batch; a trainer that knows its batches two
+    steps ahead calls prepare_begin / prepare_finish one step apart and never waits)"""
+    return prepare_finish(prepare_begin(graph, ids_dev, times_dev, k, num_layers, inputs_ready))
 
 
 def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, te_w, te_b, layer_params, ids: np.ndarray,

@@ -83,21 +83,33 @@ class TemporalGraph:
                                         _p(ln), _stream()), "tg_first_hop_window")
         return nbr, eid, tt, ln
 
-    def dedupe_pairs(self, ids: torch.Tensor, t32: torch.Tensor, row_offset: int):
-        """distinct (id, float32 time) pairs of a sampled level -> (uniq_ids i32, uniq_t f32, row_of_slot i32, pad_row or -1).
-        One 8-byte readback (the count sizes the next level)."""
-        n, dev = ids.numel(), ids.device
+    def _dedupe_ws_for(self, n, dev):
         cap = int(lib().tg_dedupe_capacity(n))
         ws = getattr(self, "_dedupe_ws", None)
-        if ws is None or ws[0].numel() < cap or ws[2].numel() < n:
+        if ws is None or ws[0].numel() < cap or ws[2].numel() < n or ws[0].device != dev:
             ws = (torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
                   torch.empty(max(n, 1), dtype=torch.int32, device=dev))
             self._dedupe_ws = ws
-        out_ids = torch.empty(n, dtype=torch.int32, device=dev)
-        out_t = torch.empty(n, dtype=torch.float32, device=dev)
-        row = torch.empty(n, dtype=torch.int32, device=dev)
+        return cap, ws
+
+    def dedupe_pairs_async(self, ids: torch.Tensor, t32: torch.Tensor, row_offset: int, out_ids: torch.Tensor, out_t: torch.Tensor,
+                           row: torch.Tensor):
+        """distinct (id, float32 time) pairs of a sampled level, written into caller buffers (each at least len(ids) long):
+        out_ids / out_t = the pairs in arrival order, row[i] = row_offset + index of slot i's pair.  Returns the DEVICE tensor
+        (count, index of the padding pair or -1): nothing is read back here.  The hash-set workspace is per graph object and is
+        reused by the next call on the same stream (calls on one graph must not run concurrently on two streams)."""
+        n, dev = ids.numel(), ids.device
+        cap, ws = self._dedupe_ws_for(n, dev)
         cp = torch.empty(2, dtype=torch.int32, device=dev)
         check(lib().tg_dedupe_pairs(_p(ids), _p(t32), n, cap, _p(ws[0]), _p(ws[1]), _p(ws[2]), int(row_offset), _p(out_ids), _p(out_t),
                                     _p(row), _p(cp), _stream()), "tg_dedupe_pairs")
-        count, pad = cp.cpu().tolist()
+        return cp
+
+    def dedupe_pairs(self, ids: torch.Tensor, t32: torch.Tensor, row_offset: int):
+        """as dedupe_pairs_async with fresh buffers and ONE 8-byte readback: (uniq_ids i32, uniq_t f32, row_of_slot i32, pad_row or -1)"""
+        n, dev = ids.numel(), ids.device
+        out_ids = torch.empty(n, dtype=torch.int32, device=dev)
+        out_t = torch.empty(n, dtype=torch.float32, device=dev)
+        row = torch.empty(n, dtype=torch.int32, device=dev)
+        count, pad = self.dedupe_pairs_async(ids, t32, row_offset, out_ids, out_t, row).cpu().tolist()
         return out_ids[:count], out_t[:count], row, (pad + row_offset if pad >= 0 else -1)

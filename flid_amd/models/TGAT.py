@@ -92,6 +92,39 @@ class TGAT(nn.Module):
         pf.nsrc = src_node_ids.numel()
         return pf
 
+    def prepare_batch_begin(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20):
+        """First half of prepare_batch for a trainer that knows its batches two steps ahead: issues the level-0 lookups and the
+        row sharing on the side stream and returns at once; prepare_batch_finish(job) one step later reads the (by then
+        complete) distinct-row count without waiting and issues the rest."""
+        job = engine.prepare_begin(self.neighbor_sampler.graph, [src_node_ids, dst_node_ids], [node_interact_times, node_interact_times],
+                                   num_neighbors, self.num_layers)
+        job.nsrc = src_node_ids.numel()
+        return job
+
+    def prepare_batch_finish(self, job):
+        pf = engine.prepare_finish(job)
+        pf.nsrc = job.nsrc
+        return pf
+
+    def train_step(self, prepared, loss_fn, num_neighbors: int = 20):
+        """Fused-trainer step (not in the reference): forward of the prepared batch, `loss_fn(emb) -> (loss, d_emb)` on
+        the detached (2 B, Dn) embedding block [src rows | dst rows], backward -- without an autograd graph.  Needs
+        flatten_parameters(); the gradient lands in the flat parameter's .grad exactly as loss.backward() would leave it."""
+        flat = getattr(self, "_flat_pack", None)
+        if flat is None:
+            raise RuntimeError("TGAT.train_step needs the flat-parameter mode: call flatten_parameters() first")
+        if self.neighbor_sampler.sample_neighbor_strategy != "recent":
+            raise NotImplementedError("train_step takes a prepared (device-sampled, 'recent') batch")
+        pf = prepared
+        assert pf.k == num_neighbors and pf.num_layers == self.num_layers and pf.graph is self.neighbor_sampler.graph, \
+            "prepared for a different sampler / k / depth"
+        torch.cuda.current_stream().wait_event(pf.ready)
+        cfg = dict(n=pf.n, k=num_neighbors, num_layers=self.num_layers, num_heads=self.num_heads, dropout=float(self.dropout),
+                   training=bool(self.training), edge_table=self.edge_raw_features, table_grad=False)
+        if self.num_heads > 2 or not engine.NATIVE:
+            raise NotImplementedError("train_step runs the one-call-per-layer path (1 or 2 heads)")
+        return engine.forward_backward(cfg, pf.frontier, self.node_raw_features, flat, loss_fn)
+
     def compute_node_temporal_embeddings(self, node_ids: np.ndarray, node_interact_times: np.ndarray,
                                          current_layer_num: int, num_neighbors: int = 20):
         assert current_layer_num >= 0

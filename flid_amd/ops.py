@@ -197,15 +197,18 @@ def attn_fwd(args: AttnArgs, u: torch.Tensor):
     return agg, prob
 
 
-def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] = None, pad_row: int = -1):
-    """returns du, (dw, db) of the time encoder; adds the neighbor-feature gradient into dfeat rows if given"""
+def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] = None, pad_row: int = -1,
+             dedge: Optional[torch.Tensor] = None):
+    """returns du, (dw, db) of the time encoder; adds the neighbor-feature gradient into dfeat rows (and the edge-row gradient into
+    dedge rows) if given"""
     assert dagg.is_contiguous() and dagg.shape == u.shape
     du = torch.empty_like(u)
     parts = lib().tg_attn_bwd_parts(args.m)
     part = torch.empty((parts, 2 * args.dt_dim), dtype=torch.float32, device=u.device)
     with _timed("attn_bwd", args.m):
         check(lib().tg_attn_bwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _p(dagg), _p(du), _p(dfeat),
-                                0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), int(pad_row), _p(part), _stream()), "tg_attn_bwd")
+                                0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), int(pad_row), _p(dedge),
+                                0 if dedge is None else _rowmajor_ld(dedge, "dedge"), _p(part), _stream()), "tg_attn_bwd")
     dwb = colsum(part)
     return du, dwb[:args.dt_dim], dwb[args.dt_dim:]
 
@@ -327,6 +330,16 @@ def time_encode_bwd(t, mask_ids, w, b, g):
     check(lib().tg_time_encode_bwd(_p(t), _p(mask_ids), t.numel(), _p(w), _p(b), dim, _p(g), _p(part), _stream()), "tg_time_encode_bwd")
     s = colsum(part)
     return s[:dim], s[dim:]
+
+
+def weighted_sum(a: torch.Tensor, w: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None):
+    """scale * sum(a * w) as a 1-element device tensor (one launch)"""
+    _chk(a, torch.float32, "a"); _chk(w, torch.float32, "w")
+    assert a.is_contiguous() and w.is_contiguous() and a.numel() == w.numel()
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(lib().tg_weighted_sum(_p(a), _p(w), a.numel(), float(scale), _p(out), _stream()), "tg_weighted_sum")
+    return out
 
 
 PROFILE_TAGS = {"attn_fwd": 1, "attn_bwd": 2, "gemm": 4}

@@ -117,11 +117,17 @@ int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg, float* d_
  * d_dfeat: if non-NULL, (rows of the feat source, ld dfeat_ld) gradient w.r.t. gathered feature rows, ADDED with
  * float atomics (rows may repeat); must be zeroed by the caller.  pad_feat_row >= 0 promises that every padded slot
  * (nbr id 0) gathers that one row: their gradients are pre-summed per workgroup instead of contending on one address.
- * d_dte_part: (parts, 2*dt_dim) per-workgroup partial sums of (dw | db); *parts is returned by tg_attn_bwd_parts(). */
+ * d_dte_part: (parts, 2*dt_dim) per-workgroup partial sums of (dw | db); *parts is returned by tg_attn_bwd_parts().
+ * d_dedge: if non-NULL (then d_dfeat must be given too), the same for the gathered edge rows (stand-alone
+ * MultiHeadAttention.forward on materialised inputs; the backbones' edge table carries no gradient, models/TGAT.py:26-29).
+ * dt_dim may be 0 (no time segment in z; d_te_w / d_te_b unused): the stand-alone forward passes [edge | time features] as its
+ * edge rows.  tg_set_attn_fast(mask): bit 0 / 1 = forward / backward on the pipelined production kernels (tg_attn_fast.hip,
+ * default 3), bit 2 = also for launches the generic one-instance-per-workgroup kernel would take; A/B tests and timing only. */
 int tg_attn_bwd_parts(int64_t m);
 int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
                 const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, int64_t pad_feat_row,
-                float* d_dte_part, void* stream);
+                float* d_dedge, int64_t dedge_ld, float* d_dte_part, void* stream);
+void tg_set_attn_fast(int mask);
 
 /* ---- one whole temporal-attention layer per call -----------------------------------------------------
  * replaces, per layer, models/modules.py:167-245 + :58-69 as called from models/TGAT.py:132-142 (and MemoryModel.py:703-713)
@@ -180,6 +186,14 @@ int tg_side_join(void* stream);
  * L2 weight decay folded into the gradient.  No amsgrad. */
 int tg_adam_f32(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1,
                 double beta2, double eps, double weight_decay, int64_t step, void* stream);
+
+/* d_teb[j] -= sin(d_b[j]) * d_cosb[j]: hands the gradient that reached cos(b) -- the encoding of a zero interval,
+ * models/TGAT.py:84-85 -- on to the time encoder's bias (last launch of a backward pass). */
+int tg_time_bias_finish(float* d_teb, const float* d_b, const float* d_cosb, int dim, void* stream);
+
+/* d_out[0] = scale * sum_i d_a[i] * d_w[i]  (the scalar of a weighted-mean loss over an embedding block; the fused trainers'
+ * stand-in for the reduction of PTCL/EM_warmup.py:222 / M_step.py:297-306).  Operands 16-byte aligned. */
+int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, float scale, float* d_out, void* stream);
 
 /* ---- synthetic feature tables (measurement only) ---------------------------
  * out[r, c] = f(row0 + r, c, seed), uniform with unit variance, row 0 = 0; the stand-in for the node / edge feature blobs

@@ -468,3 +468,43 @@ def test_sample_recent_full_size_properties(dev):
             sl = slice(lo + i - take, lo + i)
             assert np.array_equal(nbr[r, k - take:], nb[sl]) and np.array_equal(eid[r, k - take:], ei[sl])
             assert np.array_equal(ts[r, k - take:], tt[sl].astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(3000, 172, 172, 100, 20, 2), (700, 16, 8, 8, 7, 1), (64, 8, 260, 128, 64, 2)])
+def test_attention_pipelined_kernels_match_generic(shape):
+    """tg_attn_fast.hip (software-pipelined production kernels) against the generic kernels of tg_attn.hip on the same inputs:
+    aggregate, probabilities, query gradient, neighbor-feature gradient (table rows incl. the shared padding row) and the
+    time-encoder slabs -- with attention dropout on (same counter-based mask stream)."""
+    from flid_amd import ops
+    from flid_amd._lib import lib
+    m, dn, de, T, k, H = shape
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(m)
+    nrows, nedges = 500, 4000
+    feat = torch.from_numpy(rs.standard_normal((nrows, dn)).astype(np.float32)).to(dev)
+    edge = torch.from_numpy(rs.standard_normal((nedges, de)).astype(np.float32)).to(dev)
+    nbr = rs.randint(1, nrows, size=(m, k)).astype(np.int32)
+    nbr[rs.uniform(size=(m, k)) < 0.2] = 0
+    nbr[1] = 0                                                     # an all-padded instance
+    fidx = torch.from_numpy(nbr.reshape(-1).copy()).to(dev)        # feature row = node id (layer-1 form), padding -> row 0
+    eidx = torch.from_numpy(rs.randint(0, nedges, size=m * k).astype(np.int32)).to(dev)
+    dt = torch.from_numpy(rs.uniform(0, 2.6e6, size=m * k).astype(np.float32)).to(dev)
+    te_w = torch.from_numpy((1 / 10 ** np.linspace(0, 9, T)).astype(np.float32)).to(dev)
+    te_b = torch.from_numpy(rs.uniform(-1, 1, T).astype(np.float32)).to(dev)
+    dk = dn + de + T
+    u = torch.from_numpy((rs.standard_normal((m, H, dk)) * 0.2).astype(np.float32)).to(dev)
+    dagg = torch.from_numpy(rs.standard_normal((m, H, dk)).astype(np.float32)).to(dev)
+    a = ops.AttnArgs(feat, fidx, edge, eidx, torch.from_numpy(nbr.reshape(-1)).to(dev), dt, te_w, te_b, k, H, 0.3, 0.1, 99)
+    out = {}
+    for mask in (0, 7):
+        lib().tg_set_attn_fast(mask)
+        try:
+            agg, prob = ops.attn_fwd(a, u)
+            dfeat = torch.zeros_like(feat)
+            du, dw, db = ops.attn_bwd(a, u, agg, prob, dagg, dfeat, pad_row=0)
+            out[mask] = (agg, prob, du, dfeat, dw, db)
+        finally:
+            lib().tg_set_attn_fast(3)
+    for x, y, name in zip(out[0], out[7], ("agg", "prob", "du", "dfeat", "dw", "db")):
+        scale = float(x.abs().max()) + 1e-12
+        assert float((x - y).abs().max()) <= 2e-5 * scale, (name, float((x - y).abs().max()), scale)

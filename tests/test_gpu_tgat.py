@@ -302,8 +302,8 @@ def test_merged_projections_match_separate_products():
         scale = float(g0[n].abs().max()) + 1e-12
         diff = (g1[n] - g0[n]).abs()
         # a ReLU unit within rounding of zero may flip between the two evaluations: allow a few entries to move a little
-        bad = (diff > 1e-4 * scale).float().mean().item()
-        assert bad <= 0.005 and float(diff.max()) <= 0.02 * scale, (n, bad, float(diff.max()) / scale)
+        bad = (diff > 1e-4 * scale).float().sum().item()
+        assert bad <= max(1.0, 0.005 * diff.numel()) and float(diff.max()) <= 0.02 * scale, (n, bad, float(diff.max()) / scale)
 
 
 def test_tgat_full_size_equivariance_and_linearity():
@@ -430,3 +430,43 @@ def test_tgat_neighbor_count_extremes(k):
     for name, prm in m.named_parameters():
         g, go = prm.grad.cpu().numpy(), p[name].grad.numpy()
         assert np.abs(g - go).max() <= 1e-4 * max(1.0, np.abs(go).max()), name
+
+
+def test_fused_train_step_equals_autograd_path():
+    """TGAT.train_step (forward, caller's loss, backward with no autograd graph) leaves in the flat parameter's .grad what
+    loss.backward() through compute_src_dst_node_temporal_embeddings leaves there; two-stage prefetch == one-stage == direct call"""
+    from flid_amd import ops
+    g = load_golden("tgat_L2_K20")
+    dev = torch.device("cuda:0")
+    src, dst = (torch.from_numpy(g[x].astype(np.int32)).to(dev) for x in ("bs", "bd"))
+    t = torch.from_numpy(g["bt"]).to(dev)
+    n = len(g["bs"])
+    w = torch.from_numpy(np.random.RandomState(4).standard_normal((2 * n, g["node_feat"].shape[1])).astype(np.float32)).to(dev)
+    res = []
+    for mode in ("autograd", "fused"):
+        m, p, k = _model(g)
+        flat = m.flatten_parameters()
+        m.train()
+        job = m.prepare_batch_begin(src, dst, t, k)
+        pf = m.prepare_batch_finish(job)
+        if mode == "autograd":
+            s, d = m.compute_src_dst_node_temporal_embeddings(pf, None, None, k)
+            emb = torch.cat([s, d])
+            loss = (emb * w).sum() * 0.5
+            loss.backward()
+        else:
+            emb, loss = m.train_step(pf, lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w), k)
+            assert not emb.requires_grad
+        res.append((emb.detach().clone(), float(loss), flat.grad.clone()))
+        # one-stage prefetch and the plain call see the same frontier
+        with torch.no_grad():
+            s1, d1 = m.compute_src_dst_node_temporal_embeddings(m.prepare_batch(src, dst, t, k), None, None, k)
+            s2, d2 = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+        assert torch.equal(torch.cat([s1, d1]), emb.detach()) and torch.equal(torch.cat([s2, d2]), emb.detach())
+    assert torch.equal(res[0][0], res[1][0])
+    assert abs(res[0][1] - res[1][1]) <= 1e-5 * max(1.0, abs(res[0][1]))
+    scale = float(res[0][2].abs().max())
+    assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-6 * scale          # column sums fold with float atomics
+    # a second fused step ADDS to an existing .grad, as autograd accumulates
+    m.train_step(m.prepare_batch(src, dst, t, k), lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w), k)
+    assert float((flat.grad - 2.0 * res[1][2]).abs().max()) <= 2e-6 * scale
