@@ -74,6 +74,9 @@ def main():
                     help="train mode: loss and backward through torch autograd (loss.backward()) instead of the fused step "
                          "TGAT.train_step (same kernels, no autograd graph, loss scalar from one HIP reduction)")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--no-merged", action="store_true", help="tg_set_layer_merged(0): the reference's four separate projections per layer")
+    ap.add_argument("--no-grouped", action="store_true", help="tg_set_wgrad_grouped(0): one exact product + one column sum per weight gradient")
+    ap.add_argument("--overlap", type=int, default=None, help="tg_set_overlap override (experiments): 0 = weight gradients on the main stream")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -94,6 +97,15 @@ def main():
     if args.gemm_mode is not None:
         from flid_amd._lib import lib as _l
         _l().tg_set_gemm_mode(args.gemm_mode)
+    if args.no_merged or args.no_grouped:
+        from flid_amd._lib import lib as _l
+        if args.no_merged:
+            _l().tg_set_layer_merged(0)
+        if args.no_grouped:
+            _l().tg_set_wgrad_grouped(0)
+    if args.overlap is not None:
+        from flid_amd._lib import lib as _l
+        _l().tg_set_overlap(args.overlap)
     rank, world, local = fdist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product has no CPU path)"
@@ -261,9 +273,11 @@ def main():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             marks.append((ev, time.perf_counter() - t0))
+    host_issue = time.perf_counter() - t0          # the host has ISSUED every timed step (it runs ahead of the GPU when it can)
     barrier()
     elapsed = time.perf_counter() - t0
     if args.trace_steps and rank == 0:
+        print(f"[bench] host issue time {host_issue / args.steps * 1e3:.3f} ms/step, wall {elapsed / args.steps * 1e3:.3f} ms/step", file=sys.stderr)
         gpu = [marks[i - 1][0].elapsed_time(marks[i][0]) for i in range(1, len(marks))]
         host = [marks[i][1] - marks[i - 1][1] for i in range(1, len(marks))]
         print("[bench] per-step GPU ms :", " ".join(f"{x:.2f}" for x in gpu), file=sys.stderr)

@@ -42,6 +42,12 @@ class LayerBwdDesc(C.Structure):
                 ("d_own_accumulate", C.c_int), ("d_raw", c_void), ("defer_join", C.c_int)]
 
 
+class WgradJob(C.Structure):
+    """struct tg_wgrad_job"""
+    _fields_ = [("A", c_void), ("lda", c_i64), ("M", C.c_int), ("B", c_void), ("ldb", c_i64), ("N", C.c_int), ("C", c_void), ("ldc", c_i64),
+                ("colsum_A", c_void)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/flid_tg.h
 SIGNATURES = {
     "tg_last_error": (C.c_char_p, []),
@@ -70,11 +76,14 @@ SIGNATURES = {
     "tg_tgat_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), c_void]),
     "tg_tgat_layer_wt_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
     "tg_tgat_layer_part_floats": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
+    "tg_tgat_layer_vec_floats": (c_i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tg_set_wgrad_grouped": (None, [C.c_int]),
     "tg_side_join": (C.c_int, [c_void]),
     "tg_set_layer_merged": (None, [C.c_int]),
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),
     "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
                               c_void, C.c_int, C.c_int, c_void]),
+    "tg_wgrad_group": (C.c_int, [C.c_int, C.POINTER(WgradJob), c_i64, c_void]),
     "tg_set_gemm_mode": (None, [C.c_int]),
     "tg_get_gemm_mode": (C.c_int, []),
     "tg_gemm_f32_batched": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_void,

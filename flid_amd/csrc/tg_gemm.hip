@@ -479,7 +479,16 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     if (splits > 1 && (splits * nbatch) % 8 != 0) {
         int64_t up = splits;
         while ((up * nbatch) % 8 != 0) ++up;
-        if (up - splits <= 3) splits = up;
+        if (tn_bf16) {
+            // the split-bf16 weight-gradient kernel REQUIRES a multiple of 8 slices: re-cut K evenly over the rounded count (the row
+            // count of a layer changes every step; 18 slices used to fall back to the f32-input tile kernel -- 102 us instead of 35
+            // for the 272 x 888 gradient -- while 16 or 24 did not)
+            splits = up;
+            k_chunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+            if (k_chunk < BK) k_chunk = BK;
+        } else if (up - splits <= 3) {
+            splits = up;
+        }
     }
     TG_REQUIRE(splits * nbatch <= 65535, "tg_gemm_f32: too many splits");
     // split contraction: partial products into a workspace + one fixed-order fold; float atomics only if no workspace is to be had
@@ -539,6 +548,16 @@ extern "C" int tg_gemm_f32_batched2(int ta, int tb, int64_t M, int64_t N, int64_
     TG_REQUIRE(outer >= 1 && inner >= 1 && (int64_t)outer * inner <= 65535, "tg_gemm_f32_batched2: batch counts");
     return gemm_impl(ta, tb, M, N, K, alpha, d_A, lda, outer_a, d_B, ldb, outer_b, d_C, ldc, outer_c, outer * inner, nullptr, 0,
                      accumulate, (hipStream_t)stream, inner, inner_a, inner_b, inner_c);
+}
+
+extern "C" int tg_wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, void* stream) {
+    TG_REQUIRE(jobs && njobs >= 1 && njobs <= 6 && rows >= 0, "tg_wgrad_group: arguments");
+    if (rows == 0) return TG_OK;
+    if (!tg::wgrad_group(njobs, jobs, rows, (hipStream_t)stream)) {
+        tg::set_error("invalid argument: tg_wgrad_group: shape / alignment not covered (M, N, lda, ldb multiples of 4, 16-byte aligned operands)");
+        return TG_EINVAL;
+    }
+    return tg::launch_status("gemm_bf16x3_wgrad_kernel");
 }
 
 extern "C" void tg_set_gemm_mode(int mode) { g_gemm_mode = mode; }

@@ -12,6 +12,8 @@
 // Staging: global fp32 (full 128-B lines) -> split in registers -> LDS row = [32 x bf16 hi | 32 x bf16 lo] (+16 B pad, stride
 // 144 B, conflict-free ds_read_b128) -> fragments.  Two LDS stages, one barrier per 32-deep stage, global loads of stage s+2
 // in flight under stage s.
+#include <math.h>
+
 #include "tg_common.h"
 
 namespace {
@@ -407,11 +409,215 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Grouped weight-gradient launch: up to 6 products  C_j[M_j, N_j] += A_j^T B_j  over the SAME rows (the contraction index), e.g.
+// all of a layer's dW that depend on one activation gradient, in ONE launch, with
+//   * the bias gradient for free: if job.colsum is set, column N_j of the B panel reads as 1.0 (the padding of the last column
+//     tile, N_j < gx * 32 TNW), so that output column is sum_rows A = the column sums of the activation gradient;
+//   * no separate fold launch: every K slice adds its partial tile into C with float atomics, issued as contiguous 256-byte
+//     wave instructions (C / colsum accumulate: the caller zeroes them -- the gradient block of a step is one zero fill).
+// Same tiles, LDS image and schedule as gemm_bf16x3_tn_kernel; 1-D grid of (tiles of all jobs) x slices, slices in multiples of
+// 8 so that all tiles of one K slice run on one XCD (its L2 pulls that row range of the operands once).
+struct WgJob { const float* A; const float* B; float* C; float* colsum; int64_t lda, ldb, ldc; int M, N, gx, tile0; };
+struct WgJobs { WgJob j[6]; int n, total_tiles; };
+
+template <int R>
+struct PanelT1 : PanelT<R> {
+    bool ones;         // this thread's micro-tile starts at the injected ones column
+    __device__ __forceinline__ void init1(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, bool inject) {
+        this->init(X, ld, row0, nrows);
+        const int t = threadIdx.x % PanelT<R>::TILES;
+        ones = inject && (row0 + (t / 8) * 4 == nrows);
+    }
+    // as PanelT::sstore; kvalid = bit i set when k row i of the micro-tile exists (the ones column must vanish past the end of K)
+    __device__ __forceinline__ void sstore1(char* __restrict__ s, const float4 (&reg)[4], int kvalid) const {
+        float4 r0 = reg[0], r1 = reg[1], r2 = reg[2], r3 = reg[3];
+        if (ones) {
+            r0 = make_float4((kvalid & 1) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+            r1 = make_float4((kvalid & 2) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+            r2 = make_float4((kvalid & 4) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+            r3 = make_float4((kvalid & 8) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 rr[4] = {r0, r1, r2, r3};
+        PanelT<R>::sstore(s, rr);
+    }
+};
+
+template <int TNW>
+__global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int64_t K, int64_t k_chunk, const float* __restrict__ zeros) {
+    constexpr int BNt = 32 * TNW;
+    constexpr int FA = BM * ROW_BYTES, FB = BNt * ROW_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
+    auto sA = [&](int i) -> char* { return lds + i * (FA + FB); };
+    auto sB = [&](int i) -> char* { return lds + i * (FA + FB) + FA; };
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int slice = xcd + 8 * (jj / jobs.total_tiles), t = jj % jobs.total_tiles;
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < 6; ++q) if (q < jobs.n && t >= jobs.j[q].tile0) ji = q;
+    const WgJob J = jobs.j[ji];
+    const int tile = t - J.tile0, by = tile / J.gx, bx = tile % J.gx;
+    const int64_t M = J.M, N = J.N;
+    const int64_t bm = (int64_t)by * BM, bn = (int64_t)bx * BNt;
+    const int64_t kbeg = (int64_t)slice * k_chunk, kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
+    if (kbeg >= K) return;                                  // (uniform; a surplus slice has nothing to add)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[TNW];
+#pragma unroll
+    for (int tt = 0; tt < TNW; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+
+    PanelT<BM> pa;
+    PanelT1<BNt> pb;
+    pa.init(J.A, J.lda, bm, M);
+    pb.init1(J.B, J.ldb, bn, N, J.colsum != nullptr);
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    const int64_t nstage = (kend - kbeg + BK - 1) / BK;
+    auto kmask = [&](int64_t st) -> int {                   // which of this thread's 4 k rows of stage st exist
+        const int64_t k0 = kbeg + st * BK + pb.kcol;
+        int mk = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mk |= (st < nstage && k0 + i < kend) ? (1 << i) : 0;
+        return mk;
+    };
+    auto issue = [&](int64_t st, float4 (&ra)[4], float4 (&rb)[4]) {
+        pa.gload(J.lda, kbeg + st * BK, kend, st < nstage, zeros, ra);
+        pb.gload(J.ldb, kbeg + st * BK, kend, st < nstage, zeros, rb);
+    };
+    auto stage = [&](int64_t st, float4 (&ra)[4], float4 (&rb)[4]) {
+        const int cur = (int)(st & 1);
+        bf16x8 ah[2], al[2], bh[TNW][2], bl[TNW][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            read_frag(sA(cur), wave * 32, ks, ah[ks], al[ks]);
+#pragma unroll
+            for (int tt = 0; tt < TNW; ++tt) read_frag(sB(cur), 32 * tt, ks, bh[tt][ks], bl[tt][ks]);
+        }
+        pa.sstore(sA(cur ^ 1), ra);                   // (ra, rb) hold stage st + 1
+        pb.sstore1(sB(cur ^ 1), rb, kmask(st + 1));
+        issue(st + 3, ra, rb);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int tt = 0; tt < TNW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[tt][ks], acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < TNW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[tt][ks], acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < TNW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[tt][ks], acc[tt], 0, 0, 0);
+        }
+        if (SCHED) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 4 * TNW, 0);
+#pragma unroll
+            for (int i = 0; i < 6 * TNW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __syncthreads();
+    };
+    issue(0, ra0, rb0);
+    pa.sstore(sA(0), ra0);
+    pb.sstore1(sB(0), rb0, kmask(0));
+    issue(1, ra0, rb0);
+    issue(2, ra1, rb1);
+    __syncthreads();
+    for (int64_t st = 0; st < nstage; st += 2) {
+        stage(st, ra0, rb0);
+        if (st + 1 < nstage) stage(st + 1, ra1, rb1);
+    }
+    // partial tile -> LDS -> float atomics into C, 64 consecutive columns of a row per wave instruction
+    __syncthreads();
+    constexpr int CS = BNt + 8;
+    static_assert(4 * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
+    float* cs = reinterpret_cast<float*>(lds) + wave * 32 * CS;
+    {
+        const int rl = lane & 31, kh = lane >> 5;
+#pragma unroll
+        for (int tt = 0; tt < TNW; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * kh) * CS + tt * 32 + rl] = acc[tt][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int64_t row0 = bm + wave * 32;
+    for (int idx = lane; idx < 32 * BNt; idx += 64) {
+        const int r = idx / BNt, c = idx - r * BNt;
+        const int64_t row = row0 + r, col = bn + c;
+        if (row >= M) continue;
+        const float v = cs[r * CS + c];
+        if (col < N) atomicAdd(J.C + row * J.ldc + col, v);
+        else if (col == N && J.colsum) atomicAdd(J.colsum + row, v);
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
 namespace tg {
+
+// Grouped weight gradients (see gemm_bf16x3_wgrad_kernel).  false = a job's shape / alignment is not covered (nothing launched):
+// the caller takes tg_gemm_f32 + tg_colsum per job.
+bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s) {
+    if (njobs < 1 || njobs > 6 || rows < 1) return false;
+    const float* zeros = zero_block();
+    if (!zeros) return false;
+    // One column-tile width (96 or 64) and one K-slice count (a multiple of 8: XCD pinning) for the launch, by a small cost model:
+    // 512 workgroups are resident at once (2 per CU: 64 KB of LDS each), so time ~ rounds x (stages x t_stage + fixed) plus the
+    // float-atomic traffic of the fold (every slice adds a whole padded tile; ~1.3 TB/s chip-wide).  Measured t_stage: 1.15 us
+    // (128 x 96) / 0.95 us (128 x 64); fixed ~6 us (first loads, epilogue).  [The first version rounded the slice count UP: 560
+    // workgroups = two rounds for a 512-slot chip, 78 us for a 35 us launch.]
+    int best_tnw = 3;
+    int64_t best_slices = 8;
+    double best_cost = 1e30;
+    const int64_t max_slices = std::max<int64_t>(8, rows / (4 * BK) / 8 * 8);
+    for (int tnw_c = 2; tnw_c <= 3; ++tnw_c) {
+        int64_t tiles = 0;
+        for (int i = 0; i < njobs; ++i) {
+            const int64_t need = jobs[i].N + (jobs[i].colsum_A ? 1 : 0);
+            tiles += ((need + 32 * tnw_c - 1) / (32 * tnw_c)) * ((jobs[i].M + BM - 1) / BM);
+        }
+        for (int64_t sl = 8; sl <= max_slices; sl += 8) {
+            const int64_t kc = ((rows + sl - 1) / sl + BK - 1) / BK * BK;
+            const double stages = (double)kc / BK, wgs = (double)tiles * sl;
+            const double rounds = std::ceil(wgs / 512.0);
+            const double t_stage = tnw_c == 3 ? 1.15 : 0.95;
+            const double fill = std::min(1.0, wgs / 512.0);                       // a half-empty chip runs its stages faster
+            const double compute = rounds * (stages * t_stage * (0.6 + 0.4 * fill) + 6.0);
+            const double atomics = wgs * BM * 32.0 * tnw_c * 4.0 / 1.3e6;         // bytes / (1.3 TB/s) in us
+            const double cost = compute + atomics;
+            if (cost < best_cost) { best_cost = cost; best_tnw = tnw_c; best_slices = sl; }
+        }
+    }
+    const int tnw = best_tnw;
+    WgJobs wj;
+    wj.n = njobs;
+    wj.total_tiles = 0;
+    double flops = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const tg_wgrad_job& q = jobs[i];
+        if (!(q.A && q.B && q.C && q.M >= 4 && q.N >= 4 && q.M % 4 == 0 && q.N % 4 == 0 && q.lda % 4 == 0 && q.ldb % 4 == 0 && al16(q.A) && al16(q.B)))
+            return false;
+        if (q.lda < q.M || q.ldb < q.N || q.ldc < q.N) return false;
+        const int64_t need = q.N + (q.colsum_A ? 1 : 0);
+        const int gx = (int)((need + 32 * tnw - 1) / (32 * tnw)), gy = (q.M + BM - 1) / BM;
+        wj.j[i] = WgJob{q.A, q.B, q.C, q.colsum_A, q.lda, q.ldb, q.ldc, q.M, q.N, gx, wj.total_tiles};
+        wj.total_tiles += gx * gy;
+        flops += 2.0 * q.M * q.N * rows;
+    }
+    const int64_t slices = best_slices;
+    int64_t k_chunk = ((rows + slices - 1) / slices + BK - 1) / BK * BK;
+    if (k_chunk < BK) k_chunk = BK;
+    const int64_t blocks = (int64_t)wj.total_tiles * slices;
+    if (blocks >= ((int64_t)1 << 31)) return false;
+    ProfScope prof("gemm", flops, s);
+    if (tnw == 3) gemm_bf16x3_wgrad_kernel<3><<<(unsigned)blocks, NT, 0, s>>>(wj, rows, k_chunk, zeros);
+    else gemm_bf16x3_wgrad_kernel<2><<<(unsigned)blocks, NT, 0, s>>>(wj, rows, k_chunk, zeros);
+    return true;
+}
 
 // returns true when the shape was handled; false = fall back to the exact f32-input kernel
 bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,

@@ -12,6 +12,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 #include "tg_common.h"
 
@@ -406,6 +407,10 @@ struct SideStream {
         ok = true;
         return true;
     }
+    hipEvent_t mark_deferred(int* rc) {                  // an event from the ring, to be recorded later by the issuing thread
+        *rc = TG_OK;
+        return ev[next++ & 31];
+    }
     hipEvent_t mark(hipStream_t on, int* rc) {           // record "everything issued on `on` so far"
         hipEvent_t e = ev[next++ & 31];
         *rc = hipEventRecord(e, on) == hipSuccess ? TG_OK : TG_EHIP;
@@ -475,6 +480,7 @@ bool g_merged = true;      // merged projections (merge_weights_kernel); false =
 constexpr int64_t kMergedMinRows = 4096;
 SideStream g_side;
 bool g_overlap = true;
+bool g_wgrad_grouped = true;   // tg_wgrad_group for a layer's weight gradients; false = one exact product + one column sum per gradient
 
 }  // namespace
 
@@ -587,6 +593,11 @@ extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
            2 * H * dk * dn + 2 * H * dk * dq + H * dk + 16;
 }
 
+extern "C" int64_t tg_tgat_layer_vec_floats(int dn, int dq, int dk, int heads) {
+    const int64_t hk = (int64_t)heads * dk;
+    return ((dq + hk + 3) / 4) * 4 + ((int64_t)dq * hk + 3) / 4 * 4 + ((int64_t)hk * dn + 3) / 4 * 4 + 16;
+}
+
 extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
     const int64_t a = ((rows + 15) / 16) * dn;                       // ReLU-mask slabs
     const int64_t b = row_grid(rows) * 4 * dq;                       // LayerNorm slabs
@@ -643,20 +654,41 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     float* part_relu = Bw->part;
     float* part_ln = part_relu + relu_blocks * dn;
     float* part_attn = part_ln + (int64_t)ln_grid * 4 * dq;
-    float* vec_dq = vec;                                    // dq floats, zero on entry like the gradients
+    const int64_t hk = (int64_t)H * dk;
+    // zero-on-entry scratch (`vec`): [sum_rows dq (dq) or sum_rows du (H dk)] | dV (dq, H dk) | dP (H dk, dn)   (the last two: merged form)
+    float* vec_dq = vec;
+    float* dub = vec;
+    float* dVm = vec + ((dq + hk + 3) / 4) * 4;
+    float* dPm = dVm + ((int64_t)dq * hk + 3) / 4 * 4;
+    // Weight (and bias) gradients of up to 6 Linear layers in ONE launch on the side stream (tg_wgrad_group: split-bf16 MFMA, bias
+    // sums through a ones column, partial tiles folded with float atomics); shapes it does not cover fall back to one exact
+    // product + one column sum per job.
+    struct WJ { const float* A; int64_t lda; int M; const float* B; int64_t ldb; int N; float* C; int64_t ldc; float* cs; };
+    auto wgrad = [&](std::vector<WJ> jobs) -> int {
+        hipStream_t st = ws_;
+        void* stv = wstream;
+        return side([=] {
+            tg_wgrad_job q[6];
+            const int n = (int)jobs.size();
+            for (int i = 0; i < n; ++i) q[i] = tg_wgrad_job{jobs[i].A, jobs[i].lda, jobs[i].M, jobs[i].B, jobs[i].ldb, jobs[i].N, jobs[i].C, jobs[i].ldc, jobs[i].cs};
+            if (g_wgrad_grouped && tg::wgrad_group(n, q, R, st)) return tg::launch_status("gemm_bf16x3_wgrad_kernel");
+            for (int i = 0; i < n; ++i) {
+                TG_TRY(tg_gemm_f32(1, 0, q[i].M, q[i].N, R, 1.f, q[i].A, q[i].lda, q[i].B, q[i].ldb, q[i].C, q[i].ldc, nullptr, 0, 1, stv));
+                if (q[i].colsum_A) TG_TRY(colsum_seg(q[i].A, q[i].lda, R, q[i].M, seg1(q[i].colsum_A, q[i].M), st));
+            }
+            return (int)TG_OK;
+        });
+    };
     // ---- merge layer -------------------------------------------------------------------------------------------------------
-    TG_TRY(fork());                           // dout is ready
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bc.dout, dn, Lc.f1, dn, G.W2, dn, nullptr, 0, 1, wstream); }));
-    TG_TRY(side([=] { return colsum_seg(Bc.dout, dn, R, dn, seg1(G.b2, dn), ws_); }));
     TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
     TG_REQUIRE(dn <= 1024, "tg_tgat_layer_bwd: node dim > 1024 unsupported");
     if (dn <= 256) relu_bwd_colsum_kernel<1><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
     else relu_bwd_colsum_kernel<4><<<(unsigned)relu_blocks, 256, 0, s>>>(Bw->df1, L->f1, R, dn, 16, part_relu);
     TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
-    TG_TRY(fork());                           // df1 and its slabs are final
-    TG_TRY(side([=] { return colsum_seg(part_relu, dn, relu_blocks, dn, seg1(G.b1, dn), ws_); }));
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dq, R, 1.f, Bc.df1, dn, Lc.y, dq, G.W1, w1ld, nullptr, 0, 1, wstream); }));
-    TG_TRY(side([=] { return tg_gemm_f32(1, 0, dn, dn, R, 1.f, Bc.df1, dn, Lc.raw, Lc.raw_ld, G.W1 + dq, w1ld, nullptr, 0, 1, wstream); }));
+    TG_TRY(fork());                           // dout, df1 are final: dW2 (+ db2), dW1 = df1^T [y | raw] (+ db1)
+    TG_TRY(wgrad({WJ{Bc.dout, dn, dn, Lc.f1, dn, dn, G.W2, dn, G.b2},
+                  WJ{Bc.df1, dn, dn, Lc.y, dq, dq, G.W1, w1ld, G.b1},
+                  WJ{Bc.df1, dn, dn, Lc.raw, Lc.raw_ld, dn, G.W1 + dq, w1ld, nullptr}}));
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
     if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
@@ -668,52 +700,57 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         else ln_res_bwd_kernel<16><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
     }
-    if (g_merged && R >= kMergedMinRows) {
-        // gradients of the merged projections land in scratch and are chained back to Wq / Wk / Wv / Wr in weight space
-        const int64_t hk = (int64_t)H * dk;
-        float* dVm = part_attn + ((int64_t)attn_parts * 2 * T + 3) / 4 * 4;      // (dq, H dk)
-        float* dPm = dVm + ((int64_t)dq * hk + 3) / 4 * 4;                        // (H dk, dn)
-        float* dub = vec;                                                         // H dk floats, zero on entry
-        // ---- value path: dagg = dres V ----------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32(0, 1, R, hk, dq, 1.f, dres, dq, wt.VT, dq, Bw->dagg, hk, nullptr, 0, 0, stream));
-        // (issued after the main-chain product above: dV then runs under the attention backward instead of competing with dagg)
-        TG_TRY(fork());                       // dres / dsum and the LayerNorm slabs are final
-        TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, hk, R, 1.f, dres, dq, Lc.agg, hk, dVm, hk, nullptr, 0, 0, wstream); }));          // dV = dres^T agg
-        // V_h = Wr[:, h] Wv_h :  dWr[:, h] += dV_h Wv_h^T ;  dWv_h += Wr[:, h]^T dV_h
-        // (as MFMA products: one launch of merge_weights_kernel for all four chain products was tried and is slower, 433 k vs 447 k)
-        TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, dq, hd, dk, 1.f, dVm, hk, dk, P.Wv, dk, (int64_t)hd * dk, G.Wr, dq, hd, H, nullptr, 0, 1, wstream); }));
-        TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, dq, 1.f, P.Wr, dq, hd, dVm, hk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
-        {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
-            SegDst d{};
-            d.n = 5;
-            d.p[0] = G.ln_g;     d.end[0] = dq;
-            d.p[1] = G.ln_b;     d.end[1] = 2 * dq;
-            d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
-            d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
-            d.p[4] = G.br;       d.end[4] = 4 * dq;
-            TG_TRY(side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_); }));
-        }
-        // ---- fused attention backward (HBM-bound: the side streams' products run under it) ----------------------------------------
-        // (splitting this launch into two row chunks so that the first chunk's dP = du^T own runs under the second chunk was tried:
-        // 431 k vs 445 k edges/s -- two smaller launches plus the product competing with the second one cost more than the shorter tail)
-        TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
-        TG_TRY(fork());                       // du and the time-encoder slabs are final
-        TG_TRY(side([=] { return tg_gemm_f32(1, 0, hk, dn, R, 1.f, Bc.du, hk, Lc.own, Lc.own_ld, dPm, dn, nullptr, 0, 0, wstream); }));  // dP = du^T own
-        TG_TRY(side([=] { return colsum_seg(Bc.du, hk, R, (int)hk, seg1(dub, (int)hk), ws_); }));                                  // dub = sum_rows du
-        // P_h = Wk_h^T Wq_h[:, :dn] :  dWk_h += Wq_h[:, :dn] dP_h^T ;  dWq_h[:, :dn] += Wk_h dP_h ;  then the constant part (ub)
-        TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, hd, dk, dn, 1.f, P.Wq, dq, (int64_t)hd * dq, dPm, dn, (int64_t)dk * dn, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
-        TG_TRY(side([=] { return tg_gemm_f32_batched(0, 0, hd, dn, dk, 1.f, P.Wk, dk, (int64_t)hd * dk, dPm, dn, (int64_t)dk * dn, G.Wq, dq, (int64_t)hd * dq, H, nullptr, 0, 1, wstream); }));
-        TG_TRY(side([=] {
-            ub_bwd_kernel<<<dq, 256, 0, ws_>>>(dub, Lc.qbias, P.Wk, P.Wq, Lc.cosb, hd, dn, dq, dk, T, G.Wk, G.Wq, Bc.d_cosb);
-            return tg::launch_status("ub_bwd_kernel");
-        }));
-    {
+    // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres (= d br, which the
+    // weight-gradient launch delivers through its ones column instead)]
+    auto ln_slab_sums = [&]() -> int {
+        SegDst d{};
+        d.n = 5;
+        d.p[0] = G.ln_g;     d.end[0] = dq;
+        d.p[1] = G.ln_b;     d.end[1] = 2 * dq;
+        d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
+        d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
+        d.p[4] = nullptr;    d.end[4] = 4 * dq;
+        hipStream_t st = ws_;
+        return side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 3 * dq, d, st); });
+    };
+    auto attn_slab_sums = [&]() -> int {
         SegDst d{};
         d.n = 2;
         d.p[0] = Bw->d_tew; d.end[0] = T;
         d.p[1] = Bw->d_teb; d.end[1] = 2 * T;
-        TG_TRY(side([=] { return colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, ws_); }));
-    }
+        hipStream_t st = ws_;
+        return side([=] { return colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, st); });
+    };
+    if (g_merged && R >= kMergedMinRows) {
+        // gradients of the merged projections land in zeroed scratch and are chained back to Wq / Wk / Wv / Wr in weight space
+        // ---- value path: dagg = dres V ----------------------------------------------------------------------------------------------
+        TG_TRY(tg_gemm_f32(0, 1, R, hk, dq, 1.f, dres, dq, wt.VT, dq, Bw->dagg, hk, nullptr, 0, 0, stream));
+        // (issued after the main-chain product above: dV then runs under the attention backward instead of competing with dagg)
+        TG_TRY(fork());                       // dres / dsum and the LayerNorm slabs are final
+        TG_TRY(wgrad({WJ{dres, dq, dq, Lc.agg, hk, (int)hk, dVm, hk, G.br}}));                      // dV = dres^T agg, d br = sum_rows dres
+        {
+            void* stv = wstream;
+            // V_h = Wr[:, h] Wv_h :  dWr[:, h] += dV_h Wv_h^T ;  dWv_h += Wr[:, h]^T dV_h   (two small MFMA products in weight space)
+            TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, dq, hd, dk, 1.f, dVm, hk, dk, P.Wv, dk, (int64_t)hd * dk, G.Wr, dq, hd, H, nullptr, 0, 1, stv); }));
+            TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, dq, 1.f, P.Wr, dq, hd, dVm, hk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, stv); }));
+        }
+        TG_TRY(ln_slab_sums());
+        // ---- fused attention backward -------------------------------------------------------------------------------------------------
+        TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
+        TG_TRY(fork());                       // du and the time-encoder slabs are final
+        TG_TRY(wgrad({WJ{Bc.du, hk, (int)hk, Lc.own, Lc.own_ld, dn, dPm, dn, dub}}));                 // dP = du^T own, dub = sum_rows du
+        {
+            void* stv = wstream;
+            hipStream_t st = ws_;
+            // P_h = Wk_h^T Wq_h[:, :dn] :  dWk_h += Wq_h[:, :dn] dP_h^T ;  dWq_h[:, :dn] += Wk_h dP_h ;  then the constant part (ub)
+            TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, hd, dk, dn, 1.f, P.Wq, dq, (int64_t)hd * dq, dPm, dn, (int64_t)dk * dn, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, stv); }));
+            TG_TRY(side([=] { return tg_gemm_f32_batched(0, 0, hd, dn, dk, 1.f, P.Wk, dk, (int64_t)hd * dk, dPm, dn, (int64_t)dk * dn, G.Wq, dq, (int64_t)hd * dq, H, nullptr, 0, 1, stv); }));
+            TG_TRY(side([=] {
+                ub_bwd_kernel<<<dq, 256, 0, st>>>(dub, Lc.qbias, P.Wk, P.Wq, Lc.cosb, hd, dn, dq, dk, T, G.Wk, G.Wq, Bc.d_cosb);
+                return tg::launch_status("ub_bwd_kernel");
+            }));
+        }
+        TG_TRY(attn_slab_sums());
         // ---- key / query path: d own = du P (+ the residual's share) ------------------------------------------------------------------
         if (Bw->d_own) {
             TG_TRY(tg_gemm_f32(0, 1, R, dn, hk, 1.f, Bw->du, hk, wt.PT, hk, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
@@ -722,43 +759,34 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         }
     } else {
         TG_TRY(fork());                           // dres / dsum and the LayerNorm slabs are final
-        TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dq, R, 1.f, dres, dq, Lc.ctx, dq, G.Wr, dq, nullptr, 0, 1, wstream); }));
-        {   // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres]
-            SegDst d{};
-            d.n = 5;
-            d.p[0] = G.ln_g;     d.end[0] = dq;
-            d.p[1] = G.ln_b;     d.end[1] = 2 * dq;
-            d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
-            d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
-            d.p[4] = G.br;       d.end[4] = 4 * dq;
-            TG_TRY(side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 4 * dq, d, ws_); }));
-        }
+        TG_TRY(ln_slab_sums());
         // ---- output projection ------------------------------------------------------------------------------------------------------
         TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
         // ---- value path -------------------------------------------------------------------------------------------------------------
-        TG_TRY(fork());                           // dctx is final
-        TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Bc.dctx, dq, hd, Lc.agg, (int64_t)H * dk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
-        TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
-        // ---- fused attention backward (HBM-bound: the side stream's products run under it) -----------------------------------------
+        TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, hk, dk, H, nullptr, 0, 0, stream));
+        // ---- fused attention backward -------------------------------------------------------------------------------------------------
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
-        TG_TRY(fork());                           // du and the time-encoder slabs are final
-        TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, R, 1.f, Lc.q, dq, hd, Bc.du, (int64_t)H * dk, dk, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, wstream); }));
-        {
-            SegDst d{};
-            d.n = 2;
-            d.p[0] = Bw->d_tew; d.end[0] = T;
-            d.p[1] = Bw->d_teb; d.end[1] = 2 * T;
-            TG_TRY(side([=] { return colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, ws_); }));
-        }
         // ---- key / query path --------------------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, (int64_t)H * dk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
-        TG_TRY(fork());                           // dq is final
-        TG_TRY(side([=] { return tg_gemm_f32(1, 0, dq, dn, R, 1.f, Bc.dq, dq, Lc.own, Lc.own_ld, G.Wq, dq, nullptr, 0, 1, wstream); }));
-        TG_TRY(side([=] { return colsum_seg(Bc.dq, dq, R, dq, seg1(vec_dq, dq), ws_); }));                           // sum_rows dq (vec is zero on entry)
-        TG_TRY(side([=] {
-            wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, ws_>>>(vec_dq, dq, Lc.cosb, T, P.Wq + dn, G.Wq + dn, dq, Bc.d_cosb);
-            return tg::launch_status("wq_time_kernel");
-        }));
+        TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, hk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
+        TG_TRY(fork());                           // dres, dctx, du, dq are final: the attention block's five weight gradients in one launch
+        {
+            std::vector<WJ> jobs;
+            jobs.push_back(WJ{dres, dq, dq, Lc.ctx, dq, dq, G.Wr, dq, G.br});                                                    // dWr, d br
+            for (int h = 0; h < H; ++h)                                                                                           // dWv_h = dctx_h^T agg_h
+                jobs.push_back(WJ{Bc.dctx + h * hd, dq, hd, Lc.agg + (int64_t)h * dk, hk, dk, G.Wv + (int64_t)h * hd * dk, dk, nullptr});
+            for (int h = 0; h < H; ++h)                                                                                           // dWk_h = q_h^T du_h
+                jobs.push_back(WJ{Lc.q + h * hd, dq, hd, Bc.du + (int64_t)h * dk, hk, dk, G.Wk + (int64_t)h * hd * dk, dk, nullptr});
+            jobs.push_back(WJ{Bc.dq, dq, dq, Lc.own, Lc.own_ld, dn, G.Wq, dq, vec_dq});                                          // dWq[:, :dn], sum_rows dq
+            TG_TRY(wgrad(jobs));
+        }
+        {
+            hipStream_t st = ws_;
+            TG_TRY(side([=] {
+                wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, st>>>(vec_dq, dq, Lc.cosb, T, P.Wq + dn, G.Wq + dn, dq, Bc.d_cosb);
+                return tg::launch_status("wq_time_kernel");
+            }));
+        }
+        TG_TRY(attn_slab_sums());
         if (Bw->d_own) {
             TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
             add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
@@ -775,3 +803,4 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
 
 extern "C" void tg_set_overlap(int on) { g_overlap = (on & 1) != 0; g_issue_thread = (on & 2) == 0; }
 extern "C" void tg_set_layer_merged(int on) { g_merged = on != 0; }
+extern "C" void tg_set_wgrad_grouped(int on) { g_wgrad_grouped = on != 0; }

@@ -260,33 +260,57 @@ extern "C" int tg_time_bias_finish(float* d_teb, const float* d_b, const float* 
     return tg::launch_status("time_bias_finish_kernel");
 }
 
-// out[0] = scale * sum_i a[i] * w[i]: the scalar of a weighted-mean loss over an embedding block, ONE workgroup (the block is a few
-// hundred thousand elements; a second launch to fold partials would cost more than the serial tail)
-__global__ void __launch_bounds__(1024) weighted_sum_kernel(const float* __restrict__ a, const float* __restrict__ w, int64_t n, float scale,
-                                                            float* __restrict__ out) {
-    __shared__ float red[16];
+// out[0] = scale * sum_i a[i] * w[i]: the scalar of a weighted-mean loss over an embedding block.  64 workgroups leave partial sums in
+// a small workspace; the last one to arrive (agent-scope ticket) folds them in fixed order and re-arms the ticket -- one launch,
+// deterministic, ~5 us (a single workgroup walking the block took 27 us: pure load latency).
+constexpr int WS_BLOCKS = 64;
+__global__ void __launch_bounds__(256) weighted_sum_kernel(const float* __restrict__ a, const float* __restrict__ w, int64_t n, float scale,
+                                                           float* __restrict__ out, float* __restrict__ part, unsigned int* __restrict__ ticket) {
+    __shared__ float red[4];
+    __shared__ bool last;
     float s = 0.f;
     const int64_t n4 = n >> 2;
     const float4* a4 = reinterpret_cast<const float4*>(a);
     const float4* w4 = reinterpret_cast<const float4*>(w);
-    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 x = a4[i], y = w4[i];
         s = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, s))));
     }
-    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s = fmaf(a[i], w[i], s);
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s = fmaf(a[i], w[i], s);
     s = tg::wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
-        out[0] = t * scale;
+        __hip_atomic_store(part + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            float t2 = 0.f;
+            for (int i = 0; i < (int)gridDim.x; ++i) t2 += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[0] = t2 * scale;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch (stream order)
+        }
     }
 }
 extern "C" int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, float scale, float* d_out, void* stream) {
     TG_REQUIRE(d_a && d_w && d_out && n >= 0, "tg_weighted_sum: arguments");
     TG_REQUIRE(((reinterpret_cast<uintptr_t>(d_a) | reinterpret_cast<uintptr_t>(d_w)) & 15) == 0, "tg_weighted_sum: operands must be 16-byte aligned");
-    weighted_sum_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(d_a, d_w, n, scale, d_out);
+    // per-device workspace: WS_BLOCKS partial sums + the ticket (launches on one device are ordered by their stream; concurrent calls
+    // on two streams of one device would share it -- the callers are the trainers' single loss reduction per step)
+    static float* ws[16] = {};
+    int dev = 0;
+    TG_HIP_CHECK(hipGetDevice(&dev));
+    TG_REQUIRE(dev >= 0 && dev < 16, "tg_weighted_sum: device index");
+    if (!ws[dev]) {
+        TG_HIP_CHECK(hipMalloc(&ws[dev], sizeof(float) * (WS_BLOCKS + 4)));
+        TG_HIP_CHECK(hipMemset(ws[dev], 0, sizeof(float) * (WS_BLOCKS + 4)));
+    }
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(WS_BLOCKS, (n / 4 + 255) / 256));
+    weighted_sum_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(d_a, d_w, n, scale, d_out, ws[dev], reinterpret_cast<unsigned int*>(ws[dev] + WS_BLOCKS));
     return tg::launch_status("weighted_sum_kernel");
 }
 

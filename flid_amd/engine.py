@@ -356,7 +356,7 @@ class _NativeLayer:
         # scratch that lives only inside this call is kept across steps (grown on demand); saved activations are NOT cached:
         # a caller may run several forwards before one backward (positive + negative edges of the reference's trainers)
         sizes = (R * Dn, R * Dq, R * Dq, R * Dq if self.desc.res_dropout_p > 0 else 0, R * Dq, R * H * Dk, R * H * Dk, R * Dq,
-                 int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)) + Dq * H * Dk + H * Dk * Dn + 32)
+                 int(lib().tg_tgat_layer_part_floats(R, Dn, Dq, T)) + 32)
         total, offs = 0, []
         for n in sizes:
             offs.append(total)
@@ -435,12 +435,12 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH):
     every = [te_w, te_b, *layer_params]
     offs, npar = block_layout(every)
     H, Dk = cfg["num_heads"], Dn + cfg["edge_table"].shape[1] + T
-    vlen = _r4(Dq + H * Dk)                       # per layer: zero scratch of tg_tgat_layer_bwd (`vec`)
+    from ._lib import check, lib
+    vlen = _r4(int(lib().tg_tgat_layer_vec_floats(Dn, Dq, Dk, H)))      # per layer: zero scratch of tg_tgat_layer_bwd (`vec`)
     zeroed = torch.zeros(npar + _r4(T) + L * vlen, device=dev)
     d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar:npar + T]
     d_table = torch.zeros_like(table) if table_grad else None
     dH = dH.contiguous()
-    from ._lib import check, lib
     # The side streams (weight gradients) are joined ONCE, after the last layer: until then everything they read stays alive
     # (`alive`) and untouched (per-layer scratch), and nothing that lives on them is consumed.  Whatever happens in between
     # (an allocation failure, a TgError from a layer), the join runs before `alive` is released: queued side-stream products

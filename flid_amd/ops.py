@@ -332,6 +332,20 @@ def time_encode_bwd(t, mask_ids, w, b, g):
     return s[:dim], s[dim:]
 
 
+def wgrad_group(jobs):
+    """jobs: list of (A (rows, M), B (rows, N), C (M, N) accumulated into, colsum_A (M,) accumulated into or None); one launch"""
+    from ._lib import WgradJob
+    arr = (WgradJob * len(jobs))()
+    rows = jobs[0][0].shape[0]
+    for q, (a, b, c, cs) in zip(arr, jobs):
+        _chk(a, torch.float32, "A"); _chk(b, torch.float32, "B"); _chk(c, torch.float32, "C")
+        assert a.shape[0] == rows and b.shape[0] == rows and c.shape == (a.shape[1], b.shape[1])
+        q.A, q.lda, q.M, q.B, q.ldb, q.N = a.data_ptr(), _rowmajor_ld(a, "A"), a.shape[1], b.data_ptr(), _rowmajor_ld(b, "B"), b.shape[1]
+        q.C, q.ldc, q.colsum_A = c.data_ptr(), _rowmajor_ld(c, "C"), (None if cs is None else cs.data_ptr())
+    with _timed("gemm", rows):
+        check(lib().tg_wgrad_group(len(jobs), arr, rows, _stream()), "tg_wgrad_group")
+
+
 def weighted_sum(a: torch.Tensor, w: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None):
     """scale * sum(a * w) as a 1-element device tensor (one launch)"""
     _chk(a, torch.float32, "a"); _chk(w, torch.float32, "w")

@@ -151,10 +151,12 @@ typedef struct tg_layer_desc {
 } tg_layer_desc;
 /* backward: dout (R, dn) in; this layer's parameter gradients are ADDED into grads.* and into d_cosb / d_tew / d_teb (dt_dim)
  * with float atomics: the caller zeroes them (one fill for the whole gradient block of a step) -- as torch accumulates into
- * .grad.  vec (dq + heads * dk floats) must be zero on entry too.  dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional gradient
- * w.r.t. own (accumulated into if d_own_accumulate); d_raw (R, dn) optional gradient w.r.t. raw.
- * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats + dq*heads*dk +
- * heads*dk*dn + 32 floats for the merged projections' gradients). */
+ * .grad.  vec (tg_tgat_layer_vec_floats floats: column-sum scratch + the merged projections' gradients) must be zero on entry too.
+ * dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional gradient w.r.t. own (accumulated into if d_own_accumulate); d_raw
+ * (R, dn) optional gradient w.r.t. raw.
+ * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats floats of slabs).
+ * All weight / bias gradients of the layer leave in 2-3 grouped launches (tg_wgrad_group) on the side streams;
+ * tg_set_wgrad_grouped(0) restores one exact product + one column sum per gradient (A/B tests). */
 typedef struct tg_layer_bwd_desc {
     tg_layer_grads grads;
     const float* dout;
@@ -169,6 +171,8 @@ typedef struct tg_layer_bwd_desc {
 int tg_tgat_layer_fwd(const tg_layer_desc* layer, void* stream);
 int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk);
 int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim);
+int64_t tg_tgat_layer_vec_floats(int dn, int dq, int dk, int heads);
+void tg_set_wgrad_grouped(int on);
 int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, void* stream);
 /* weight-gradient products of tg_tgat_layer_bwd go to an internal side stream and are issued by an internal helper thread
  * (default, on = 1); both are joined before the call returns.  on = 3: side stream, launches issued by the calling thread;
@@ -194,6 +198,20 @@ int tg_time_bias_finish(float* d_teb, const float* d_b, const float* d_cosb, int
 /* d_out[0] = scale * sum_i d_a[i] * d_w[i]  (the scalar of a weighted-mean loss over an embedding block; the fused trainers'
  * stand-in for the reduction of PTCL/EM_warmup.py:222 / M_step.py:297-306).  Operands 16-byte aligned. */
 int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, float scale, float* d_out, void* stream);
+
+/* ---- grouped weight gradients (split-bf16 MFMA) ------------------------------------------------------
+ * replaces the autograd weight / bias gradients of the nn.Linear layers in models/modules.py:54-69,152-163,235 for one layer:
+ * up to 6 products C_j[M_j, N_j] += A_j^T B_j over the same `rows` (A_j: rows x M_j, B_j: rows x N_j, row-major) in ONE launch;
+ * colsum_A_j[M_j] += column sums of A_j when non-NULL (the bias gradient: A_j is the gradient of the layer's output).
+ * C_j and colsum_A_j are ACCUMULATED into with float atomics (zero them, or pass a running gradient).  M_j, N_j, lda, ldb
+ * multiples of 4, operands 16-byte aligned; returns TG_EINVAL for other shapes (use tg_gemm_f32 + tg_colsum). */
+typedef struct tg_wgrad_job {
+    const float* A; int64_t lda; int M;
+    const float* B; int64_t ldb; int N;
+    float* C; int64_t ldc;
+    float* colsum_A;
+} tg_wgrad_job;
+int tg_wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, void* stream);
 
 /* ---- synthetic feature tables (measurement only) ---------------------------
  * out[r, c] = f(row0 + r, c, seed), uniform with unit variance, row 0 = 0; the stand-in for the node / edge feature blobs

@@ -508,3 +508,44 @@ def test_attention_pipelined_kernels_match_generic(shape):
     for x, y, name in zip(out[0], out[7], ("agg", "prob", "du", "dfeat", "dw", "db")):
         scale = float(x.abs().max()) + 1e-12
         assert float((x - y).abs().max()) <= 2e-5 * scale, (name, float((x - y).abs().max()), scale)
+
+
+def test_weighted_sum_loss_reduction():
+    from flid_amd import ops
+    torch.manual_seed(3)
+    for n in (7, 1024, 206400, 206403):
+        a, w = torch.randn(n, device="cuda:0"), torch.randn(n, device="cuda:0")
+        for _ in range(3):                                  # the ticket re-arms itself between launches
+            got = float(ops.weighted_sum(a, w, 0.25))
+        ref = float((a.double() * w.double()).sum()) * 0.25
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)) + 1e-6 * float((a.double() * w.double()).abs().sum())
+
+
+@pytest.mark.parametrize("rows", [1200, 13622, 333])
+def test_grouped_weight_gradients_vs_fp64(rows):
+    """tg_wgrad_group: several C_j += A_j^T B_j over the same rows in one launch (split-bf16 MFMA, K split folded with float
+    atomics), bias gradients through the ones column; against float64, accumulating into non-zero C"""
+    from flid_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(rows)
+    f = lambda *s: torch.randn(*s, device=dev)
+    dout, f1, df1, y, raw = f(rows, 172), f(rows, 172), f(rows, 172), f(rows, 272), f(rows, 172)
+    dres, agg = f(rows, 272), f(rows, 888)
+    W1 = f(172, 444)                              # the two W1 jobs write column blocks of one matrix (ldc = 444)
+    W2, b2, b1, dV, br = f(172, 172), f(172), f(172), f(272, 888), f(272)
+    ref = dict(W2=W2.double() + dout.double().T @ f1.double(), b2=b2.double() + dout.double().sum(0),
+               W1=W1.double() + torch.cat([df1.double().T @ y.double(), df1.double().T @ raw.double()], 1), b1=b1.double() + df1.double().sum(0),
+               dV=dV.double() + dres.double().T @ agg.double(), br=br.double() + dres.double().sum(0))
+    ops.wgrad_group([(dout, f1, W2, b2), (df1, y, W1[:, :272], b1), (df1, raw, W1[:, 272:], None), (dres, agg, dV, br)])
+    for name, got in (("W2", W2), ("b2", b2), ("W1", W1), ("b1", b1), ("dV", dV), ("br", br)):
+        mag = float(ref[name].abs().max())
+        err = float((got.double() - ref[name]).abs().max())
+        assert err <= 3e-5 * mag, (name, err, mag)
+    # strided head blocks (the attention block's per-head gradients)
+    q, du = f(rows, 272), f(rows, 888)
+    Wk = torch.zeros(272, 444, device=dev)
+    ops.wgrad_group([(q[:, :136], du[:, :444], Wk[:136], None), (q[:, 136:], du[:, 444:], Wk[136:], None)])
+    refk = torch.cat([q[:, :136].double().T @ du[:, :444].double(), q[:, 136:].double().T @ du[:, 444:].double()])
+    assert float((Wk.double() - refk).abs().max()) <= 3e-5 * float(refk.abs().max())
+    with pytest.raises(Exception):
+        ops.wgrad_group([(f(rows, 10), f(rows, 6), torch.zeros(10, 6, device=dev), None)])          # widths not multiples of 4

@@ -46,8 +46,13 @@ def main():
             a, b = idx[-3], idx[-2]
             t0 = rows[a][2]
             print(f"--- one step: {(rows[b][2] - t0) / 1e3:.1f} us, {b - a} dispatches")
+            busy, last_end = {}, {}
             for r in rows[a + 1:b + 1]:
-                print(f"{(r[1] - t0) / 1e3:9.1f} {(r[2] - r[1]) / 1e3:7.1f} q{r[3]} s{r[4]} g{r[5]:>7} v{r[7]:>3} {short(r[0], 70)}")
+                gap = (r[1] - last_end[r[4]]) / 1e3 if r[4] in last_end else 0.0
+                last_end[r[4]] = r[2]
+                busy[r[4]] = busy.get(r[4], 0) + (r[2] - r[1])
+                print(f"{(r[1] - t0) / 1e3:9.1f} {(r[2] - r[1]) / 1e3:7.1f} gap{gap:7.1f} q{r[3]} s{r[4]} g{r[5]:>7} v{r[7]:>3} {short(r[0], 70)}")
+            print("busy us per stream:", {k: round(v / 1e3, 1) for k, v in busy.items()})
 
 
 if __name__ == "__main__":
