@@ -10,16 +10,29 @@ __version__ = "0.1.0"
 
 
 def install(prefix_models: str = "models", prefix_utils: str = "utils"):
-    """Alias this package's mirrors under the reference's import names (`from models.TGAT import TGAT`, ...)."""
+    """Alias this package's mirrors under the reference's import names (`from models.TGAT import TGAT`, `from utils.utils import
+    get_neighbor_sampler`, ...) so that the reference's trainers run on the HIP engine unchanged.
+
+    Only the five hot-path modules are replaced: models.TGAT, models.MemoryModel, models.DyGFormer, models.modules, utils.utils.
+    If a package named `models` / `utils` is importable (the reference checkout on sys.path) it is KEPT as the holder, so that
+    everything else the trainers import keeps resolving to the reference's own files -- `from models.TCL import TCL`,
+    `from models.GraphMixer import GraphMixer` (PTCL/EM_init.py:3-4), `utils.metrics`, `utils.EarlyStopping`, `utils.load_configs` --
+    and those, importing `models.modules` / `utils.utils` in turn (models/TCL.py:5-6), get the mirrors.  Without such a package an
+    empty holder is created.  Call before the first `import models...` of the host program."""
     import importlib
     import types
 
     for pkg, subs in ((prefix_models, ("TGAT", "MemoryModel", "DyGFormer", "modules")), (prefix_utils, ("utils",))):
         src_pkg = "flid_amd.models" if pkg == prefix_models else "flid_amd.utils"
         holder = sys.modules.get(pkg)
-        if holder is None:
-            holder = types.ModuleType(pkg)
-            holder.__path__ = []
+        if holder is None or holder.__name__.startswith("flid_amd"):
+            try:
+                holder = importlib.import_module(pkg)              # the host program's own package, if there is one
+                if getattr(holder, "__name__", "").startswith("flid_amd"):
+                    raise ImportError
+            except Exception:
+                holder = types.ModuleType(pkg)
+                holder.__path__ = []
             sys.modules[pkg] = holder
         for s in subs:
             mod = importlib.import_module(f"{src_pkg}.{s}")

@@ -72,12 +72,14 @@ SIGNATURES = {
     "tg_attn_bwd_parts": (C.c_int, [c_i64]),
     "tg_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_void, c_i64, c_void, c_void]),
     "tg_set_attn_fast": (None, [C.c_int]),
+    "tg_attn_dropped_scores": (C.c_int, [c_void, c_i64, C.c_int, C.c_int, c_f32, C.c_uint64, c_void, c_void]),
     "tg_set_overlap": (None, [C.c_int]),
     "tg_tgat_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), c_void]),
     "tg_tgat_layer_wt_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
     "tg_tgat_layer_part_floats": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
     "tg_tgat_layer_vec_floats": (c_i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "tg_set_wgrad_grouped": (None, [C.c_int]),
+    "tg_set_merged_min_rows": (None, [c_i64]),
     "tg_side_join": (C.c_int, [c_void]),
     "tg_set_layer_merged": (None, [C.c_int]),
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),

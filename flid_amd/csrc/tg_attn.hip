@@ -11,6 +11,8 @@
 // dk floats is read as 16-byte chunks, lane l owning chunks l, l+64, ...  (688-B table rows -> 43 chunks).
 #include <math.h>
 
+#include <algorithm>
+
 #include "tg_common.h"
 
 namespace {
@@ -576,6 +578,26 @@ extern "C" int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg
 extern "C" int tg_attn_bwd_parts(int64_t m) { return (int)attn_grid(m); }
 
 extern "C" void tg_set_attn_fast(int mask) { g_fast = mask; }
+
+namespace {
+__global__ void __launch_bounds__(256) dropped_scores_kernel(const float* __restrict__ prob, int64_t m, int heads, int k, float p, uint64_t seed,
+                                                             float* __restrict__ out) {
+    const int64_t total = m * heads * k;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % k), h = (int)((i / k) % heads);
+        out[i] = prob[i] * tg::dropout_keep_scale(seed, i / ((int64_t)k * heads), h, s, p);
+    }
+}
+}  // namespace
+
+extern "C" int tg_attn_dropped_scores(const float* d_prob, int64_t m, int heads, int k, float dropout_p, uint64_t seed, float* d_out,
+                                      void* stream) {
+    TG_REQUIRE(d_prob && d_out && m >= 0 && heads > 0 && k > 0, "tg_attn_dropped_scores: arguments");
+    if (m == 0) return TG_OK;
+    const int64_t total = m * heads * k;
+    dropped_scores_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, tg::kMaxGridBlocks), 256, 0, (hipStream_t)stream>>>(d_prob, m, heads, k, dropout_p, seed, d_out);
+    return tg::launch_status("dropped_scores_kernel");
+}
 
 extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
                            const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, int64_t pad_feat_row,

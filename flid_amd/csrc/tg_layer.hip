@@ -477,7 +477,7 @@ bool g_issue_thread = true;
 bool g_merged = true;      // merged projections (merge_weights_kernel); false = the reference's four separate products per layer
 // the weight-space work of the merged form (one merge kernel forward, ~6 small launches backward) is a fixed cost per layer call:
 // it pays from a few thousand rows on (TGAT layer 1: 12 k rows), not for the 1 200-row root layer or a TGN batch
-constexpr int64_t kMergedMinRows = 4096;
+int64_t kMergedMinRows = 4096;
 SideStream g_side;
 bool g_overlap = true;
 bool g_wgrad_grouped = true;   // tg_wgrad_group for a layer's weight gradients; false = one exact product + one column sum per gradient
@@ -804,3 +804,4 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
 extern "C" void tg_set_overlap(int on) { g_overlap = (on & 1) != 0; g_issue_thread = (on & 2) == 0; }
 extern "C" void tg_set_layer_merged(int on) { g_merged = on != 0; }
 extern "C" void tg_set_wgrad_grouped(int on) { g_wgrad_grouped = on != 0; }
+extern "C" void tg_set_merged_min_rows(int64_t rows) { kMergedMinRows = rows; }

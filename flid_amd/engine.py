@@ -80,9 +80,15 @@ class Frontier:
     S: tuple                          # (nbr i32, eid i32, t f32, dt f32) each (R_1, k): slot lists of levels 0..L-1
     child: Optional[torch.Tensor]     # int32 (R_2 * k,) row index of each slot's node, for levels 0..L-2 (None if L == 1)
     pad_rows: List[int] = field(default_factory=list)   # per level d+1: the shared row of the padding pair (0, 0.0), or -1
+    # layer -> its own slot lists (random sampling strategies: the reference draws a FRESH sample for the same root at every layer
+    # of its recursion, models/TGAT.py:94,104, so the layers cannot share the level-0 lists); None = S serves every layer
+    S_layers: Optional[dict] = None
 
     def rows(self, upto_level: int) -> int:
         return sum(self.counts[:upto_level + 1])
+
+    def S_at(self, layer: int) -> tuple:
+        return self.S if self.S_layers is None else self.S_layers[layer]
 
 
 def sample_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torch.Tensor, k: int, num_layers: int,
@@ -115,6 +121,52 @@ def sample_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: torc
                     child=torch.cat(child_parts) if child_parts else None, pad_rows=pad_rows)
 
 
+def frontier_from_host_sampler(sampler, ids: np.ndarray, times: np.ndarray, k: int, num_layers: int, dev, groups=None) -> Frontier:
+    """Frontier of the `uniform` / `time_interval_aware` strategies: the neighbor lists come from the sampler mirror's numpy path,
+    which consumes numpy's RandomState stream exactly as the reference does (utils/utils.py:176-199), in the reference's CALL ORDER:
+    compute_node_temporal_embeddings(ids, L) first recurses for the node's own lower-layer embedding (which samples at the lower
+    layers), THEN samples at its own layer, then recurses for the sampled neighbors (models/TGAT.py:94,104,110) -- and
+    compute_src_dst... does all of that for the sources before the destinations (`groups` = row ranges processed one after the
+    other, default one group).  Rows are not shared (an embedding is no longer a function of (node, time) alone)."""
+    if num_layers > 2:
+        raise NotImplementedError("random sampling strategies: the device engine lays out at most 2 layers of independent samples")
+    ids = np.asarray(ids, dtype=np.int64)
+    times = np.asarray(times)
+    n = len(ids)
+    groups = groups or [(0, n)]
+
+    def draw(node_ids, t):
+        nb, ne, nt = sampler.get_historical_neighbors(node_ids, t, k)
+        dt = (np.asarray(t)[:, None] - nt).astype(np.float32)               # TGAT.py:120 (float64 - float32, or float32 - float32)
+        return nb.astype(np.int32), ne.astype(np.int32), nt.astype(np.float32), dt
+
+    def stack(parts):
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(4))
+
+    if num_layers == 1:
+        host = {1: stack([draw(ids[a:b], times[a:b]) for a, b in groups])}
+        counts, ids_all, child = [n], ids.astype(np.int32), None
+    else:
+        own, top, below = [], [], []
+        for a, b in groups:
+            own.append(draw(ids[a:b], times[a:b]))                              # layer-1 sample of the roots (the `own` recursion)
+            t2 = draw(ids[a:b], times[a:b])                                     # layer-2 sample of the same roots: a fresh draw
+            top.append(t2)
+            below.append(draw(t2[0].reshape(-1).astype(np.int64), t2[2].reshape(-1)))   # layer-1 sample of the layer-2 neighbors
+        top_s, own_s, below_s = stack(top), stack(own), stack(below)
+        host = {2: top_s, 1: tuple(np.concatenate([own_s[i], below_s[i]]) for i in range(4))}
+        counts = [n, n * k]
+        ids_all = np.concatenate([ids.astype(np.int32), top_s[0].reshape(-1)])
+        child = np.arange(n, n + n * k, dtype=np.int32)
+    flat = [ids_all] + ([child] if child is not None else []) + [a for l in sorted(host) for a in host[l]]
+    devs = ops.h2d(flat, dev)
+    ids_d = devs[0]
+    child_d = devs[1] if child is not None else None
+    rest = devs[2:] if child is not None else devs[1:]
+    S_layers = {l: tuple(rest[4 * i:4 * i + 4]) for i, l in enumerate(sorted(host))}
+    return Frontier(counts=counts, ids_all=ids_d, S=S_layers[num_layers], child=child_d, pad_rows=[-1] * (num_layers - 1), S_layers=S_layers)
+
+
 class _EmbedFn(torch.autograd.Function):
     """One autograd node for the whole L-layer embedding.  Inputs after the fixed ones: te_w, te_b, then per layer the
     7 attention + 4 merge parameters, then (optionally) the layer-0 base table when it carries gradient (TGN)."""
@@ -128,7 +180,6 @@ class _EmbedFn(torch.autograd.Function):
         Dn, T = table.shape[1], te_w.numel()
         Dq = Dn + T
         hd = Dq // H
-        S_nbr, S_eid, S_t, S_dt = fr.S
         st = _Ctx(n=n, k=k)
         st.table = table
         st.table_grad = cfg["table_grad"]
@@ -143,6 +194,7 @@ class _EmbedFn(torch.autograd.Function):
         for l in range(1, L + 1):
             Wq, Wk, Wv, ln_g, ln_b, Wr, br, W1, b1, W2, b2 = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
             R = fr.rows(L - l)
+            S_nbr, S_eid, S_t, S_dt = fr.S_at(l)
             lc = _LayerCtx(R=R)
             lc.raw = ops.gather_rows(table, ids_all[:R])
             lc.own = lc.raw if l == 1 else H_prev[:R]
@@ -402,7 +454,6 @@ def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
     dev = table.device
     Dn, T = table.shape[1], te_w.numel()
     hd = (Dn + T) // H
-    S_nbr, S_eid, S_t, S_dt = fr.S
     te_w_flat = te_w.reshape(-1)
     cosb = ops.time_encode(_zero1(dev), te_w_flat, te_b).reshape(-1)
     p_eff = p_drop if training else 0.0
@@ -410,6 +461,7 @@ def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
     for l in range(1, L + 1):
         params = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
         R = fr.rows(L - l)
+        S_nbr, S_eid, S_t, S_dt = fr.S_at(l)
         raw = ops.gather_rows(table, fr.ids_all[:R])
         own = raw if l == 1 else H_prev[:R]
         feat, feat_idx = (table, S_nbr[:R].reshape(-1)) if l == 1 else (H_prev, fr.child[:R * k])
@@ -693,7 +745,7 @@ def prepare_frontier(graph: TemporalGraph, ids_dev: torch.Tensor, times_dev: tor
 
 def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, te_w, te_b, layer_params, ids: np.ndarray,
           times: np.ndarray, k: int, num_layers: int, num_heads: int, dropout: float, training: bool,
-          table_requires_grad: bool = False, flat=None):
+          table_requires_grad: bool = False, flat=None, host_sampler=None, groups=None):
     """H^L for `ids` at `times` (host numpy in, device tensor out, autograd-connected to the parameters).
     `ids` may also be a PreparedFrontier (prepare_frontier): the neighbor lookups of that batch were already done."""
     dev = table.device
@@ -721,7 +773,12 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
         return torch.zeros((0, table.shape[1]), device=dev)
     if num_layers == 0:
         return ops.gather_rows(table, ids_dev)
-    fr = sample_frontier(graph, ids_dev, times_dev, k, num_layers, dedupe=DEDUPE)
+    if host_sampler is not None:          # uniform / time_interval_aware: numpy RandomState stream on the host, kernels unchanged
+        if torch.is_tensor(ids):
+            ids, times = ids.cpu().numpy(), times.cpu().numpy()
+        fr = frontier_from_host_sampler(host_sampler, ids, times, k, num_layers, dev, groups)
+    else:
+        fr = sample_frontier(graph, ids_dev, times_dev, k, num_layers, dedupe=DEDUPE)
     cfg = dict(n=n, k=k, num_layers=num_layers, num_heads=num_heads, dropout=float(dropout), training=bool(training),
                edge_table=edge_table, table_grad=bool(table_requires_grad))
     return _apply(cfg, fr, table, te_w, te_b, layer_params, flat)

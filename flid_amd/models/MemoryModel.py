@@ -249,10 +249,13 @@ class MemoryModel(torch.nn.Module):
         lo, hi = (0, len(src_node_ids)) if shard is None else shard
         emb_ids = np.concatenate([src_node_ids[lo:hi], dst_node_ids[lo:hi]])
         emb_t = np.concatenate([node_interact_times[lo:hi], node_interact_times[lo:hi]])
-        emb = engine.embed(self.embedding_module.neighbor_sampler.graph, base, self.edge_raw_features,
+        smp = self.embedding_module.neighbor_sampler
+        emb = engine.embed(smp.graph, base, self.edge_raw_features,
                            self.time_encoder.w.weight, self.time_encoder.w.bias, self.embedding_module.layer_params(),
                            emb_ids, emb_t, num_neighbors, self.num_layers,
-                           self.num_heads, self.dropout, self.training, table_requires_grad=torch.is_grad_enabled())
+                           self.num_heads, self.dropout, self.training, table_requires_grad=torch.is_grad_enabled(),
+                           host_sampler=(None if smp.sample_neighbor_strategy == "recent" else smp),      # random strategies: host RNG
+                           groups=None)
         src_emb, dst_emb = engine.split_rows(emb, hi - lo)
         if edges_are_positive:
             assert edge_ids is not None

@@ -80,7 +80,7 @@ class TGAT(nn.Module):
         else:
             ids = np.concatenate([src_node_ids, dst_node_ids])
             times = np.concatenate([node_interact_times, node_interact_times])
-        emb = self.compute_node_temporal_embeddings(ids, times, self.num_layers, num_neighbors)
+        emb = self.compute_node_temporal_embeddings(ids, times, self.num_layers, num_neighbors, _groups=[(0, nsrc), (nsrc, len(ids))])
         return engine.split_rows(emb, nsrc)
 
     def prepare_batch(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20):
@@ -126,21 +126,24 @@ class TGAT(nn.Module):
         return engine.forward_backward(cfg, pf.frontier, self.node_raw_features, flat, loss_fn)
 
     def compute_node_temporal_embeddings(self, node_ids: np.ndarray, node_interact_times: np.ndarray,
-                                         current_layer_num: int, num_neighbors: int = 20):
+                                         current_layer_num: int, num_neighbors: int = 20, _groups=None):
         assert current_layer_num >= 0
-        if self.neighbor_sampler.sample_neighbor_strategy != "recent":
-            raise NotImplementedError("the device path samples 'recent' neighbors (the FLiD default, load_configs.py:115); "
-                                      "uniform / time_interval_aware are host-RNG strategies")
+        # 'recent' (the FLiD default, load_configs.py:115) is sampled on the device.  'uniform' / 'time_interval_aware' draw from
+        # numpy's RandomState on the host in the reference's order (bit-exact neighbor choice), the kernels are the same.
+        host_sampler = None if self.neighbor_sampler.sample_neighbor_strategy == "recent" else self.neighbor_sampler
+        if host_sampler is not None and isinstance(node_ids, engine.PreparedFrontier):
+            raise NotImplementedError("prepared batches are device-sampled ('recent')")
         flat = getattr(self, "_flat_pack", None)
         if flat is not None and current_layer_num == self.num_layers and torch.is_grad_enabled():
             views = flat[1]
             return engine.embed(self.neighbor_sampler.graph, self.node_raw_features, self.edge_raw_features, views[0], views[1],
                                 views[2:], node_ids, node_interact_times, num_neighbors, current_layer_num, self.num_heads,
-                                self.dropout, self.training, flat=flat)
+                                self.dropout, self.training, flat=flat, host_sampler=host_sampler, groups=_groups)
         params = self._layer_params()[:11 * current_layer_num]
         return engine.embed(self.neighbor_sampler.graph, self.node_raw_features, self.edge_raw_features,
                             self.time_encoder.w.weight, self.time_encoder.w.bias, params, node_ids, node_interact_times,
-                            num_neighbors, current_layer_num, self.num_heads, self.dropout, self.training)
+                            num_neighbors, current_layer_num, self.num_heads, self.dropout, self.training,
+                            host_sampler=host_sampler, groups=_groups)
 
     def set_neighbor_sampler(self, neighbor_sampler: NeighborSampler):
         self.neighbor_sampler = neighbor_sampler

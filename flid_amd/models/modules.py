@@ -27,12 +27,18 @@ class _LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         if y is not None:
             dy2 = ops.relu_bwd_(dy2.clone(), y)
-        dx = torch.empty_like(x2)
-        ops.gemm(dy2, w, dx)
-        dw = torch.empty_like(w)
-        ops.gemm(dy2, x2, dw, ta=True)
-        db = ops.colsum(dy2) if ctx.has_bias else None
-        return dx.reshape(ctx.shape), dw, db, None
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = None
+        if need_x:                                   # (raw-feature projections have no input gradient: skip the product)
+            dx = torch.empty_like(x2)
+            ops.gemm(dy2, w, dx)
+            dx = dx.reshape(ctx.shape)
+        if need_w:
+            dw = torch.empty_like(w)
+            ops.gemm(dy2, x2, dw, ta=True)
+        if need_b:
+            db = ops.colsum(dy2)
+        return dx, dw, db, None
 
 
 def linear(x, w, b=None, relu=False):
@@ -102,6 +108,131 @@ class MLPClassifier(nn.Module):
         return linear(x, self.fc3.weight, self.fc3.bias)
 
 
+class MLPClassifier_BN(nn.Module):
+    """decoder head with batch norm (reference models/modules.py:99-123; PTCL/EM_init.py:55-60 builds it for --emodel mlp_bn).
+    Caller-side: HIP GEMMs, torch BatchNorm1d / Dropout."""
+
+    def __init__(self, input_dim: int, dropout: float = 0.1, num_classes: int = 1):
+        super().__init__()
+        self.fc1 = nn.Linear(input_dim, 80)
+        self.bn1 = nn.BatchNorm1d(80)
+        self.fc2 = nn.Linear(80, 10)
+        self.bn2 = nn.BatchNorm1d(10)
+        self.fc3 = nn.Linear(10, num_classes)
+        self.act = nn.ReLU()
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x: torch.Tensor):
+        x = self.dropout(self.act(self.bn1(linear(x, self.fc1.weight, self.fc1.bias))))
+        x = self.dropout(self.act(self.bn2(linear(x, self.fc2.weight, self.fc2.bias))))
+        return linear(x, self.fc3.weight, self.fc3.bias)
+
+
+class TransformerEncoder(nn.Module):
+    """post-LN encoder block of the reference's TCL backbone (models/modules.py:248-312).  TCL is outside the accelerated path
+    (SURVEY 8f-4); the class is provided so that `from models.modules import TimeEncoder, TransformerEncoder` (models/TCL.py:5)
+    resolves after flid_amd.install().  Parameter names / shapes as the reference's (nn.MultiheadAttention inside); the two
+    feed-forward products run on the HIP GEMM, the attention itself is torch's."""
+
+    def __init__(self, attention_dim: int, num_heads: int, dropout: float = 0.1):
+        super().__init__()
+        self.multi_head_attention = nn.MultiheadAttention(embed_dim=attention_dim, num_heads=num_heads, dropout=dropout)
+        self.dropout = nn.Dropout(dropout)
+        self.linear_layers = nn.ModuleList([nn.Linear(attention_dim, 4 * attention_dim), nn.Linear(4 * attention_dim, attention_dim)])
+        self.norm_layers = nn.ModuleList([nn.LayerNorm(attention_dim), nn.LayerNorm(attention_dim)])
+
+    def forward(self, inputs_query: torch.Tensor, inputs_key: torch.Tensor = None, inputs_value: torch.Tensor = None,
+                neighbor_masks: np.ndarray = None):
+        if inputs_key is None or inputs_value is None:
+            assert inputs_key is None and inputs_value is None
+            inputs_key = inputs_value = inputs_query
+        pad = None if neighbor_masks is None else (torch.from_numpy(neighbor_masks).to(inputs_query.device) == 0)
+        att = self.multi_head_attention(query=inputs_query.transpose(0, 1), key=inputs_key.transpose(0, 1),
+                                        value=inputs_value.transpose(0, 1), key_padding_mask=pad)[0].transpose(0, 1)
+        out = self.norm_layers[0](inputs_query + self.dropout(att))
+        ff = linear(self.dropout(linear(out, self.linear_layers[0].weight, self.linear_layers[0].bias, relu=True)),
+                    self.linear_layers[1].weight, self.linear_layers[1].bias)
+        return self.norm_layers[1](out + self.dropout(ff))
+
+
+class _StandaloneAttnFn(torch.autograd.Function):
+    """MultiHeadAttention.forward on materialised inputs, on the same gather-fused kernels the backbones use: the neighbor rows
+    are handed over as tables with identity indices (node rows | [edge | time-feature] rows, dt_dim = 0), the query side runs on the
+    HIP GEMMs.  Differentiable w.r.t. all five inputs and the seven parameters (the golden `attention.npz` pins all of them)."""
+
+    @staticmethod
+    def forward(ctx, node, ntime, nbr, nbrt, nbre, Wq, Wk, Wv, ln_g, ln_b, Wr, br, masks, heads, p_drop, training):
+        n, k, dn = nbr.shape
+        de, T = nbre.shape[2], nbrt.shape[2]
+        dq, dk, dev = dn + T, dn + de + T, node.device
+        hd = dq // heads
+        x = torch.cat([node, ntime.reshape(n, T)], dim=1).contiguous()                    # query = residual (modules.py:183)
+        q = torch.empty((n, dq), device=dev)
+        ops.gemm(x, Wq, q, tb=True)
+        u = torch.empty((n, heads, dk), device=dev)                                       # u_h = Wk_h^T q_h
+        ops.gemm_batched(q[:, :hd], Wk[:hd], u[:, 0, :], heads, hd, hd * dk, dk)
+        feat = nbr.reshape(n * k, dn).contiguous()
+        et = torch.cat([nbre, nbrt], dim=2).reshape(n * k, de + T).contiguous()           # [edge | time features] as the "edge" rows
+        ident = torch.arange(n * k, dtype=torch.int32, device=dev)
+        ids = torch.from_numpy(np.ascontiguousarray(masks).astype(np.int32)).to(dev).reshape(-1)
+        seeds = _seeds(2) if (training and p_drop > 0) else [0, 0]
+        zero = torch.zeros(n * k, device=dev)
+        a = ops.AttnArgs(feat, ident, et, ident, ids, zero, None, None, k, heads, hd ** -0.5, p_drop if training else 0.0, seeds[0])
+        agg, prob = ops.attn_fwd(a, u)
+        ctxv = torch.empty((n, dq), device=dev)
+        ops.gemm_batched(agg[:, 0, :], Wv[:hd], ctxv[:, :hd], heads, dk, hd * dk, hd, tb=True)
+        res = torch.empty((n, dq), device=dev)
+        ops.gemm(ctxv, Wr, res, tb=True, bias=br)
+        drop = None
+        if training and p_drop > 0:
+            drop = (torch.rand_like(res) >= p_drop).to(torch.float32) / (1.0 - p_drop)
+            res = res * drop
+        y, mean, rstd = ops.add_layernorm_fwd(res, x, ln_g, ln_b)
+        scores = prob if not (training and p_drop > 0) else ops.attn_dropped_scores(a, prob)
+        ctx.args, ctx.dims = a, (n, k, dn, de, T, heads)
+        ctx.save_for_backward(x, q, u, agg, prob, ctxv, res, drop, mean, rstd, Wq, Wk, Wv, ln_g, Wr)
+        ctx.mark_non_differentiable(scores)
+        return y, scores
+
+    @staticmethod
+    def backward(ctx, dy, _):
+        x, q, u, agg, prob, ctxv, res, drop, mean, rstd, Wq, Wk, Wv, ln_g, Wr = ctx.saved_tensors
+        n, k, dn, de, T, heads = ctx.dims
+        dq, dk, dev = dn + T, dn + de + T, dy.device
+        hd = dq // heads
+        dsum, dg, dbeta = ops.add_layernorm_bwd(res, x, dy.contiguous(), ln_g, mean, rstd)
+        dres = dsum * drop if drop is not None else dsum
+        dWr = torch.empty_like(Wr)
+        ops.gemm(dres, ctxv, dWr, ta=True)
+        dbr = ops.colsum(dres)
+        dctx = torch.empty((n, dq), device=dev)
+        ops.gemm(dres, Wr, dctx)
+        dagg = torch.empty((n, heads, dk), device=dev)
+        dWv = torch.empty_like(Wv)
+        ops.gemm_batched(dctx[:, :hd], Wv[:hd], dagg[:, 0, :], heads, hd, hd * dk, dk)
+        ops.gemm_batched(dctx[:, :hd], agg[:, 0, :], dWv[:hd], heads, hd, dk, hd * dk, ta=True)
+        dfeat = torch.zeros((n * k, dn), device=dev)
+        det = torch.zeros((n * k, de + T), device=dev)
+        du, _, _ = ops.attn_bwd(ctx.args, u, agg, prob, dagg, dfeat, -1, dedge=det)
+        dqq = torch.empty((n, dq), device=dev)
+        dWk = torch.empty_like(Wk)
+        ops.gemm_batched(du[:, 0, :], Wk[:hd], dqq[:, :hd], heads, dk, hd * dk, hd, tb=True)
+        ops.gemm_batched(q[:, :hd], du[:, 0, :], dWk[:hd], heads, hd, dk, hd * dk, ta=True)
+        dWq = torch.empty_like(Wq)
+        ops.gemm(dqq, x, dWq, ta=True)
+        dx = torch.empty((n, dq), device=dev)
+        ops.gemm(dqq, Wq, dx)
+        dx += dsum
+        det = det.reshape(n, k, de + T)
+        return (dx[:, :dn].contiguous(), dx[:, dn:].reshape(n, 1, T), dfeat.reshape(n, k, dn), det[:, :, de:].contiguous(),
+                det[:, :, :de].contiguous(), dWq, dWk, dWv, dg, dbeta, dWr, dbr, None, None, None, None)
+
+
+def _seeds(n):
+    from ..engine import _next_seeds
+    return _next_seeds(n)
+
+
 class MultiHeadAttention(nn.Module):
     """Parameter holder with the reference's names/shapes (models/modules.py:126-165).  The backbones run it through the
     gather-fused kernels (flid_amd/engine.py); forward() on materialised inputs uses the same kernels with identity
@@ -125,3 +256,14 @@ class MultiHeadAttention(nn.Module):
     def fused_params(self):
         return [self.query_projection.weight, self.key_projection.weight, self.value_projection.weight,
                 self.layer_norm.weight, self.layer_norm.bias, self.residual_fc.weight, self.residual_fc.bias]
+
+    def forward(self, node_features: torch.Tensor, node_time_features: torch.Tensor, neighbor_node_features: torch.Tensor,
+                neighbor_node_time_features: torch.Tensor, neighbor_node_edge_features: torch.Tensor, neighbor_masks: np.ndarray):
+        """stand-alone call on materialised inputs (reference modules.py:167-245): node (n, dn), node time (n, 1, T), neighbor node /
+        time / edge features (n, k, .), masks np (n, k) with 0 = padded.  Returns (output (n, dn + T), attention scores (n, H, k))."""
+        if not node_features.is_cuda:
+            raise RuntimeError("flid_amd.MultiHeadAttention runs on a ROCm device only; there is no CPU path")
+        f32 = lambda t: t.contiguous().float()
+        return _StandaloneAttnFn.apply(f32(node_features), f32(node_time_features), f32(neighbor_node_features),
+                                       f32(neighbor_node_time_features), f32(neighbor_node_edge_features), *self.fused_params(),
+                                       neighbor_masks, self.num_heads, float(self.dropout.p), bool(self.training))

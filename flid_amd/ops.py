@@ -181,7 +181,8 @@ class AttnArgs:
         self.keep = (feat, feat_idx, edge, edge_idx, nbr, dt, te_w, te_b)
         m = nbr.numel() // k
         self.m, self.k, self.heads = m, k, heads
-        self.dn, self.de, self.dt_dim = feat.shape[1], edge.shape[1], te_w.numel()
+        self.p, self.seed = float(dropout_p), int(seed)
+        self.dn, self.de, self.dt_dim = feat.shape[1], edge.shape[1], (0 if te_w is None else te_w.numel())
         self.dk = self.dn + self.de + self.dt_dim
         self.desc = AttnDesc(_p(feat), _rowmajor_ld(feat, "feat"), _p(feat_idx), _p(edge), _rowmajor_ld(edge, "edge"), _p(edge_idx),
                              _p(nbr), _p(dt), _p(te_w), _p(te_b), m, k, heads, self.dn, self.de, self.dt_dim,
@@ -197,6 +198,14 @@ def attn_fwd(args: AttnArgs, u: torch.Tensor):
     return agg, prob
 
 
+def attn_dropped_scores(args: AttnArgs, prob: torch.Tensor):
+    """the attention scores AFTER dropout (what the reference's MultiHeadAttention.forward returns, modules.py:224,242): prob times
+    the keep / rescale factor of the kernels' counter-based mask stream"""
+    out = torch.empty_like(prob)
+    check(lib().tg_attn_dropped_scores(_p(prob), args.m, args.heads, args.k, args.p, args.seed, _p(out), _stream()), "tg_attn_dropped_scores")
+    return out
+
+
 def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] = None, pad_row: int = -1,
              dedge: Optional[torch.Tensor] = None):
     """returns du, (dw, db) of the time encoder; adds the neighbor-feature gradient into dfeat rows (and the edge-row gradient into
@@ -204,11 +213,13 @@ def attn_bwd(args: AttnArgs, u, agg, prob, dagg, dfeat: Optional[torch.Tensor] =
     assert dagg.is_contiguous() and dagg.shape == u.shape
     du = torch.empty_like(u)
     parts = lib().tg_attn_bwd_parts(args.m)
-    part = torch.empty((parts, 2 * args.dt_dim), dtype=torch.float32, device=u.device)
+    part = torch.empty((parts, max(1, 2 * args.dt_dim)), dtype=torch.float32, device=u.device)
     with _timed("attn_bwd", args.m):
         check(lib().tg_attn_bwd(C.byref(args.desc), _p(u), _p(agg), _p(prob), _p(dagg), _p(du), _p(dfeat),
                                 0 if dfeat is None else _rowmajor_ld(dfeat, "dfeat"), int(pad_row), _p(dedge),
                                 0 if dedge is None else _rowmajor_ld(dedge, "dedge"), _p(part), _stream()), "tg_attn_bwd")
+    if args.dt_dim == 0:                     # no time segment in z (stand-alone MultiHeadAttention.forward): nothing to sum
+        return du, None, None
     dwb = colsum(part)
     return du, dwb[:args.dt_dim], dwb[args.dt_dim:]
 

@@ -4,12 +4,125 @@
 int64 / float32 arrays) and error behaviour, so the reference's trainers and its out-of-scope backbones (TCL, GraphMixer)
 keep working against it.  The in-scope backbones do not go through these numpy methods: they read `sampler.graph`
 (a flid_amd.graph.TemporalGraph) and sample on the device."""
+import random
 from typing import Optional
 
 import numpy as np
 import torch
+import torch.nn as nn
 
 from ..graph import TemporalGraph
+
+
+# ---- host glue the reference's trainers import from utils.utils (PTCL/trainer.py:12, PTCL/E_step.py:24-25, train.py:13) ----------
+def set_random_seed(seed: int = 0):
+    """seed python / numpy / torch (reference utils/utils.py:9-21)"""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+
+
+def convert_to_gpu(*data, device: str):
+    """`.to(device)` on every argument; one argument comes back bare, several as a tuple (reference utils/utils.py:24-38)"""
+    moved = tuple(item.to(device) for item in data)
+    return moved if len(moved) > 1 else moved[0]
+
+
+def get_parameter_sizes(model: nn.Module):
+    """number of trainable scalars (reference utils/utils.py:41-47)"""
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def create_optimizer(model: nn.Module, optimizer_name: str, learning_rate: float, weight_decay: float = 0.0):
+    """Adam / SGD / RMSprop over model.parameters() (reference utils/utils.py:50-68)"""
+    table = {"Adam": torch.optim.Adam, "SGD": torch.optim.SGD, "RMSprop": torch.optim.RMSprop}
+    if optimizer_name not in table:
+        raise ValueError(f"Wrong value for optimizer {optimizer_name}!")
+    return table[optimizer_name](params=model.parameters(), lr=learning_rate, weight_decay=weight_decay)
+
+
+class NegativeEdgeSampler(object):
+    """Negative destination sampling for the link-prediction warm-up (reference utils/utils.py:305-495): strategies "random"
+    (the trainers' choice, PTCL/EM_warmup.py:78-83), "historical" and "inductive".  Same constructor, attributes, method names and
+    numpy RandomState consumption order as the reference, so a seeded run draws the same negatives."""
+
+    def __init__(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray, interact_times: np.ndarray = None, last_observed_time: float = None,
+                 negative_sample_strategy: str = 'random', seed: int = None):
+        self.seed = seed
+        self.negative_sample_strategy = negative_sample_strategy
+        self.src_node_ids, self.dst_node_ids, self.interact_times = src_node_ids, dst_node_ids, interact_times
+        self.unique_src_node_ids = np.unique(src_node_ids)
+        self.unique_dst_node_ids = np.unique(dst_node_ids)
+        self.unique_interact_times = np.unique(interact_times)
+        self.earliest_time = min(self.unique_interact_times)
+        self.last_observed_time = last_observed_time
+        if negative_sample_strategy != 'random':
+            self.possible_edges = set((s, d) for s in self.unique_src_node_ids for d in self.unique_dst_node_ids)
+        if negative_sample_strategy == 'inductive':
+            self.observed_edges = self.get_unique_edges_between_start_end_time(self.earliest_time, self.last_observed_time)
+        if seed is not None:
+            self.random_state = np.random.RandomState(seed)
+
+    def reset_random_state(self):
+        self.random_state = np.random.RandomState(self.seed)
+
+    def get_unique_edges_between_start_end_time(self, start_time: float, end_time: float):
+        inside = np.logical_and(self.interact_times >= start_time, self.interact_times <= end_time)
+        return set(zip(self.src_node_ids[inside], self.dst_node_ids[inside]))
+
+    def sample(self, size: int, batch_src_node_ids: np.ndarray = None, batch_dst_node_ids: np.ndarray = None,
+               current_batch_start_time: float = 0.0, current_batch_end_time: float = 0.0):
+        if self.negative_sample_strategy == 'random':
+            return self.random_sample(size=size)
+        if self.negative_sample_strategy == 'historical':
+            return self.historical_sample(size, batch_src_node_ids, batch_dst_node_ids, current_batch_start_time, current_batch_end_time)
+        if self.negative_sample_strategy == 'inductive':
+            return self.inductive_sample(size, batch_src_node_ids, batch_dst_node_ids, current_batch_start_time, current_batch_end_time)
+        raise ValueError(f'Not implemented error for negative_sample_strategy {self.negative_sample_strategy}!')
+
+    def random_sample(self, size: int):
+        rng = np.random if self.seed is None else self.random_state
+        si = rng.randint(0, len(self.unique_src_node_ids), size)          # source indices are drawn first, then destinations
+        di = rng.randint(0, len(self.unique_dst_node_ids), size)
+        return self.unique_src_node_ids[si], self.unique_dst_node_ids[di]
+
+    def random_sample_with_collision_check(self, size: int, batch_src_node_ids: np.ndarray, batch_dst_node_ids: np.ndarray):
+        assert batch_src_node_ids is not None and batch_dst_node_ids is not None
+        free = list(self.possible_edges - set(zip(batch_src_node_ids, batch_dst_node_ids)))
+        assert len(free) > 0
+        pick = self.random_state.choice(len(free), size=size, replace=len(free) < size)
+        return np.array([free[i][0] for i in pick]), np.array([free[i][1] for i in pick])
+
+    def _from_pool(self, pool, size, batch_src_node_ids, batch_dst_node_ids):
+        """`size` negatives from the edge set `pool`, topped up with collision-checked random edges when the pool is too small
+        (the shared tail of the historical and inductive strategies)"""
+        ps = np.array([e[0] for e in pool])
+        pd = np.array([e[1] for e in pool])
+        if size > len(pool):
+            rs, rd = self.random_sample_with_collision_check(size - len(pool), batch_src_node_ids, batch_dst_node_ids)
+            ns, nd = np.concatenate([rs, ps]), np.concatenate([rd, pd])
+        else:
+            pick = self.random_state.choice(len(pool), size=size, replace=False)
+            ns, nd = ps[pick], pd[pick]
+        return ns.astype(np.longlong), nd.astype(np.longlong)       # (an empty operand makes concatenate return floats)
+
+    def historical_sample(self, size: int, batch_src_node_ids: np.ndarray, batch_dst_node_ids: np.ndarray,
+                          current_batch_start_time: float, current_batch_end_time: float):
+        assert self.seed is not None
+        past = self.get_unique_edges_between_start_end_time(self.earliest_time, current_batch_start_time)
+        now = self.get_unique_edges_between_start_end_time(current_batch_start_time, current_batch_end_time)
+        return self._from_pool(past - now, size, batch_src_node_ids, batch_dst_node_ids)
+
+    def inductive_sample(self, size: int, batch_src_node_ids: np.ndarray, batch_dst_node_ids: np.ndarray,
+                         current_batch_start_time: float, current_batch_end_time: float):
+        assert self.seed is not None
+        past = self.get_unique_edges_between_start_end_time(self.earliest_time, current_batch_start_time)
+        now = self.get_unique_edges_between_start_end_time(current_batch_start_time, current_batch_end_time)
+        return self._from_pool(past - self.observed_edges - now, size, batch_src_node_ids, batch_dst_node_ids)
 
 
 def _device():

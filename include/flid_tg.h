@@ -128,6 +128,9 @@ int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, con
                 const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, int64_t pad_feat_row,
                 float* d_dedge, int64_t dedge_ld, float* d_dte_part, void* stream);
 void tg_set_attn_fast(int mask);
+/* d_out (m, heads, k) = d_prob * keep-scale of the dropout stream (seed, row, head, slot) the attention kernels use: the scores
+ * AFTER dropout that models/modules.py:224,242 returns (callers of the backbones discard them). */
+int tg_attn_dropped_scores(const float* d_prob, int64_t m, int heads, int k, float dropout_p, uint64_t seed, float* d_out, void* stream);
 
 /* ---- one whole temporal-attention layer per call -----------------------------------------------------
  * replaces, per layer, models/modules.py:167-245 + :58-69 as called from models/TGAT.py:132-142 (and MemoryModel.py:703-713)
@@ -173,6 +176,7 @@ int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk);
 int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim);
 int64_t tg_tgat_layer_vec_floats(int dn, int dq, int dk, int heads);
 void tg_set_wgrad_grouped(int on);
+void tg_set_merged_min_rows(int64_t rows);   /* layers with at least this many rows take the merged projections (default 4096) */
 int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, void* stream);
 /* weight-gradient products of tg_tgat_layer_bwd go to an internal side stream and are issued by an internal helper thread
  * (default, on = 1); both are joined before the call returns.  on = 3: side stream, launches issued by the calling thread;

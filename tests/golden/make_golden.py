@@ -37,7 +37,7 @@ class Data:  # minimal stand-in used only as a record
 _stub.Data = Data
 sys.modules["utils.DataLoader"] = _stub
 
-from utils.utils import get_neighbor_sampler  # noqa: E402
+from utils.utils import get_neighbor_sampler, NegativeEdgeSampler  # noqa: E402
 from models.modules import TimeEncoder, MultiHeadAttention  # noqa: E402
 from models.TGAT import TGAT  # noqa: E402
 from models.MemoryModel import MemoryModel  # noqa: E402
@@ -118,6 +118,24 @@ def gold_sampler():
         a, b, c = nu.get_historical_neighbors(ids, qt, 5)
         out[f"{strat}R_n"] = a
     save("sampler", **out)
+
+
+def gold_neg_sampler():
+    """NegativeEdgeSampler (utils/utils.py:305-495): the draws of the three strategies for fixed seeds"""
+    src, dst, eid, t, num_rows = toy_graph(21, n_users=12, n_items=7, n_edges=120, isolated=0)
+    out = {"src": src, "dst": dst, "t": t}
+    half = len(src) // 2
+    for strat in ("random", "historical", "inductive"):
+        ns = NegativeEdgeSampler(src, dst, interact_times=t, last_observed_time=float(t[half]), negative_sample_strategy=strat, seed=3)
+        for call, (lo, hi) in enumerate(((60, 80), (80, 100), (100, 120))):
+            a, b = ns.sample(size=hi - lo, batch_src_node_ids=src[lo:hi], batch_dst_node_ids=dst[lo:hi],
+                             current_batch_start_time=float(t[lo]), current_batch_end_time=float(t[hi - 1]))
+            out[f"{strat}{call}_s"], out[f"{strat}{call}_d"] = np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)
+        ns.reset_random_state()
+        a, b = ns.sample(size=20, batch_src_node_ids=src[60:80], batch_dst_node_ids=dst[60:80],
+                         current_batch_start_time=float(t[60]), current_batch_end_time=float(t[79]))
+        out[f"{strat}R_s"], out[f"{strat}R_d"] = np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)
+    save("neg_sampler", **out)
 
 
 # ------------------------------------------------------------------------------------------------- time encoder
@@ -458,6 +476,7 @@ def gold_dyg_b600(num_edges=24000, lo=20000, seed=71, scale=0.04):
 
 
 FULL = {
+    "neg_sampler": gold_neg_sampler,
     "tgat_B600_full": lambda: run_tgat_b600("tgat_B600_full", seed=46, lo=20000, zero_node_feat=True, bias_te=False),
     # non-zero node features, trained-like time-encoder bias, ReLU units away from their kink: gradients comparable at 1e-4 max|g|
     "tgat_B600_kinkfree": lambda: run_tgat_b600("tgat_B600_kinkfree", seed=47, lo=25000, zero_node_feat=False, bias_te=True,

@@ -549,3 +549,32 @@ def test_grouped_weight_gradients_vs_fp64(rows):
     assert float((Wk.double() - refk).abs().max()) <= 3e-5 * float(refk.abs().max())
     with pytest.raises(Exception):
         ops.wgrad_group([(f(rows, 10), f(rows, 6), torch.zeros(10, 6, device=dev), None)])          # widths not multiples of 4
+
+
+def test_multihead_attention_forward_standalone_matches_reference_golden():
+    """flid_amd.models.modules.MultiHeadAttention.forward on materialised inputs (the fused kernels with identity indices) against
+    the reference's own output, attention scores, and gradients w.r.t. all five inputs and all parameters (attention.npz)"""
+    from conftest import assert_grads_match
+    from flid_amd.models.modules import MultiHeadAttention
+    g = load_golden("attention")
+    dn, de, dt, heads = [int(v) for v in g["dims"]]
+    dq, dk = dn + dt, dn + de + dt
+    mha = MultiHeadAttention(dn, de, dt, num_heads=heads, dropout=0.0).to("cuda:0")
+    shapes = {k_: tuple(v.shape) for k_, v in mha.state_dict().items()}
+    mha.load_state_dict(O.seeded_like(shapes, int(g["seed"]), float(g["scale"])))
+    ins = {k_: torch.from_numpy(g[k_]).cuda().requires_grad_(True) for k_ in ("node", "ntime", "nbr", "nbrt", "nbre")}
+    mha.train()
+    out, sc = mha(ins["node"], ins["ntime"], ins["nbr"], ins["nbrt"], ins["nbre"], g["ids"])
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], atol=2e-5)
+    np.testing.assert_allclose(sc.detach().cpu().numpy(), g["scores"], atol=2e-6)
+    (out * torch.from_numpy(g["r"]).cuda()).sum().backward()
+    for k_, v in ins.items():
+        np.testing.assert_allclose(v.grad.cpu().numpy(), g["gi:" + k_], atol=2e-5, err_msg=k_)
+    assert_grads_match(g, {k_: v.grad.cpu().numpy() for k_, v in mha.named_parameters()}, atol=2e-5)
+    # dropout: the returned scores are the DROPPED ones (modules.py:224,242): zero or prob / (1 - p)
+    mha.dropout.p = 0.5
+    _, sd = mha(ins["node"], ins["ntime"], ins["nbr"], ins["nbrt"], ins["nbre"], g["ids"])
+    ratio = (sd.detach().cpu().numpy() / np.maximum(g["scores"], 1e-30))
+    assert np.all((np.abs(ratio) < 1e-6) | (np.abs(ratio - 2.0) < 1e-4)) and (np.abs(ratio) < 1e-6).any() and (np.abs(ratio - 2.0) < 1e-4).any()
+    with pytest.raises(RuntimeError, match="ROCm device only"):
+        MultiHeadAttention(dn, de, dt, heads, 0.0)(*(v.detach().cpu() for v in ins.values()), g["ids"])

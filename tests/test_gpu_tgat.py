@@ -470,3 +470,37 @@ def test_fused_train_step_equals_autograd_path():
     # a second fused step ADDS to an existing .grad, as autograd accumulates
     m.train_step(m.prepare_batch(src, dst, t, k), lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w), k)
     assert float((flat.grad - 2.0 * res[1][2]).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("strategy,tsf", [("uniform", 0.0), ("time_interval_aware", 1e-5)])
+def test_tgat_random_sampling_strategies_follow_the_reference_rng_stream(strategy, tsf):
+    """uniform / time_interval_aware: the neighbor draws come from numpy's RandomState on the host in the reference's call order
+    (own recursion, then this layer, then the neighbors; sources before destinations) and feed the device engine.  Oracle: the same
+    recursion with oracle.sample_random on an equally seeded RandomState.  Embeddings and gradients, L = 2 and L = 1."""
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = wikipedia_like(num_edges=5000, num_users=200, num_items=40, feat_dim=12, seed=6, zero_node_feat=False)
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    sl = slice(4000, 4024)
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    for layers in (2, 1):
+        sampler = get_neighbor_sampler(data, strategy, time_scaling_factor=tsf, seed=11)
+        torch.manual_seed(0)
+        m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 8, layers, 2, 0.0, "cuda:0").to("cuda:0").train()
+        with torch.no_grad():
+            m.time_encoder.w.bias.zero_()
+        m.set_neighbor_sampler(sampler)                       # resets the random state, as the trainers do every epoch
+        s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 6)
+        (s.sum() - 2.0 * d.sum()).backward()
+        p = {k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in m.state_dict().items()}
+        rng = np.random.RandomState(11)
+        orc = O.TGATOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, layers, 2,
+                           sampler_fn=lambda i, t, kk: O.sample_random(adj, i, t, kk, rng, None if strategy == "uniform" else tsf))
+        os_, od_ = orc.src_dst(bs, bd, bt, 6)
+        (os_.sum() - 2.0 * od_.sum()).backward()
+        np.testing.assert_allclose(s.detach().cpu().numpy(), os_.detach().numpy(), atol=TOL)
+        np.testing.assert_allclose(d.detach().cpu().numpy(), od_.detach().numpy(), atol=TOL)
+        for name, prm in m.named_parameters():
+            gm, go = prm.grad.cpu().numpy(), p[name].grad.numpy()
+            assert np.abs(gm - go).max() <= 1e-4 * max(1.0, np.abs(go).max()), (layers, name)
