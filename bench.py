@@ -58,9 +58,12 @@ def main():
                     help="train = fwd+bwd+Adam (the headline metric); fwd = eval-mode embedding regeneration sweep (M_step.py:456-509); "
                          "lp = link-prediction train step of EM_warmup.py:126-231: src, dst and a random negative dst embedded in ONE "
                          "call (3 roots per edge), MergeLayer head, BCE loss, Adam on backbone + head")
-    ap.add_argument("--workload", default="wikipedia", choices=["wikipedia", "scale"],
-                    help="wikipedia = BASELINE configs[1] (the headline); scale = SURVEY 8d config 5 (10 M nodes / 100 M edges, tables "
-                         "hashed into HBM: 79 GB resident, the cache-defeating case)")
+    ap.add_argument("--model", default="tgat", choices=["tgat", "tgn", "dygformer"],
+                    help="tgat = BASELINE configs[1] (the headline) / configs[4]; tgn = configs[2] (Reddit-shape, memory + GRU update + "
+                         "message scatter); dygformer = configs[3] (Reddit-shape, first-hop sequence transformer)")
+    ap.add_argument("--workload", default=None, choices=["wikipedia", "reddit", "scale"],
+                    help="wikipedia = BASELINE configs[1] (default for tgat); reddit = configs[2]/[3] (default for tgn / dygformer); "
+                         "scale = SURVEY 8d config 5 (10 M nodes / 100 M edges, tables hashed into HBM: 79 GB resident)")
     ap.add_argument("--scale-users", type=int, default=9_000_000)
     ap.add_argument("--scale-items", type=int, default=1_000_000)
     ap.add_argument("--scale-edges", type=int, default=100_000_000)
@@ -88,6 +91,11 @@ def main():
                "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env))
+
+    if args.workload is None:
+        args.workload = "wikipedia" if args.model == "tgat" else "reddit"
+    if args.model != "tgat":
+        return bench_memory_or_sequence_model(args)
 
     from flid_amd import dist as fdist
     from flid_amd import ops
@@ -363,6 +371,204 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def bench_memory_or_sequence_model(args):
+    """BASELINE configs[2] / configs[3]: TGN (MemoryModel) and DyGFormer on the Reddit-shape synthetic graph through the class API
+    the reference's trainers call (host numpy ids per call: the 14-KB pinned H2D copy is inside the timed call), fwd + bwd + Adam per
+    600-edge batch per GPU; TGN in the M-step order (positive batches, PTCL/M_step.py:224-257, detach_memory_bank after every step)."""
+    from flid_amd import dist as fdist
+    from flid_amd import ops
+    from flid_amd.synth import reddit_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+    rank, world, local = fdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product has no CPU path)"
+    if os.environ.get("FLID_BENCH_SHARE_GPU"):
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    assert args.workload == "reddit", "tgn / dygformer are benchmarked on the Reddit-shape graph (BASELINE configs[2], [3])"
+    data = reddit_like(seed=0)
+    n_train = int(0.7 * data.num_interactions)
+    sampler = get_neighbor_sampler(data.slice(0, n_train), "recent", seed=0)
+    torch.manual_seed(0)
+    if args.model == "tgn":
+        from flid_amd.models.MemoryModel import MemoryModel
+        model = MemoryModel(data.node_raw_features, data.edge_raw_features, sampler, DT, "TGN", 1, H, args.dropout, device=str(dev))
+        model.memory_bank.__init_memory_bank__()
+        desc = "TGN (MemoryModel) L=1 H=2 T=100, 20 recent neighbors, GRU memory, last-message aggregation"
+    else:
+        from flid_amd.models.DyGFormer import DyGFormer
+        model = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, DT, 50, 1, 2, 2, args.dropout, 32, str(dev))
+        desc = "DyGFormer L=2 H=2 C=50 patch 1, max sequence 32"
+    model = model.to(dev).train()
+    fdist.broadcast_parameters(model)
+    fused = args.model == "tgn" and not args.autograd and not args.no_flat
+    if fused:
+        from flid_amd.optim import FlatAdam
+        params = [model.flatten_parameters()]
+        opt = FlatAdam(params, lr=1e-4)
+    else:
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+    reducer = fdist.GradAllReducer(params) if world > 1 else None
+    total_steps = args.warmup + args.steps
+    n_batches = n_train // BATCH
+    first = n_batches // 2
+    span = n_batches - first
+    rw = torch.randn(2, BATCH, DN, device=dev)
+    rw_flat = rw.reshape(2 * BATCH, DN).contiguous()
+    rw_grad = rw_flat / float(BATCH * DN)
+    loss_out = torch.zeros(1, device=dev)
+
+    def mean_loss(emb):
+        return ops.weighted_sum(emb, rw_flat, 1.0 / (BATCH * DN), out=loss_out), rw_grad
+
+    def batch(step):
+        # TGN's state makes the call order significant: every rank walks the SAME chronological stream (rank r embeds its shard of
+        # the global batch of world x 600 edges and advances the replicated state with the whole batch); DyGFormer: rank r takes
+        # batch step * world + r
+        if args.model == "tgn":
+            b = first + step % max(1, span // world)
+            return slice(b * BATCH * world, (b + 1) * BATCH * world)
+        b = first + (step * world + rank) % span
+        return slice(b * BATCH, (b + 1) * BATCH)
+
+    jobs, prepared = {}, {}
+
+    def tgn_begin(s_):
+        sl_ = batch(s_)
+        return model.prepare_batch_begin(data.src_node_ids[sl_], data.dst_node_ids[sl_], data.node_interact_times[sl_], K,
+                                         None if world == 1 else (rank * BATCH, (rank + 1) * BATCH))
+
+    def step(s):
+        sl = batch(s)
+        a = (data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl])
+        opt.zero_grad(set_to_none=True)
+        if args.model == "tgn":
+            # graph-only part of the NEXT batches on the side stream (ids, neighbor lookups, distinct touched nodes): two-stage, no wait
+            if s not in prepared:
+                prepared[s] = model.prepare_batch_finish(jobs.pop(s) if s in jobs else tgn_begin(s))
+            if s + 1 not in prepared:
+                prepared[s + 1] = model.prepare_batch_finish(jobs.pop(s + 1) if s + 1 in jobs else tgn_begin(s + 1))
+            if s + 2 not in jobs:
+                jobs[s + 2] = tgn_begin(s + 2)
+            pf = prepared.pop(s)
+            if fused:                                        # forward, loss, backward, state advance: no autograd graph
+                model.train_step(pf, data.edge_ids[sl], mean_loss, K)
+                if reducer is not None:
+                    reducer.reduce()
+                opt.step()
+                return
+            if world > 1:
+                se, de = model.compute_shard_embeddings_and_advance(pf, None, None, data.edge_ids[sl], (rank * BATCH, (rank + 1) * BATCH), True, K)
+            else:
+                se, de = model.compute_src_dst_node_temporal_embeddings(pf, None, None, data.edge_ids[sl], True, K)
+        else:
+            se, de = model.compute_src_dst_node_temporal_embeddings(*a)
+        loss = torch.addcmul(se * rw[0], de, rw[1]).mean()
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce()
+        opt.step()
+        if args.model == "tgn":
+            model.memory_bank.detach_memory_bank()                                    # M_step.py:325
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(s)
+    torch.cuda.synchronize()
+    fam_name = "attn_bwd" if args.model == "tgn" else "gemm"
+    ops.profile_enable(fam_name)
+    ops.profile_collect(fam_name)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        step(s)
+    host_issue = time.perf_counter() - t0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms, units, cnt = ops.profile_collect(fam_name)
+    ops.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = args.steps * BATCH * world / elapsed
+    secs = max(ms * 1e-3, 1e-12)
+    if args.model == "tgn":
+        # SURVEY 8d "Algorithmic bytes (TGN, L=1)": per edge fwd, 2 roots: node rows (raw + memory) 2 x 2 (1 + K) x 688, edge rows 2 K x 688,
+        # sampler 2 x 400, lazy memory update <= 2 (1 + K) (616 + 172) x 4; the positive step adds 2 x (616 x 4 written + 172 x 4 r/w + 8);
+        # backward re-reads the gathered inputs once
+        fwd = 2 * 2 * (1 + K) * 4 * DN + 2 * K * 4 * DE + 2 * 400 + 2 * (1 + K) * (616 + 172) * 4
+        bpe = 2 * fwd + 2 * (616 * 4 + 172 * 4 * 2 + 8)
+        roof = {"bound": "hbm", "kernel": "attn_bwd_fast_kernel<2,2,true,false> (fused attention backward, compact memory table)",
+                "achieved": round(units / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(units / secs / HBM_PEAK, 4),
+                "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / max(1, cnt), 4),
+                "bytes_per_instance": attn_bytes_per_instance(backward=True)}
+        path = {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4), "edges_per_s_at_100pct": round(HBM_PEAK / bpe, 1)}
+        metric = "edges/sec (temporal-embedding fwd+bwd, memory update + message scatter), TGN Reddit, 1/2/4/8 MI355X"
+    else:
+        roof = {"bound": "mfma", "kernel": "tg_gemm_f32* (all product launches of a step: projections, feed-forward, attention products)",
+                "achieved": round(units / secs / 1e12, 2), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
+                "frac": round(units / secs / MFMA_F32_PEAK, 4), "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / max(1, cnt), 4),
+                "gflop_per_step": round(units / args.steps / 1e9, 2)}
+        flops_edge = units / (args.steps * BATCH)
+        path = {"flops_per_edge_fwd_bwd": round(flops_edge, 1), "mfma_frac": round(value / world * flops_edge / MFMA_F32_PEAK, 4),
+                "edges_per_s_at_100pct": round(MFMA_F32_PEAK / max(flops_edge, 1.0), 1)}
+        metric = "edges/sec (temporal-embedding fwd+bwd), DyGFormer Reddit, 1/2/4/8 MI355X"
+    out = {"metric": metric, "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Reddit-shape synthetic (10984 nodes, 672447 edges, 172-d edge feats) + {desc}, batch 600 edges/GPU, "
+                                  f"dropout {args.dropout:.2f}, host numpy ids per call, fwd+bwd+Adam ({'fused step' if fused else 'autograd'})",
+                      "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+           "path_roofline": path, "roofline": roof, "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 4)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_model(args.model, data, n_train, model, batch(args.warmup), args.dropout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline_model(name, data, n_train, model, sl, dropout):
+    """the oracle (kind "port") of TGN / DyGFormer on this box's host cores: same graph and weights; TGN: 3 chronological positive
+    batches of 600 from a fresh memory (the oracle walks every node per call, as the reference does); DyGFormer: one batch; fwd + bwd"""
+    from oracle import flid_oracle as O
+    threads = torch.get_num_threads()
+    sd = {k_: v.detach().cpu().clone() for k_, v in model.state_dict().items()}
+    adj = O.build_adjacency(data.src_node_ids[:n_train], data.dst_node_ids[:n_train], data.edge_ids[:n_train], data.node_interact_times[:n_train])
+    nt, et = torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features)
+    t0 = time.perf_counter()
+    if name == "tgn":
+        p = {k_: v.requires_grad_(True) for k_, v in sd.items() if v.is_floating_point() and "memory_bank" not in k_ and not k_.startswith("embedding_module.time_encoder")}
+        orc = O.TGNOracle(nt, et, adj, p, 1, H, dropout=dropout, training=True)
+        edges = 0
+        for b in range(3):
+            s_ = slice(sl.start + b * BATCH, sl.start + (b + 1) * BATCH)
+            a, c = orc.src_dst(data.src_node_ids[s_], data.dst_node_ids[s_], data.node_interact_times[s_], data.edge_ids[s_], True, K)
+            (a.mean() + c.mean()).backward()
+            orc.detach()
+            edges += BATCH
+        what = "3 chronological positive batches of 600 from a fresh memory"
+    else:
+        p = {k_: v.requires_grad_(True) for k_, v in sd.items()}
+        orc = O.DyGFormerOracle(nt, et, adj, p, 50, 1, 2, 2, 32, dropout=dropout, training=True)
+        s_ = slice(sl.start, sl.start + BATCH)
+        a, c = orc.src_dst(data.src_node_ids[s_], data.dst_node_ids[s_], data.node_interact_times[s_])
+        (a.mean() + c.mean()).backward()
+        edges = BATCH
+        what = "one batch of 600"
+    dt = time.perf_counter() - t0
+    return {"value": round(edges / dt, 2), "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"{what}, fwd+bwd, oracle/flid_oracle.py on torch CPU ({threads} threads), {dt:.1f} s"}
 
 
 def cpu_baseline(data, n_train, model, sl, sample_edges):

@@ -111,6 +111,8 @@ SIGNATURES = {
     "tg_relu_bwd_inplace": (C.c_int, [c_void, c_void, c_i64, c_void]),
     "tg_gru_gates_fwd": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void]),
     "tg_gru_gates_bwd": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void]),
+    "tg_tgn_persist": (C.c_int, [c_void, c_i64, c_void, c_void, c_void, c_void, c_void, c_i64, c_void, c_i64, C.c_int, c_void]),
+    "tg_msg_scatter_last": (C.c_int, [c_void, c_void, c_i64, c_void, c_i64, C.c_int, c_void, c_i64, c_void, c_void, c_void, c_void]),
     "tg_build_messages": (C.c_int, [c_void, c_i64, c_void, c_void, c_void, c_void, c_void, c_i64, c_void, c_void, c_void, c_i64,
                                     C.c_int, C.c_int, C.c_int, c_void, c_void]),
 }

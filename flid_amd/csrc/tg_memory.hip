@@ -71,7 +71,63 @@ __global__ void __launch_bounds__(256) build_messages_kernel(const float* __rest
     }
 }
 
+// persist the (already computed) GRU rows of the batch nodes that had a pending message: memory[node] = rows[row_of[i]],
+// last_update[node] = time of that message (models/MemoryModel.py:214-231, :472-499).  One wave per batch entry; a node that
+// occurs twice writes the same values twice.
+__global__ void __launch_bounds__(256) tgn_persist_kernel(const float* __restrict__ rows, int64_t rows_ld, const int32_t* __restrict__ row_of,
+        const int32_t* __restrict__ nodes, const int32_t* __restrict__ has, const float* __restrict__ msg_time, float* __restrict__ memory,
+        int64_t mem_ld, float* __restrict__ last_update, int64_t count, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < count; i += (int64_t)gridDim.x * 4) {
+        const int64_t v = nodes[i];
+        if (!has[v]) continue;                                   // wave-uniform
+        const float* src = rows + (int64_t)row_of[i] * rows_ld;
+        for (int c = lane; c < d; c += 64) memory[v * mem_ld + c] = src[c];
+        if (lane == 0) last_update[v] = msg_time[v];
+    }
+}
+
+// "last message wins" (models/MemoryModel.py:312-320 reads only [-1] of a node's list; the lists are filled source role first, then
+// destination role, :177-180): of the entries i = 0..count-1 naming the same node, the LARGEST i files its message.
+__global__ void __launch_bounds__(256) msg_last_index_kernel(const int32_t* __restrict__ nodes, int64_t count, int32_t* __restrict__ last_idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        atomicMax(last_idx + nodes[i], (int32_t)i);
+}
+__global__ void __launch_bounds__(256) msg_scatter_last_kernel(const int32_t* __restrict__ nodes, const float* __restrict__ msgs, int64_t msg_ld,
+        const float* __restrict__ t32, int64_t count, int width, float* __restrict__ table, int64_t table_ld, int32_t* __restrict__ has,
+        float* __restrict__ msg_time, int32_t* __restrict__ last_idx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < count; i += (int64_t)gridDim.x * 4) {
+        const int64_t v = nodes[i];
+        if (last_idx[v] != (int32_t)i) continue;                 // wave-uniform: not the last entry of its node
+        const float* src = msgs + i * msg_ld;
+        for (int c = lane; c < width; c += 64) table[v * table_ld + c] = src[c];
+        if (lane == 0) { has[v] = 1; msg_time[v] = t32[i]; last_idx[v] = -1; }      // the workspace is left all -1 for the next call
+    }
+}
+
 }  // namespace
+
+extern "C" int tg_tgn_persist(const float* d_rows, int64_t rows_ld, const int32_t* d_row_of, const int32_t* d_nodes, const int32_t* d_has,
+                              const float* d_msg_time, float* d_memory, int64_t mem_ld, float* d_last_update, int64_t count, int d,
+                              void* stream) {
+    TG_REQUIRE(d_rows && d_row_of && d_nodes && d_has && d_msg_time && d_memory && d_last_update && count >= 0 && d > 0, "tg_tgn_persist: arguments");
+    if (count == 0) return TG_OK;
+    tgn_persist_kernel<<<(unsigned)std::min<int64_t>((count + 3) / 4, tg::kMaxGridBlocks), 256, 0, (hipStream_t)stream>>>(d_rows, rows_ld,
+        d_row_of, d_nodes, d_has, d_msg_time, d_memory, mem_ld, d_last_update, count, d);
+    return tg::launch_status("tgn_persist_kernel");
+}
+
+extern "C" int tg_msg_scatter_last(const int32_t* d_nodes, const float* d_msgs, int64_t msg_ld, const float* d_t32, int64_t count, int width,
+                                   float* d_table, int64_t table_ld, int32_t* d_has, float* d_msg_time, int32_t* d_last_idx_ws, void* stream) {
+    TG_REQUIRE(d_nodes && d_msgs && d_t32 && d_table && d_has && d_msg_time && d_last_idx_ws && count >= 0 && width > 0, "tg_msg_scatter_last: arguments");
+    if (count == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    msg_last_index_kernel<<<(unsigned)std::min<int64_t>((count + 255) / 256, tg::kMaxGridBlocks), 256, 0, s>>>(d_nodes, count, d_last_idx_ws);
+    msg_scatter_last_kernel<<<(unsigned)std::min<int64_t>((count + 3) / 4, tg::kMaxGridBlocks), 256, 0, s>>>(d_nodes, d_msgs, msg_ld, d_t32, count,
+        width, d_table, table_ld, d_has, d_msg_time, d_last_idx_ws);
+    return tg::launch_status("msg_scatter_last_kernel");
+}
 
 extern "C" int tg_gru_gates_fwd(const float* d_gi, const float* d_gh, const float* d_h, int64_t n, int d, float* d_out, void* stream) {
     TG_REQUIRE(d_gi && d_gh && d_h && d_out && n >= 0 && d > 0, "tg_gru_gates_fwd: arguments");

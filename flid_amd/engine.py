@@ -83,6 +83,10 @@ class Frontier:
     # layer -> its own slot lists (random sampling strategies: the reference draws a FRESH sample for the same root at every layer
     # of its recursion, models/TGAT.py:94,104, so the layers cannot share the level-0 lists); None = S serves every layer
     S_layers: Optional[dict] = None
+    # compact base table (TGN's lazily updated memory rows): row of the table that holds each deepest-level slot's node / the
+    # padding node, when the table is NOT indexed by node id
+    feat_idx0: Optional[torch.Tensor] = None
+    pad_row0: int = 0
 
     def rows(self, upto_level: int) -> int:
         return sum(self.counts[:upto_level + 1])
@@ -208,7 +212,7 @@ class _EmbedFn(torch.autograd.Function):
             lc.u = torch.empty((R, H, Dk), device=dev)
             ops.gemm_batched(lc.q[:, :hd], Wk[:hd], lc.u[:, 0, :], H, hd, hd * Dk, Dk)
             if l == 1:
-                feat, feat_idx = table, S_nbr[:R].reshape(-1)
+                feat, feat_idx = table, (S_nbr[:R].reshape(-1) if fr.feat_idx0 is None else fr.feat_idx0[:R * k])
             else:
                 feat, feat_idx = H_prev, fr.child[:R * k]
             seed = _next_seeds(1)[0] if (training and p_drop > 0) else 0
@@ -299,7 +303,7 @@ class _EmbedFn(torch.autograd.Function):
             else:
                 dH_prev = None
                 dfeat = d_table
-                pad_row = 0                      # node table: the padding node is row 0
+                pad_row = st.fr.pad_row0         # node table: the padding node is row 0
             du, dw_part, db_part = ops.attn_bwd(lc.attn, lc.u, lc.agg, lc.prob, dagg, dfeat, pad_row)
             d_tew += dw_part
             d_teb += db_part
@@ -464,7 +468,7 @@ def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
         S_nbr, S_eid, S_t, S_dt = fr.S_at(l)
         raw = ops.gather_rows(table, fr.ids_all[:R])
         own = raw if l == 1 else H_prev[:R]
-        feat, feat_idx = (table, S_nbr[:R].reshape(-1)) if l == 1 else (H_prev, fr.child[:R * k])
+        feat, feat_idx = (table, S_nbr[:R].reshape(-1) if fr.feat_idx0 is None else fr.feat_idx0[:R * k]) if l == 1 else (H_prev, fr.child[:R * k])
         seeds = _next_seeds(2) if p_eff > 0 else [0, 0]
         attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
                             te_w_flat, te_b, k, H, hd ** -0.5, p_eff, seeds[0])
@@ -474,7 +478,7 @@ def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
     return H_prev, (layers, cosb)
 
 
-def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH):
+def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_floats: int = 0):
     """every layer = one native backward call; returns (d_table or None, gradient block, offsets of [te_w, te_b, *layer_params]
     inside it, number of gradient floats).  The block is laid out like TGAT.flatten_parameters()' flat parameter."""
     layers, cosb = saved
@@ -489,8 +493,11 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH):
     H, Dk = cfg["num_heads"], Dn + cfg["edge_table"].shape[1] + T
     from ._lib import check, lib
     vlen = _r4(int(lib().tg_tgat_layer_vec_floats(Dn, Dq, Dk, H)))      # per layer: zero scratch of tg_tgat_layer_bwd (`vec`)
-    zeroed = torch.zeros(npar + _r4(T) + L * vlen, device=dev)
-    d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar:npar + T]
+    # (extra_floats: room right behind the parameter gradients for the caller's own ones -- TGN's GRU -- so that a flat parameter
+    # spanning both gets its gradient as one tensor)
+    xt = _r4(extra_floats)
+    zeroed = torch.zeros(npar + xt + _r4(T) + L * vlen, device=dev)
+    d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar + xt:npar + xt + T]
     d_table = torch.zeros_like(table) if table_grad else None
     dH = dH.contiguous()
     # The side streams (weight gradients) are joined ONCE, after the last layer: until then everything they read stays alive
@@ -508,9 +515,9 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH):
                 dfeat, pad_row = dH_prev, (fr.pad_rows[0] if (l == L and fr.pad_rows) else -1)
                 d_own, acc = dH_prev[:R], True               # rows [0, R) of the lower layer's gradient: its "own" inputs
             else:
-                dH_prev, dfeat, pad_row = None, d_table, 0
+                dH_prev, dfeat, pad_row = None, d_table, fr.pad_row0
                 d_own, acc = (torch.empty((R, Dn), device=dev), False) if table_grad else (None, False)
-            v0 = npar + _r4(T) + (l - 1) * vlen
+            v0 = npar + xt + _r4(T) + (l - 1) * vlen
             d_raw = lay.backward(dH[:R], params, zeroed[offs[2 + (l - 1) * 11]:], zeroed[v0:v0 + vlen], d_cosb, d_tew, d_teb,
                                  dfeat, pad_row, d_own, acc, table_grad, slot=l, defer_join=True)
             alive += [dH_prev, d_own, d_raw]

@@ -52,6 +52,12 @@ class MemoryBank(nn.Module):
         self._has = np.zeros(self.num_nodes, dtype=bool)
         self._msg_time = np.zeros(self.num_nodes, dtype=np.float64)
         self._h_last = np.zeros(self.num_nodes, dtype=np.float32)
+        # device copies of the flags / message times (float32, what the memory's last-update time becomes) for the lazy update path,
+        # the all -1 workspace of tg_msg_scatter_last, and a latch for the reference's "time in the past" assertion
+        self._has_dev = torch.zeros(self.num_nodes, dtype=torch.int32, device=dev)
+        self._msg_time_dev = torch.zeros(self.num_nodes, dtype=torch.float32, device=dev)
+        self._last_idx_ws = torch.full((self.num_nodes,), -1, dtype=torch.int32, device=dev)
+        self._past_violation = False
 
     def __init_memory_bank__(self):
         """zero memories / last-update times and drop all pending messages (start of every epoch, reference :357-364)"""
@@ -62,7 +68,9 @@ class MemoryBank(nn.Module):
     def _apply(self, fn, *a, **kw):          # keep the message table on the module's device across .to()/.cuda()
         out = super()._apply(fn, *a, **kw)
         if getattr(self, "_msg", None) is not None and self._msg.device != self.node_memories.device:
-            self._msg = self._msg.to(self.node_memories.device)
+            dev = self.node_memories.device
+            self._msg, self._has_dev = self._msg.to(dev), self._has_dev.to(dev)
+            self._msg_time_dev, self._last_idx_ws = self._msg_time_dev.to(dev), self._last_idx_ws.to(dev)
         return out
 
     def get_memories(self, node_ids: np.ndarray):
@@ -95,11 +103,17 @@ class MemoryBank(nn.Module):
                 self._has[int(nid)] = True
                 self._msg_time[int(nid)] = float(ts)
         self._h_last = self.node_last_updated_times.detach().cpu().numpy().astype(np.float32)
+        self._sync_device_flags()
+
+    def _sync_device_flags(self):
+        dev = self._msg.device
+        self._has_dev = torch.from_numpy(self._has.astype(np.int32)).to(dev)
+        self._msg_time_dev = torch.from_numpy(self._msg_time.astype(np.float32)).to(dev)
 
     def backup_memory_bank(self):
         """(memories, last-update times, messages) copies -- reference :383-393; the third item is this class's table form"""
         return (self.node_memories.data.clone(), self.node_last_updated_times.data.clone(),
-                (self._msg.clone(), self._has.copy(), self._msg_time.copy(), self._h_last.copy()))
+                (self._msg.clone(), self._has.copy(), self._msg_time.copy(), self._h_last.copy(), self._past_violation))
 
     def reload_memory_bank(self, backup_memory_bank: tuple):
         self.node_memories.data, self.node_last_updated_times.data = backup_memory_bank[0].clone(), backup_memory_bank[1].clone()
@@ -108,6 +122,8 @@ class MemoryBank(nn.Module):
             self.node_raw_messages = third
         else:
             self._msg, self._has, self._msg_time, self._h_last = third[0].clone(), third[1].copy(), third[2].copy(), third[3].copy()
+            self._past_violation = bool(third[4]) if len(third) > 4 else False
+            self._sync_device_flags()
 
     def detach_memory_bank(self):
         """reference :409-423.  State here is always stored detached (gradient flows only through the same-call GRU)."""
@@ -169,6 +185,39 @@ class _GRURowsFn(torch.autograd.Function):
         msg_rows, h_rows, gi, gh, w_ih, w_hh = ctx.saved_tensors
         dw_ih, dw_hh, db_ih, db_hh = ops.gru_cell_bwd(msg_rows, h_rows, gi, gh, dout, w_ih, w_hh)
         return None, None, dw_ih, dw_hh, db_ih, db_hh
+
+
+class _GRURowsMaskedFn(torch.autograd.Function):
+    """lazy form: rows of the touched nodes; out = GRU(msg, mem) where the node has a pending message, mem otherwise.  Parameter
+    gradients (both weight matrices and both biases) leave in ONE grouped launch (tg_wgrad_group)."""
+
+    @staticmethod
+    def forward(ctx, msg_rows, h_rows, has, w_ih, w_hh, b_ih, b_hh):
+        new, gi, gh = ops.gru_cell_fwd(msg_rows, h_rows, w_ih, w_hh, b_ih, b_hh)
+        mask = has.view(-1, 1)
+        out = torch.where(mask > 0, new, h_rows)
+        ctx.save_for_backward(msg_rows, h_rows, gi, gh, mask, w_ih, w_hh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        msg_rows, h_rows, gi, gh, mask, w_ih, w_hh = ctx.saved_tensors
+        n, d = h_rows.shape
+        dgi, dgh = torch.empty_like(gi), torch.empty_like(gh)
+        dm = (dout * mask.to(dout.dtype)).contiguous()
+        from .._lib import check, lib
+        check(lib().tg_gru_gates_bwd(ops._p(gi), ops._p(gh), ops._p(h_rows), ops._p(dm), n, d, ops._p(dgi), ops._p(dgh), ops._p(None), ops._stream()),
+              "tg_gru_gates_bwd")
+        dw_ih, dw_hh = torch.zeros_like(w_ih), torch.zeros_like(w_hh)
+        db_ih = torch.zeros(w_ih.shape[0], device=dout.device)
+        db_hh = torch.zeros(w_hh.shape[0], device=dout.device)
+        try:
+            ops.wgrad_group([(dgi, msg_rows, dw_ih, db_ih), (dgh, h_rows, dw_hh, db_hh)])
+        except Exception:                      # widths that are not multiples of 4: one exact product + one column sum each
+            ops.gemm(dgi, msg_rows, dw_ih, ta=True)
+            ops.gemm(dgh, h_rows, dw_hh, ta=True)
+            db_ih, db_hh = ops.colsum(dgi), ops.colsum(dgh)
+        return None, None, None, dw_ih, dw_hh, db_ih, db_hh
 
 
 class MemoryModel(torch.nn.Module):
@@ -239,7 +288,218 @@ class MemoryModel(torch.nn.Module):
         collective of a TGN step is the gradient all-reduce (flid_amd.dist.GradAllReducer)."""
         return self._step(src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, shard)
 
+    LAZY = True      # one-layer 'recent' calls update only the memory rows the call touches (False: the full-table path below)
+
     def _step(self, src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, shard):
+        smp = self.embedding_module.neighbor_sampler
+        if isinstance(src_node_ids, dict) or (self.LAZY and self.num_layers == 1 and smp.sample_neighbor_strategy == "recent" and len(src_node_ids) > 0):
+            return self._step_lazy(src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, shard)
+        return self._step_full(src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, shard)
+
+    # ---- flat-parameter mode + fused step (not in the reference; SURVEY 8f-1) ------------------------------------------------------
+    def _trainable(self):
+        g = self.memory_updater.memory_updater
+        return [self.time_encoder.w.weight, self.time_encoder.w.bias] + self.embedding_module.layer_params() + \
+               [g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh]
+
+    def flatten_parameters(self) -> nn.Parameter:
+        """Opt-in, as TGAT.flatten_parameters(): every trainable tensor (time encoder, attention + merge layers, GRU) becomes a view
+        of ONE flat nn.Parameter, returned for the optimizer; state_dict keys are unchanged.  Needed by train_step()."""
+        params = self._trainable()
+        offs, total = engine.block_layout(params)
+        flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        views = []
+        with torch.no_grad():
+            for o, p in zip(offs, params):
+                v = flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                p.requires_grad_(False)
+                views.append(v)
+        flat_param = nn.Parameter(flat)
+        self._flat_pack = [flat_param, views]
+        return flat_param
+
+    def train_step(self, prepared, edge_ids, loss_fn, num_neighbors: int = 20):
+        """Fused-trainer step on a prepared (prepare_batch_begin / _finish) POSITIVE batch: updated memory rows of the touched
+        nodes, embeddings, `loss_fn(emb) -> (loss, d_emb)` on the detached (2 B, D) block [src rows | dst rows], backward into the
+        flat parameter's .grad (added, as autograd accumulates), and the state advance (persist, new messages, last-message-wins
+        scatter) -- no autograd graph, ~40 launches.  Same kernels and numbers as compute_src_dst_node_temporal_embeddings +
+        loss.backward()."""
+        from .._lib import check, lib
+        flat = getattr(self, "_flat_pack", None)
+        if flat is None:
+            raise RuntimeError("MemoryModel.train_step needs the flat-parameter mode: call flatten_parameters() first")
+        if self.num_layers != 1 or self.num_heads > 2 or not engine.NATIVE:
+            raise NotImplementedError("train_step covers the one-layer TGN of the reference's CLI (1 or 2 heads)")
+        job = prepared
+        assert isinstance(job, dict) and job.get("finished") and job["k"] == int(num_neighbors), "pass a finished prepare_batch_begin() job"
+        bank, dev = self.memory_bank, self.node_raw_features.device
+        views = flat[1]
+        te_w, te_b, layer_params, (w_ih, w_hh, b_ih, b_hh) = views[0], views[1], views[2:13], views[13:17]
+        torch.cuda.current_stream().wait_event(job["ready"])
+        n, m, k = job["n"], job["m"], job["k"]
+        S, uniq, rowmap, batch_d = job["S"], job["uniq"], job["rowmap"], job["batch_d"]
+        assert not bank._past_violation, "Trying to update memory to time in the past!"
+        with torch.no_grad():
+            mem = bank.node_memories.data
+            h_rows = ops.gather_rows(mem, uniq)
+            pending = bool(bank._has.any())
+            if pending:
+                msg_rows = ops.gather_rows(bank._msg, uniq)
+                new, gi, gh = ops.gru_cell_fwd(msg_rows, h_rows, w_ih, w_hh, b_ih, b_hh)
+                mask = bank._has_dev[uniq.long()].view(-1, 1)
+                rows = torch.where(mask > 0, new, h_rows)
+            else:
+                rows = h_rows
+            base = rows + ops.gather_rows(self.node_raw_features, uniq)
+            fr = engine.Frontier(counts=[m], ids_all=rowmap[:m], S=S, child=None, pad_rows=[], feat_idx0=rowmap[m:m + m * k], pad_row0=job["pad"])
+            cfg = dict(n=m, k=k, num_layers=1, num_heads=self.num_heads, dropout=float(self.dropout), training=bool(self.training),
+                       edge_table=self.edge_raw_features, table_grad=pending)
+            emb, saved = engine._native_forward(cfg, fr, base, te_w, te_b, layer_params)
+        loss, d_emb = loss_fn(emb)
+        with torch.no_grad():
+            gru_offs, gru_len = engine.block_layout([w_ih, w_hh, b_ih, b_hh])
+            d_table, zeroed, offs, npar = engine._native_backward(cfg, fr, base, te_w, te_b, layer_params, saved, d_emb, extra_floats=gru_len)
+            if pending:
+                tail = zeroed[npar:npar + gru_len]
+                gv = [tail[o:o + t.numel()].view(t.shape) for o, t in zip(gru_offs, (w_ih, w_hh, b_ih, b_hh))]
+                dm = (d_table * mask.to(d_table.dtype)).contiguous()
+                dgi, dgh = torch.empty_like(gi), torch.empty_like(gh)
+                check(lib().tg_gru_gates_bwd(ops._p(gi), ops._p(gh), ops._p(h_rows), ops._p(dm), dm.shape[0], dm.shape[1], ops._p(dgi), ops._p(dgh),
+                                             ops._p(None), ops._stream()), "tg_gru_gates_bwd")
+                ops.wgrad_group([(dgi, msg_rows, gv[0], gv[2]), (dgh, h_rows, gv[1], gv[3])])
+            g = zeroed[:npar + gru_len]
+            if flat[0].grad is None:
+                flat[0].grad = g
+            else:
+                flat[0].grad.add_(g)
+        self._advance_state(job, rows, edge_ids)
+        return emb, loss
+
+    def _advance_state(self, job, rows, edge_ids):
+        """positive call: persist the batch nodes' GRU rows, build the new raw messages from the post-update state, file them
+        last-message-wins, update the host mirrors (reference :155-180)"""
+        from .._lib import check, lib
+        bank, dev = self.memory_bank, self.node_raw_features.device
+        n, m, k = job["n"], job["m"], job["k"]
+        node_ids, times, rowmap, batch_d, b_d, t32_d = job["node_ids"], job["times"], job["rowmap"], job["batch_d"], job["b_d"], job["t32_d"]
+        assert edge_ids is not None
+        e_d, = ops.h2d([np.concatenate([np.asarray(edge_ids), np.asarray(edge_ids)]).astype(np.int32)], dev)
+        uniq_h = np.unique(node_ids)
+        upd = uniq_h[bank._has[uniq_h]]
+        self._check_not_in_the_past(upd)                                                       # reference :485-486
+        with torch.no_grad():
+            check(lib().tg_tgn_persist(ops._p(rows.detach()), rows.stride(0), ops._p(rowmap[m + m * k:]), ops._p(batch_d), ops._p(bank._has_dev),
+                                       ops._p(bank._msg_time_dev), ops._p(bank.node_memories.data), bank.node_memories.stride(0),
+                                       ops._p(bank.node_last_updated_times.data), 2 * n, self.memory_dim, ops._stream()), "tg_tgn_persist")
+            msgs = ops.build_messages(bank.node_memories.data, bank.node_last_updated_times.data, batch_d, b_d, t32_d,
+                                      self.edge_raw_features, e_d, self.time_encoder.w.weight.detach().reshape(-1),
+                                      self.time_encoder.w.bias.detach())
+            check(lib().tg_msg_scatter_last(ops._p(batch_d), ops._p(msgs), msgs.stride(0), ops._p(t32_d), 2 * n, self.message_dim,
+                                            ops._p(bank._msg), bank._msg.stride(0), ops._p(bank._has_dev), ops._p(bank._msg_time_dev),
+                                            ops._p(bank._last_idx_ws), ops._stream()), "tg_msg_scatter_last")
+        if len(upd):
+            bank._h_last[upd] = bank._msg_time[upd].astype(np.float32)
+        u, first_rev = np.unique(node_ids[::-1], return_index=True)
+        last_pos = (2 * n - 1 - first_rev).astype(np.int64)
+        new_t = times[last_pos % n]
+        bank._has[u] = True
+        bank._msg_time[u] = new_t
+        if np.any(bank._h_last[u] > new_t.astype(np.float32)):
+            bank._past_violation = True         # the reference's next get_updated_memories would raise on this message
+
+    # ---- lazy path: graph-only part (prefetchable) ----------------------------------------------------------------------------
+    def prepare_batch_begin(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20, shard=None):
+        """Optional prefetch (not in the reference): the part of a call that depends on the graph and the batch only -- the H2D copy of
+        the ids, the neighbor lookups, and the hash set of distinct touched nodes -- issued on a side stream; the count of distinct
+        nodes travels to pinned memory.  prepare_batch_finish(job) (a step later: no wait) yields the object to pass as
+        `src_node_ids` of compute_src_dst_node_temporal_embeddings / compute_shard_embeddings_and_advance (dst / times then None)."""
+        dev = self.node_raw_features.device
+        src_node_ids, dst_node_ids = np.asarray(src_node_ids), np.asarray(dst_node_ids)
+        times = np.asarray(node_interact_times, dtype=np.float64)
+        n, k = len(src_node_ids), int(num_neighbors)
+        assert k > 0, 'Number of sampled neighbors for each node should be greater than 0!'
+        node_ids = np.concatenate([src_node_ids, dst_node_ids])
+        if int(node_ids.max()) >= self.num_nodes or int(node_ids.min()) < 0:
+            raise IndexError("list index out of range")
+        lo, hi = (0, n) if shard is None else shard
+        emb_ids = np.concatenate([src_node_ids[lo:hi], dst_node_ids[lo:hi]])
+        emb_t = np.concatenate([times[lo:hi], times[lo:hi]])
+        m = len(emb_ids)
+        graph = self.embedding_module.neighbor_sampler.graph
+        side, main = engine._side_stream(), torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            ids_d, t_d, batch_d, b_d, t32_d = ops.h2d([emb_ids.astype(np.int32), emb_t, node_ids.astype(np.int32),
+                                                       np.concatenate([dst_node_ids, src_node_ids]).astype(np.int32),
+                                                       np.concatenate([times, times]).astype(np.float32)], dev)
+            S = graph.sample_recent(ids_d, t_d, k)
+            total = m + m * k + 2 * n
+            all_nodes = torch.empty(total, dtype=torch.int32, device=dev)      # [embedded roots | their sampled neighbors | every batch node]
+            all_nodes[:m].copy_(ids_d)
+            all_nodes[m:m + m * k].copy_(S[0].reshape(-1))
+            all_nodes[m + m * k:].copy_(batch_d)
+            zt = getattr(self, "_zero_t", None)
+            if zt is None or zt.numel() < total:
+                zt = self._zero_t = torch.zeros(total, dtype=torch.float32, device=dev)
+            uniq = torch.empty(total, dtype=torch.int32, device=dev)
+            uniq_t = torch.empty(total, dtype=torch.float32, device=dev)
+            rowmap = torch.empty(total, dtype=torch.int32, device=dev)
+            cp = graph.dedupe_pairs_async(all_nodes, zt[:total], 0, uniq, uniq_t, rowmap)
+            count_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            count_host.copy_(cp, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return dict(n=n, m=m, k=k, lo=lo, hi=hi, node_ids=node_ids, times=times, S=S, uniq=uniq, rowmap=rowmap, batch_d=batch_d, b_d=b_d,
+                    t32_d=t32_d, count_host=count_host, ready=ev, main=main, graph=graph, keep=(ids_d, t_d, all_nodes, uniq_t))
+
+    def prepare_batch_finish(self, job):
+        job["ready"].synchronize()
+        count, pad = job["count_host"].tolist()
+        job["uniq"] = job["uniq"][:count]
+        job["pad"] = pad
+        for t in (job["uniq"], job["rowmap"], job["batch_d"], job["b_d"], job["t32_d"]) + tuple(job["S"]):
+            t.record_stream(job["main"])
+        job["finished"] = True
+        return job
+
+    def _step_lazy(self, src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, shard):
+        """Lazy memory: the reference applies every pending message of the WHOLE graph before each call
+        (get_updated_memories over all nodes, :117) although a one-layer embedding reads only the rows of the batch nodes and of
+        their sampled neighbors.  Here the distinct touched nodes are found on the device (hash set), the GRU runs on exactly those
+        rows, `memory' + raw` is a compact gathered table the attention kernels index through a row map, and the state update
+        (persist, new messages, last-message-wins scatter) is three kernels with no host-side unique / index_copy.  Results are the
+        reference's: a node's updated memory depends only on its own pending message."""
+        from .._lib import check, lib
+        bank, gru, dev = self.memory_bank, self.memory_updater.memory_updater, self.node_raw_features.device
+        if isinstance(src_node_ids, dict):
+            job = src_node_ids
+            assert job.get("finished") and job["k"] == int(num_neighbors) and job["graph"] is self.embedding_module.neighbor_sampler.graph, \
+                "prepared for a different sampler / num_neighbors"
+        else:
+            job = self.prepare_batch_finish(self.prepare_batch_begin(src_node_ids, dst_node_ids, node_interact_times, num_neighbors, shard))
+        torch.cuda.current_stream().wait_event(job["ready"])
+        n, m, k, lo, hi = job["n"], job["m"], job["k"], job["lo"], job["hi"]
+        node_ids, times, S, uniq, rowmap, batch_d = job["node_ids"], job["times"], job["S"], job["uniq"], job["rowmap"], job["batch_d"]
+        assert not bank._past_violation, "Trying to update memory to time in the past!"        # reference :515-516 (raised by the view)
+        mem = bank.node_memories.detach()
+        if bank._has.any():
+            has_rows = bank._has_dev[uniq.long()]
+            rows = _GRURowsMaskedFn.apply(ops.gather_rows(bank._msg, uniq), ops.gather_rows(mem, uniq), has_rows,
+                                          gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh)
+        else:
+            rows = ops.gather_rows(mem, uniq)             # nothing pending anywhere (first batch of an epoch): the GRU is not called (:203-212)
+        base = rows + ops.gather_rows(self.node_raw_features, uniq)                                # reference :654-655 on the touched rows
+        fr = engine.Frontier(counts=[m], ids_all=rowmap[:m], S=S, child=None, pad_rows=[], feat_idx0=rowmap[m:m + m * k], pad_row0=job["pad"])
+        cfg = dict(n=m, k=k, num_layers=1, num_heads=self.num_heads, dropout=float(self.dropout), training=bool(self.training),
+                   edge_table=self.edge_raw_features, table_grad=bool(torch.is_grad_enabled() and rows.requires_grad))
+        emb = engine._apply(cfg, fr, base, self.time_encoder.w.weight, self.time_encoder.w.bias, self.embedding_module.layer_params(), None)
+        src_emb, dst_emb = engine.split_rows(emb, hi - lo)
+        if edges_are_positive:
+            self._advance_state(job, rows, edge_ids)
+        return src_emb, dst_emb
+
+    def _step_full(self, src_node_ids, dst_node_ids, node_interact_times, edge_ids, edges_are_positive, num_neighbors, shard):
         src_node_ids = np.asarray(src_node_ids)
         dst_node_ids = np.asarray(dst_node_ids)
         node_interact_times = np.asarray(node_interact_times, dtype=np.float64)
@@ -292,6 +552,7 @@ class MemoryModel(torch.nn.Module):
                 bank._msg.index_copy_(0, u_dev, msgs[last_dev])
             bank._has[u] = True
             bank._msg_time[u] = node_interact_times[last_pos % n]
+            bank._sync_device_flags()
         return src_emb, dst_emb
 
     # kept for callers / tests that poke the reference's helper methods

@@ -287,6 +287,15 @@ int tg_gru_gates_bwd(const float* d_gi, const float* d_gh, const float* d_h, con
 int tg_build_messages(const float* d_mem, int64_t mem_ld, const float* d_last_update, const int32_t* d_a_ids,
                       const int32_t* d_b_ids, const float* d_t32, const float* d_edge, int64_t edge_ld, const int32_t* d_eids,
                       const float* d_te_w, const float* d_te_b, int64_t n, int d, int de, int T, float* d_out, void* stream);
+/* persist the GRU rows of the batch nodes that have a pending message (models/MemoryModel.py:214-231, :472-499):
+ * for i < count with d_has[d_nodes[i]]: d_memory[d_nodes[i]] = d_rows[d_row_of[i]], d_last_update[d_nodes[i]] = d_msg_time[d_nodes[i]]. */
+int tg_tgn_persist(const float* d_rows, int64_t rows_ld, const int32_t* d_row_of, const int32_t* d_nodes, const int32_t* d_has,
+                   const float* d_msg_time, float* d_memory, int64_t mem_ld, float* d_last_update, int64_t count, int d, void* stream);
+/* file the new raw messages in the (num_nodes, width) pending-message table, "last message wins" per node in entry order (the
+ * reference appends source-role then destination-role messages and reads only [-1]: MemoryModel.py:177-180, :312-320); sets
+ * d_has[node] = 1 and d_msg_time[node] = t32 of the winning entry.  d_last_idx_ws: (num_nodes) int32, all -1 on entry and on exit. */
+int tg_msg_scatter_last(const int32_t* d_nodes, const float* d_msgs, int64_t msg_ld, const float* d_t32, int64_t count, int width,
+                        float* d_table, int64_t table_ld, int32_t* d_has, float* d_msg_time, int32_t* d_last_idx_ws, void* stream);
 
 /* ---- DyGFormer sequence side --------------------------------------------------------------------------
  * neighbor co-occurrence counts (models/DyGFormer.py:337-393): for every slot of the source rows (n, wa) and destination

@@ -170,3 +170,84 @@ def test_tgn_uniform_sampling_follows_the_reference_rng_stream():
             os_, od_ = orc.src_dst(*args)
         np.testing.assert_allclose(s.cpu().numpy(), os_.numpy(), atol=TOL, err_msg=f"batch {b}")
         np.testing.assert_allclose(d.cpu().numpy(), od_.numpy(), atol=TOL, err_msg=f"batch {b}")
+
+
+def test_tgn_lazy_memory_equals_full_table_update():
+    """MemoryModel.LAZY (GRU only on the memory rows a call touches, compact base table, device-side persist + last-message
+    scatter) against the full-table form (every pending node updated before every call, as the reference does): embeddings,
+    gradients and the whole state after each of 6 neg-then-pos batches"""
+    from flid_amd.models.MemoryModel import MemoryModel
+    g = load_golden("tgn_small")
+    models = []
+    for lazy in (True, False):
+        m, p, k = _model(g)
+        m.LAZY = lazy
+        m.memory_bank.__init_memory_bank__()
+        models.append(m)
+    bsz = 12
+    for b in range(6):
+        sl = slice(b * bsz, (b + 1) * bsz)
+        outs = []
+        for m in models:
+            m.zero_grad(set_to_none=True)
+            ns_, nd_ = m.compute_src_dst_node_temporal_embeddings(g["src"][sl], g[f"neg{b}"], g["t"][sl], None, False, k)
+            ps_, pd_ = m.compute_src_dst_node_temporal_embeddings(g["src"][sl], g["dst"][sl], g["t"][sl], g["eid"][sl], True, k)
+            (ns_.sum() + 2 * nd_.sum() + 3 * ps_.sum() - pd_.sum()).backward()
+            m.memory_bank.detach_memory_bank()
+            outs.append((torch.cat([ns_, nd_, ps_, pd_]).detach(), {n_: q.grad.clone() for n_, q in m.named_parameters() if q.grad is not None}))
+        assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6
+        # (with nothing pending the full-table form never calls the GRU: its parameters then have no gradient at all)
+        assert set(outs[1][1]) <= set(outs[0][1]) and all(float(outs[0][1][n_].abs().max()) == 0.0 for n_ in set(outs[0][1]) - set(outs[1][1]))
+        for n_ in outs[1][1]:
+            ref = outs[1][1][n_]
+            assert float((outs[0][1][n_] - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (b, n_)
+        a, c = models[0].memory_bank, models[1].memory_bank
+        assert torch.allclose(a.node_memories, c.node_memories, atol=1e-6) and torch.equal(a.node_last_updated_times, c.node_last_updated_times)
+        assert np.array_equal(a._has, c._has) and np.array_equal(a._msg_time, c._msg_time)
+        idx = torch.from_numpy(np.nonzero(a._has)[0]).cuda()
+        assert torch.allclose(a._msg[idx], c._msg[idx], atol=1e-6)
+        assert np.array_equal(a._has, a._has_dev.cpu().numpy().astype(bool))
+
+
+def test_tgn_fused_train_step_equals_autograd_path():
+    """MemoryModel.flatten_parameters() + train_step (no autograd graph) against compute_src_dst... + loss.backward() on two
+    identically initialised models over 4 positive batches: embeddings, loss, every gradient, and the advanced state"""
+    from flid_amd import engine, ops
+    g = load_golden("tgn_small")
+    ma, p, k = _model(g)
+    mf, _, _ = _model(g)
+    flat = mf.flatten_parameters()
+    assert sorted(mf.state_dict().keys()) == sorted(ma.state_dict().keys())
+    for m in (ma, mf):
+        m.memory_bank.__init_memory_bank__()
+    bsz = 12
+    w = torch.from_numpy(np.random.RandomState(1).standard_normal((2 * bsz, g["node_feat"].shape[1])).astype(np.float32)).cuda()
+    for b in range(4):
+        sl = slice(b * bsz, (b + 1) * bsz)
+        args = (g["src"][sl], g["dst"][sl], g["t"][sl])
+        ma.zero_grad(set_to_none=True)
+        s, d = ma.compute_src_dst_node_temporal_embeddings(*args, g["eid"][sl], True, k)
+        ea = torch.cat([s, d])
+        la = (ea * w).sum() * 0.5
+        la.backward()
+        flat.grad = None
+        job = mf.prepare_batch_finish(mf.prepare_batch_begin(*args, k))
+        ef, lf = mf.train_step(job, g["eid"][sl], lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w), k)
+        assert float((ea.detach() - ef).abs().max()) < 2e-6 and abs(float(la) - float(lf)) <= 1e-5 * max(1.0, abs(float(la)))
+        named = mf._trainable()
+        offs, _ = engine.block_layout(named)
+        ref = dict(ma.named_parameters())
+        for (name, q), o in zip([(n_, q_) for n_, q_ in mf.named_parameters() if any(q_ is t for t in named)], offs):
+            pass
+        by_id = {id(q): flat.grad[o:o + q.numel()].view(q.shape) for o, q in zip(offs, named)}
+        for name, q in mf.named_parameters():
+            if id(q) not in by_id:
+                continue
+            ga = ref[name].grad
+            if ga is None:                       # nothing pending yet: the autograd path never called the GRU
+                assert float(by_id[id(q)].abs().max()) == 0.0, name
+                continue
+            assert float((by_id[id(q)] - ga).abs().max()) <= 2e-5 * max(1.0, float(ga.abs().max())), (b, name)
+        a, c = ma.memory_bank, mf.memory_bank
+        assert torch.allclose(a.node_memories, c.node_memories, atol=1e-6) and torch.equal(a.node_last_updated_times, c.node_last_updated_times)
+        assert np.array_equal(a._has, c._has) and torch.allclose(a._msg, c._msg, atol=1e-6)
