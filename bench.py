@@ -440,7 +440,7 @@ def bench_memory_or_sequence_model(args):
     def tgn_begin(s_):
         sl_ = batch(s_)
         return model.prepare_batch_begin(data.src_node_ids[sl_], data.dst_node_ids[sl_], data.node_interact_times[sl_], K,
-                                         None if world == 1 else (rank * BATCH, (rank + 1) * BATCH))
+                                         None if world == 1 else (rank * BATCH, (rank + 1) * BATCH), edge_ids=data.edge_ids[sl_])
 
     def step(s):
         sl = batch(s)

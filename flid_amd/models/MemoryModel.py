@@ -384,10 +384,12 @@ class MemoryModel(torch.nn.Module):
         bank, dev = self.memory_bank, self.node_raw_features.device
         n, m, k = job["n"], job["m"], job["k"]
         node_ids, times, rowmap, batch_d, b_d, t32_d = job["node_ids"], job["times"], job["rowmap"], job["batch_d"], job["b_d"], job["t32_d"]
-        assert edge_ids is not None
-        e_d, = ops.h2d([np.concatenate([np.asarray(edge_ids), np.asarray(edge_ids)]).astype(np.int32)], dev)
-        uniq_h = np.unique(node_ids)
-        upd = uniq_h[bank._has[uniq_h]]
+        e_d = job["e_d"]
+        if e_d is None:
+            assert edge_ids is not None
+            e_d, = ops.h2d([np.concatenate([np.asarray(edge_ids), np.asarray(edge_ids)]).astype(np.int32)], dev)
+        u, new_t = job["u"], job["new_t"]
+        upd = u[bank._has[u]]
         self._check_not_in_the_past(upd)                                                       # reference :485-486
         with torch.no_grad():
             check(lib().tg_tgn_persist(ops._p(rows.detach()), rows.stride(0), ops._p(rowmap[m + m * k:]), ops._p(batch_d), ops._p(bank._has_dev),
@@ -401,16 +403,13 @@ class MemoryModel(torch.nn.Module):
                                             ops._p(bank._last_idx_ws), ops._stream()), "tg_msg_scatter_last")
         if len(upd):
             bank._h_last[upd] = bank._msg_time[upd].astype(np.float32)
-        u, first_rev = np.unique(node_ids[::-1], return_index=True)
-        last_pos = (2 * n - 1 - first_rev).astype(np.int64)
-        new_t = times[last_pos % n]
         bank._has[u] = True
         bank._msg_time[u] = new_t
         if np.any(bank._h_last[u] > new_t.astype(np.float32)):
             bank._past_violation = True         # the reference's next get_updated_memories would raise on this message
 
     # ---- lazy path: graph-only part (prefetchable) ----------------------------------------------------------------------------
-    def prepare_batch_begin(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20, shard=None):
+    def prepare_batch_begin(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20, shard=None, edge_ids=None):
         """Optional prefetch (not in the reference): the part of a call that depends on the graph and the batch only -- the H2D copy of
         the ids, the neighbor lookups, and the hash set of distinct touched nodes -- issued on a side stream; the count of distinct
         nodes travels to pinned memory.  prepare_batch_finish(job) (a step later: no wait) yields the object to pass as
@@ -430,9 +429,10 @@ class MemoryModel(torch.nn.Module):
         graph = self.embedding_module.neighbor_sampler.graph
         side, main = engine._side_stream(), torch.cuda.current_stream()
         with torch.cuda.stream(side):
-            ids_d, t_d, batch_d, b_d, t32_d = ops.h2d([emb_ids.astype(np.int32), emb_t, node_ids.astype(np.int32),
-                                                       np.concatenate([dst_node_ids, src_node_ids]).astype(np.int32),
-                                                       np.concatenate([times, times]).astype(np.float32)], dev)
+            eid2 = np.zeros(2 * n, dtype=np.int32) if edge_ids is None else np.concatenate([np.asarray(edge_ids), np.asarray(edge_ids)]).astype(np.int32)
+            ids_d, t_d, batch_d, b_d, t32_d, e_d = ops.h2d([emb_ids.astype(np.int32), emb_t, node_ids.astype(np.int32),
+                                                            np.concatenate([dst_node_ids, src_node_ids]).astype(np.int32),
+                                                            np.concatenate([times, times]).astype(np.float32), eid2], dev)
             S = graph.sample_recent(ids_d, t_d, k)
             total = m + m * k + 2 * n
             all_nodes = torch.empty(total, dtype=torch.int32, device=dev)      # [embedded roots | their sampled neighbors | every batch node]
@@ -450,16 +450,21 @@ class MemoryModel(torch.nn.Module):
             count_host.copy_(cp, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
+        # host side of the state advance: the distinct batch nodes and, per node, its LAST position in [src role | dst role] order
+        u, first_rev = np.unique(node_ids[::-1], return_index=True)
+        last_pos = (2 * n - 1 - first_rev).astype(np.int64)
         return dict(n=n, m=m, k=k, lo=lo, hi=hi, node_ids=node_ids, times=times, S=S, uniq=uniq, rowmap=rowmap, batch_d=batch_d, b_d=b_d,
-                    t32_d=t32_d, count_host=count_host, ready=ev, main=main, graph=graph, keep=(ids_d, t_d, all_nodes, uniq_t))
+                    t32_d=t32_d, e_d=(e_d if edge_ids is not None else None), u=u, new_t=times[last_pos % n],
+                    count_host=count_host, ready=ev, main=main, graph=graph, keep=(ids_d, t_d, all_nodes, uniq_t))
 
     def prepare_batch_finish(self, job):
         job["ready"].synchronize()
         count, pad = job["count_host"].tolist()
         job["uniq"] = job["uniq"][:count]
         job["pad"] = pad
-        for t in (job["uniq"], job["rowmap"], job["batch_d"], job["b_d"], job["t32_d"]) + tuple(job["S"]):
-            t.record_stream(job["main"])
+        for t in (job["uniq"], job["rowmap"], job["batch_d"], job["b_d"], job["t32_d"], job["e_d"]) + tuple(job["S"]):
+            if t is not None:
+                t.record_stream(job["main"])
         job["finished"] = True
         return job
 
