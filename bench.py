@@ -54,10 +54,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--roofline-kernel", default="attn_bwd", choices=["attn_fwd", "attn_bwd", "gemm"])
-    ap.add_argument("--mode", default="train", choices=["train", "fwd", "lp"],
+    ap.add_argument("--chunk-edges", type=int, default=4096, help="--mode sweep: edges per chunk of the regeneration sweep")
+    ap.add_argument("--mode", default="train", choices=["train", "fwd", "lp", "sweep"],
                     help="train = fwd+bwd+Adam (the headline metric); fwd = eval-mode embedding regeneration sweep (M_step.py:456-509); "
                          "lp = link-prediction train step of EM_warmup.py:126-231: src, dst and a random negative dst embedded in ONE "
-                         "call (3 roots per edge), MergeLayer head, BCE loss, Adam on backbone + head")
+                         "call (3 roots per edge), MergeLayer head, BCE loss, Adam on backbone + head; "
+                         "sweep = the whole embedding-regeneration sweep of M_step.py:456-509 over EVERY edge of the graph into the (E, 172) "
+                         "stores (flid_amd.sweep.regenerate_embeddings; full-graph sampler, chunked, prefetched)")
     ap.add_argument("--model", default="tgat", choices=["tgat", "tgn", "dygformer"],
                     help="tgat = BASELINE configs[1] (the headline) / configs[4]; tgn = configs[2] (Reddit-shape, memory + GRU update + "
                          "message scatter); dygformer = configs[3] (Reddit-shape, first-hop sequence transformer)")
@@ -139,6 +142,8 @@ def main():
         node_tab, edge_tab = data.node_raw_features, data.edge_raw_features
         workload = "Wikipedia-shape synthetic (9227 nodes, 157474 edges, 172-d edge feats)"
     n_train = int(0.7 * data.num_interactions)
+    if args.mode == "sweep":
+        return bench_sweep(args, data, node_tab, edge_tab, workload, dev, rank, world)
     sampler = get_neighbor_sampler(data.slice(0, n_train), "recent", seed=0)       # train graph, as EM_warmup.py:71-76
     if args.workload == "scale" and rank == 0:
         print(f"[bench] scale workload built in {time.perf_counter() - t_gen:.1f} s", file=sys.stderr, flush=True)
@@ -366,6 +371,43 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:        # reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(data, n_train, model, batch_slice(args.warmup), args.cpu_sample_edges)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def bench_sweep(args, data, node_tab, edge_tab, workload, dev, rank, world):
+    """--mode sweep: M_step.py:456-509 over the whole stream (full-graph sampler, eval mode), timed end to end"""
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.sweep import regenerate_embeddings
+    from flid_amd.utils.utils import get_neighbor_sampler
+    sampler = get_neighbor_sampler(data, "recent", seed=1)                         # full graph, as train.py:707
+    torch.manual_seed(0)
+    model = TGAT(node_tab, edge_tab, sampler, time_feat_dim=DT, num_layers=L, num_heads=H, dropout=args.dropout, device=str(dev)).to(dev)
+    E = data.num_interactions
+    stores = (torch.zeros((E, DN), device=dev), torch.zeros((E, DN), device=dev))
+    warm = min(E, args.warmup * args.chunk_edges)
+    regenerate_embeddings(model, data, 200, K, args.chunk_edges, out=stores, first_edge=0, num_edges=warm, rank=rank, world=world)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    regenerate_embeddings(model, data, 200, K, args.chunk_edges, out=stores, rank=rank, world=world)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    chunks = -(-E // args.chunk_edges)
+    bpe = tgat_bytes_per_edge() // 2
+    out = {"metric": "edges/sec (embedding-regeneration sweep, fwd only, eval), TGAT Wikipedia", "value": round(E / elapsed, 1), "unit": "edges/s",
+           "n_gpus": world, "steps": chunks, "warmup": args.warmup, "ms_per_step": round(elapsed / chunks * 1e3, 4), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": workload + f" + TGAT L=2 H=2 T=100, 20 recent neighbors, whole stream ({E} edges) in chunks of {args.chunk_edges}, "
+                                             "full-graph sampler, eval mode, stores (E, 172) x 2 resident", "parallelism": f"dp{world}"},
+           "path_roofline": {"bytes_per_edge_fwd": bpe, "hbm_frac": round(E / elapsed / world * bpe / HBM_PEAK, 4),
+                             "edges_per_s_at_100pct": round(HBM_PEAK / bpe, 1)}, "sweep_seconds": round(elapsed, 4)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -457,7 +457,7 @@ def test_fused_train_step_equals_autograd_path():
         else:
             emb, loss = m.train_step(pf, lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w), k)
             assert not emb.requires_grad
-        res.append((emb.detach().clone(), float(loss), flat.grad.clone()))
+        res.append((emb.detach().clone(), float(loss.detach()), flat.grad.clone()))
         # one-stage prefetch and the plain call see the same frontier
         with torch.no_grad():
             s1, d1 = m.compute_src_dst_node_temporal_embeddings(m.prepare_batch(src, dst, t, k), None, None, k)
@@ -504,3 +504,39 @@ def test_tgat_random_sampling_strategies_follow_the_reference_rng_stream(strateg
         for name, prm in m.named_parameters():
             gm, go = prm.grad.cpu().numpy(), p[name].grad.numpy()
             assert np.abs(gm - go).max() <= 1e-4 * max(1.0, np.abs(go).max()), (layers, name)
+
+
+def test_regeneration_sweep_fills_the_stores_like_the_per_batch_loop():
+    """flid_amd.sweep.regenerate_embeddings (chunked, prefetched, written in place) == the reference's loop of per-batch calls
+    (M_step.py:456-509) == the oracle on a sample of edges; two-"rank" chunk interleaving fills disjoint rows"""
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.sweep import regenerate_embeddings
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = wikipedia_like(num_edges=2400, num_users=150, num_items=30, feat_dim=16, seed=12, zero_node_feat=False)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    torch.manual_seed(0)
+    m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 8, 2, 2, 0.1, "cuda:0").to("cuda:0").train()
+    with torch.no_grad():
+        m.time_encoder.w.bias.zero_()
+    s_store, d_store = regenerate_embeddings(m, data, batch_size=200, num_neighbors=7, chunk_edges=512)
+    assert m.training and s_store.shape == (2400, 16)
+    m.eval()
+    ref_s, ref_d = [], []
+    with torch.no_grad():
+        for lo in range(0, 2400, 200):                                     # the reference's loop
+            a, b = m.compute_src_dst_node_temporal_embeddings(data.src_node_ids[lo:lo + 200], data.dst_node_ids[lo:lo + 200],
+                                                              data.node_interact_times[lo:lo + 200], 7)
+            ref_s.append(a); ref_d.append(b)
+    assert float((torch.cat(ref_s) - s_store).abs().max()) < 2e-5 and float((torch.cat(ref_d) - d_store).abs().max()) < 2e-5
+    # rank-interleaved chunks: each "rank" fills its own rows, the sum of the two stores is the full result
+    r0 = regenerate_embeddings(m, data, 200, 7, chunk_edges=512, out=(torch.zeros_like(s_store), torch.zeros_like(d_store)), first_edge=0, num_edges=1024)
+    assert float((r0[0][:1024] - s_store[:1024]).abs().max()) < 2e-5 and float(r0[0][1024:].abs().max()) == 0.0
+    p = {k_: v.detach().cpu() for k_, v in m.state_dict().items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    orc = O.TGATOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 2, 2)
+    pick = np.arange(5, 2400, 97)
+    with torch.no_grad():
+        os_, od_ = orc.src_dst(data.src_node_ids[pick], data.dst_node_ids[pick], data.node_interact_times[pick], 7)
+    np.testing.assert_allclose(s_store.cpu().numpy()[pick], os_.numpy(), atol=TOL)
+    np.testing.assert_allclose(d_store.cpu().numpy()[pick], od_.numpy(), atol=TOL)

@@ -251,3 +251,24 @@ def test_tgn_fused_train_step_equals_autograd_path():
         a, c = ma.memory_bank, mf.memory_bank
         assert torch.allclose(a.node_memories, c.node_memories, atol=1e-6) and torch.equal(a.node_last_updated_times, c.node_last_updated_times)
         assert np.array_equal(a._has, c._has) and torch.allclose(a._msg, c._msg, atol=1e-6)
+
+
+def test_tgn_regeneration_sweep_equals_sequential_positive_calls():
+    """TGN sweep (M_step.py:456-509 with the memory bank reset first): stores == the loop of positive calls; state advanced alike"""
+    from flid_amd.sweep import regenerate_embeddings
+    g = load_golden("tgn_small")
+    ma, p, k = _model(g)
+    mb, _, _ = _model(g)
+    for m in (ma, mb):
+        m.eval()
+        m.memory_bank.__init_memory_bank__()
+    d = _Data(g)
+    n = 84
+    d.src_node_ids, d.dst_node_ids, d.node_interact_times, d.edge_ids = g["src"][:n], g["dst"][:n], g["t"][:n], g["eid"][:n]
+    d.num_interactions = n
+    s_store, d_store = regenerate_embeddings(ma, d, batch_size=12, num_neighbors=k)
+    with torch.no_grad():
+        for lo in range(0, n, 12):
+            a, b = mb.compute_src_dst_node_temporal_embeddings(g["src"][lo:lo + 12], g["dst"][lo:lo + 12], g["t"][lo:lo + 12], g["eid"][lo:lo + 12], True, k)
+            assert float((a - s_store[lo:lo + 12]).abs().max()) < 2e-6 and float((b - d_store[lo:lo + 12]).abs().max()) < 2e-6
+    assert torch.allclose(ma.memory_bank.node_memories, mb.memory_bank.node_memories, atol=1e-6)
