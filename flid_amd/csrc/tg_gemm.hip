@@ -19,6 +19,8 @@
 // MFMA step q uses k = 16*(lane>>5) + q for BOTH operands (any bijection of k is a valid contraction order).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "tg_common.h"
 
 namespace tg {
@@ -320,8 +322,13 @@ struct SplitWs { hipStream_t stream; float* p; size_t floats; };
 SplitWs g_split_ws[4] = {};
 constexpr size_t kSplitWsMaxFloats = (size_t)256 << 20;       // 1 GiB per stream; larger splits fall back to atomics
 
+// tg_gemm_f32 is reachable from two host threads (the side-stream issuing thread of tg_layer.hip and the caller's): slot claims and
+// growth of the per-stream workspaces are serialised
+std::mutex g_ws_mutex;
+
 float* split_workspace(size_t need, hipStream_t s) {
     if (need > kSplitWsMaxFloats) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
     SplitWs* w = nullptr;
     for (auto& c : g_split_ws) if (c.p && c.stream == s) { w = &c; break; }
     if (!w) for (auto& c : g_split_ws) if (!c.p) { w = &c; w->stream = s; break; }
@@ -355,6 +362,7 @@ __global__ void __launch_bounds__(256) transpose_kn_kernel(const float* __restri
 }
 SplitWs g_tr_ws[4] = {};
 float* transpose_workspace(size_t need, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
     SplitWs* w = nullptr;
     for (auto& c : g_tr_ws) if (c.p && c.stream == s) { w = &c; break; }
     if (!w) for (auto& c : g_tr_ws) if (!c.p) { w = &c; w->stream = s; break; }

@@ -108,6 +108,7 @@ extern "C" int tg_graph_create(const int64_t* h_src, const int64_t* h_dst, const
     bool chronological = true;
     {
         // degrees: per-thread edge chunks, atomic increments (relaxed) on the shared counters
+        static_assert(sizeof(std::atomic<int64_t>) == sizeof(int64_t) && alignof(std::atomic<int64_t>) == alignof(int64_t), "lock-free 64-bit counters");
         std::atomic<int64_t>* cnt = reinterpret_cast<std::atomic<int64_t>*>(row_ptr.data());
         std::vector<int> unsorted(nt, 0);
         parallel_for_threads(nt, [&](int t) {

@@ -400,7 +400,7 @@ struct SideStream {
         // evenly (three concurrent products each ran 2-3x slower, and the main-chain one is on the critical path)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        static const bool flat_prio = getenv("FLID_SIDE_PRIO_DEFAULT") != nullptr;
+        static const bool flat_prio = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_SIDE_PRIO_DEFAULT") != nullptr;
         for (auto& st : side)
             if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, flat_prio ? 0 : lo) != hipSuccess) return false;
         for (auto& e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
@@ -629,7 +629,13 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const bool threaded = overlap && g_issue_thread;
     const bool defer = overlap && Bw->defer_join != 0;             // the caller joins once, after its last layer (tg_side_join)
     struct Drain { bool on; ~Drain() { if (on) (void)g_issuer.drain(); } } drain_guard{threaded};    // disarmed on the success paths below
-    static const bool exp_skip_side = getenv("FLID_EXP_SKIP_SIDE") != nullptr;   // timing experiment (wrong gradients): the main chain alone
+    // timing experiment (WRONG gradients: every weight-gradient launch is dropped): the main chain alone.  Read only in tuning
+    // mode, like the other experiment knobs, and announced once -- a stray variable must not silently zero a training run's gradients.
+    static const bool exp_skip_side = [] {
+        const bool on = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_EXP_SKIP_SIDE") != nullptr;
+        if (on) fprintf(stderr, "[flid_tg] FLID_EXP_SKIP_SIDE: weight-gradient launches are SKIPPED (timing experiment, gradients are wrong)\n");
+        return on;
+    }();
     auto side = [&](std::function<int()> f) -> int {
         if (exp_skip_side) return TG_OK;
         if (!threaded) return f();

@@ -134,6 +134,10 @@ class TGAT(nn.Module):
         if host_sampler is not None and isinstance(node_ids, engine.PreparedFrontier):
             raise NotImplementedError("prepared batches are device-sampled ('recent')")
         flat = getattr(self, "_flat_pack", None)
+        if flat is not None and current_layer_num != self.num_layers and torch.is_grad_enabled():
+            # the named parameters are views with requires_grad off in this mode: a partial-depth call would train nothing, silently
+            raise RuntimeError("flatten_parameters(): only full-depth calls (current_layer_num == num_layers) are differentiable; "
+                               "use torch.no_grad() for partial depths or do not flatten")
         if flat is not None and current_layer_num == self.num_layers and torch.is_grad_enabled():
             views = flat[1]
             return engine.embed(self.neighbor_sampler.graph, self.node_raw_features, self.edge_raw_features, views[0], views[1],
