@@ -444,6 +444,9 @@ struct PanelT1 : PanelT<R> {
     }
 };
 
+#ifndef FLID_WG_EXP
+#define FLID_WG_EXP 0   // timing experiments only (results wrong): 1 = no atomic fold, 2 = no MFMAs
+#endif
 template <int TNW>
 __global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int64_t K, int64_t k_chunk, const float* __restrict__ zeros) {
     constexpr int BNt = 32 * TNW;
@@ -548,6 +551,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int6
         const int64_t row = row0 + r, col = bn + c;
         if (row >= M) continue;
         const float v = cs[r * CS + c];
+        if (FLID_WG_EXP == 1) { if (v == 12345.678f) J.C[0] = v; continue; }
         if (col < N) atomicAdd(J.C + row * J.ldc + col, v);
         else if (col == N && J.colsum) atomicAdd(J.colsum + row, v);
     }

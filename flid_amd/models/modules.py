@@ -34,8 +34,17 @@ class _LinearFn(torch.autograd.Function):
             ops.gemm(dy2, w, dx)
             dx = dx.reshape(ctx.shape)
         if need_w:
-            dw = torch.empty_like(w)
-            ops.gemm(dy2, x2, dw, ta=True)
+            # weight and bias gradient in ONE launch (tg_wgrad_group: split-bf16 MFMA, bias sum through the ones column, atomic fold)
+            # when the shapes allow it; otherwise one exact product + one column sum
+            n_out, n_in = w.shape
+            if n_out % 4 == 0 and n_in % 4 == 0 and dy2.shape[0] >= 256 and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0:
+                dw = torch.zeros_like(w)
+                db = torch.zeros(n_out, device=w.device) if need_b else None
+                ops.wgrad_group([(dy2, x2, dw, db)])
+                need_b = False
+            else:
+                dw = torch.empty_like(w)
+                ops.gemm(dy2, x2, dw, ta=True)
         if need_b:
             db = ops.colsum(dy2)
         return dx, dw, db, None
