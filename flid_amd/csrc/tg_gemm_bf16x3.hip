@@ -13,6 +13,7 @@
 // 144 B, conflict-free ds_read_b128) -> fragments.  Two LDS stages, one barrier per 32-deep stage, global loads of stage s+2
 // in flight under stage s.
 #include <math.h>
+#include <stdlib.h>
 
 #include "tg_common.h"
 
@@ -23,7 +24,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32;
 constexpr int ROW_BYTES = 144;                 // 64 B hi + 64 B lo + 16 B pad
-constexpr int BM = 128, NT = 256;
+#ifndef FLID_BF_BM
+#define FLID_BF_BM 128
+#endif
+constexpr int BM = FLID_BF_BM, NT = 2 * FLID_BF_BM;      // one wave per 32 rows of the block tile
 #ifndef FLID_NT_SCHED
 #define FLID_NT_SCHED 1
 #endif
@@ -213,7 +217,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
     // 16-byte-aligned row segments (bias / accumulate / ReLU applied on the way).
     __syncthreads();                                    // all waves are done reading the operand stages
     constexpr int CS = BNt + 8;                         // row stride in floats: 4 rows further = 32 banks further
-    static_assert(4 * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
+    static_assert((NT / 64) * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
     float* cs = reinterpret_cast<float*>(lds) + wave * 32 * CS;
     {
         const int rl = lane & 31, kh = lane >> 5;
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N
     // partial tile -> LDS -> whole 16-byte chunks of ws[slice] (N % 4 == 0, checked by the launcher)
     __syncthreads();
     constexpr int CS = BNt + 8;
-    static_assert(4 * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
+    static_assert((NT / 64) * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
     float* cs = reinterpret_cast<float*>(lds) + wave * 32 * CS;
     {
         const int rl = lane & 31, kh = lane >> 5;
@@ -422,35 +426,72 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N
 struct WgJob { const float* A; const float* B; float* C; float* colsum; int64_t lda, ldb, ldc; int M, N, gx, tile0; };
 struct WgJobs { WgJob j[6]; int n, total_tiles; };
 
-template <int R>
-struct PanelT1 : PanelT<R> {
-    bool ones;         // this thread's micro-tile starts at the injected ones column
-    __device__ __forceinline__ void init1(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, bool inject) {
-        this->init(X, ld, row0, nrows);
-        const int t = threadIdx.x % PanelT<R>::TILES;
-        ones = inject && (row0 + (t / 8) * 4 == nrows);
-    }
-    // as PanelT::sstore; kvalid = bit i set when k row i of the micro-tile exists (the ones column must vanish past the end of K)
-    __device__ __forceinline__ void sstore1(char* __restrict__ s, const float4 (&reg)[4], int kvalid) const {
-        float4 r0 = reg[0], r1 = reg[1], r2 = reg[2], r3 = reg[3];
-        if (ones) {
-            r0 = make_float4((kvalid & 1) ? 1.f : 0.f, 0.f, 0.f, 0.f);
-            r1 = make_float4((kvalid & 2) ? 1.f : 0.f, 0.f, 0.f, 0.f);
-            r2 = make_float4((kvalid & 4) ? 1.f : 0.f, 0.f, 0.f, 0.f);
-            r3 = make_float4((kvalid & 8) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+// K-major panel of R output rows x 32 k for a workgroup of NTH threads: (R / 4) * 8 micro-tiles of 4 (k) x 4 (rows), PER per thread
+// (threads past the last micro-tile redo an earlier one: same loads, same bytes into LDS -- no inactive-thread branches in a stage).
+template <int R, int NTH>
+struct PanelK {
+    static constexpr int TILES = (R / 4) * 8;
+    static constexpr int PER = (TILES + NTH - 1) / NTH;
+    const float* src[PER];     // micro-tile origin at k = 0
+    int lds_off[PER];          // byte offset of (row group, k group)
+    int kcol[PER];
+    bool ones[PER];            // the micro-tile starts at the injected ones column
+
+    __device__ __forceinline__ void init(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, bool inject) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int t = (threadIdx.x + j * NTH) % TILES;
+            const int kg = t % 8, rg = t / 8;
+            int64_t row = row0 + rg * 4;
+            ones[j] = inject && row == nrows;
+            if (row > nrows - 4) row = nrows - 4;                   // nrows % 4 == 0 (checked by the launcher)
+            if (row < 0) row = 0;
+            src[j] = X + (int64_t)(kg * 4) * ld + row;
+            lds_off[j] = (rg * 4) * ROW_BYTES + kg * 8;
+            kcol[j] = kg * 4;
         }
-        const float4 rr[4] = {r0, r1, r2, r3};
-        PanelT<R>::sstore(s, rr);
+    }
+    __device__ __forceinline__ void gload(int64_t ld, int64_t k0, int64_t kend, bool ok, const float* __restrict__ zeros, float4 (&reg)[PER][4]) const {
+        const int64_t lim = ok ? kend : 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* p = (k0 + kcol[j] + i < lim) ? src[j] + (k0 + i) * ld : zeros;
+                reg[j][i] = *reinterpret_cast<const float4*>(p);
+            }
+    }
+    // 4x4 register transpose, split, 8-byte stores: 4 consecutive k of one output row per word.  k rows past the end of K were
+    // loaded from the zero block; the ones column of such rows is multiplied by zero rows of the other operand, so it needs no mask.
+    __device__ __forceinline__ void sstore(char* __restrict__ s, const float4 (&reg)[PER][4]) const {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            float4 r0 = reg[j][0], r1 = reg[j][1], r2 = reg[j][2], r3 = reg[j][3];
+            if (ones[j]) { r0 = r1 = r2 = r3 = make_float4(1.f, 0.f, 0.f, 0.f); }
+            const float4 rows[4] = {make_float4(r0.x, r1.x, r2.x, r3.x), make_float4(r0.y, r1.y, r2.y, r3.y),
+                                    make_float4(r0.z, r1.z, r2.z, r3.z), make_float4(r0.w, r1.w, r2.w, r3.w)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint2 hi, lo;
+                split4(rows[r], hi, lo);
+                *reinterpret_cast<uint2*>(s + lds_off[j] + r * ROW_BYTES) = hi;
+                *reinterpret_cast<uint2*>(s + lds_off[j] + r * ROW_BYTES + 64) = lo;
+            }
+        }
     }
 };
 
 #ifndef FLID_WG_EXP
-#define FLID_WG_EXP 0   // timing experiments only (results wrong): 1 = no atomic fold, 2 = no MFMAs
+#define FLID_WG_EXP 0   // timing experiments only (results wrong): 1 = no atomic fold
 #endif
+constexpr int WBM = 64, WNT = 128;     // weight-gradient workgroup: 2 waves x (32 x 32 TNW), block tile 64 x 32 TNW.  64 rows fit the
+                                       // output heights of this path (172 -> 192, 272 -> 320, 136 -> 192; 128-row tiles padded them to
+                                       // 256 / 384 / 256) and 46 KB of LDS lets 3 workgroups share a CU: measured 80 / 99 / 57 us ->
+                                       // 52 / 73 / 50 us for the three launches of a 13.6 k-row layer.
 template <int TNW>
-__global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int64_t K, int64_t k_chunk, const float* __restrict__ zeros) {
+__global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int64_t K, int64_t k_chunk, const float* __restrict__ zeros) {
     constexpr int BNt = 32 * TNW;
-    constexpr int FA = BM * ROW_BYTES, FB = BNt * ROW_BYTES;
+    constexpr int FA = WBM * ROW_BYTES, FB = BNt * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
     auto sA = [&](int i) -> char* { return lds + i * (FA + FB); };
     auto sB = [&](int i) -> char* { return lds + i * (FA + FB) + FA; };
@@ -462,7 +503,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int6
     const WgJob J = jobs.j[ji];
     const int tile = t - J.tile0, by = tile / J.gx, bx = tile % J.gx;
     const int64_t M = J.M, N = J.N;
-    const int64_t bm = (int64_t)by * BM, bn = (int64_t)bx * BNt;
+    const int64_t bm = (int64_t)by * WBM, bn = (int64_t)bx * BNt;
     const int64_t kbeg = (int64_t)slice * k_chunk, kend = (kbeg + k_chunk < K) ? kbeg + k_chunk : K;
     if (kbeg >= K) return;                                  // (uniform; a surplus slice has nothing to add)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -472,24 +513,19 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int6
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
 
-    PanelT<BM> pa;
-    PanelT1<BNt> pb;
-    pa.init(J.A, J.lda, bm, M);
-    pb.init1(J.B, J.ldb, bn, N, J.colsum != nullptr);
-    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    using PA = PanelK<WBM, WNT>;
+    using PB = PanelK<BNt, WNT>;
+    PA pa;
+    PB pb;
+    pa.init(J.A, J.lda, bm, M, false);
+    pb.init(J.B, J.ldb, bn, N, J.colsum != nullptr);
+    float4 ra0[PA::PER][4], rb0[PB::PER][4], ra1[PA::PER][4], rb1[PB::PER][4];
     const int64_t nstage = (kend - kbeg + BK - 1) / BK;
-    auto kmask = [&](int64_t st) -> int {                   // which of this thread's 4 k rows of stage st exist
-        const int64_t k0 = kbeg + st * BK + pb.kcol;
-        int mk = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mk |= (st < nstage && k0 + i < kend) ? (1 << i) : 0;
-        return mk;
-    };
-    auto issue = [&](int64_t st, float4 (&ra)[4], float4 (&rb)[4]) {
+    auto issue = [&](int64_t st, float4 (&ra)[PA::PER][4], float4 (&rb)[PB::PER][4]) {
         pa.gload(J.lda, kbeg + st * BK, kend, st < nstage, zeros, ra);
         pb.gload(J.ldb, kbeg + st * BK, kend, st < nstage, zeros, rb);
     };
-    auto stage = [&](int64_t st, float4 (&ra)[4], float4 (&rb)[4]) {
+    auto stage = [&](int64_t st, float4 (&ra)[PA::PER][4], float4 (&rb)[PB::PER][4]) {
         const int cur = (int)(st & 1);
         bf16x8 ah[2], al[2], bh[TNW][2], bl[TNW][2];
 #pragma unroll
@@ -499,7 +535,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int6
             for (int tt = 0; tt < TNW; ++tt) read_frag(sB(cur), 32 * tt, ks, bh[tt][ks], bl[tt][ks]);
         }
         pa.sstore(sA(cur ^ 1), ra);                   // (ra, rb) hold stage st + 1
-        pb.sstore1(sB(cur ^ 1), rb, kmask(st + 1));
+        pb.sstore(sB(cur ^ 1), rb);
         issue(st + 3, ra, rb);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -515,8 +551,8 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int6
 #pragma unroll
             for (int i = 0; i < 6 * TNW; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
@@ -524,7 +560,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int6
     };
     issue(0, ra0, rb0);
     pa.sstore(sA(0), ra0);
-    pb.sstore1(sB(0), rb0, kmask(0));
+    pb.sstore(sB(0), rb0);
     issue(1, ra0, rb0);
     issue(2, ra1, rb1);
     __syncthreads();
@@ -535,7 +571,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int6
     // partial tile -> LDS -> float atomics into C, 64 consecutive columns of a row per wave instruction
     __syncthreads();
     constexpr int CS = BNt + 8;
-    static_assert(4 * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
+    static_assert((WNT / 64) * 32 * CS * 4 <= 2 * (FA + FB), "C staging must fit the operand stages");
     float* cs = reinterpret_cast<float*>(lds) + wave * 32 * CS;
     {
         const int rl = lane & 31, kh = lane >> 5;
@@ -569,32 +605,28 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
     if (njobs < 1 || njobs > 6 || rows < 1) return false;
     const float* zeros = zero_block();
     if (!zeros) return false;
-    // One column-tile width (96 or 64) and one K-slice count (a multiple of 8: XCD pinning) for the launch, by a small cost model:
-    // 512 workgroups are resident at once (2 per CU: 64 KB of LDS each), so time ~ rounds x (stages x t_stage + fixed) plus the
-    // float-atomic traffic of the fold (every slice adds a whole padded tile; ~1.3 TB/s chip-wide).  Measured t_stage: 1.15 us
-    // (128 x 96) / 0.95 us (128 x 64); fixed ~6 us (first loads, epilogue).  [The first version rounded the slice count UP: 560
-    // workgroups = two rounds for a 512-slot chip, 78 us for a 35 us launch.]
-    int best_tnw = 3;
-    int64_t best_slices = 8;
-    double best_cost = 1e30;
-    const int64_t max_slices = std::max<int64_t>(8, rows / (4 * BK) / 8 * 8);
-    for (int tnw_c = 2; tnw_c <= 3; ++tnw_c) {
-        int64_t tiles = 0;
+    // One column-tile width (64 or 96) and one K-slice count (a multiple of 8: XCD pinning) for the launch.  Swept on MI355X
+    // (tools/wgrad_sweep.py, 13.6 k rows): the best point of every launch of a layer has 500-700 workgroups (768 are resident at
+    // once: 3 per CU at 46 KB of LDS) and the 64-wide tile unless it pads the outputs > 10 % more than the 96-wide one:
+    //   dW2 + dW1a + dW1b: 33 tiles x 16 slices 52.6 us (x8 71.8, x24 58.6, x32 71.6);  dP: 42 x 16 51.6 us (x8 67.6, x24 54.9);
+    //   dV: 70 x 8 83.5 us (x16 87.9).  More slices only multiply the atomic fold's traffic, fewer leave the chip half empty.
+    int64_t tiles_c[2] = {0, 0};
+    for (int c = 0; c < 2; ++c) {
+        const int w = 32 * (c + 2);
         for (int i = 0; i < njobs; ++i) {
             const int64_t need = jobs[i].N + (jobs[i].colsum_A ? 1 : 0);
-            tiles += ((need + 32 * tnw_c - 1) / (32 * tnw_c)) * ((jobs[i].M + BM - 1) / BM);
+            tiles_c[c] += ((need + w - 1) / w) * ((jobs[i].M + WBM - 1) / WBM);
         }
-        for (int64_t sl = 8; sl <= max_slices; sl += 8) {
-            const int64_t kc = ((rows + sl - 1) / sl + BK - 1) / BK * BK;
-            const double stages = (double)kc / BK, wgs = (double)tiles * sl;
-            const double rounds = std::ceil(wgs / 512.0);
-            const double t_stage = tnw_c == 3 ? 1.15 : 0.95;
-            const double fill = std::min(1.0, wgs / 512.0);                       // a half-empty chip runs its stages faster
-            const double compute = rounds * (stages * t_stage * (0.6 + 0.4 * fill) + 6.0);
-            const double atomics = wgs * BM * 32.0 * tnw_c * 4.0 / 1.3e6;         // bytes / (1.3 TB/s) in us
-            const double cost = compute + atomics;
-            if (cost < best_cost) { best_cost = cost; best_tnw = tnw_c; best_slices = sl; }
-        }
+    }
+    int best_tnw = (double)tiles_c[0] * 64 <= (double)tiles_c[1] * 96 * 1.1 ? 2 : 3;
+    const int64_t max_slices = std::max<int64_t>(8, rows / (4 * BK) / 8 * 8);
+    int64_t best_slices = std::max<int64_t>(8, 700 / std::max<int64_t>(1, tiles_c[best_tnw - 2]) / 8 * 8);
+    if (best_slices > max_slices) best_slices = max_slices;
+    static const bool tuning = getenv("FLID_GEMM_TUNE") != nullptr;          // overrides are read only in tuning mode (tools/)
+    if (tuning) {
+        if (const char* e = getenv("FLID_WG_TNW")) { const int v = atoi(e); if (v == 2 || v == 3) best_tnw = v; }
+        if (const char* e = getenv("FLID_WG_SLICES")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) best_slices = v; }
+        if (getenv("FLID_WG_VERBOSE")) fprintf(stderr, "[wgrad] jobs=%d rows=%lld tnw=%d slices=%lld\n", njobs, (long long)rows, best_tnw, (long long)best_slices);
     }
     const int tnw = best_tnw;
     WgJobs wj;
@@ -607,7 +639,7 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
             return false;
         if (q.lda < q.M || q.ldb < q.N || q.ldc < q.N) return false;
         const int64_t need = q.N + (q.colsum_A ? 1 : 0);
-        const int gx = (int)((need + 32 * tnw - 1) / (32 * tnw)), gy = (q.M + BM - 1) / BM;
+        const int gx = (int)((need + 32 * tnw - 1) / (32 * tnw)), gy = (q.M + WBM - 1) / WBM;
         wj.j[i] = WgJob{q.A, q.B, q.C, q.colsum_A, q.lda, q.ldb, q.ldc, q.M, q.N, gx, wj.total_tiles};
         wj.total_tiles += gx * gy;
         flops += 2.0 * q.M * q.N * rows;
@@ -618,8 +650,8 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
     const int64_t blocks = (int64_t)wj.total_tiles * slices;
     if (blocks >= ((int64_t)1 << 31)) return false;
     ProfScope prof("gemm", flops, s);
-    if (tnw == 3) gemm_bf16x3_wgrad_kernel<3><<<(unsigned)blocks, NT, 0, s>>>(wj, rows, k_chunk, zeros);
-    else gemm_bf16x3_wgrad_kernel<2><<<(unsigned)blocks, NT, 0, s>>>(wj, rows, k_chunk, zeros);
+    if (tnw == 3) gemm_bf16x3_wgrad_kernel<3><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk, zeros);
+    else gemm_bf16x3_wgrad_kernel<2><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk, zeros);
     return true;
 }
 
