@@ -518,11 +518,16 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     // the constant half of the query, qb = Wq[:, dn:] cos b
     TG_TRY(tg_gemm_f32(0, 1, 1, dq, T, 1.f, L->cosb, T, P.Wq + dn, dq, L->qbias, dq, nullptr, 0, 0, stream));
     if (g_merged && R >= kMergedMinRows) {
+        // merged QUERY side (u = own P^T + ub: the q intermediate and one product per direction leave the chain); the value side keeps
+        // the reference's two products (ctx_h = Wv_h agg_h, res = Wr ctx + br): its merged form V_h = Wr[:, h] Wv_h cost as much on the
+        // main chain but needed a (dq x H dk) gradient product over all rows (89 us) plus a weight-space chain behind it
         TrJobs jobs;
         int n = 0;
         jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
         jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
         jobs.j[n++] = TrJob{P.W1 + dq, wt.W1b, dn, dn, (int64_t)dq + dn, dn};
+        for (int h = 0; h < H; ++h) jobs.j[n++] = TrJob{P.Wv + (int64_t)h * hd * dk, wt.Wv + (int64_t)h * dk * hd, hd, dk, dk, hd};
+        jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
         jobs.n = n;
         transpose_many_kernel<<<dim3(64, n), 256, 0, s>>>(jobs);
         TG_TRY(tg::launch_status("transpose_many_kernel"));
@@ -533,9 +538,6 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
             for (int h = 0; h < H; ++h)         // P_h (dk x dn): A(m = j, k) = Wk[h hd + k, j], B(k, n = i) = Wq[h hd + k, i]
                 add_job(mj, P.Wk + (int64_t)h * hd * dk, P.Wq + (int64_t)h * hd * dq, wt.P + (int64_t)h * dk * dn, wt.PT + (int64_t)h * dk,
                         dk, dn, hd, 1, dk, dq, 1, dn, H * dk, 0);
-            for (int h = 0; h < H; ++h)         // V_h (dq x dk): A(m = r, k) = Wr[r, h hd + k], B(k, n = j) = Wv[h hd + k, j]
-                add_job(mj, P.Wr + (int64_t)h * hd, P.Wv + (int64_t)h * hd * dk, wt.V + (int64_t)h * dk, wt.VT + (int64_t)h * dk * dq,
-                        dq, dk, hd, dq, 1, dk, 1, H * dk, dq, 0);
             const unsigned blocks = (unsigned)(mj.total_tiles + ((int64_t)H * dk + 255) / 256);
             merge_weights_kernel<<<blocks, 256, 0, s>>>(mj, P.Wk, L->qbias, H, hd, dk, wt.ub);
             TG_TRY(tg::launch_status("merge_weights_kernel"));
@@ -543,8 +545,9 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         // u = own P^T + ub   (all heads in one product, K = dn)
         TG_TRY(tg_gemm_f32(0, 1, R, H * dk, dn, 1.f, L->own, L->own_ld, wt.P, dn, L->u, (int64_t)H * dk, wt.ub, 0, 0, stream));
         TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
-        // res = agg V^T + br   (K = H dk)
-        TG_TRY(tg_gemm_f32(0, 1, R, dq, H * dk, 1.f, L->agg, (int64_t)H * dk, wt.V, (int64_t)H * dk, L->res, dq, P.br, 0, 0, stream));
+        // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
+        TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
+        TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
     } else {
         // Transposed copies of the weights that the chain multiplies "from the right" (u = q Wk, and every dX = dY W of the
         // backward): with them EVERY product of the main chain has two k-contiguous operands and runs on the split-bf16 kernel.
@@ -595,7 +598,8 @@ extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
 
 extern "C" int64_t tg_tgat_layer_vec_floats(int dn, int dq, int dk, int heads) {
     const int64_t hk = (int64_t)heads * dk;
-    return ((dq + hk + 3) / 4) * 4 + ((int64_t)dq * hk + 3) / 4 * 4 + ((int64_t)hk * dn + 3) / 4 * 4 + 16;
+    (void)dq;
+    return ((dq + hk + 3) / 4) * 4 + ((int64_t)hk * dn + 3) / 4 * 4 + 16;
 }
 
 extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
@@ -661,11 +665,10 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     float* part_ln = part_relu + relu_blocks * dn;
     float* part_attn = part_ln + (int64_t)ln_grid * 4 * dq;
     const int64_t hk = (int64_t)H * dk;
-    // zero-on-entry scratch (`vec`): [sum_rows dq (dq) or sum_rows du (H dk)] | dV (dq, H dk) | dP (H dk, dn)   (the last two: merged form)
+    // zero-on-entry scratch (`vec`): [sum_rows dq (dq) or sum_rows du (H dk)] | dP (H dk, dn) (merged query side)
     float* vec_dq = vec;
     float* dub = vec;
-    float* dVm = vec + ((dq + hk + 3) / 4) * 4;
-    float* dPm = dVm + ((int64_t)dq * hk + 3) / 4 * 4;
+    float* dPm = vec + ((dq + hk + 3) / 4) * 4;                 // gradient of the merged query projection, (H dk, dn)
     // Weight (and bias) gradients of up to 6 Linear layers in ONE launch on the side stream (tg_wgrad_group: split-bf16 MFMA, bias
     // sums through a ones column, partial tiles folded with float atomics); shapes it does not cover fall back to one exact
     // product + one column sum per job.
@@ -728,17 +731,16 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         return side([=] { return colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, st); });
     };
     if (g_merged && R >= kMergedMinRows) {
-        // gradients of the merged projections land in zeroed scratch and are chained back to Wq / Wk / Wv / Wr in weight space
-        // ---- value path: dagg = dres V ----------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32(0, 1, R, hk, dq, 1.f, dres, dq, wt.VT, dq, Bw->dagg, hk, nullptr, 0, 0, stream));
-        // (issued after the main-chain product above: dV then runs under the attention backward instead of competing with dagg)
-        TG_TRY(fork());                       // dres / dsum and the LayerNorm slabs are final
-        TG_TRY(wgrad({WJ{dres, dq, dq, Lc.agg, hk, (int)hk, dVm, hk, G.br}}));                      // dV = dres^T agg, d br = sum_rows dres
+        // ---- output projection + value path (the reference's two products; weight gradients in one grouped launch) ------------------
+        TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
+        TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, hk, dk, H, nullptr, 0, 0, stream));
+        TG_TRY(fork());                       // dres / dsum, dctx and the LayerNorm slabs are final
         {
-            void* stv = wstream;
-            // V_h = Wr[:, h] Wv_h :  dWr[:, h] += dV_h Wv_h^T ;  dWv_h += Wr[:, h]^T dV_h   (two small MFMA products in weight space)
-            TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, dq, hd, dk, 1.f, dVm, hk, dk, P.Wv, dk, (int64_t)hd * dk, G.Wr, dq, hd, H, nullptr, 0, 1, stv); }));
-            TG_TRY(side([=] { return tg_gemm_f32_batched(1, 0, hd, dk, dq, 1.f, P.Wr, dq, hd, dVm, hk, dk, G.Wv, dk, (int64_t)hd * dk, H, nullptr, 0, 1, stv); }));
+            std::vector<WJ> jobs;
+            jobs.push_back(WJ{dres, dq, dq, Lc.ctx, dq, dq, G.Wr, dq, G.br});                                                    // dWr, d br
+            for (int h = 0; h < H; ++h)                                                                                           // dWv_h = dctx_h^T agg_h
+                jobs.push_back(WJ{Bc.dctx + h * hd, dq, hd, Lc.agg + (int64_t)h * dk, hk, dk, G.Wv + (int64_t)h * hd * dk, dk, nullptr});
+            TG_TRY(wgrad(jobs));
         }
         TG_TRY(ln_slab_sums());
         // ---- fused attention backward -------------------------------------------------------------------------------------------------

@@ -46,7 +46,10 @@ def test_tgat_b600_matches_reference(name, flat):
         grads = {k_: by_id[id(v)].cpu().numpy() for k_, v in m.named_parameters()}
     else:
         grads = {k_: v.grad.cpu().numpy() for k_, v in m.named_parameters()}
-    assert_grads_match(g, grads, atol=1e-4, rtol=1e-3, strict=bool(g["kink_free"]))
+    # kink-free fixture: every sampled entry within 1e-4 max|g|.  Realistic weights: 2 400 rows x 172 ReLU units sit wherever they
+    # sit, a few within rounding of zero; each unit masked differently by two correct evaluations shifts whole upstream tensors by
+    # ~1e-4..1e-3 of their largest entry (tests/conftest.py), so a few per cent of the entries may move, by < 2 % of max|g|
+    assert_grads_match(g, grads, atol=1e-4, rtol=1e-3, kink_frac=0.03, strict=bool(g["kink_free"]))
     assert lib().tg_version() >= 1
 
 
