@@ -85,6 +85,7 @@ SIGNATURES = {
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),
     "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
                               c_void, C.c_int, C.c_int, c_void]),
+    "tg_gemm_f32_nt_masked": (C.c_int, [c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void]),
     "tg_wgrad_group": (C.c_int, [C.c_int, C.POINTER(WgradJob), c_i64, c_void]),
     "tg_set_gemm_mode": (None, [C.c_int]),
     "tg_get_gemm_mode": (C.c_int, []),

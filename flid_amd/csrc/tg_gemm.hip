@@ -24,12 +24,13 @@
 #include "tg_common.h"
 
 namespace tg {
+// (mask, ldm): optional (M x N) matrix whose non-positive entries zero the output -- the ReLU backward fused into the product
 bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
-                    hipStream_t s);
+                    hipStream_t s, const float* mask, int64_t ldm);
 bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
-                    hipStream_t s);
+                    hipStream_t s, const float* mask, int64_t ldm);
 bool gemm_bf16x3_tn_partials(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                              int64_t strideB, float* ws, int nbatch, int nsplit, int64_t k_chunk, hipStream_t s);
 }
@@ -415,7 +416,7 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* d_A, int64_t lda, int64_t strideA,
               const float* d_B, int64_t ldb, int64_t strideB, float* d_C, int64_t ldc, int64_t strideC, int nbatch,
               const float* d_bias, int relu, int accumulate, hipStream_t s, int inner = 1, int64_t innerA = 0, int64_t innerB = 0,
-              int64_t innerC = 0) {
+              int64_t innerC = 0, const float* d_mask = nullptr, int64_t ldm = 0) {
     TG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nbatch >= 1, "tg_gemm_f32: negative size");
     if (M == 0 || N == 0) return TG_OK;
     TG_REQUIRE(d_A && d_B && d_C, "tg_gemm_f32: null pointer");
@@ -435,11 +436,12 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     static const bool no_direct = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_GEMM_NODIRECT") != nullptr;
     // few rows (the root layer's 2 x batch): exact fp32, contraction split over the 4 waves of a workgroup (tg_gemm_direct.hip)
     if (!no_direct && a_kc && b_kc && inner == 1 && alpha == 1.f &&
-        tg::gemm_direct_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s))
+        tg::gemm_direct_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s, d_mask, ldm))
         return tg::launch_status("gemm_direct_nt_kernel");
     if (g_gemm_mode >= 1 && a_kc && b_kc && inner == 1 && alpha == 1.f &&
-        tg::gemm_bf16x3_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s))
+        tg::gemm_bf16x3_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s, d_mask, ldm))
         return tg::launch_status("gemm_bf16x3_nt_kernel");
+    TG_REQUIRE(!d_mask, "tg_gemm_f32_nt_masked: operands must be 16-byte aligned with leading dimensions / K multiples of 4");
     bool vec = al16(d_A) && al16(d_B) && lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 &&
                innerA % 4 == 0 && innerB % 4 == 0;
     vec = vec && (a_kc ? K % 4 == 0 : M % 4 == 0) && (b_kc ? K % 4 == 0 : N % 4 == 0);
@@ -556,6 +558,12 @@ extern "C" int tg_gemm_f32_batched2(int ta, int tb, int64_t M, int64_t N, int64_
     TG_REQUIRE(outer >= 1 && inner >= 1 && (int64_t)outer * inner <= 65535, "tg_gemm_f32_batched2: batch counts");
     return gemm_impl(ta, tb, M, N, K, alpha, d_A, lda, outer_a, d_B, ldb, outer_b, d_C, ldc, outer_c, outer * inner, nullptr, 0,
                      accumulate, (hipStream_t)stream, inner, inner_a, inner_b, inner_c);
+}
+
+extern "C" int tg_gemm_f32_nt_masked(int64_t M, int64_t N, int64_t K, const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C,
+                                     int64_t ldc, const float* d_Y, int64_t ldy, void* stream) {
+    TG_REQUIRE(d_Y && ldy >= N, "tg_gemm_f32_nt_masked: mask matrix");
+    return gemm_impl(0, 1, M, N, K, 1.f, d_A, lda, 0, d_B, ldb, 0, d_C, ldc, 0, 1, nullptr, 0, 0, (hipStream_t)stream, 1, 0, 0, 0, d_Y, ldy);
 }
 
 extern "C" int tg_wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, void* stream) {

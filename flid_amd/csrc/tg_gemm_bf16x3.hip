@@ -122,7 +122,8 @@ __device__ __forceinline__ void read_frag(const char* __restrict__ s, int tile_r
 template <int TNW>
 __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
         const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int relu,
-        int accumulate, int gx, int gy, int64_t strideA, int64_t strideB, int64_t strideC, const float* __restrict__ zeros, int vec_c) {
+        int accumulate, int gx, int gy, int64_t strideA, int64_t strideB, int64_t strideC, const float* __restrict__ zeros, int vec_c,
+        const float* __restrict__ mask, int64_t ldm) {
     constexpr int BNt = 32 * TNW;
     constexpr int FA = BM * ROW_BYTES, FB = BNt * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
@@ -240,6 +241,10 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
             if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
             if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (mask) {                               // ReLU backward fused: keep the entries whose forward output was positive
+                const float4 y = *reinterpret_cast<const float4*>(mask + row * ldm + col);
+                v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f; v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
+            }
             *reinterpret_cast<float4*>(p) = v;
         } else {
             const float e[4] = {v.x, v.y, v.z, v.w};
@@ -249,6 +254,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
                 float x = e[q] + (bias ? bias[col + q] : 0.f);
                 if (accumulate) x += p[q];
                 if (relu) x = fmaxf(x, 0.f);
+                if (mask && !(mask[row * ldm + col + q] > 0.f)) x = 0.f;
                 p[q] = x;
             }
         }
@@ -658,7 +664,8 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
 // returns true when the shape was handled; false = fall back to the exact f32-input kernel
 bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
-                    hipStream_t s) {
+                    hipStream_t s, const float* mask, int64_t ldm) {
+    if (mask && nbatch != 1) return false;
     if (!(al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0)) return false;
     if (M < 1 || N < 1 || K < 8 || nbatch > 65535) return false;
     // column block 96 or 64: the smaller padded N wins (272 -> 288, 172 -> 192, 444 -> 480, 136 -> 192 either way), ties to 96
@@ -668,13 +675,13 @@ bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     if (gx * gy >= ((int64_t)1 << 30)) return false;
     const float* zeros = zero_block();      // the kernel's out-of-range loads are pointed at it
     if (!zeros) return false;
-    const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias));
+    const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias)) && (!mask || (al16(mask) && ldm % 4 == 0));
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     const dim3 grid((unsigned)(gx * gy), 1, (unsigned)nbatch);
     if (tnw == 3)
-        gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c);
+        gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c, mask, ldm);
     else
-        gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c);
+        gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c, mask, ldm);
     return true;
 }
 

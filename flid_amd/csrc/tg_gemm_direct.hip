@@ -18,7 +18,8 @@ constexpr int U = 8;   // chunks (of 8 k) in flight per wave and operand: 16 flo
 __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
                                                              int64_t lda, int64_t sA, const float* __restrict__ B, int64_t ldb,
                                                              int64_t sB, float* __restrict__ C, int64_t ldc, int64_t sC,
-                                                             const float* __restrict__ bias, int relu, int accumulate, int gx, int vec_c) {
+                                                             const float* __restrict__ bias, int relu, int accumulate, int gx, int vec_c,
+                                                             const float* __restrict__ mask, int64_t ldm) {
     __shared__ float red[4][32][36];                // stride 36 floats: 16-byte aligned rows for the fold's float4 reads
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -74,6 +75,10 @@ __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t 
         if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + ocol); o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w; }
         if (accumulate) { const float4 c = *reinterpret_cast<const float4*>(p); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if (mask) {                                   // ReLU backward fused: keep the entries whose forward output was positive
+            const float4 y = *reinterpret_cast<const float4*>(mask + orow * ldm + ocol);
+            o.x = y.x > 0.f ? o.x : 0.f; o.y = y.y > 0.f ? o.y : 0.f; o.z = y.z > 0.f ? o.z : 0.f; o.w = y.w > 0.f ? o.w : 0.f;
+        }
         *reinterpret_cast<float4*>(p) = o;
     } else {
 #pragma unroll
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t 
             float x = v[q] + (bias ? bias[ocol + q] : 0.f);
             if (accumulate) x += p[q];
             if (relu) x = fmaxf(x, 0.f);
+            if (mask && !(mask[orow * ldm + ocol + q] > 0.f)) x = 0.f;
             p[q] = x;
         }
     }
@@ -94,16 +100,17 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // true = launched (or nothing to do); false = shape not handled here, the caller falls through to the tiled kernels
 bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
-                    hipStream_t s) {
+                    hipStream_t s, const float* mask, int64_t ldm) {
     if (K <= 0 || K % 4 || lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !al16(A) || !al16(B)) return false;
     const int64_t gx = (N + 31) / 32, gy = (M + 31) / 32;
     // the point of this kernel is a chip that would otherwise be mostly idle: beyond ~8 workgroups per CU the tiled kernels'
     // operand reuse wins
     if (gx * gy * nbatch > 2048 || nbatch > 65535 || K > 4096) return false;
-    const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias));
+    const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias)) && (!mask || (al16(mask) && ldm % 4 == 0));
+    if (mask && nbatch != 1) return false;
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     hipLaunchKernelGGL(gemm_direct_nt_kernel, dim3((unsigned)(gx * gy), (unsigned)nbatch), dim3(256), 0, s, M, N, K, A, lda, strideA,
-                       B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx, vec_c);
+                       B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx, vec_c, mask, ldm);
     return true;
 }
 

@@ -203,6 +203,12 @@ int tg_time_bias_finish(float* d_teb, const float* d_b, const float* d_cosb, int
  * stand-in for the reduction of PTCL/EM_warmup.py:222 / M_step.py:297-306).  Operands 16-byte aligned. */
 int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, float scale, float* d_out, void* stream);
 
+/* C[M,N] = (Y > 0) ? A[M,K] B[N,K]^T : 0   -- the input gradient of `relu(x W^T)` with the ReLU mask applied in the product's
+ * epilogue (Y = the forward output; models/modules.py:68 `self.act(self.fc1(...))` differentiated).  Operands 16-byte aligned,
+ * lda / ldb / K multiples of 4. */
+int tg_gemm_f32_nt_masked(int64_t M, int64_t N, int64_t K, const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
+                          const float* d_Y, int64_t ldy, void* stream);
+
 /* ---- grouped weight gradients (split-bf16 MFMA) ------------------------------------------------------
  * replaces the autograd weight / bias gradients of the nn.Linear layers in models/modules.py:54-69,152-163,235 for one layer:
  * up to 6 products C_j[M_j, N_j] += A_j^T B_j over the same `rows` (A_j: rows x M_j, B_j: rows x N_j, row-major) in ONE launch;
