@@ -80,6 +80,7 @@ SIGNATURES = {
     "tg_tgat_layer_vec_floats": (c_i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "tg_set_wgrad_grouped": (None, [C.c_int]),
     "tg_set_merged_min_rows": (None, [c_i64]),
+    "tg_set_chain": (None, [C.c_int]),
     "tg_side_join": (C.c_int, [c_void]),
     "tg_set_layer_merged": (None, [C.c_int]),
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),

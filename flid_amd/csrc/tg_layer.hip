@@ -482,7 +482,8 @@ SideStream g_side;
 bool g_overlap = false;     // weight gradients on side streams under the main chain: measured 1-2 % SLOWER than issuing them in line
                             // (TGAT 1.066 vs 1.057 ms, link prediction 1.633 vs 1.598, TGN 0.904 vs 0.899) since the grouped launches;
                             // tg_set_overlap(1) turns it back on
-bool g_wgrad_grouped = true;   // tg_wgrad_group for a layer's weight gradients; false = one exact product + one column sum per gradient
+bool g_wgrad_grouped = true;
+bool g_chain = false;          // EXPERIMENTAL row-block chain kernel (tg_chain.hip) for the products behind the attention: correct, but 140 us per workgroup (weights read per wave, uncoalesced) against ~50 us for the six launches it replaces -- off until its weight staging goes through LDS
 
 }  // namespace
 
@@ -547,9 +548,6 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         // u = own P^T + ub   (all heads in one product, K = dn)
         TG_TRY(tg_gemm_f32(0, 1, R, H * dk, dn, 1.f, L->own, L->own_ld, wt.P, dn, L->u, (int64_t)H * dk, wt.ub, 0, 0, stream));
         TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
-        // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
-        TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
-        TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
     } else {
         // Transposed copies of the weights that the chain multiplies "from the right" (u = q Wk, and every dX = dY W of the
         // backward): with them EVERY product of the main chain has two k-contiguous operands and runs on the split-bf16 kernel.
@@ -575,10 +573,13 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         // u_h = Wk_h^T q_h
         TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, L->q, dq, hd, wt.Wk, hd, (int64_t)dk * hd, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
         TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
-        // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
-        TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
-        TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
     }
+    // ---- everything behind the attention: value projection, residual_fc, dropout + residual + LayerNorm, merge layer -- ONE launch
+    // (tg_chain.hip) when the dimensions allow it, else six
+    if (g_chain && tg::chain_fwd(L, s)) return tg::launch_status("chain_fwd_kernel");
+    // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
+    TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
     const unsigned g = (unsigned)row_grid(R);
     if (dq <= 64) ln_res_fwd_kernel<1><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
     else if (dq <= 320) ln_res_fwd_kernel<5><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
@@ -821,3 +822,4 @@ extern "C" void tg_set_overlap(int on) { g_overlap = (on & 1) != 0; g_issue_thre
 extern "C" void tg_set_layer_merged(int on) { g_merged = on != 0; }
 extern "C" void tg_set_wgrad_grouped(int on) { g_wgrad_grouped = on != 0; }
 extern "C" void tg_set_merged_min_rows(int64_t rows) { kMergedMinRows = rows; }
+extern "C" void tg_set_chain(int on) { g_chain = on != 0; }

@@ -176,6 +176,7 @@ int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk);
 int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim);
 int64_t tg_tgat_layer_vec_floats(int dn, int dq, int dk, int heads);
 void tg_set_wgrad_grouped(int on);
+void tg_set_chain(int on);                   /* experimental one-launch chain behind the attention (default off: slower than the six launches it replaces) */
 void tg_set_merged_min_rows(int64_t rows);   /* layers with at least this many rows take the merged projections (default 4096) */
 int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, void* stream);
 /* weight-gradient products of tg_tgat_layer_bwd go to an internal side stream and are issued by an internal helper thread
