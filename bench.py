@@ -334,12 +334,13 @@ def main():
                 "avg_launch_ms": round(ms / max(1, cnt), 4), "flops_per_step": units / args.steps}
     else:
         bwd = args.roofline_kernel == "attn_bwd"
-        roof = {"bound": "hbm", "kernel": "attn_bwd_kernel<4,2,2,false,4>" if bwd else "attn_fwd_kernel<4,2,2,false>",
+        roof = {"bound": "hbm", "kernel": ("attn_bwd_fast_kernel<2,2,*> (tg_attn_fast.hip; layer-1 + root launch)" if bwd else
+                           "attn_fwd_fast_kernel<2,2> (layer 1) + attn_fwd_kernel (root)"),
                 "achieved": round(units / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(units / secs / HBM_PEAK, 4), "traffic": None, "launches": cnt,
                 "avg_launch_ms": round(ms / max(1, cnt), 4), "bytes_per_instance": attn_bytes_per_instance(backward=bwd),
                 "bytes_per_launch_avg": round(units / max(1, cnt), 1)}
-        tr = os.path.join(REPO, "profiles", "traffic_r01.json")
+        tr = os.path.join(REPO, "profiles", "traffic_r02.json")     # PMC passes of the same command (tools/traffic_from_pmc.py)
         if os.path.exists(tr) and args.workload == "wikipedia" and args.mode == "train":
             try:
                 roof["traffic"] = json.load(open(tr)).get(args.roofline_kernel)

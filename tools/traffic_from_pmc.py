@@ -1,11 +1,14 @@
 """Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) of
-`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline` into profiles/traffic_r01.json (HBM bytes per launch per kernel family).
+`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown` into profiles/traffic_rNN.json (HBM bytes per launch per
+kernel family).  Both passes run with `--output-format csv`.
 
-    python tools/traffic_from_pmc.py gpurun_out/pmcB_FETCH_SIZE gpurun_out/pmcB_WRITE_SIZE profiles/traffic_r01.json
+    python tools/traffic_from_pmc.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/traffic_r02.json "<source>"
+
+`<source>` (commit + the profiled command) is stored in every entry so a reader can tell which build the bytes belong to.
 
 gfx950 correction: FETCH_SIZE is reported in KB assuming 64-B requests while the requests are 128 B -> doubled.  WRITE_SIZE is KB.
-Attention kernels: only the layer-1 launches (the largest grid of each kernel) are averaged, the ones bench.py's roofline is
-dominated by; GEMM: mean over every GEMM launch."""
+`hbm_bytes_per_launch` is the mean over EVERY launch of the family (what bench.py's `achieved` averages over: the big layer-1
+launch and the small root launch of the attention kernels alike); `hbm_bytes_layer1_launch` is the largest-grid launches only."""
 import csv
 import glob
 import json
@@ -24,9 +27,9 @@ def load(d, counter):
 
 
 def family(name):
-    if "attn_fwd_kernel" in name:
+    if "attn_fwd" in name:
         return "attn_fwd"
-    if "attn_bwd_kernel" in name:
+    if "attn_bwd" in name:
         return "attn_bwd"
     if "gemm" in name:
         return "gemm"
@@ -41,24 +44,28 @@ def reduce(rows, big_only):
             acc[fam] += lst
     out = {}
     for fam, lst in acc.items():
-        if big_only(fam):
+        if big_only:
+            # one family = several kernels (fast / generic); "layer 1" = launches whose grid is within 2x of the family's largest
             g = max(x[0] for x in lst)
-            lst = [x for x in lst if x[0] == g]
+            lst = [x for x in lst if 2 * x[0] >= g]
         out[fam] = sum(x[1] for x in lst) / len(lst)
     return out
 
 
 def main():
     fdir, wdir, dst = sys.argv[1:4]
-    big = lambda fam: fam.startswith("attn")
-    fetch = reduce(load(fdir, "FETCH_SIZE"), big)
-    write = reduce(load(wdir, "WRITE_SIZE"), big)
+    source = sys.argv[4] if len(sys.argv) > 4 else None
+    frows, wrows = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+    fetch, write = reduce(frows, False), reduce(wrows, False)
+    fetch1, write1 = reduce(frows, True), reduce(wrows, True)
     res = {}
     for fam in sorted(fetch):
         res[fam] = {"fetch_size_kb_raw": round(fetch[fam], 1), "write_size_kb": round(write.get(fam, 0.0), 1),
                     "hbm_bytes_per_launch": int((2 * fetch[fam] + write.get(fam, 0.0)) * 1024),
-                    "note": ("FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); " +
-                             ("layer-1 launches only" if big(fam) else "mean over all GEMM launches of a step"))}
+                    "hbm_bytes_layer1_launch": int((2 * fetch1[fam] + write1.get(fam, 0.0)) * 1024),
+                    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); mean over every launch "
+                            "of the family in the profiled steps",
+                    "source": source}
     json.dump(res, open(dst, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
