@@ -82,7 +82,6 @@ def main():
     ap.add_argument("--master-port", type=int, default=29533)
     ap.add_argument("--no-merged", action="store_true", help="tg_set_layer_merged(0): the reference's four separate projections per layer")
     ap.add_argument("--no-grouped", action="store_true", help="tg_set_wgrad_grouped(0): one exact product + one column sum per weight gradient")
-    ap.add_argument("--chain", action="store_true", help="tg_set_chain(1): experimental one-launch chain behind the attention")
     ap.add_argument("--merged-min-rows", type=int, default=None, help="tg_set_merged_min_rows override (experiments)")
     ap.add_argument("--overlap", type=int, default=None, help="tg_set_overlap override (experiments): 0 = weight gradients on the main stream")
     args = ap.parse_args()
@@ -116,9 +115,6 @@ def main():
             _l().tg_set_layer_merged(0)
         if args.no_grouped:
             _l().tg_set_wgrad_grouped(0)
-    if args.chain:
-        from flid_amd._lib import lib as _l
-        _l().tg_set_chain(1)
     if args.merged_min_rows is not None:
         from flid_amd._lib import lib as _l
         _l().tg_set_merged_min_rows(args.merged_min_rows)

@@ -31,7 +31,7 @@ class LayerDesc(C.Structure):
     """struct tg_layer_desc"""
     _fields_ = [("attn", AttnDesc), ("params", LayerParams), ("own", c_void), ("own_ld", c_i64), ("raw", c_void), ("raw_ld", c_i64),
                 ("cosb", c_void), ("res_dropout_p", c_f32), ("res_seed", C.c_uint64)] + \
-               [(n, c_void) for n in ("qbias", "q", "u", "agg", "prob", "ctx", "res", "y", "mean", "rstd", "f1", "out", "wT")]
+               [(n, c_void) for n in ("qbias", "q", "u", "agg", "prob", "ctx", "res", "y", "mean", "rstd", "f1", "out", "wT")] + [("y_ld", c_i64)]
 
 
 class LayerBwdDesc(C.Structure):
@@ -80,7 +80,6 @@ SIGNATURES = {
     "tg_tgat_layer_vec_floats": (c_i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "tg_set_wgrad_grouped": (None, [C.c_int]),
     "tg_set_merged_min_rows": (None, [c_i64]),
-    "tg_set_chain": (None, [C.c_int]),
     "tg_side_join": (C.c_int, [c_void]),
     "tg_set_layer_merged": (None, [C.c_int]),
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),

@@ -68,7 +68,6 @@ inline int64_t attn_grid_blocks(int64_t m) {
     return b < 1 ? 1 : (b > kAttnMaxBlocks ? kAttnMaxBlocks : b);
 }
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);   // tg_gemm_bf16x3.hip; false = shapes not covered
-bool chain_fwd(const tg_layer_desc* L, hipStream_t s);                                  // tg_chain.hip; false = dimensions not covered
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
                   float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s);

@@ -36,7 +36,7 @@ __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p)
 template <int MAXC>
 __global__ void __launch_bounds__(256) ln_res_fwd_kernel(const float* __restrict__ res, const float* __restrict__ own, int64_t own_ld,
         const float* __restrict__ cosb, int64_t n, int dn, int cols, float p, uint64_t seed, const float* __restrict__ gamma,
-        const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+        const float* __restrict__ beta, float* __restrict__ y, int64_t ldy, float* __restrict__ mean, float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
         float x[MAXC];
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) ln_res_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
-            if (c < cols) y[r * cols + c] = (x[i] - mu) * rs * gamma[c] + beta[c];
+            if (c < cols) y[r * ldy + c] = (x[i] - mu) * rs * gamma[c] + beta[c];
         }
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
     }
@@ -483,7 +483,6 @@ bool g_overlap = false;     // weight gradients on side streams under the main c
                             // (TGAT 1.066 vs 1.057 ms, link prediction 1.633 vs 1.598, TGN 0.904 vs 0.899) since the grouped launches;
                             // tg_set_overlap(1) turns it back on
 bool g_wgrad_grouped = true;
-bool g_chain = false;          // EXPERIMENTAL row-block chain kernel (tg_chain.hip) for the products behind the attention: correct, but 140 us per workgroup (weights read per wave, uncoalesced) against ~50 us for the six launches it replaces -- off until its weight staging goes through LDS
 
 }  // namespace
 
@@ -503,6 +502,9 @@ int side_join(hipStream_t s) {
 }  // namespace
 
 extern "C" int tg_side_join(void* stream) { return side_join((hipStream_t)stream); }
+
+// [y | raw] laid out as one (R, dq + dn) buffer by the caller (y_ld = raw_ld = dq + dn, raw = y + dq)
+static inline bool yr_joined(const tg_layer_desc* L, int dq) { return L->y_ld != 0 && L->raw == L->y + dq && L->raw_ld == L->y_ld; }
 
 extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     TG_REQUIRE(L, "tg_tgat_layer_fwd: null descriptor");
@@ -574,21 +576,23 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, L->q, dq, hd, wt.Wk, hd, (int64_t)dk * hd, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
         TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
     }
-    // ---- everything behind the attention: value projection, residual_fc, dropout + residual + LayerNorm, merge layer -- ONE launch
-    // (tg_chain.hip) when the dimensions allow it, else six
-    if (g_chain && tg::chain_fwd(L, s)) return tg::launch_status("chain_fwd_kernel");
     // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
     TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
     const unsigned g = (unsigned)row_grid(R);
-    if (dq <= 64) ln_res_fwd_kernel<1><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
-    else if (dq <= 320) ln_res_fwd_kernel<5><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
-    else ln_res_fwd_kernel<16><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, L->mean, L->rstd);
+    const int64_t ldy = L->y_ld ? L->y_ld : dq;
+    if (dq <= 64) ln_res_fwd_kernel<1><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, ldy, L->mean, L->rstd);
+    else if (dq <= 320) ln_res_fwd_kernel<5><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, ldy, L->mean, L->rstd);
+    else ln_res_fwd_kernel<16><<<g, 256, 0, s>>>(L->res, L->own, L->own_ld, L->cosb, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, P.ln_b, L->y, ldy, L->mean, L->rstd);
     TG_TRY(tg::launch_status("ln_res_fwd_kernel"));
     // merge: relu([y | raw] W1^T + b1) W2^T + b2
     const int64_t w1ld = dq + dn;
-    TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, L->y, dq, P.W1, w1ld, L->f1, dn, P.b1, 0, 0, stream));
-    TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, L->raw, L->raw_ld, P.W1 + dq, w1ld, L->f1, dn, nullptr, 1, 1, stream));
+    if (yr_joined(L, dq)) {          // raw sits right behind y in one (R, dq + dn) buffer: fc1 is ONE product over K = dq + dn
+        TG_TRY(tg_gemm_f32(0, 1, R, dn, dq + dn, 1.f, L->y, ldy, P.W1, w1ld, L->f1, dn, P.b1, 1, 0, stream));
+    } else {
+        TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, L->y, ldy, P.W1, w1ld, L->f1, dn, P.b1, 0, 0, stream));
+        TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, L->raw, L->raw_ld, P.W1 + dq, w1ld, L->f1, dn, nullptr, 1, 1, stream));
+    }
     TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, L->f1, dn, P.W2, dn, L->out, dn, P.b2, 0, 0, stream));
     return TG_OK;
 }
@@ -704,9 +708,14 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(tg::launch_status("relu_bwd_colsum_kernel"));
     }
     TG_TRY(fork());                           // dout, df1 are final: dW2 (+ db2), dW1 = df1^T [y | raw] (+ db1)
-    TG_TRY(wgrad({WJ{Bc.dout, dn, dn, Lc.f1, dn, dn, G.W2, dn, G.b2},
-                  WJ{Bc.df1, dn, dn, Lc.y, dq, dq, G.W1, w1ld, G.b1},
-                  WJ{Bc.df1, dn, dn, Lc.raw, Lc.raw_ld, dn, G.W1 + dq, w1ld, nullptr}}));
+    const int64_t ldy = L->y_ld ? L->y_ld : dq;
+    if (yr_joined(L, dq))
+        TG_TRY(wgrad({WJ{Bc.dout, dn, dn, Lc.f1, dn, dn, G.W2, dn, G.b2},
+                      WJ{Bc.df1, dn, dn, Lc.y, ldy, dq + dn, G.W1, w1ld, G.b1}}));
+    else
+        TG_TRY(wgrad({WJ{Bc.dout, dn, dn, Lc.f1, dn, dn, G.W2, dn, G.b2},
+                      WJ{Bc.df1, dn, dn, Lc.y, ldy, dq, G.W1, w1ld, G.b1},
+                      WJ{Bc.df1, dn, dn, Lc.raw, Lc.raw_ld, dn, G.W1 + dq, w1ld, nullptr}}));
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
     if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
@@ -822,4 +831,3 @@ extern "C" void tg_set_overlap(int on) { g_overlap = (on & 1) != 0; g_issue_thre
 extern "C" void tg_set_layer_merged(int on) { g_merged = on != 0; }
 extern "C" void tg_set_wgrad_grouped(int on) { g_wgrad_grouped = on != 0; }
 extern "C" void tg_set_merged_min_rows(int64_t rows) { kMergedMinRows = rows; }
-extern "C" void tg_set_chain(int on) { g_chain = on != 0; }

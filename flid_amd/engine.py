@@ -356,16 +356,18 @@ class _NativeLayer:
     the Python around them was as long as the GPU work): the saved activations of a layer are ONE allocation addressed by
     offset, the backward scratch is one cached allocation, and only tensors that leave this class are torch views."""
 
-    def __init__(self, attn: ops.AttnArgs, params, own, raw, cosb, p_res, seed_res):
+    def __init__(self, attn: ops.AttnArgs, params, own, table, ids, cosb, p_res, seed_res):
+        """own = None: the layer's own rows ARE its raw rows (layer 1).  The raw rows are gathered (table[ids]) straight into the
+        right part of the saved [y | raw] buffer: the merge layer's torch.cat (modules.py:66) never materialises."""
         from ._lib import LayerDesc, LayerParams, lib
-        dev = own.device
+        dev = table.device
         R, H, Dn, T, Dk = attn.m, attn.heads, attn.dn, attn.dt_dim, attn.dk
         Dq = Dn + T
         self.attn, self.R, self.dims = attn, R, (H, Dn, T, Dq, Dk)
         # sized for the row count rounded up to a multiple of 1024: the number of distinct rows changes every step, and a fresh
         # 160 MB request that no cached block fits costs the caching allocator a hipMalloc (4-6 ms stalls, seen in step traces)
         Rc = (R + 1023) // 1024 * 1024
-        sizes = (Dq, Rc * Dq, Rc * H * Dk, Rc * H * Dk, Rc * H * attn.k, Rc * Dq, Rc * Dq, Rc * Dq, Rc, Rc, Rc * Dn,
+        sizes = (Dq, Rc * Dq, Rc * H * Dk, Rc * H * Dk, Rc * H * attn.k, Rc * Dq, Rc * Dq, Rc * (Dq + Dn), Rc, Rc, Rc * Dn,
                  int(lib().tg_tgat_layer_wt_floats(Dn, Dq, Dk)))
         total = 0
         offs = []
@@ -374,7 +376,12 @@ class _NativeLayer:
             total += _r4(n)
         self.act = torch.empty(total, dtype=torch.float32, device=dev)          # saved for backward as a whole
         self.out = torch.empty((R, Dn), dtype=torch.float32, device=dev)
-        self.keep = (params, own, raw, cosb)
+        yo = offs[_FWD_FIELDS.index("y")]
+        yr = self.act[yo:yo + R * (Dq + Dn)].view(R, Dq + Dn)
+        raw = ops.gather_rows(table, ids, out=yr[:, Dq:])
+        if own is None:
+            own = raw
+        self.keep = (params, own, cosb)
         base = self.act.data_ptr()
         d = LayerDesc()
         d.attn = attn.desc
@@ -384,6 +391,7 @@ class _NativeLayer:
         for name, o in zip(_FWD_FIELDS, offs):
             setattr(d, name, base + 4 * o)
         d.out = self.out.data_ptr()
+        d.y_ld = Dq + Dn
         self.desc = d
 
     def forward(self):
@@ -466,13 +474,12 @@ def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
         params = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
         R = fr.rows(L - l)
         S_nbr, S_eid, S_t, S_dt = fr.S_at(l)
-        raw = ops.gather_rows(table, fr.ids_all[:R])
-        own = raw if l == 1 else H_prev[:R]
+        own = None if l == 1 else H_prev[:R]
         feat, feat_idx = (table, S_nbr[:R].reshape(-1) if fr.feat_idx0 is None else fr.feat_idx0[:R * k]) if l == 1 else (H_prev, fr.child[:R * k])
         seeds = _next_seeds(2) if p_eff > 0 else [0, 0]
         attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
                             te_w_flat, te_b, k, H, hd ** -0.5, p_eff, seeds[0])
-        lay = _NativeLayer(attn, params, own, raw, cosb, p_eff, seeds[1])
+        lay = _NativeLayer(attn, params, own, table, fr.ids_all[:R], cosb, p_eff, seeds[1])
         H_prev = lay.forward()
         layers.append(lay)
     return H_prev, (layers, cosb)

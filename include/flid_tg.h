@@ -151,6 +151,8 @@ typedef struct tg_layer_desc {
     float res_dropout_p; uint64_t res_seed;      /* dropout after residual_fc (modules.py:235) */
     float *qbias, *q, *u, *agg, *prob, *ctx, *res, *y, *mean, *rstd, *f1, *out;
     float* wT;   /* tg_tgat_layer_wt_floats(dn, dq, dk) floats: transposed weights, written by fwd, read by bwd of the same step */
+    int64_t y_ld; /* row stride of y (0 = dq).  With y_ld = raw_ld = dq + dn and raw = y + dq the merge layer's input [y | raw]
+                   * (modules.py:66 torch.cat) is one buffer: fc1 and its weight gradient are one product each instead of two */
 } tg_layer_desc;
 /* backward: dout (R, dn) in; this layer's parameter gradients are ADDED into grads.* and into d_cosb / d_tew / d_teb (dt_dim)
  * with float atomics: the caller zeroes them (one fill for the whole gradient block of a step) -- as torch accumulates into
@@ -176,7 +178,6 @@ int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk);
 int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim);
 int64_t tg_tgat_layer_vec_floats(int dn, int dq, int dk, int heads);
 void tg_set_wgrad_grouped(int on);
-void tg_set_chain(int on);                   /* experimental one-launch chain behind the attention (default off: slower than the six launches it replaces) */
 void tg_set_merged_min_rows(int64_t rows);   /* layers with at least this many rows take the merged projections (default 4096) */
 int tg_tgat_layer_bwd(const tg_layer_desc* layer, const tg_layer_bwd_desc* bwd, void* stream);
 /* weight-gradient products of tg_tgat_layer_bwd go to an internal side stream and are issued by an internal helper thread

@@ -306,34 +306,6 @@ def test_merged_projections_match_separate_products():
         assert bad <= max(1.0, 0.005 * diff.numel()) and float(diff.max()) <= 0.02 * scale, (n, bad, float(diff.max()) / scale)
 
 
-def test_chain_kernel_forward_matches_separate_launches():
-    """tg_set_chain(1): the experimental one-launch chain behind the attention (value projection, residual_fc, dropout + residual +
-    LayerNorm, merge layer) computes what the six separate launches compute, with and without dropout (same Philox stream)."""
-    from flid_amd._lib import lib
-    from flid_amd import engine
-    from flid_amd.synth import wikipedia_like
-    from flid_amd.models.TGAT import TGAT
-    from flid_amd.utils.utils import get_neighbor_sampler
-    data = wikipedia_like(num_edges=30000, seed=0)
-    sampler = get_neighbor_sampler(data, "recent", seed=0)
-    sl = slice(20000, 20600)
-    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
-    for dropout in (0.0, 0.1):
-        out = []
-        for chain in (1, 0):
-            lib().tg_set_chain(chain)
-            try:
-                torch.manual_seed(0)
-                m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 100, 2, 2, dropout, "cuda:0").to("cuda:0").train()
-                engine.seed_dropout(123)
-                with torch.no_grad():
-                    s, d = m.compute_src_dst_node_temporal_embeddings(bs, bd, bt, 20)
-                out.append(torch.cat([s, d]))
-            finally:
-                lib().tg_set_chain(0)
-        assert float((out[0] - out[1]).abs().max()) < 2e-5, dropout
-
-
 def test_tgat_full_size_equivariance_and_linearity():
     """BASELINE-size batch (600 edges, K=20, L=2, full dims), properties that need no oracle: permuting the batch permutes the
     embeddings (each root is a function of its own (node, time) only), and the backward pass is linear in the upstream gradient."""
