@@ -27,7 +27,7 @@ namespace tg {
 // (mask, ldm): optional (M x N) matrix whose non-positive entries zero the output -- the ReLU backward fused into the product
 bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
-                    hipStream_t s, const float* mask, int64_t ldm);
+                    hipStream_t s, const float* mask, int64_t ldm, bool b_kc = true);
 bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
                     hipStream_t s, const float* mask, int64_t ldm);
@@ -435,8 +435,8 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     }
     static const bool no_direct = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_GEMM_NODIRECT") != nullptr;
     // few rows (the root layer's 2 x batch): exact fp32, contraction split over the 4 waves of a workgroup (tg_gemm_direct.hip)
-    if (!no_direct && a_kc && b_kc && inner == 1 && alpha == 1.f &&
-        tg::gemm_direct_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s, d_mask, ldm))
+    if (!no_direct && a_kc && inner == 1 && alpha == 1.f && (b_kc || !d_mask) &&
+        tg::gemm_direct_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s, d_mask, ldm, b_kc))
         return tg::launch_status("gemm_direct_nt_kernel");
     if (g_gemm_mode >= 1 && a_kc && b_kc && inner == 1 && alpha == 1.f &&
         tg::gemm_bf16x3_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s, d_mask, ldm))

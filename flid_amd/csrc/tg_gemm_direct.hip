@@ -7,6 +7,8 @@
 //   * every load of a wave's slice is issued before its first MFMA (<= 8 chunks = 64 k per batch), the four partial tiles are
 //     folded through LDS.
 // Exact fp32 (f32-input MFMA).  Operands are L2 resident at these sizes, the kernel is latency-, not bandwidth-bound.
+// BT = false: B is given as K x N (n contiguous, "NN" products such as dWq_h += Wk_h dP_h): lane (n, h) then reads the four k of
+// its half chunk as four scalar loads, each coalesced over the 32 lanes of a half wave.
 #include "tg_common.h"
 
 namespace tg {
@@ -15,6 +17,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int U = 8;   // chunks (of 8 k) in flight per wave and operand: 16 float4 = 64 VGPRs
 
+template <bool BT>
 __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
                                                              int64_t lda, int64_t sA, const float* __restrict__ B, int64_t ldb,
                                                              int64_t sB, float* __restrict__ C, int64_t ldc, int64_t sC,
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t 
     const int64_t per = (k8 + 3) >> 2;
     const int64_t c0 = w * per, c1 = (c0 + per < k8) ? c0 + per : k8;
     const float* ap = A + row * lda + 4 * h;
-    const float* bp = B + col * ldb + 4 * h;
+    const float* bp = BT ? B + col * ldb + 4 * h : B + (int64_t)4 * h * ldb + col;
 
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t c = c0; c < c1; c += U) {
@@ -46,7 +49,12 @@ __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t 
             const bool ok = (c + u < c1) && (k < K);
             const int64_t off = ok ? (c + u) * 8 : 0;
             av[u] = *reinterpret_cast<const float4*>(ap + off);
-            bv[u] = *reinterpret_cast<const float4*>(bp + off);
+            if (BT) {
+                bv[u] = *reinterpret_cast<const float4*>(bp + off);
+            } else {
+                const float* q = bp + off * ldb;
+                bv[u] = make_float4(q[0], q[ldb], q[2 * ldb], q[3 * ldb]);
+            }
             if (!ok) { av[u] = make_float4(0.f, 0.f, 0.f, 0.f); bv[u] = av[u]; }
         }
 #pragma unroll
@@ -100,8 +108,9 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // true = launched (or nothing to do); false = shape not handled here, the caller falls through to the tiled kernels
 bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
-                    hipStream_t s, const float* mask, int64_t ldm) {
-    if (K <= 0 || K % 4 || lda % 4 || ldb % 4 || strideA % 4 || strideB % 4 || !al16(A) || !al16(B)) return false;
+                    hipStream_t s, const float* mask, int64_t ldm, bool b_kc) {
+    if (K <= 0 || K % 4 || lda % 4 || strideA % 4 || !al16(A)) return false;
+    if (b_kc ? (ldb % 4 || strideB % 4 || !al16(B)) : K < 8) return false;       // (K x N form: the guard rows 4..7 must exist)
     const int64_t gx = (N + 31) / 32, gy = (M + 31) / 32;
     // the point of this kernel is a chip that would otherwise be mostly idle: beyond ~8 workgroups per CU the tiled kernels'
     // operand reuse wins
@@ -109,8 +118,12 @@ bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias)) && (!mask || (al16(mask) && ldm % 4 == 0));
     if (mask && nbatch != 1) return false;
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
-    hipLaunchKernelGGL(gemm_direct_nt_kernel, dim3((unsigned)(gx * gy), (unsigned)nbatch), dim3(256), 0, s, M, N, K, A, lda, strideA,
-                       B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx, vec_c, mask, ldm);
+    if (b_kc)
+        hipLaunchKernelGGL(gemm_direct_nt_kernel<true>, dim3((unsigned)(gx * gy), (unsigned)nbatch), dim3(256), 0, s, M, N, K, A, lda, strideA,
+                           B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx, vec_c, mask, ldm);
+    else
+        hipLaunchKernelGGL(gemm_direct_nt_kernel<false>, dim3((unsigned)(gx * gy), (unsigned)nbatch), dim3(256), 0, s, M, N, K, A, lda, strideA,
+                           B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx, vec_c, mask, ldm);
     return true;
 }
 

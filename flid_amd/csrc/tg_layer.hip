@@ -70,11 +70,13 @@ __global__ void __launch_bounds__(256) ln_res_fwd_kernel(const float* __restrict
 }
 
 // dsum = dLN(dy); dres = dsum * dropout mask.  Workgroup slab (4 * cols): [dgamma | dbeta | colsum(dsum) | colsum(dres)].
+// d_own (optional): the residual's share of the gradient w.r.t. the layer's own rows, d_own[r, :dn] (+)= dsum[r, :dn] -- the
+// product that delivers the query path's share later accumulates into it.
 template <int MAXC>
 __global__ void __launch_bounds__(256) ln_res_bwd_kernel(const float* __restrict__ res, const float* __restrict__ own, int64_t own_ld,
         const float* __restrict__ cosb, const float* __restrict__ dy, int64_t n, int dn, int cols, float p, uint64_t seed,
         const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dsum,
-        float* __restrict__ dres, float* __restrict__ part) {
+        float* __restrict__ dres, float* __restrict__ part, float* __restrict__ d_own, int64_t d_own_ld, int d_own_acc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     extern __shared__ float red[];   // ROW_WAVES * 4 * cols
     float a0[MAXC], a1[MAXC], a2[MAXC], a3[MAXC], gm[MAXC];
@@ -115,6 +117,10 @@ __global__ void __launch_bounds__(256) ln_res_bwd_kernel(const float* __restrict
                 const float dr = dx * ks[i];
                 dsum[r * cols + c] = dx;
                 if (dres != dsum) dres[r * cols + c] = dr;
+                if (d_own && c < dn) {
+                    float* o = d_own + r * d_own_ld + c;
+                    *o = d_own_acc ? *o + dx : dx;
+                }
                 a2[i] += dx;
                 a3[i] += dr;
             }
@@ -162,16 +168,6 @@ __global__ void __launch_bounds__(256) relu_bwd_colsum_kernel(float* __restrict_
     for (int i = 0; i < MAXC; ++i) {
         const int c = threadIdx.x + 256 * i;
         if (c < cols) part[(int64_t)blockIdx.x * cols + c] = acc[i];
-    }
-}
-
-__global__ void __launch_bounds__(256) add_cols_kernel(float* __restrict__ dst, int64_t dld, const float* __restrict__ src, int64_t sld,
-                                                       int64_t n, int cols) {
-    const int64_t total = n * cols;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / cols;
-        const int c = (int)(i - r * cols);
-        dst[r * dld + c] += src[r * sld + c];
     }
 }
 
@@ -234,11 +230,23 @@ __global__ void __launch_bounds__(64) wq_time_kernel(const float* __restrict__ s
     atomicAdd(d_cosb + c, acc);
 }
 
-// up to 8 small matrix transposes in one launch (weights, once per step): dst[c * ldd + r] = src[r * lds + c]
+// up to 10 small matrix transposes in one launch (weights, once per step): dst[c * ldd + r] = src[r * lds + c]; the blocks of
+// one extra grid row (blockIdx.y == n, when mv_y is set) compute the matrix-vector product mv_y[i] = sum_t mv_W[i * mv_ld + t] mv_x[t]
+// (the constant half of the query, qb = Wq[:, dn:] cos b), one wave per output
 struct TrJob { const float* src; float* dst; int rows, cols; int64_t lds, ldd; };
-struct TrJobs { TrJob j[8]; int n; };
+struct TrJobs { TrJob j[10]; int n; const float *mv_W, *mv_x; float* mv_y; int mv_rows, mv_cols; int64_t mv_ld; };
 __global__ void __launch_bounds__(256) transpose_many_kernel(TrJobs jobs) {
     __shared__ float tile[32][33];
+    if ((int)blockIdx.y >= jobs.n) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int i = blockIdx.x * 4 + wave; i < jobs.mv_rows; i += gridDim.x * 4) {
+            float acc = 0.f;
+            for (int t = lane; t < jobs.mv_cols; t += 64) acc = fmaf(jobs.mv_W[(int64_t)i * jobs.mv_ld + t], jobs.mv_x[t], acc);
+            acc = tg::wave_sum(acc);
+            if (lane == 0) jobs.mv_y[i] = acc;
+        }
+        return;
+    }
     const TrJob jb = jobs.j[blockIdx.y];
     const int tiles_c = (jb.cols + 31) / 32, tiles_r = (jb.rows + 31) / 32;
     for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
@@ -520,8 +528,10 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     // backward): with them EVERY product of the main chain has two k-contiguous operands and runs on the split-bf16 kernel.
     const WT wt = wt_layout(L->wT, H, dn, dq, dk);
     TG_REQUIRE(H <= 2, "tg_tgat_layer_fwd: the native layer path supports 1 or 2 heads");
-    // the constant half of the query, qb = Wq[:, dn:] cos b
-    TG_TRY(tg_gemm_f32(0, 1, 1, dq, T, 1.f, L->cosb, T, P.Wq + dn, dq, L->qbias, dq, nullptr, 0, 0, stream));
+    // the constant half of the query, qb = Wq[:, dn:] cos b, rides in the transposes' launch
+    auto with_qbias = [&](TrJobs& jobs) {
+        jobs.mv_W = P.Wq + dn; jobs.mv_x = L->cosb; jobs.mv_y = L->qbias; jobs.mv_rows = dq; jobs.mv_cols = T; jobs.mv_ld = dq;
+    };
     if (g_merged && R >= kMergedMinRows) {
         // merged QUERY side (u = own P^T + ub: the q intermediate and one product per direction leave the chain); the value side keeps
         // the reference's two products (ctx_h = Wv_h agg_h, res = Wr ctx + br): its merged form V_h = Wr[:, h] Wv_h cost as much on the
@@ -534,7 +544,8 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         for (int h = 0; h < H; ++h) jobs.j[n++] = TrJob{P.Wv + (int64_t)h * hd * dk, wt.Wv + (int64_t)h * dk * hd, hd, dk, dk, hd};
         jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
         jobs.n = n;
-        transpose_many_kernel<<<dim3(64, n), 256, 0, s>>>(jobs);
+        with_qbias(jobs);
+        transpose_many_kernel<<<dim3(64, n + 1), 256, 0, s>>>(jobs);
         TG_TRY(tg::launch_status("transpose_many_kernel"));
         {
             MergeJobs mj;
@@ -563,12 +574,10 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
         jobs.j[n++] = TrJob{P.W1 + dq, wt.W1b, dn, dn, (int64_t)dq + dn, dn};
         jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
+        jobs.j[n++] = TrJob{P.Wq, wt.WqL, dq, dn, dq, dq};
         jobs.n = n;
-        transpose_many_kernel<<<dim3(64, n), 256, 0, s>>>(jobs);
-        TrJobs j2;
-        j2.j[0] = TrJob{P.Wq, wt.WqL, dq, dn, dq, dq};
-        j2.n = 1;
-        transpose_many_kernel<<<dim3(64, 1), 256, 0, s>>>(j2);
+        with_qbias(jobs);
+        transpose_many_kernel<<<dim3(64, n + 1), 256, 0, s>>>(jobs);
         TG_TRY(tg::launch_status("transpose_many_kernel"));
         // q = [own | cos b] Wq^T : the constant half is a bias row
         TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
@@ -722,9 +731,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     float* dres = L->res_dropout_p > 0.f ? Bw->dres : Bw->dsum;
     {
         const size_t lds = sizeof(float) * ROW_WAVES * 4 * dq;
-        if (dq <= 64) ln_res_bwd_kernel<1><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
-        else if (dq <= 320) ln_res_bwd_kernel<5><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
-        else ln_res_bwd_kernel<16><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln);
+        if (dq <= 64) ln_res_bwd_kernel<1><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln, Bw->d_own, Bw->d_own_ld, Bw->d_own_accumulate);
+        else if (dq <= 320) ln_res_bwd_kernel<5><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln, Bw->d_own, Bw->d_own_ld, Bw->d_own_accumulate);
+        else ln_res_bwd_kernel<16><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln, Bw->d_own, Bw->d_own_ld, Bw->d_own_accumulate);
         TG_TRY(tg::launch_status("ln_res_bwd_kernel"));
     }
     // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres (= d br, which the
@@ -779,9 +788,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(attn_slab_sums());
         // ---- key / query path: d own = du P (+ the residual's share) ------------------------------------------------------------------
         if (Bw->d_own) {
-            TG_TRY(tg_gemm_f32(0, 1, R, dn, hk, 1.f, Bw->du, hk, wt.PT, hk, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
-            add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
-            TG_TRY(tg::launch_status("add_cols_kernel"));
+            // (the residual's share is already there: ln_res_bwd_kernel)
+            TG_TRY(tg_gemm_f32(0, 1, R, dn, hk, 1.f, Bw->du, hk, wt.PT, hk, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
         }
     } else {
         TG_TRY(fork());                           // dres / dsum and the LayerNorm slabs are final
@@ -814,9 +822,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         }
         TG_TRY(attn_slab_sums());
         if (Bw->d_own) {
-            TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, Bw->d_own_accumulate, stream));
-            add_cols_kernel<<<ew_grid(R * dn), 256, 0, s>>>(Bw->d_own, Bw->d_own_ld, Bw->dsum, dq, R, dn);
-            TG_TRY(tg::launch_status("add_cols_kernel"));
+            // (the residual's share is already there: ln_res_bwd_kernel)
+            TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
         }
     }
     if (overlap && !defer) {

@@ -503,7 +503,14 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_
     # (extra_floats: room right behind the parameter gradients for the caller's own ones -- TGN's GRU -- so that a flat parameter
     # spanning both gets its gradient as one tensor)
     xt = _r4(extra_floats)
-    zeroed = torch.zeros(npar + xt + _r4(T) + L * vlen, device=dev)
+    nz = npar + xt + _r4(T) + L * vlen
+    # ... and, in the same fill, the lower layers' gradient rows (the attention backward scatters into them with atomics)
+    dh_off, tot = {}, nz
+    for l in range(L, 1, -1):
+        dh_off[l] = tot
+        tot += _r4(fr.rows(L - l + 1) * Dn)
+    whole = torch.zeros(tot, device=dev)
+    zeroed = whole[:nz]
     d_tew, d_teb, d_cosb = zeroed[:T], zeroed[offs[1]:offs[1] + T], zeroed[npar + xt:npar + xt + T]
     d_table = torch.zeros_like(table) if table_grad else None
     dH = dH.contiguous()
@@ -518,7 +525,8 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_
             R = lay.R
             params = layer_params[(l - 1) * 11:(l - 1) * 11 + 11]
             if l >= 2:
-                dH_prev = torch.zeros((fr.rows(L - l + 1), Dn), device=dev)
+                nr = fr.rows(L - l + 1)
+                dH_prev = whole[dh_off[l]:dh_off[l] + nr * Dn].view(nr, Dn)
                 dfeat, pad_row = dH_prev, (fr.pad_rows[0] if (l == L and fr.pad_rows) else -1)
                 d_own, acc = dH_prev[:R], True               # rows [0, R) of the lower layer's gradient: its "own" inputs
             else:
