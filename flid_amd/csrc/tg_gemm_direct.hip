@@ -1,7 +1,9 @@
 // Small-M products C = A B^T (+ bias, relu) for the root layer of the TGAT stack (M = 2 x batch = 1200 rows) and other short
 // operands.  With so few rows the LDS-tiled kernels run a handful of workgroups whose K loop is a chain of dependent
 // global -> LDS -> MFMA stages: 16..30 us for 0.3 GFLOP (rocprof, r01_v3).  Here the chain is cut instead of pipelined:
-//   * one workgroup per 32 x 32 tile of C, its 4 waves split the contraction 4 ways (fixed order, so results are reproducible);
+//   * one workgroup per 32 x 32 tile of C, its NW = 4 / 8 / 16 waves split the contraction NW ways (fixed order, so results are
+//     reproducible): NW is the smallest that gives every wave ONE batch of loads (<= 8 chunks of 8 k) -- a second batch is a second
+//     exposed round trip to L2 (K = 272 on 4 waves: 8 + 1 chunks; measured 12.5 us against 8.6 us for K = 172);
 //   * no LDS staging: both operands are k-contiguous, so lane (i, h) loads float4s of row i at k = 8c + 4h straight into the
 //     A/B operand registers of v_mfma_f32_32x32x2_f32 -- the k order inside a product is free as long as A and B agree;
 //   * every load of a wave's slice is issued before its first MFMA (<= 8 chunks = 64 k per batch), the four partial tiles are
@@ -9,6 +11,8 @@
 // Exact fp32 (f32-input MFMA).  Operands are L2 resident at these sizes, the kernel is latency-, not bandwidth-bound.
 // BT = false: B is given as K x N (n contiguous, "NN" products such as dWq_h += Wk_h dP_h): lane (n, h) then reads the four k of
 // its half chunk as four scalar loads, each coalesced over the 32 lanes of a half wave.
+#include <stdlib.h>
+
 #include "tg_common.h"
 
 namespace tg {
@@ -17,13 +21,13 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int U = 8;   // chunks (of 8 k) in flight per wave and operand: 16 float4 = 64 VGPRs
 
-template <bool BT>
-__global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
+template <bool BT, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_direct_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
                                                              int64_t lda, int64_t sA, const float* __restrict__ B, int64_t ldb,
                                                              int64_t sB, float* __restrict__ C, int64_t ldc, int64_t sC,
                                                              const float* __restrict__ bias, int relu, int accumulate, int gx, int vec_c,
                                                              const float* __restrict__ mask, int64_t ldm) {
-    __shared__ float red[4][32][36];                // stride 36 floats: 16-byte aligned rows for the fold's float4 reads
+    __shared__ float red[NW][32][36];               // stride 36 floats: 16-byte aligned rows for the fold's float4 reads
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int64_t tn = blockIdx.x % gx, tm = blockIdx.x / gx;
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t 
     row = row < M ? row : M - 1;                    // clamped rows are loaded but never stored
     col = col < N ? col : N - 1;
     const int64_t k8 = (K + 7) >> 3;                // chunks of 8 k; K % 4 == 0, so each half chunk is wholly in or out
-    const int64_t per = (k8 + 3) >> 2;
+    const int64_t per = (k8 + NW - 1) / NW;
     const int64_t c0 = w * per, c1 = (c0 + per < k8) ? c0 + per : k8;
     const float* ap = A + row * lda + 4 * h;
     const float* bp = BT ? B + col * ldb + 4 * h : B + (int64_t)4 * h * ldb + col;
@@ -71,12 +75,18 @@ __global__ __launch_bounds__(256) void gemm_direct_nt_kernel(int64_t M, int64_t 
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[w][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
     __syncthreads();
+    if (threadIdx.x >= 256) return;
     const int rr = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
     const int64_t orow = tm * 32 + rr, ocol = tn * 32 + c4;
     if (orow >= M || ocol >= N) return;
     float v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = ((red[0][rr][c4 + q] + red[1][rr][c4 + q]) + red[2][rr][c4 + q]) + red[3][rr][c4 + q];
+    for (int q = 0; q < 4; ++q) {
+        float t = red[0][rr][c4 + q];
+#pragma unroll
+        for (int x = 1; x < NW; ++x) t += red[x][rr][c4 + q];
+        v[q] = t;
+    }
     float* p = C + orow * ldc + ocol;
     if (vec_c) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -118,12 +128,25 @@ bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias)) && (!mask || (al16(mask) && ldm % 4 == 0));
     if (mask && nbatch != 1) return false;
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
-    if (b_kc)
-        hipLaunchKernelGGL(gemm_direct_nt_kernel<true>, dim3((unsigned)(gx * gy), (unsigned)nbatch), dim3(256), 0, s, M, N, K, A, lda, strideA,
-                           B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx, vec_c, mask, ldm);
-    else
-        hipLaunchKernelGGL(gemm_direct_nt_kernel<false>, dim3((unsigned)(gx * gy), (unsigned)nbatch), dim3(256), 0, s, M, N, K, A, lda, strideA,
-                           B, ldb, strideB, C, ldc, strideC, bias, relu, accumulate, (int)gx, vec_c, mask, ldm);
+    const int64_t k8 = (K + 7) / 8;
+    int nw = 4;
+    static const int force_nw = (getenv("FLID_GEMM_TUNE") && getenv("FLID_DIRECT_NW")) ? atoi(getenv("FLID_DIRECT_NW")) : 0;
+    if (force_nw) nw = force_nw;
+    else while (nw < 16 && (k8 + nw - 1) / nw > U) nw *= 2;
+    const dim3 grid((unsigned)(gx * gy), (unsigned)nbatch);
+#define FLID_DIRECT_LAUNCH(BTV, NWV)                                                                                                 \
+    hipLaunchKernelGGL((gemm_direct_nt_kernel<BTV, NWV>), grid, dim3(64 * NWV), 0, s, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, \
+                       strideC, bias, relu, accumulate, (int)gx, vec_c, mask, ldm)
+    if (b_kc) {
+        if (nw == 4) FLID_DIRECT_LAUNCH(true, 4);
+        else if (nw == 8) FLID_DIRECT_LAUNCH(true, 8);
+        else FLID_DIRECT_LAUNCH(true, 16);
+    } else {
+        if (nw == 4) FLID_DIRECT_LAUNCH(false, 4);
+        else if (nw == 8) FLID_DIRECT_LAUNCH(false, 8);
+        else FLID_DIRECT_LAUNCH(false, 16);
+    }
+#undef FLID_DIRECT_LAUNCH
     return true;
 }
 

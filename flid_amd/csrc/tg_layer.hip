@@ -206,6 +206,41 @@ int colsum_seg(const float* x, int64_t ld, int64_t n, int cols, const SegDst& d,
 }
 SegDst seg1(float* p, int cols) { SegDst d{}; d.p[0] = p; d.end[0] = cols; d.n = 1; return d; }
 
+// two slabs in one launch (a layer's LayerNorm slabs and its attention backward's time-encoder slabs)
+struct ColJob { const float* x; int64_t ld, n; int cols; SegDst d; };
+__global__ void __launch_bounds__(256) colsum_seg2_kernel(ColJob a, ColJob b, int groups_a) {
+    __shared__ float red[4][64];
+    const bool first = (int)blockIdx.x < groups_a;
+    const ColJob& j = first ? a : b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - (first ? 0 : groups_a)) * 64 + lane;
+    if ((int64_t)blockIdx.y * 4 >= j.n) return;                  // (uniform per workgroup) no rows for this slice
+    float s = 0.f;
+    if (c < j.cols)
+        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < j.n; r += (int64_t)gridDim.y * 4) s += j.x[r * j.ld + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0 || c >= j.cols) return;
+    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    int beg = 0;
+    for (int i = 0; i < j.d.n; ++i) {
+        if (c < j.d.end[i]) {
+            if (j.d.p[i]) atomicAdd(j.d.p[i] + (c - beg), t);
+            return;
+        }
+        beg = j.d.end[i];
+    }
+}
+int colsum_seg2(const ColJob& a, const ColJob& b, hipStream_t s) {
+    if (a.n == 0) return colsum_seg(b.x, b.ld, b.n, b.cols, b.d, s);
+    if (b.n == 0) return colsum_seg(a.x, a.ld, a.n, a.cols, a.d, s);
+    const int ga = (a.cols + 63) / 64, gb = (b.cols + 63) / 64;
+    const int64_t max_slices = std::max<int64_t>(64, std::min<int64_t>(512, 2048 / (ga + gb)));
+    const int slices = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, std::max(a.n, b.n) / 32));
+    colsum_seg2_kernel<<<dim3(ga + gb, slices), 256, 0, s>>>(a, b, ga);
+    return tg::launch_status("colsum_seg2_kernel");
+}
+
 // The query projection sees [own | cos(b)]: with sq = sum_rows dq,
 //   dWq[:, dn:] += sq (x) cos(b)      and      d cos(b) += sq^T Wq[:, dn:].
 // Thread = one time column x 16 rows (independent loads), grid.y walks the rows.
@@ -738,24 +773,20 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     }
     // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres (= d br, which the
     // weight-gradient launch delivers through its ones column instead)]
-    auto ln_slab_sums = [&]() -> int {
-        SegDst d{};
-        d.n = 5;
-        d.p[0] = G.ln_g;     d.end[0] = dq;
-        d.p[1] = G.ln_b;     d.end[1] = 2 * dq;
-        d.p[2] = nullptr;    d.end[2] = 2 * dq + dn;
-        d.p[3] = Bw->d_cosb; d.end[3] = 3 * dq;
-        d.p[4] = nullptr;    d.end[4] = 4 * dq;
+    auto slab_sums = [&]() -> int {         // after the attention backward: LayerNorm slabs + time-encoder slabs, one launch
+        ColJob ln{part_ln, 4 * (int64_t)dq, (int64_t)ln_grid, 3 * dq, SegDst{}};
+        ln.d.n = 5;
+        ln.d.p[0] = G.ln_g;     ln.d.end[0] = dq;
+        ln.d.p[1] = G.ln_b;     ln.d.end[1] = 2 * dq;
+        ln.d.p[2] = nullptr;    ln.d.end[2] = 2 * dq + dn;
+        ln.d.p[3] = Bw->d_cosb; ln.d.end[3] = 3 * dq;
+        ln.d.p[4] = nullptr;    ln.d.end[4] = 4 * dq;
+        ColJob at{part_attn, 2 * (int64_t)T, T > 0 ? (int64_t)attn_parts : 0, 2 * T, SegDst{}};
+        at.d.n = 2;
+        at.d.p[0] = Bw->d_tew; at.d.end[0] = T;
+        at.d.p[1] = Bw->d_teb; at.d.end[1] = 2 * T;
         hipStream_t st = ws_;
-        return side([=] { return colsum_seg(part_ln, 4 * dq, ln_grid, 3 * dq, d, st); });
-    };
-    auto attn_slab_sums = [&]() -> int {
-        SegDst d{};
-        d.n = 2;
-        d.p[0] = Bw->d_tew; d.end[0] = T;
-        d.p[1] = Bw->d_teb; d.end[1] = 2 * T;
-        hipStream_t st = ws_;
-        return side([=] { return colsum_seg(part_attn, 2 * T, attn_parts, 2 * T, d, st); });
+        return side([=] { return colsum_seg2(ln, at, st); });
     };
     if (g_merged && R >= kMergedMinRows) {
         // ---- output projection + value path (the reference's two products; weight gradients in one grouped launch) ------------------
@@ -769,7 +800,6 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
                 jobs.push_back(WJ{Bc.dctx + h * hd, dq, hd, Lc.agg + (int64_t)h * dk, hk, dk, G.Wv + (int64_t)h * hd * dk, dk, nullptr});
             TG_TRY(wgrad(jobs));
         }
-        TG_TRY(ln_slab_sums());
         // ---- fused attention backward -------------------------------------------------------------------------------------------------
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         TG_TRY(fork());                       // du and the time-encoder slabs are final
@@ -785,7 +815,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
                 return tg::launch_status("ub_bwd_kernel");
             }));
         }
-        TG_TRY(attn_slab_sums());
+        TG_TRY(slab_sums());
         // ---- key / query path: d own = du P (+ the residual's share) ------------------------------------------------------------------
         if (Bw->d_own) {
             // (the residual's share is already there: ln_res_bwd_kernel)
@@ -793,7 +823,6 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         }
     } else {
         TG_TRY(fork());                           // dres / dsum and the LayerNorm slabs are final
-        TG_TRY(ln_slab_sums());
         // ---- output projection ------------------------------------------------------------------------------------------------------
         TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
         // ---- value path -------------------------------------------------------------------------------------------------------------
@@ -820,7 +849,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
                 return tg::launch_status("wq_time_kernel");
             }));
         }
-        TG_TRY(attn_slab_sums());
+        TG_TRY(slab_sums());
         if (Bw->d_own) {
             // (the residual's share is already there: ln_res_bwd_kernel)
             TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
