@@ -488,7 +488,7 @@ struct PanelK {
 };
 
 #ifndef FLID_WG_EXP
-#define FLID_WG_EXP 0   // timing experiments only (results wrong): 1 = no atomic fold
+#define FLID_WG_EXP 0   // timing experiments only (results wrong): 1 = no atomic fold, 2 = no MFMAs, 3 = no fragment reads, 4 = no LDS stores
 #endif
 constexpr int WBM = 64, WNT = 128;     // weight-gradient workgroup: 2 waves x (32 x 32 TNW), block tile 64 x 32 TNW.  64 rows fit the
                                        // output heights of this path (172 -> 192, 272 -> 320, 136 -> 192; 128-row tiles padded them to
@@ -536,15 +536,38 @@ __global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int
         bf16x8 ah[2], al[2], bh[TNW][2], bl[TNW][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (FLID_WG_EXP == 3) {
+                const bf16x8 c = __builtin_bit_cast(bf16x8, make_uint4((unsigned)st, lane, ks, 1));
+                ah[ks] = al[ks] = c;
+#pragma unroll
+                for (int tt = 0; tt < TNW; ++tt) bh[tt][ks] = bl[tt][ks] = c;
+                continue;
+            }
             read_frag(sA(cur), wave * 32, ks, ah[ks], al[ks]);
 #pragma unroll
             for (int tt = 0; tt < TNW; ++tt) read_frag(sB(cur), 32 * tt, ks, bh[tt][ks], bl[tt][ks]);
         }
-        pa.sstore(sA(cur ^ 1), ra);                   // (ra, rb) hold stage st + 1
-        pb.sstore(sB(cur ^ 1), rb);
-        issue(st + 3, ra, rb);
+        if (FLID_WG_EXP != 4) {
+            pa.sstore(sA(cur ^ 1), ra);                   // (ra, rb) hold stage st + 1
+            pb.sstore(sB(cur ^ 1), rb);
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int j = 0; j < PA::PER; ++j) acc[0][j] += ra[j][0].x + ra[j][1].y + ra[j][2].z + ra[j][3].w;
+#pragma unroll
+            for (int j = 0; j < PB::PER; ++j) acc[0][j + 4] += rb[j][0].x + rb[j][1].y + rb[j][2].z + rb[j][3].w;
+        }
+        issue(st + 3, ra, rb);
+        if (FLID_WG_EXP == 2) {                        // keep the fragment reads alive without the MFMAs
+            auto fs = [](const bf16x8& v) { const float4 f = __builtin_bit_cast(float4, v); return (f.x + f.y) + (f.z + f.w); };
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc[0][ks] += fs(ah[ks]) + fs(al[ks]);
+#pragma unroll
+                for (int tt = 0; tt < TNW; ++tt) acc[tt][2 + ks] += fs(bh[tt][ks]) + fs(bl[tt][ks]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < (FLID_WG_EXP == 2 ? 0 : 2); ++ks) {
 #pragma unroll
             for (int tt = 0; tt < TNW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[tt][ks], acc[tt], 0, 0, 0);
 #pragma unroll

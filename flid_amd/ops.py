@@ -9,7 +9,15 @@ import torch
 from ._lib import AttnDesc, check, lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """the calling thread's current HIP stream as a void*.  Two C calls (~0.3 us): torch.cuda.current_stream() builds a Stream object
+    through several Python layers (~4 us), and a training step asks 30-70 times."""
+    if _raw_stream is not None and _cur_device is not None:
+        return C.c_void_p(_raw_stream(_cur_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
