@@ -434,58 +434,70 @@ struct WgJobs { WgJob j[6]; int n, total_tiles; };
 
 // K-major panel of R output rows x 32 k for a workgroup of NTH threads: (R / 4) * 8 micro-tiles of 4 (k) x 4 (rows), PER per thread
 // (threads past the last micro-tile redo an earlier one: same loads, same bytes into LDS -- no inactive-thread branches in a stage).
-template <int R, int NTH>
+// Loads are BUFFER loads: the descriptor of a stage covers exactly the k rows that exist (base = first row of the stage, size =
+// what is left of the K slice), so rows past the end of the slice -- and the micro-tiles past the last output row, whose offset
+// is set out of range -- read as zero from the bounds check.  No per-load address arithmetic, compares or selects in the stage
+// (the pointer form cost ~50 of its ~170 VALU instructions, against 12 MFMAs), and the stage stays ONE basic block, which the
+// interleaving hints below need: with a branch in it the compiler left all 12 MFMAs in a row behind the whole split.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int R, int NTH, bool INJECT>
 struct PanelK {
     static constexpr int TILES = (R / 4) * 8;
     static constexpr int PER = (TILES + NTH - 1) / NTH;
-    const float* src[PER];     // micro-tile origin at k = 0
+    unsigned voff[PER][4];     // byte offset of the micro-tile's 4 k rows from the stage base (out of range = reads zero)
     int lds_off[PER];          // byte offset of (row group, k group)
-    int kcol[PER];
-    bool ones[PER];            // the micro-tile starts at the injected ones column
+    float onef[PER];           // 1.0 for the micro-tile that starts at the injected ones column (its loads are out of range)
 
-    __device__ __forceinline__ void init(const float* __restrict__ X, int64_t ld, int64_t row0, int64_t nrows, bool inject) {
+    __device__ __forceinline__ void init(int64_t ld, int64_t row0, int64_t nrows, bool inject) {
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int t = (threadIdx.x + j * NTH) % TILES;
             const int kg = t % 8, rg = t / 8;
-            int64_t row = row0 + rg * 4;
-            ones[j] = inject && row == nrows;
-            if (row > nrows - 4) row = nrows - 4;                   // nrows % 4 == 0 (checked by the launcher)
-            if (row < 0) row = 0;
-            src[j] = X + (int64_t)(kg * 4) * ld + row;
+            const int64_t row = row0 + rg * 4;                      // nrows % 4 == 0 (checked by the launcher)
+            onef[j] = (INJECT && inject && row == nrows) ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) voff[j][i] = row >= nrows ? 0x80000000u : (unsigned)((((int64_t)(kg * 4 + i)) * ld + row) * 4);
             lds_off[j] = (rg * 4) * ROW_BYTES + kg * 8;
-            kcol[j] = kg * 4;
         }
     }
-    __device__ __forceinline__ void gload(int64_t ld, int64_t k0, int64_t kend, bool ok, const float* __restrict__ zeros, float4 (&reg)[PER][4]) const {
-        const int64_t lim = ok ? kend : 0;
+    __device__ __forceinline__ void gload(__amdgpu_buffer_rsrc_t rs, float4 (&reg)[PER][4]) const {
 #pragma unroll
         for (int j = 0; j < PER; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float* p = (k0 + kcol[j] + i < lim) ? src[j] + (k0 + i) * ld : zeros;
-                reg[j][i] = *reinterpret_cast<const float4*>(p);
-            }
+            for (int i = 0; i < 4; ++i) reg[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j][i], 0, 0));
     }
-    // 4x4 register transpose, split, 8-byte stores: 4 consecutive k of one output row per word.  k rows past the end of K were
-    // loaded from the zero block; the ones column of such rows is multiplied by zero rows of the other operand, so it needs no mask.
+    // 4x4 register transpose, split, 8-byte stores: 4 consecutive k of one output row per word; one call = output row r of micro-tile
+    // j (the stage interleaves these calls with its MFMAs).  The ones column's k rows past the end of K are 1.0 too: they meet zero
+    // rows of the other operand.
+    __device__ __forceinline__ void sstore_row(char* __restrict__ s, const float4 (&reg)[PER][4], int j, int r) const {
+        const float4 r0 = reg[j][0], r1 = reg[j][1], r2 = reg[j][2], r3 = reg[j][3];
+        float4 v = r == 0 ? make_float4(r0.x, r1.x, r2.x, r3.x) : r == 1 ? make_float4(r0.y, r1.y, r2.y, r3.y)
+                 : r == 2 ? make_float4(r0.z, r1.z, r2.z, r3.z) : make_float4(r0.w, r1.w, r2.w, r3.w);
+        if (INJECT && r == 0) { v.x += onef[j]; v.y += onef[j]; v.z += onef[j]; v.w += onef[j]; }
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<uint2*>(s + lds_off[j] + r * ROW_BYTES) = hi;
+        *reinterpret_cast<uint2*>(s + lds_off[j] + r * ROW_BYTES + 64) = lo;
+    }
     __device__ __forceinline__ void sstore(char* __restrict__ s, const float4 (&reg)[PER][4]) const {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            float4 r0 = reg[j][0], r1 = reg[j][1], r2 = reg[j][2], r3 = reg[j][3];
-            if (ones[j]) { r0 = r1 = r2 = r3 = make_float4(1.f, 0.f, 0.f, 0.f); }
-            const float4 rows[4] = {make_float4(r0.x, r1.x, r2.x, r3.x), make_float4(r0.y, r1.y, r2.y, r3.y),
-                                    make_float4(r0.z, r1.z, r2.z, r3.z), make_float4(r0.w, r1.w, r2.w, r3.w)};
+        for (int j = 0; j < PER; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                uint2 hi, lo;
-                split4(rows[r], hi, lo);
-                *reinterpret_cast<uint2*>(s + lds_off[j] + r * ROW_BYTES) = hi;
-                *reinterpret_cast<uint2*>(s + lds_off[j] + r * ROW_BYTES + 64) = lo;
-            }
-        }
+            for (int r = 0; r < 4; ++r) sstore_row(s, reg, j, r);
+    }
+    __device__ __forceinline__ void gload1(__amdgpu_buffer_rsrc_t rs, float4 (&reg)[PER][4], int j) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reg[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j][i], 0, 0));
     }
 };
+// descriptor of stage `st` of an operand: base = first k row of the stage, size = the bytes left of the slice from there on
+// (0 when the stage does not exist: every load then returns zero without touching memory).  All scalar arithmetic.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stage_rsrc(const float* base, int64_t ld, int64_t bytes, int64_t st) {
+    const int64_t adv = st * BK * ld;
+    int64_t rem = bytes - adv * 4;
+    if (rem < 0) rem = 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + adv), 0, (int)rem, 0x00020000);
+}
 
 #ifndef FLID_WG_EXP
 #define FLID_WG_EXP 0   // timing experiments only (results wrong): 1 = no atomic fold, 2 = no MFMAs, 3 = no fragment reads, 4 = no LDS stores
@@ -495,7 +507,7 @@ constexpr int WBM = 64, WNT = 128;     // weight-gradient workgroup: 2 waves x (
                                        // 256 / 384 / 256) and 46 KB of LDS lets 3 workgroups share a CU: measured 80 / 99 / 57 us ->
                                        // 52 / 73 / 50 us for the three launches of a 13.6 k-row layer.
 template <int TNW>
-__global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int64_t K, int64_t k_chunk, const float* __restrict__ zeros) {
+__global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int64_t K, int64_t k_chunk) {
     constexpr int BNt = 32 * TNW;
     constexpr int FA = WBM * ROW_BYTES, FB = BNt * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
@@ -519,18 +531,27 @@ __global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
 
-    using PA = PanelK<WBM, WNT>;
-    using PB = PanelK<BNt, WNT>;
+    using PA = PanelK<WBM, WNT, false>;
+    using PB = PanelK<BNt, WNT, true>;
     PA pa;
     PB pb;
-    pa.init(J.A, J.lda, bm, M, false);
-    pb.init(J.B, J.ldb, bn, N, J.colsum != nullptr);
+    pa.init(J.lda, bm, M, false);
+    pb.init(J.ldb, bn, N, J.colsum != nullptr);
     float4 ra0[PA::PER][4], rb0[PB::PER][4], ra1[PA::PER][4], rb1[PB::PER][4];
     const int64_t nstage = (kend - kbeg + BK - 1) / BK;
+    const float* a_base = J.A + kbeg * J.lda;
+    const float* b_base = J.B + kbeg * J.ldb;
+    const int64_t a_bytes = ((kend - kbeg - 1) * J.lda + M) * 4, b_bytes = ((kend - kbeg - 1) * J.ldb + N) * 4;
     auto issue = [&](int64_t st, float4 (&ra)[PA::PER][4], float4 (&rb)[PB::PER][4]) {
-        pa.gload(J.lda, kbeg + st * BK, kend, st < nstage, zeros, ra);
-        pb.gload(J.ldb, kbeg + st * BK, kend, st < nstage, zeros, rb);
+        pa.gload(stage_rsrc(a_base, J.lda, a_bytes, st), ra);
+        pb.gload(stage_rsrc(b_base, J.ldb, b_bytes, st), rb);
     };
+    // One stage = one basic block, scheduled by hand: the fragment reads of stage st, then MFMA c followed by chunk c of the staging
+    // of stage st + 1 (split + LDS stores of one output row of one micro-tile; the loads of stage st + 3 refill a micro-tile's
+    // registers as soon as its fourth row is done).  A chunk is ~12 VALU instructions (48 cycles), an MFMA 32: both pipes stay busy
+    // from ONE wave, where the compiler's own order (all splits, then all MFMAs back to back) left each idle half of the time.
+    constexpr int NM = 6 * TNW, NCH = 4 * (PA::PER + PB::PER);
+    static_assert(NM >= NCH, "every staging chunk needs an MFMA to hide under");
     auto stage = [&](int64_t st, float4 (&ra)[PA::PER][4], float4 (&rb)[PB::PER][4]) {
         const int cur = (int)(st & 1);
         bf16x8 ah[2], al[2], bh[TNW][2], bl[TNW][2];
@@ -547,16 +568,28 @@ __global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int
 #pragma unroll
             for (int tt = 0; tt < TNW; ++tt) read_frag(sB(cur), 32 * tt, ks, bh[tt][ks], bl[tt][ks]);
         }
-        if (FLID_WG_EXP != 4) {
-            pa.sstore(sA(cur ^ 1), ra);                   // (ra, rb) hold stage st + 1
-            pb.sstore(sB(cur ^ 1), rb);
-        } else {
+        const __amdgpu_buffer_rsrc_t rsa = stage_rsrc(a_base, J.lda, a_bytes, st + 3), rsb = stage_rsrc(b_base, J.ldb, b_bytes, st + 3);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < PA::PER; ++j) acc[0][j] += ra[j][0].x + ra[j][1].y + ra[j][2].z + ra[j][3].w;
-#pragma unroll
-            for (int j = 0; j < PB::PER; ++j) acc[0][j + 4] += rb[j][0].x + rb[j][1].y + rb[j][2].z + rb[j][3].w;
+        for (int c = 0; c < NM; ++c) {
+            if (FLID_WG_EXP != 2) {
+                const int ks = c / (3 * TNW), kind = (c % (3 * TNW)) / TNW, tt = c % TNW;
+                if (kind == 0) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[tt][ks], acc[tt], 0, 0, 0);
+                else if (kind == 1) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[tt][ks], acc[tt], 0, 0, 0);
+                else acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[tt][ks], acc[tt], 0, 0, 0);
+            }
+            if (c < NCH && FLID_WG_EXP != 4) {
+                const int jt = c / 4, r = c % 4;                  // micro-tile (A's first, then B's), output row
+                if (jt < PA::PER) {
+                    pa.sstore_row(sA(cur ^ 1), ra, jt, r);
+                    if (r == 3) pa.gload1(rsa, ra, jt);
+                } else {
+                    pb.sstore_row(sB(cur ^ 1), rb, jt - PA::PER, r);
+                    if (r == 3) pb.gload1(rsb, rb, jt - PA::PER);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        issue(st + 3, ra, rb);
         if (FLID_WG_EXP == 2) {                        // keep the fragment reads alive without the MFMAs
             auto fs = [](const bf16x8& v) { const float4 f = __builtin_bit_cast(float4, v); return (f.x + f.y) + (f.z + f.w); };
 #pragma unroll
@@ -566,24 +599,11 @@ __global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int
                 for (int tt = 0; tt < TNW; ++tt) acc[tt][2 + ks] += fs(bh[tt][ks]) + fs(bl[tt][ks]);
             }
         }
+        if (FLID_WG_EXP == 4) {
 #pragma unroll
-        for (int ks = 0; ks < (FLID_WG_EXP == 2 ? 0 : 2); ++ks) {
+            for (int q = 0; q < PA::PER; ++q) { acc[0][q] += ra[q][0].x + ra[q][1].y + ra[q][2].z + ra[q][3].w; pa.gload1(rsa, ra, q); }
 #pragma unroll
-            for (int tt = 0; tt < TNW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh[tt][ks], acc[tt], 0, 0, 0);
-#pragma unroll
-            for (int tt = 0; tt < TNW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl[tt][ks], acc[tt], 0, 0, 0);
-#pragma unroll
-            for (int tt = 0; tt < TNW; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh[tt][ks], acc[tt], 0, 0, 0);
-        }
-        if (SCHED) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 4 * TNW, 0);
-#pragma unroll
-            for (int i = 0; i < 6 * TNW; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
+            for (int q = 0; q < PB::PER; ++q) { acc[0][q + 4] += rb[q][0].x + rb[q][1].y + rb[q][2].z + rb[q][3].w; pb.gload1(rsb, rb, q); }
         }
         __syncthreads();
     };
@@ -632,8 +652,6 @@ namespace tg {
 // the caller takes tg_gemm_f32 + tg_colsum per job.
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s) {
     if (njobs < 1 || njobs > 6 || rows < 1) return false;
-    const float* zeros = zero_block();
-    if (!zeros) return false;
     // One column-tile width (64 or 96) and one K-slice count (a multiple of 8: XCD pinning) for the launch.  Swept on MI355X
     // (tools/wgrad_sweep.py, 13.6 k rows): the best point of every launch of a layer has 500-700 workgroups (768 are resident at
     // once: 3 per CU at 46 KB of LDS) and the 64-wide tile unless it pads the outputs > 10 % more than the 96-wide one:
@@ -649,7 +667,9 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
     }
     int best_tnw = (double)tiles_c[0] * 64 <= (double)tiles_c[1] * 96 * 1.1 ? 2 : 3;
     const int64_t max_slices = std::max<int64_t>(8, rows / (4 * BK) / 8 * 8);
-    int64_t best_slices = std::max<int64_t>(8, 700 / std::max<int64_t>(1, tiles_c[best_tnw - 2]) / 8 * 8);
+    // (re-swept with the buffer-load staging: 67 tiles x 16 slices 67.6 us against x 8 77.1 -- up to ~70 tiles take 16 slices)
+    const int64_t per = 700 / std::max<int64_t>(1, tiles_c[best_tnw - 2]);
+    int64_t best_slices = per >= 10 ? std::max<int64_t>(16, per / 8 * 8) : 8;
     if (best_slices > max_slices) best_slices = max_slices;
     static const bool tuning = getenv("FLID_GEMM_TUNE") != nullptr;          // overrides are read only in tuning mode (tools/)
     if (tuning) {
@@ -678,9 +698,11 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
     if (k_chunk < BK) k_chunk = BK;
     const int64_t blocks = (int64_t)wj.total_tiles * slices;
     if (blocks >= ((int64_t)1 << 31)) return false;
+    for (int i = 0; i < njobs; ++i)          // a K slice of either operand is addressed with 32-bit byte offsets (buffer loads)
+        if ((k_chunk + 2 * BK) * std::max(jobs[i].lda, jobs[i].ldb) * 4 >= ((int64_t)1 << 31)) return false;
     ProfScope prof("gemm", flops, s);
-    if (tnw == 3) gemm_bf16x3_wgrad_kernel<3><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk, zeros);
-    else gemm_bf16x3_wgrad_kernel<2><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk, zeros);
+    if (tnw == 3) gemm_bf16x3_wgrad_kernel<3><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk);
+    else gemm_bf16x3_wgrad_kernel<2><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk);
     return true;
 }
 

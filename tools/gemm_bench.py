@@ -36,6 +36,19 @@ def time_us(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+def wgrad_groups(R, dev):
+    """the three grouped weight-gradient launches of a merged-projection layer's backward (tg_layer.hip): name -> (jobs, M x N summed);
+    A = the activation gradient, B = the layer input"""
+    f = lambda *s: torch.randn(*s, device=dev)
+    dout, f1, df1, yr, dres, ctx, dctx, agg, du, own = f(R, 172), f(R, 172), f(R, 172), f(R, 444), f(R, 272), f(R, 272), f(R, 272), f(R, 888), f(R, 888), f(R, 172)
+    z = lambda *s_: torch.zeros(*s_, device=dev)
+    W2, W1, Wr, Wv, dP, b = z(172, 172), z(172, 444), z(272, 272), z(272, 444), z(888, 172), z(888)
+    return {"merge: dW2, dW1 (+ biases)": ([(dout, f1, W2, b[:172]), (df1, yr, W1, b[:172])], 172 * 172 + 172 * 444),
+            "dWr (+ d br), dWv_h x 2": ([(dres, ctx, Wr, b[:272]), (dctx[:, :136], agg[:, :444], Wv[:136], None),
+                                         (dctx[:, 136:], agg[:, 444:], Wv[136:], None)], 272 * 272 + 272 * 444),
+            "dP = du^T own (+ dub)": ([(du, own, dP, b)], 888 * 172)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", action="append", help="ta,tb,M,N,K (repeatable)")
@@ -46,14 +59,7 @@ def main():
     f = lambda *s: torch.randn(*s, device=dev)
     if args.wgrad is not None:
         R = args.wgrad
-        dout, f1, df1, yr, dres, ctx, dctx, agg, du, own = f(R, 172), f(R, 172), f(R, 172), f(R, 444), f(R, 272), f(R, 272), f(R, 272), f(R, 888), f(R, 888), f(R, 172)
-        z = lambda *s_: torch.zeros(*s_, device=dev)
-        W2, W1, Wr, Wv, dP, b = z(172, 172), z(172, 444), z(272, 272), z(272, 444), z(888, 172), z(888)
-        # the three grouped launches of a merged-projection layer's backward (tg_layer.hip): A = the activation gradient, B = the input
-        groups = {"merge: dW2, dW1 (+ biases)": ([(dout, f1, W2, b[:172]), (df1, yr, W1, b[:172])], 172 * 172 + 172 * 444),
-                  "dWr (+ d br), dWv_h x 2": ([(dres, ctx, Wr, b[:272]), (dctx[:, :136], agg[:, :444], Wv[:136], None),
-                                               (dctx[:, 136:], agg[:, 444:], Wv[136:], None)], 272 * 272 + 272 * 444),
-                  "dP = du^T own (+ dub)": ([(du, own, dP, b)], 888 * 172)}
+        groups = wgrad_groups(R, dev)
         for name, (jobs, mn) in groups.items():
             us = time_us(lambda: ops.wgrad_group(jobs))
             print(f"{name:36s} {us:8.1f} us  {2.0 * mn * R / us / 1e6:7.1f} TFLOP/s")
