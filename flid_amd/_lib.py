@@ -99,6 +99,8 @@ SIGNATURES = {
     "tg_gelu_fwd": (C.c_int, [c_void, c_i64, c_void, c_void]),
     "tg_gelu_bwd": (C.c_int, [c_void, c_void, c_i64, c_void, c_void]),
     "tg_softmax_fwd": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_void]),
+    "tg_softmax_keymask_fwd": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_i64, c_void, c_void]),
+    "tg_recent_window_mean": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
     "tg_softmax_bwd": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void]),
     "tg_dropout": (C.c_int, [c_void, c_i64, c_f32, C.c_uint64, c_void, c_void]),
     "tg_segment_mean_fwd": (C.c_int, [c_void, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void]),

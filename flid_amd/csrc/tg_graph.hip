@@ -368,6 +368,80 @@ extern "C" int tg_first_hop_window(const tg_graph* g, const int32_t* d_ids, cons
     return tg::launch_status("first_hop_window_kernel");
 }
 
+// GraphMixer's node encoder (models/GraphMixer.py:125-150): for every root, the feature rows of its `window` most recent neighbors
+// before the query time, weighted by softmax(1 for a real neighbor, -1e10 for a padded slot) and then AVERAGED over all `window`
+// slots -- i.e. (1 / window) (1 / nv) sum_valid X[nbr] with nv real neighbors; with none, every slot is the padding row with weight
+// 1 / window.  The reference materialises (B, 2000, Dn) for this; here one workgroup walks a root's window and keeps the sum in
+// registers: the ids of 256 entries at a time go through LDS, the rows are read 4 entries deep.
+__global__ void __launch_bounds__(256) recent_window_mean_kernel(const int64_t* __restrict__ row_ptr, const tg::Incidence* __restrict__ inc,
+        int64_t num_rows, const int32_t* __restrict__ ids, const double* __restrict__ t64, int64_t n, int window,
+        const float* __restrict__ table, int64_t ld, int cols, float* __restrict__ out, int64_t out_ld) {
+    __shared__ int32_t s_nbr[256];
+    __shared__ int64_t s_cnt;
+    __shared__ int s_nv;
+    for (int64_t q = blockIdx.x; q < n; q += gridDim.x) {
+        const int32_t v = ids[q];
+        if (threadIdx.x == 0) {
+            s_cnt = (v >= 0 && v < num_rows) ? history_end(inc, row_ptr[v], row_ptr[v + 1], t64[q]) : 0;
+            s_nv = 0;
+        }
+        __syncthreads();
+        const int64_t cnt = s_cnt, lo = (v >= 0 && v < num_rows) ? row_ptr[v] : 0;
+        const int64_t take = cnt < window ? cnt : window;
+        const int64_t first = lo + cnt - take;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};            // columns threadIdx.x + 256 j  (cols <= 1024)
+        int nv_local = 0;
+        for (int64_t base = 0; base < take; base += 256) {
+            const int chunk = (int)((take - base) < 256 ? (take - base) : 256);
+            __syncthreads();
+            if ((int)threadIdx.x < chunk) {
+                const int32_t nb = inc[first + base + threadIdx.x].nbr;
+                s_nbr[threadIdx.x] = nb;
+                nv_local += nb > 0;
+            }
+            __syncthreads();
+            for (int e = 0; e < chunk; e += 4) {
+                float x[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t nb = (e + u < chunk) ? s_nbr[e + u] : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = threadIdx.x + 256 * j;
+                        x[u][j] = (nb > 0 && c < cols) ? table[(int64_t)nb * ld + c] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += x[u][j];
+            }
+        }
+        if (nv_local) atomicAdd(&s_nv, nv_local);
+        __syncthreads();
+        const int nv = s_nv;
+        const float inv_w = 1.f / (float)window;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c < cols) out[q * out_ld + c] = nv > 0 ? (acc[j] * (1.f / (float)nv)) * inv_w : table[c] * inv_w;   // table row 0 = the padding row
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int tg_recent_window_mean(const tg_graph* g, const int32_t* d_ids, const double* d_times64, int64_t n, int window,
+                                     const float* d_table, int64_t table_ld, int cols, float* d_out, int64_t out_ld, void* stream) {
+    TG_REQUIRE(g && d_ids && d_times64 && d_table && d_out, "tg_recent_window_mean: null pointer");
+    TG_REQUIRE(window > 0, "Number of sampled neighbors for each node should be greater than 0!");
+    TG_REQUIRE(cols > 0 && cols <= 1024 && n >= 0, "tg_recent_window_mean: cols must be in 1..1024");
+    if (n == 0) return TG_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>(n, tg::kMaxGridBlocks);
+    recent_window_mean_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g->d_row_ptr, g->d_inc, g->num_rows, d_ids, d_times64, n, window,
+                                                                       d_table, table_ld, cols, d_out, out_ld);
+    return tg::launch_status("recent_window_mean_kernel");
+}
+
 extern "C" int64_t tg_dedupe_capacity(int64_t n) {
     int64_t c = 1024;
     while (c < 2 * n) c <<= 1;

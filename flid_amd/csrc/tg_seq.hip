@@ -46,17 +46,21 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const float* __restrict__
     }
 }
 
-// one wave per row, cols <= 64 * MAXC
+// one wave per row, cols <= 64 * MAXC.  key_ids (optional, (n / rows_per_batch, cols) int32): column c of the rows of batch b is
+// masked out (its score reads as -inf) where key_ids[b, c] == 0 -- nn.MultiheadAttention's key_padding_mask as the reference's
+// TransformerEncoder builds it from the neighbor ids (models/modules.py:297-303).  A row whose keys are all masked is NaN, as there.
 template <int MAXC>
-__global__ void __launch_bounds__(256) softmax_fwd_kernel(const float* __restrict__ x, int64_t n, int cols, float* __restrict__ y) {
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(const float* __restrict__ x, int64_t n, int cols, float* __restrict__ y,
+                                                          const int32_t* __restrict__ key_ids, int64_t rows_per_batch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
         float v[MAXC];
         float m = -INFINITY;
+        const int32_t* km = key_ids ? key_ids + (r / rows_per_batch) * cols : nullptr;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
-            v[i] = c < cols ? x[r * cols + c] : -INFINITY;
+            v[i] = (c < cols && !(km && km[c] == 0)) ? x[r * cols + c] : -INFINITY;
             m = fmaxf(m, v[i]);
         }
         m = tg::wave_max(m);
@@ -152,15 +156,24 @@ extern "C" int tg_gelu_bwd(const float* d_x, const float* d_dy, int64_t n, float
     return tg::launch_status("gelu_bwd_kernel");
 }
 
-extern "C" int tg_softmax_fwd(const float* d_x, int64_t n, int cols, float* d_y, void* stream) {
-    TG_REQUIRE(d_x && d_y && n >= 0 && cols > 0 && cols <= 1024, "tg_softmax_fwd: cols must be in 1..1024");
+static int softmax_fwd_impl(const float* d_x, int64_t n, int cols, float* d_y, const int32_t* d_key_ids, int64_t rows_per_batch, void* stream) {
     if (n == 0) return TG_OK;
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, tg::kMaxGridBlocks));
-    if (cols <= 64) softmax_fwd_kernel<1><<<g, 256, 0, s>>>(d_x, n, cols, d_y);
-    else if (cols <= 256) softmax_fwd_kernel<4><<<g, 256, 0, s>>>(d_x, n, cols, d_y);
-    else softmax_fwd_kernel<16><<<g, 256, 0, s>>>(d_x, n, cols, d_y);
+    if (cols <= 64) softmax_fwd_kernel<1><<<g, 256, 0, s>>>(d_x, n, cols, d_y, d_key_ids, rows_per_batch);
+    else if (cols <= 256) softmax_fwd_kernel<4><<<g, 256, 0, s>>>(d_x, n, cols, d_y, d_key_ids, rows_per_batch);
+    else softmax_fwd_kernel<16><<<g, 256, 0, s>>>(d_x, n, cols, d_y, d_key_ids, rows_per_batch);
     return tg::launch_status("softmax_fwd_kernel");
+}
+extern "C" int tg_softmax_fwd(const float* d_x, int64_t n, int cols, float* d_y, void* stream) {
+    TG_REQUIRE(d_x && d_y && n >= 0 && cols > 0 && cols <= 1024, "tg_softmax_fwd: cols must be in 1..1024");
+    return softmax_fwd_impl(d_x, n, cols, d_y, nullptr, 1, stream);
+}
+extern "C" int tg_softmax_keymask_fwd(const float* d_x, int64_t n, int cols, const int32_t* d_key_ids, int64_t rows_per_batch, float* d_y,
+                                      void* stream) {
+    TG_REQUIRE(d_x && d_y && d_key_ids && n >= 0 && cols > 0 && cols <= 1024, "tg_softmax_keymask_fwd: cols must be in 1..1024");
+    TG_REQUIRE(rows_per_batch > 0 && n % rows_per_batch == 0, "tg_softmax_keymask_fwd: n must be a multiple of rows_per_batch");
+    return softmax_fwd_impl(d_x, n, cols, d_y, d_key_ids, rows_per_batch, stream);
 }
 extern "C" int tg_softmax_bwd(const float* d_y, const float* d_dy, int64_t n, int cols, float* d_dx, void* stream) {
     TG_REQUIRE(d_y && d_dy && d_dx && n >= 0 && cols > 0 && cols <= 1024, "tg_softmax_bwd: cols must be in 1..1024");

@@ -83,6 +83,14 @@ class TemporalGraph:
                                         _p(ln), _stream()), "tg_first_hop_window")
         return nbr, eid, tt, ln
 
+    def recent_window_mean(self, ids: torch.Tensor, times: torch.Tensor, window: int, table: torch.Tensor):
+        """GraphMixer's node encoder (models/GraphMixer.py:125-150) without the (n, window, D) intermediate: (n, D)"""
+        n = ids.numel()
+        out = torch.empty((n, table.shape[1]), dtype=torch.float32, device=ids.device)
+        check(lib().tg_recent_window_mean(self._h, _p(ids), _p(times), n, int(window), _p(table), table.stride(0), table.shape[1],
+                                          _p(out), out.stride(0), _stream()), "tg_recent_window_mean")
+        return out
+
     def _dedupe_ws_for(self, n, dev):
         cap = int(lib().tg_dedupe_capacity(n))
         ws = getattr(self, "_dedupe_ws", None)

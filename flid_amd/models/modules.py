@@ -9,16 +9,39 @@ import torch.nn as nn
 from .. import ops
 
 
+class _exact_products:
+    """`with _exact_products(on):` -- the products issued inside run on the f32-input MFMA kernels (tg_set_gemm_mode(0), exact fp32
+    multiply-add chains) instead of the split-bf16 ones (2^-17 per product).  For the deep sequence backbones: through TCL's eight
+    post-LN block applications the split products' error reaches 1e-3 of the first layers' gradients (tests/test_gpu_backbones.py),
+    the exact ones stay at 1e-4."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        if self.on:
+            from .._lib import lib
+            self.prev = lib().tg_get_gemm_mode()
+            lib().tg_set_gemm_mode(0)
+
+    def __exit__(self, *exc):
+        if self.on:
+            from .._lib import lib
+            lib().tg_set_gemm_mode(self.prev)
+        return False
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b on the MFMA GEMM (tg_gemm_f32), with its two transposed products in backward."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, exact=False):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         y = torch.empty((x2.shape[0], w.shape[0]), device=x.device)
-        ops.gemm(x2, w, y, tb=True, bias=b, relu=relu)
+        with _exact_products(exact):
+            ops.gemm(x2, w, y, tb=True, bias=b, relu=relu)
         ctx.save_for_backward(x2, w, y if relu else None)
-        ctx.has_bias, ctx.shape = b is not None, x.shape
+        ctx.has_bias, ctx.shape, ctx.exact = b is not None, x.shape, exact
         return y.reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
@@ -31,9 +54,14 @@ class _LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if need_x:                                   # (raw-feature projections have no input gradient: skip the product)
             dx = torch.empty_like(x2)
-            ops.gemm(dy2, w, dx)
+            with _exact_products(ctx.exact):
+                ops.gemm(dy2, w, dx)
             dx = dx.reshape(ctx.shape)
-        if need_w:
+        if need_w and ctx.exact:
+            dw = torch.empty_like(w)
+            with _exact_products(True):
+                ops.gemm(dy2, x2, dw, ta=True)
+        elif need_w:
             # weight and bias gradient in ONE launch (tg_wgrad_group: split-bf16 MFMA, bias sum through the ones column, atomic fold)
             # when the shapes allow it; otherwise one exact product + one column sum
             n_out, n_in = w.shape
@@ -47,11 +75,11 @@ class _LinearFn(torch.autograd.Function):
                 ops.gemm(dy2, x2, dw, ta=True)
         if need_b:
             db = ops.colsum(dy2)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, w, b=None, relu=False):
-    return _LinearFn.apply(x, w, b, relu)
+def linear(x, w, b=None, relu=False, exact=False):
+    return _LinearFn.apply(x, w, b, relu, exact)
 
 
 class _TimeEncodeFn(torch.autograd.Function):
@@ -138,30 +166,46 @@ class MLPClassifier_BN(nn.Module):
 
 
 class TransformerEncoder(nn.Module):
-    """post-LN encoder block of the reference's TCL backbone (models/modules.py:248-312).  TCL is outside the accelerated path
-    (SURVEY 8f-4); the class is provided so that `from models.modules import TimeEncoder, TransformerEncoder` (models/TCL.py:5)
-    resolves after flid_amd.install().  Parameter names / shapes as the reference's (nn.MultiheadAttention inside); the two
-    feed-forward products run on the HIP GEMM, the attention itself is torch's."""
+    """post-LN encoder block of the reference's TCL backbone (models/modules.py:248-312): nn.MultiheadAttention with a key padding
+    mask built from the neighbor ids, residual + LayerNorm, Linear -> ReLU -> Linear, residual + LayerNorm.  Parameter names / shapes
+    are the reference's (nn.MultiheadAttention stays as the parameter holder); every product, the masked softmax, LayerNorm and
+    dropout run in libflid_tg (seqops.py)."""
 
     def __init__(self, attention_dim: int, num_heads: int, dropout: float = 0.1):
         super().__init__()
         self.multi_head_attention = nn.MultiheadAttention(embed_dim=attention_dim, num_heads=num_heads, dropout=dropout)
+        self.num_heads, self.p = num_heads, dropout
+        self.exact_products = True          # f32-input MFMA products (see _exact_products); False = the faster split-bf16 ones
         self.dropout = nn.Dropout(dropout)
         self.linear_layers = nn.ModuleList([nn.Linear(attention_dim, 4 * attention_dim), nn.Linear(4 * attention_dim, attention_dim)])
         self.norm_layers = nn.ModuleList([nn.LayerNorm(attention_dim), nn.LayerNorm(attention_dim)])
 
     def forward(self, inputs_query: torch.Tensor, inputs_key: torch.Tensor = None, inputs_value: torch.Tensor = None,
-                neighbor_masks: np.ndarray = None):
+                neighbor_masks=None):
+        """neighbor_masks: (batch, source_seq_length) neighbor ids, numpy (as the reference passes them) or an int32 device tensor"""
+        from .. import seqops
         if inputs_key is None or inputs_value is None:
             assert inputs_key is None and inputs_value is None
             inputs_key = inputs_value = inputs_query
-        pad = None if neighbor_masks is None else (torch.from_numpy(neighbor_masks).to(inputs_query.device) == 0)
-        att = self.multi_head_attention(query=inputs_query.transpose(0, 1), key=inputs_key.transpose(0, 1),
-                                        value=inputs_value.transpose(0, 1), key_padding_mask=pad)[0].transpose(0, 1)
-        out = self.norm_layers[0](inputs_query + self.dropout(att))
-        ff = linear(self.dropout(linear(out, self.linear_layers[0].weight, self.linear_layers[0].bias, relu=True)),
-                    self.linear_layers[1].weight, self.linear_layers[1].bias)
-        return self.norm_layers[1](out + self.dropout(ff))
+        mha, tr, p = self.multi_head_attention, self.training, self.p
+        d = inputs_query.shape[-1]
+        W, b = mha.in_proj_weight, mha.in_proj_bias
+        key_ids = None
+        if neighbor_masks is not None:
+            key_ids = neighbor_masks if torch.is_tensor(neighbor_masks) else torch.from_numpy(np.ascontiguousarray(neighbor_masks))
+            key_ids = key_ids.to(device=inputs_query.device, dtype=torch.int32)
+        ex = self.exact_products
+        q = linear(inputs_query, W[:d], b[:d], exact=ex)
+        if inputs_key is inputs_value:
+            kv = linear(inputs_key, W[d:], b[d:], exact=ex)                         # keys and values in one product
+        else:
+            kv = torch.cat([linear(inputs_key, W[d:2 * d], b[d:2 * d], exact=ex), linear(inputs_value, W[2 * d:], b[2 * d:], exact=ex)], dim=-1)
+        att = seqops.attention(q, kv, key_ids, self.num_heads, p, tr)
+        att = linear(att, mha.out_proj.weight, mha.out_proj.bias, exact=ex)
+        out = seqops.layer_norm(inputs_query + seqops.dropout(att, p, tr), self.norm_layers[0].weight, self.norm_layers[0].bias)
+        ff = linear(seqops.dropout(linear(out, self.linear_layers[0].weight, self.linear_layers[0].bias, relu=True, exact=ex), p, tr),
+                    self.linear_layers[1].weight, self.linear_layers[1].bias, exact=ex)
+        return seqops.layer_norm(out + seqops.dropout(ff, p, tr), self.norm_layers[1].weight, self.norm_layers[1].bias)
 
 
 class _StandaloneAttnFn(torch.autograd.Function):

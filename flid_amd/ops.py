@@ -314,6 +314,15 @@ def softmax_fwd(x):
     return y
 
 
+def softmax_keymask_fwd(x, key_ids, rows_per_batch):
+    """row softmax with the columns whose key id is 0 masked out; x: (..., cols), key_ids: (batches, cols) int32"""
+    _chk(key_ids, torch.int32, "key_ids")
+    y = torch.empty_like(x)
+    check(lib().tg_softmax_keymask_fwd(_p(x), x.numel() // x.shape[-1], x.shape[-1], _p(key_ids.contiguous()), int(rows_per_batch), _p(y),
+                                       _stream()), "tg_softmax_keymask_fwd")
+    return y
+
+
 def softmax_bwd(y, dy):
     dx = torch.empty_like(y)
     check(lib().tg_softmax_bwd(_p(y), _p(dy), y.numel() // y.shape[-1], y.shape[-1], _p(dx), _stream()), "tg_softmax_bwd")

@@ -126,6 +126,53 @@ def self_attention(qkv, heads, p_drop, training):
     return _SelfAttentionFn.apply(qkv, heads, p, _seed(training, p))
 
 
+class _AttentionFn(torch.autograd.Function):
+    """nn.MultiheadAttention's core with a key padding mask and separate query / key-value sequences (the reference's TCL blocks,
+    models/modules.py:297-307): softmax(Q K^T / sqrt(hd) with masked keys) V per (sequence, head).  q: (B, Sq, d); kv: (B, Sk, 2 d)
+    = [keys | values] as the packed in-projection leaves them; key_ids: (B, Sk) int32, id 0 = padding (None: no mask)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, key_ids, heads, p_drop, seed):
+        B, Sq, d = q.shape
+        Sk = kv.shape[1]
+        hd = d // heads
+        q, kv = q.contiguous(), kv.contiguous()
+        sq, sk, sp, so = (Sq * d, hd), (Sk * 2 * d, hd), (heads * Sq * Sk, Sq * Sk), (Sq * d, hd)
+        scores = torch.empty((B, heads, Sq, Sk), device=q.device)
+        ops.gemm_batched2(q[0, :, 0:hd], kv[0, :, 0:hd], scores[0, 0], B, heads, sq, sk, sp, tb=True, alpha=hd ** -0.5)
+        prob = ops.softmax_fwd(scores) if key_ids is None else ops.softmax_keymask_fwd(scores, key_ids, heads * Sq)
+        pd = ops.dropout(prob, p_drop, seed) if p_drop > 0 else prob
+        out = torch.empty((B, Sq, d), device=q.device)
+        ops.gemm_batched2(pd[0, 0], kv[0, :, d:d + hd], out[0, :, 0:hd], B, heads, sp, sk, so)
+        ctx.save_for_backward(q, kv, prob, pd)
+        ctx.cfg = (heads, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, prob, pd = ctx.saved_tensors
+        heads, p_drop, seed = ctx.cfg
+        B, Sq, d = q.shape
+        Sk = kv.shape[1]
+        hd = d // heads
+        dout = dout.contiguous()
+        sq, sk, sp, so = (Sq * d, hd), (Sk * 2 * d, hd), (heads * Sq * Sk, Sq * Sk), (Sq * d, hd)
+        dq, dkv, dpd = torch.empty_like(q), torch.empty_like(kv), torch.empty_like(prob)
+        ops.gemm_batched2(dout[0, :, 0:hd], kv[0, :, d:d + hd], dpd[0, 0], B, heads, so, sk, sp, tb=True)          # dP = dO V^T
+        ops.gemm_batched2(pd[0, 0], dout[0, :, 0:hd], dkv[0, :, d:d + hd], B, heads, sp, so, sk, ta=True)           # dV = P^T dO
+        dp = ops.dropout(dpd, p_drop, seed) if p_drop > 0 else dpd
+        ds = ops.softmax_bwd(prob, dp)
+        scale = hd ** -0.5
+        ops.gemm_batched2(ds[0, 0], kv[0, :, 0:hd], dq[0, :, 0:hd], B, heads, sp, sk, sq, alpha=scale)              # dQ = dS K
+        ops.gemm_batched2(ds[0, 0], q[0, :, 0:hd], dkv[0, :, 0:hd], B, heads, sp, sq, sk, ta=True, alpha=scale)     # dK = dS^T Q
+        return dq, dkv, None, None, None, None
+
+
+def attention(q, kv, key_ids, heads, p_drop, training):
+    p = p_drop if training else 0.0
+    return _AttentionFn.apply(q, kv, key_ids, heads, p, _seed(training, p))
+
+
 class _MaskedTimeEncodeFn(torch.autograd.Function):
     """cos(dt w + b), zero where the slot is padding (models/DyGFormer.py:263-266)"""
 

@@ -76,6 +76,11 @@ int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n, int64_t c
 int tg_first_hop_window(const tg_graph* g, const int32_t* d_ids, const double* d_times64, int64_t n, int max_len,
                         int width, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, int32_t* d_out_len,
                         void* stream);
+/* GraphMixer's node encoder, models/GraphMixer.py:125-150 (get_historical_neighbors(num_neighbors=time_gap) + softmax over the
+ * validity mask + torch.mean over the time_gap slots): out[q] = (1 / window) (1 / nv) sum of the table rows of the nv most recent
+ * neighbors (at most `window`) of d_ids[q] strictly before d_times64[q]; with no neighbor, table row 0 / window. */
+int tg_recent_window_mean(const tg_graph* g, const int32_t* d_ids, const double* d_times64, int64_t n, int window,
+                          const float* d_table, int64_t table_ld, int cols, float* d_out, int64_t out_ld, void* stream);
 
 /* ---- time encoding --------------------------------------------------------------------------------
  * replaces models/modules.py:28-40 TimeEncoder.forward: out[i, j] = cos(fma(t[i], w[j], b[j])).
@@ -317,6 +322,10 @@ int tg_gelu_bwd(const float* d_x, const float* d_dy, int64_t n, float* d_dx, voi
 /* row softmax over the last dimension (cols <= 1024) and its backward from the probabilities */
 int tg_softmax_fwd(const float* d_x, int64_t n, int cols, float* d_y, void* stream);
 int tg_softmax_bwd(const float* d_y, const float* d_dy, int64_t n, int cols, float* d_dx, void* stream);
+/* the same with nn.MultiheadAttention's key_padding_mask as models/modules.py:297-303 builds it for the TCL backbone: column c of
+ * the rows_per_batch rows of batch b counts as -inf where d_key_ids[b * cols + c] == 0 (backward: tg_softmax_bwd, masked
+ * probabilities are exactly 0).  Rows with every key masked are NaN, as in the reference. */
+int tg_softmax_keymask_fwd(const float* d_x, int64_t n, int cols, const int32_t* d_key_ids, int64_t rows_per_batch, float* d_y, void* stream);
 /* y[i] = x[i] / (1-p) if hash(seed, i) >= p else 0.  Applying it to dy with the same seed is the backward. */
 int tg_dropout(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream);
 /* out[i, :] = mean over positions [lo, hi) of x (n, s, d); backward writes dout/(hi-lo) into those positions of dx */

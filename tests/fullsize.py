@@ -78,3 +78,15 @@ def dyg_case(g):
     sl = slice(lo, lo + B)
     r = np.random.RandomState(int(g["r_seed"])).standard_normal((2, B, 172)).astype(np.float32)
     return data, p, (data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]), r
+
+
+def backbone_case(g, shapes):
+    """TCL / GraphMixer at the BASELINE dims (make_golden.py::gold_tcl_full / gold_mixer_full) -> data, params, (bs, bd, bt), r"""
+    from flid_amd.synth import wikipedia_like
+    data = wikipedia_like(num_edges=int(g["num_edges"]), seed=0, zero_node_feat=False)
+    _check(g, data)
+    p = O.seeded_like(shapes, int(g["seed"]), float(g["scale"]))
+    lo, nb = int(g["lo"]), int(g["batch"])
+    sl = slice(lo, lo + nb)
+    r = np.random.RandomState(int(g["r_seed"])).standard_normal((2, nb, 172)).astype(np.float32)
+    return data, p, (data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]), r

@@ -42,6 +42,8 @@ from models.modules import TimeEncoder, MultiHeadAttention  # noqa: E402
 from models.TGAT import TGAT  # noqa: E402
 from models.MemoryModel import MemoryModel  # noqa: E402
 from models.DyGFormer import DyGFormer  # noqa: E402
+from models.TCL import TCL  # noqa: E402
+from models.GraphMixer import GraphMixer  # noqa: E402
 
 from oracle import flid_oracle as O  # noqa: E402  (seed formula + shape tables only)
 
@@ -475,7 +477,119 @@ def gold_dyg_b600(num_edges=24000, lo=20000, seed=71, scale=0.04):
          **grads_compact({k_: p.grad for k_, p in model.named_parameters()}))
 
 
+def run_tcl(tag, dn, de, dt, layers, heads, k, batch, seed, graph_seed, scale=0.2, strategy="recent"):
+    """TCL (models/TCL.py) on the toy stream: embeddings + parameter gradients; batch rows with no history / a short history, and one
+    edge whose two endpoints are the same node (identical sequences on both sides of the cross-attention)"""
+    src, dst, eid, t, num_rows = toy_graph(graph_seed)
+    rs = np.random.RandomState(seed)
+    node_feat = rs.standard_normal((num_rows, dn)).astype(np.float32)
+    edge_feat = rs.standard_normal((len(eid) + 1, de)).astype(np.float32)
+    node_feat[0] = 0
+    edge_feat[0] = 0
+    ns = get_neighbor_sampler(Data(src, dst, t, eid), strategy, seed=3)
+    model = TCL(node_feat, edge_feat, ns, time_feat_dim=dt, num_layers=layers, num_heads=heads, num_depths=k + 1, dropout=0.0)
+    shapes = {k_: tuple(v.shape) for k_, v in model.state_dict().items()}
+    assert shapes == O.tcl_shapes(dn, de, dt, layers, k + 1), "state_dict contract drifted"
+    params = O.seeded_like(shapes, seed=seed, scale=scale)
+    model.load_state_dict(params)
+    model.train()
+    pick = np.sort(rs.choice(len(eid), size=batch, replace=False))
+    bs, bd, bt = src[pick].copy(), dst[pick].copy(), t[pick].copy()
+    bs[0], bd[0], bt[0] = src[0], dst[0], t[0]              # no history on either side: every key but the node itself is masked
+    bd[1] = bs[1]
+    s_emb, d_emb = model.compute_src_dst_node_temporal_embeddings(bs, bd, bt, num_neighbors=k)
+    r = rs.standard_normal((2, batch, dn)).astype(np.float32)
+    (s_emb * torch.from_numpy(r[0])).sum().add((d_emb * torch.from_numpy(r[1])).sum()).backward()
+    save(tag, src=src, dst=dst, eid=eid, t=t, num_rows=np.int64(num_rows), node_feat=node_feat, edge_feat=edge_feat,
+         dims=np.array([dn, de, dt, layers, heads, k]), seed=np.int64(seed), scale=np.float64(scale), strategy=np.array(strategy),
+         bs=bs, bd=bd, bt=bt, r=r, s_emb=s_emb.detach().numpy(), d_emb=d_emb.detach().numpy(), keys=np.array(sorted(shapes)),
+         **grads_compact({k_: p.grad for k_, p in model.named_parameters()}))
+
+
+def run_mixer(tag, dn, dt, layers, k, gap, batch, seed, graph_seed, scale=0.2, strategy="recent"):
+    """GraphMixer (models/GraphMixer.py) on the toy stream; `gap` smaller than some histories and larger than others"""
+    src, dst, eid, t, num_rows = toy_graph(graph_seed)
+    rs = np.random.RandomState(seed)
+    node_feat = rs.standard_normal((num_rows, dn)).astype(np.float32)
+    node_feat[0] = rs.standard_normal(dn).astype(np.float32) * 0.5       # a NON-zero padding row: it shows in roots without neighbors
+    edge_feat = np.zeros((len(eid) + 1, 4), dtype=np.float32)
+    ns = get_neighbor_sampler(Data(src, dst, t, eid), strategy, seed=3)
+    model = GraphMixer(node_feat, edge_feat, ns, time_feat_dim=dt, num_tokens=k, num_layers=layers, dropout=0.0)
+    shapes = {k_: tuple(v.shape) for k_, v in model.state_dict().items()}
+    assert shapes == O.mixer_shapes(dn, dt, k, layers), "state_dict contract drifted"
+    params = O.seeded_like(shapes, seed=seed, scale=scale)
+    model.load_state_dict(params)
+    model.train()
+    pick = np.sort(rs.choice(len(eid), size=batch, replace=False))
+    bs, bd, bt = src[pick].copy(), dst[pick].copy(), t[pick].copy()
+    bs[0], bd[0], bt[0] = src[0], dst[0], t[0]
+    s_emb, d_emb = model.compute_src_dst_node_temporal_embeddings(bs, bd, bt, num_neighbors=k, time_gap=gap)
+    r = rs.standard_normal((2, batch, dn)).astype(np.float32)
+    (s_emb * torch.from_numpy(r[0])).sum().add((d_emb * torch.from_numpy(r[1])).sum()).backward()
+    grads = {k_: p.grad for k_, p in model.named_parameters() if p.grad is not None}
+    save(tag, src=src, dst=dst, eid=eid, t=t, num_rows=np.int64(num_rows), node_feat=node_feat,
+         dims=np.array([dn, dt, layers, k, gap]), seed=np.int64(seed), scale=np.float64(scale), strategy=np.array(strategy),
+         bs=bs, bd=bd, bt=bt, r=r, s_emb=s_emb.detach().numpy(), d_emb=d_emb.detach().numpy(), keys=np.array(sorted(shapes)),
+         **grads_compact(grads))
+
+
+def gold_tcl_full(num_edges=24000, lo=20000, batch=200, seed=81, scale=0.05):
+    """TCL at the BASELINE dims (172 / 172 / 100, K = 20, 2 layers, 2 heads), 200 edges of the Wikipedia-shape stream"""
+    from flid_amd.synth import wikipedia_like
+    data = wikipedia_like(num_edges=num_edges, seed=0, zero_node_feat=False)
+    src, dst, t, eid = data.src_node_ids, data.dst_node_ids, data.node_interact_times, data.edge_ids
+    ns = get_neighbor_sampler(Data(src, dst, t, eid), "recent", seed=0)
+    model = TCL(data.node_raw_features, data.edge_raw_features, ns, time_feat_dim=100, num_layers=2, num_heads=2, num_depths=21, dropout=0.0)
+    shapes = {k_: tuple(v.shape) for k_, v in model.state_dict().items()}
+    assert shapes == O.tcl_shapes(172, 172, 100, 2, 21)
+    params = O.seeded_like(shapes, seed=seed, scale=scale)
+    model.load_state_dict(params)
+    model.train()
+    sl = slice(lo, lo + batch)
+    s_emb, d_emb = model.compute_src_dst_node_temporal_embeddings(src[sl], dst[sl], t[sl], num_neighbors=20)
+    r = np.random.RandomState(seed + 1000).standard_normal((2, batch, 172)).astype(np.float32)
+    (s_emb * torch.from_numpy(r[0])).sum().add((d_emb * torch.from_numpy(r[1])).sum()).backward()
+    save("tcl_full", num_edges=np.int64(num_edges), lo=np.int64(lo), batch=np.int64(batch), seed=np.int64(seed), scale=np.float64(scale),
+         r_seed=np.int64(seed + 1000), crc=_crc(src, dst, t, data.edge_raw_features[:64]),
+         s_emb=s_emb.detach().numpy(), d_emb=d_emb.detach().numpy(),
+         **grads_compact({k_: p.grad for k_, p in model.named_parameters()}))
+
+
+def gold_mixer_full(num_edges=60000, lo=56000, batch=200, seed=91, scale=0.05):
+    """GraphMixer at the BASELINE dims (172 / 100, K = 20 tokens, time_gap = 2000: popular items have longer histories than that)"""
+    from flid_amd.synth import wikipedia_like
+    data = wikipedia_like(num_edges=num_edges, seed=0, zero_node_feat=False)
+    src, dst, t, eid = data.src_node_ids, data.dst_node_ids, data.node_interact_times, data.edge_ids
+    ns = get_neighbor_sampler(Data(src, dst, t, eid), "recent", seed=0)
+    model = GraphMixer(data.node_raw_features, data.edge_raw_features, ns, time_feat_dim=100, num_tokens=20, num_layers=2, dropout=0.0)
+    shapes = {k_: tuple(v.shape) for k_, v in model.state_dict().items()}
+    assert shapes == O.mixer_shapes(172, 100, 20, 2)
+    params = O.seeded_like(shapes, seed=seed, scale=scale)
+    model.load_state_dict(params)
+    model.train()
+    sl = slice(lo, lo + batch)
+    longest = max(int(((src[:lo] == v) | (dst[:lo] == v)).sum()) for v in np.unique(dst[sl]))
+    assert longest > 2000, longest
+    s_emb, d_emb = model.compute_src_dst_node_temporal_embeddings(src[sl], dst[sl], t[sl], num_neighbors=20, time_gap=2000)
+    r = np.random.RandomState(seed + 1000).standard_normal((2, batch, 172)).astype(np.float32)
+    (s_emb * torch.from_numpy(r[0])).sum().add((d_emb * torch.from_numpy(r[1])).sum()).backward()
+    save("mixer_full", num_edges=np.int64(num_edges), lo=np.int64(lo), batch=np.int64(batch), seed=np.int64(seed), scale=np.float64(scale),
+         r_seed=np.int64(seed + 1000), crc=_crc(src, dst, t, data.edge_raw_features[:64]),
+         s_emb=s_emb.detach().numpy(), d_emb=d_emb.detach().numpy(),
+         **grads_compact({k_: p.grad for k_, p in model.named_parameters() if p.grad is not None}))
+
+
+def gold_backbones_small():
+    run_tcl("tcl_K5", 8, 6, 4, 2, 2, 5, 9, seed=83, graph_seed=8)
+    run_tcl("tcl_K3_uniform", 8, 6, 4, 1, 2, 3, 7, seed=84, graph_seed=8, strategy="uniform")
+    run_mixer("mixer_K6", 8, 4, 2, 6, 7, 9, seed=93, graph_seed=9)
+    run_mixer("mixer_K4_uniform", 8, 4, 1, 4, 5, 7, seed=94, graph_seed=9, strategy="uniform")
+
+
 FULL = {
+    "backbones_small": gold_backbones_small,
+    "tcl_full": gold_tcl_full,
+    "mixer_full": gold_mixer_full,
     "neg_sampler": gold_neg_sampler,
     "tgat_B600_full": lambda: run_tgat_b600("tgat_B600_full", seed=46, lo=20000, zero_node_feat=True, bias_te=False),
     # non-zero node features, trained-like time-encoder bias, ReLU units away from their kink: gradients comparable at 1e-4 max|g|

@@ -34,6 +34,8 @@ def test_install_resolves_every_name_the_trainers_import(clean_modules):
     from models.TGAT import TGAT                                                                      # noqa: F401
     from models.MemoryModel import MemoryModel, compute_src_dst_node_time_shifts                     # noqa: F401
     from models.DyGFormer import DyGFormer                                                            # noqa: F401
+    from models.TCL import TCL                                                                        # noqa: F401  (PTCL/EM_init.py:3)
+    from models.GraphMixer import GraphMixer                                                          # noqa: F401  (PTCL/EM_init.py:4)
     from models.modules import MergeLayer, MLPClassifier, MLPClassifier_BN                            # noqa: F401
     from models.modules import TimeEncoder, TransformerEncoder, MultiHeadAttention                    # noqa: F401  (models/TCL.py:5)
     from utils.utils import convert_to_gpu                                                            # noqa: F401
@@ -42,6 +44,7 @@ def test_install_resolves_every_name_the_trainers_import(clean_modules):
     from utils.utils import get_neighbor_sampler, NegativeEdgeSampler                                 # noqa: F401,F811
     import flid_amd.models.TGAT as mine
     assert TGAT is mine.TGAT
+    assert TCL.__module__ == "flid_amd.models.TCL" and GraphMixer.__module__ == "flid_amd.models.GraphMixer"
     head = MLPClassifier_BN(input_dim=172, dropout=0.1)
     assert sorted(head.state_dict()) == sorted(["fc1.weight", "fc1.bias", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var",
                                                 "bn1.num_batches_tracked", "fc2.weight", "fc2.bias", "bn2.weight", "bn2.bias",
@@ -62,30 +65,32 @@ def test_install_resolves_every_name_the_trainers_import(clean_modules):
 
 
 def test_install_keeps_the_host_packages_other_modules(clean_modules, tmp_path):
-    """a host checkout with its own models/ and utils/ packages: install() overrides the five hot-path modules and leaves the rest
-    (models.TCL here, utils.metrics) importable -- and THEIR imports of models.modules / utils.utils get the mirrors"""
+    """a host checkout with its own models/ and utils/ packages: install() overrides the backbone modules and leaves the rest
+    (models.EdgeBank here, utils.metrics) importable -- and THEIR imports of models.modules / utils.utils get the mirrors"""
     (tmp_path / "models").mkdir()
     (tmp_path / "utils").mkdir()
     (tmp_path / "models" / "__init__.py").write_text("")
     (tmp_path / "utils" / "__init__.py").write_text("")
-    (tmp_path / "models" / "TCL.py").write_text(textwrap.dedent("""
+    (tmp_path / "models" / "EdgeBank.py").write_text(textwrap.dedent("""
         from models.modules import TimeEncoder, TransformerEncoder
         from utils.utils import NeighborSampler
-        class TCL:
+        class EdgeBank:
             parts = (TimeEncoder, TransformerEncoder, NeighborSampler)
     """))
-    (tmp_path / "models" / "TGAT.py").write_text("raise ImportError('the host TGAT must have been replaced')\n")
+    for name in ("TGAT", "TCL", "GraphMixer"):
+        (tmp_path / "models" / f"{name}.py").write_text(f"raise ImportError('the host {name} must have been replaced')\n")
     (tmp_path / "utils" / "metrics.py").write_text("def get_link_prediction_metrics():\n    return 'host'\n")
     sys.path.insert(0, str(tmp_path))
     import flid_amd
     flid_amd.install()
-    from models.TCL import TCL
+    from models.EdgeBank import EdgeBank
     from models.TGAT import TGAT
+    from models.TCL import TCL
     from utils.metrics import get_link_prediction_metrics
     import flid_amd.models.modules as mm
     import flid_amd.utils.utils as uu
-    assert TCL.parts == (mm.TimeEncoder, mm.TransformerEncoder, uu.NeighborSampler)
-    assert TGAT.__module__ == "flid_amd.models.TGAT" and get_link_prediction_metrics() == "host"
+    assert EdgeBank.parts == (mm.TimeEncoder, mm.TransformerEncoder, uu.NeighborSampler)
+    assert TGAT.__module__ == "flid_amd.models.TGAT" and TCL.__module__ == "flid_amd.models.TCL" and get_link_prediction_metrics() == "host"
     assert os.path.dirname(importlib.import_module("models").__file__) == str(tmp_path / "models")
 
 

@@ -242,3 +242,74 @@ def test_dygformer_full_size():
     rr = torch.from_numpy(r)
     ((s * rr[0]).sum() + (d * rr[1]).sum()).backward()
     assert_grads_match(g, {k_: v.grad.numpy() for k_, v in p.items()}, atol=1e-4, rtol=1e-3)
+
+
+# ---- the two further backbones: oracle vs vectors the reference produced -------------------------------------------
+def _toy_sampler_fn(g, adj):
+    """`recent`: the oracle's default; `uniform`: numpy's stream, consumed in the reference's call order (seed 3 in make_golden.py)"""
+    if str(g["strategy"]) == "recent":
+        return None
+    rng = np.random.RandomState(3)
+    return lambda ids, times, k: O.sample_random(adj, ids, times, k, rng)
+
+
+@pytest.mark.parametrize("name", ["tcl_K5", "tcl_K3_uniform"])
+def test_tcl(name):
+    g = load_golden(name)
+    dn, de, dt, layers, heads, k = [int(v) for v in g["dims"]]
+    shapes = O.tcl_shapes(dn, de, dt, layers, k + 1)
+    assert sorted(shapes) == list(g["keys"])
+    p = {k_: v.requires_grad_(True) for k_, v in O.seeded_like(shapes, int(g["seed"]), float(g["scale"])).items()}
+    adj = _adj(g)
+    m = O.TCLOracle(torch.from_numpy(g["node_feat"]), torch.from_numpy(g["edge_feat"]), adj, p, layers, heads, sampler_fn=_toy_sampler_fn(g, adj))
+    s, d = m.src_dst(g["bs"], g["bd"], g["bt"], k)
+    np.testing.assert_allclose(s.detach().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().numpy(), g["d_emb"], atol=TOL)
+    r = torch.from_numpy(g["r"])
+    ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.numpy() for k_, v in p.items()}, atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["mixer_K6", "mixer_K4_uniform"])
+def test_graphmixer(name):
+    g = load_golden(name)
+    dn, dt, layers, k, gap = [int(v) for v in g["dims"]]
+    shapes = O.mixer_shapes(dn, dt, k, layers)
+    assert sorted(shapes) == list(g["keys"])
+    p = {k_: v.requires_grad_(True) for k_, v in O.seeded_like(shapes, int(g["seed"]), float(g["scale"])).items()}
+    adj = _adj(g)
+    m = O.GraphMixerOracle(torch.from_numpy(g["node_feat"]), adj, p, layers, sampler_fn=_toy_sampler_fn(g, adj))
+    s, d = m.src_dst(g["bs"], g["bd"], g["bt"], k, gap)
+    np.testing.assert_allclose(s.detach().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().numpy(), g["d_emb"], atol=TOL)
+    r = torch.from_numpy(g["r"])
+    ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.numpy() for k_, v in p.items() if v.grad is not None}, atol=1e-4, rtol=1e-3)
+
+
+def test_tcl_full_dims():
+    g = load_golden("tcl_full")
+    data, p, (bs, bd, bt), r = fullsize.backbone_case(g, O.tcl_shapes(172, 172, 100, 2, 21))
+    p = {k_: v.requires_grad_(True) for k_, v in p.items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    m = O.TCLOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 2, 2)
+    s, d = m.src_dst(bs, bd, bt, 20)
+    np.testing.assert_allclose(s.detach().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().numpy(), g["d_emb"], atol=TOL)
+    rr = torch.from_numpy(r)
+    ((s * rr[0]).sum() + (d * rr[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.numpy() for k_, v in p.items()}, atol=1e-4, rtol=1e-3)
+
+
+def test_graphmixer_full_dims():
+    g = load_golden("mixer_full")
+    data, p, (bs, bd, bt), r = fullsize.backbone_case(g, O.mixer_shapes(172, 100, 20, 2))
+    p = {k_: v.requires_grad_(True) for k_, v in p.items()}
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    m = O.GraphMixerOracle(torch.from_numpy(data.node_raw_features), adj, p, 2)
+    s, d = m.src_dst(bs, bd, bt, 20, 2000)
+    np.testing.assert_allclose(s.detach().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(d.detach().numpy(), g["d_emb"], atol=TOL)
+    rr = torch.from_numpy(r)
+    ((s * rr[0]).sum() + (d * rr[1]).sum()).backward()
+    assert_grads_match(g, {k_: v.grad.numpy() for k_, v in p.items() if v.grad is not None}, atol=1e-4, rtol=1e-3)
