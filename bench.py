@@ -61,7 +61,7 @@ def main():
                          "call (3 roots per edge), MergeLayer head, BCE loss, Adam on backbone + head; "
                          "sweep = the whole embedding-regeneration sweep of M_step.py:456-509 over EVERY edge of the graph into the (E, 172) "
                          "stores (flid_amd.sweep.regenerate_embeddings; full-graph sampler, chunked, prefetched)")
-    ap.add_argument("--model", default="tgat", choices=["tgat", "tgn", "dygformer"],
+    ap.add_argument("--model", default="tgat", choices=["tgat", "tgn", "dygformer", "tcl", "graphmixer"],
                     help="tgat = BASELINE configs[1] (the headline) / configs[4]; tgn = configs[2] (Reddit-shape, memory + GRU update + "
                          "message scatter); dygformer = configs[3] (Reddit-shape, first-hop sequence transformer)")
     ap.add_argument("--workload", default=None, choices=["wikipedia", "reddit", "scale"],
@@ -441,6 +441,14 @@ def bench_memory_or_sequence_model(args):
         model = MemoryModel(data.node_raw_features, data.edge_raw_features, sampler, DT, "TGN", 1, H, args.dropout, device=str(dev))
         model.memory_bank.__init_memory_bank__()
         desc = "TGN (MemoryModel) L=1 H=2 T=100, 20 recent neighbors, GRU memory, last-message aggregation"
+    elif args.model == "tcl":
+        from flid_amd.models.TCL import TCL
+        model = TCL(data.node_raw_features, data.edge_raw_features, sampler, DT, 2, H, K + 1, args.dropout, str(dev))
+        desc = "TCL L=2 H=2 T=100, 20 recent neighbors + the node (depth 21), exact-fp32 products"
+    elif args.model == "graphmixer":
+        from flid_amd.models.GraphMixer import GraphMixer
+        model = GraphMixer(data.node_raw_features, data.edge_raw_features, sampler, DT, K, 2, 0.5, 4.0, args.dropout, str(dev))
+        desc = "GraphMixer L=2, 20 tokens, 100 channels, time_gap 2000"
     else:
         from flid_amd.models.DyGFormer import DyGFormer
         model = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, DT, 50, 1, 2, 2, args.dropout, 32, str(dev))
@@ -564,7 +572,7 @@ def bench_memory_or_sequence_model(args):
         flops_edge = units / (args.steps * BATCH)
         path = {"flops_per_edge_fwd_bwd": round(flops_edge, 1), "mfma_frac": round(value / world * flops_edge / MFMA_F32_PEAK, 4),
                 "edges_per_s_at_100pct": round(MFMA_F32_PEAK / max(flops_edge, 1.0), 1)}
-        metric = "edges/sec (temporal-embedding fwd+bwd), DyGFormer Reddit, 1/2/4/8 MI355X"
+        metric = "edges/sec (temporal-embedding fwd+bwd), %s Reddit, 1/2/4/8 MI355X" % {"dygformer": "DyGFormer", "tcl": "TCL", "graphmixer": "GraphMixer"}[args.model]
     out = {"metric": metric, "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
@@ -602,10 +610,17 @@ def cpu_baseline_model(name, data, n_train, model, sl, dropout):
             edges += BATCH
         what = "3 chronological positive batches of 600 from a fresh memory"
     else:
-        p = {k_: v.requires_grad_(True) for k_, v in sd.items()}
-        orc = O.DyGFormerOracle(nt, et, adj, p, 50, 1, 2, 2, 32, dropout=dropout, training=True)
+        p = {k_: (v.requires_grad_(True) if not (name == "graphmixer" and k_.startswith("time_encoder")) else v) for k_, v in sd.items()}
         s_ = slice(sl.start, sl.start + BATCH)
-        a, c = orc.src_dst(data.src_node_ids[s_], data.dst_node_ids[s_], data.node_interact_times[s_])
+        if name == "tcl":
+            orc = O.TCLOracle(nt, et, adj, p, 2, H, dropout=dropout, training=True)
+            a, c = orc.src_dst(data.src_node_ids[s_], data.dst_node_ids[s_], data.node_interact_times[s_], K)
+        elif name == "graphmixer":
+            orc = O.GraphMixerOracle(nt, adj, p, 2, dropout=dropout, training=True)
+            a, c = orc.src_dst(data.src_node_ids[s_], data.dst_node_ids[s_], data.node_interact_times[s_], K, 2000)
+        else:
+            orc = O.DyGFormerOracle(nt, et, adj, p, 50, 1, 2, 2, 32, dropout=dropout, training=True)
+            a, c = orc.src_dst(data.src_node_ids[s_], data.dst_node_ids[s_], data.node_interact_times[s_])
         (a.mean() + c.mean()).backward()
         edges = BATCH
         what = "one batch of 600"
