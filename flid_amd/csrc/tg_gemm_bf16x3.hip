@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N
 
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Grouped weight-gradient launch: up to 6 products  C_j[M_j, N_j] += A_j^T B_j  over the SAME rows (the contraction index), e.g.
+// Grouped weight-gradient launch: up to 8 products  C_j[M_j, N_j] += A_j^T B_j  over the SAME rows (the contraction index), e.g.
 // all of a layer's dW that depend on one activation gradient, in ONE launch, with
 //   * the bias gradient for free: if job.colsum is set, column N_j of the B panel reads as 1.0 (the padding of the last column
 //     tile, N_j < gx * 32 TNW), so that output column is sum_rows A = the column sums of the activation gradient;
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_tn_kernel(int64_t M, int64_t N
 // Same tiles, LDS image and schedule as gemm_bf16x3_tn_kernel; 1-D grid of (tiles of all jobs) x slices, slices in multiples of
 // 8 so that all tiles of one K slice run on one XCD (its L2 pulls that row range of the operands once).
 struct WgJob { const float* A; const float* B; float* C; float* colsum; int64_t lda, ldb, ldc; int M, N, gx, tile0; };
-struct WgJobs { WgJob j[6]; int n, total_tiles; };
+struct WgJobs { WgJob j[8]; int n, total_tiles; };
 
 // K-major panel of R output rows x 32 k for a workgroup of NTH threads: (R / 4) * 8 micro-tiles of 4 (k) x 4 (rows), PER per thread
 // (threads past the last micro-tile redo an earlier one: same loads, same bytes into LDS -- no inactive-thread branches in a stage).
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int
     const int slice = xcd + 8 * (jj / jobs.total_tiles), t = jj % jobs.total_tiles;
     int ji = 0;
 #pragma unroll
-    for (int q = 1; q < 6; ++q) if (q < jobs.n && t >= jobs.j[q].tile0) ji = q;
+    for (int q = 1; q < 8; ++q) if (q < jobs.n && t >= jobs.j[q].tile0) ji = q;
     const WgJob J = jobs.j[ji];
     const int tile = t - J.tile0, by = tile / J.gx, bx = tile % J.gx;
     const int64_t M = J.M, N = J.N;
@@ -537,7 +537,10 @@ __global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int
     PB pb;
     pa.init(J.lda, bm, M, false);
     pb.init(J.ldb, bn, N, J.colsum != nullptr);
-    float4 ra0[PA::PER][4], rb0[PB::PER][4], ra1[PA::PER][4], rb1[PB::PER][4];
+    // THREE register sets: the loads of stages st + 2, st + 3, st + 4 are in flight while stage st computes -- a stage is short
+    // (12-18 MFMAs, ~0.5 us) and a slice's operands come from MALL / HBM (1.5-2.5 us loaded latency): with two sets the kernel ran
+    // at one stage per half latency, whatever its instruction schedule
+    float4 ra0[PA::PER][4], rb0[PB::PER][4], ra1[PA::PER][4], rb1[PB::PER][4], ra2[PA::PER][4], rb2[PB::PER][4];
     const int64_t nstage = (kend - kbeg + BK - 1) / BK;
     const float* a_base = J.A + kbeg * J.lda;
     const float* b_base = J.B + kbeg * J.ldb;
@@ -568,7 +571,7 @@ __global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int
 #pragma unroll
             for (int tt = 0; tt < TNW; ++tt) read_frag(sB(cur), 32 * tt, ks, bh[tt][ks], bl[tt][ks]);
         }
-        const __amdgpu_buffer_rsrc_t rsa = stage_rsrc(a_base, J.lda, a_bytes, st + 3), rsb = stage_rsrc(b_base, J.ldb, b_bytes, st + 3);
+        const __amdgpu_buffer_rsrc_t rsa = stage_rsrc(a_base, J.lda, a_bytes, st + 4), rsb = stage_rsrc(b_base, J.ldb, b_bytes, st + 4);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < NM; ++c) {
@@ -612,10 +615,14 @@ __global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int
     pb.sstore(sB(0), rb0);
     issue(1, ra0, rb0);
     issue(2, ra1, rb1);
+    issue(3, ra2, rb2);
     __syncthreads();
-    for (int64_t st = 0; st < nstage; st += 2) {
+    // (always three stages per trip -- a stage past the end multiplies zero rows: with conditional stages the compiler's wait-count
+    // model gave up across the back edge and waited for all but 6 of the 24 loads in flight before the first stage of a trip)
+    for (int64_t st = 0; st < nstage; st += 3) {
         stage(st, ra0, rb0);
-        if (st + 1 < nstage) stage(st + 1, ra1, rb1);
+        stage(st + 1, ra1, rb1);
+        stage(st + 2, ra2, rb2);
     }
     // partial tile -> LDS -> float atomics into C, 64 consecutive columns of a row per wave instruction
     __syncthreads();
@@ -651,7 +658,7 @@ namespace tg {
 // Grouped weight gradients (see gemm_bf16x3_wgrad_kernel).  false = a job's shape / alignment is not covered (nothing launched):
 // the caller takes tg_gemm_f32 + tg_colsum per job.
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s) {
-    if (njobs < 1 || njobs > 6 || rows < 1) return false;
+    if (njobs < 1 || njobs > 8 || rows < 1) return false;
     // One column-tile width (64 or 96) and one K-slice count (a multiple of 8: XCD pinning) for the launch.  Swept on MI355X
     // (tools/wgrad_sweep.py, 13.6 k rows): the best point of every launch of a layer has 500-700 workgroups (768 are resident at
     // once: 3 per CU at 46 KB of LDS) and the 64-wide tile unless it pads the outputs > 10 % more than the 96-wide one:
@@ -699,7 +706,7 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
     const int64_t blocks = (int64_t)wj.total_tiles * slices;
     if (blocks >= ((int64_t)1 << 31)) return false;
     for (int i = 0; i < njobs; ++i)          // a K slice of either operand is addressed with 32-bit byte offsets (buffer loads)
-        if ((k_chunk + 2 * BK) * std::max(jobs[i].lda, jobs[i].ldb) * 4 >= ((int64_t)1 << 31)) return false;
+        if ((k_chunk + 4 * BK) * std::max(jobs[i].lda, jobs[i].ldb) * 4 >= ((int64_t)1 << 31)) return false;
     ProfScope prof("gemm", flops, s);
     if (tnw == 3) gemm_bf16x3_wgrad_kernel<3><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk);
     else gemm_bf16x3_wgrad_kernel<2><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk);

@@ -724,11 +724,16 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // sums through a ones column, partial tiles folded with float atomics); shapes it does not cover fall back to one exact
     // product + one column sum per job.
     struct WJ { const float* A; int64_t lda; int M; const float* B; int64_t ldb; int N; float* C; int64_t ldc; float* cs; };
-    auto wgrad = [&](std::vector<WJ> jobs) -> int {
+    // Without side streams every weight gradient of the layer waits for the attention backward and leaves in ONE launch (flush_wgrad):
+    // a grouped launch costs ~24 us whatever its row count (launch, first-load latency, the atomic fold of slices x outputs), so
+    // three launches per layer were 72 us of fixed cost for 93 us of work.  Their operands (dout, f1, df1, [y | raw], dres, ctx,
+    // dctx, agg, du, own) are all distinct buffers that stay untouched until the call returns.
+    std::vector<WJ> pending;
+    auto issue_wgrad = [&](std::vector<WJ> jobs) -> int {
         hipStream_t st = ws_;
         void* stv = wstream;
         return side([=] {
-            tg_wgrad_job q[6];
+            tg_wgrad_job q[8];
             const int n = (int)jobs.size();
             for (int i = 0; i < n; ++i) q[i] = tg_wgrad_job{jobs[i].A, jobs[i].lda, jobs[i].M, jobs[i].B, jobs[i].ldb, jobs[i].N, jobs[i].C, jobs[i].ldc, jobs[i].cs};
             if (g_wgrad_grouped && tg::wgrad_group(n, q, R, st)) return tg::launch_status("gemm_bf16x3_wgrad_kernel");
@@ -738,6 +743,17 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             }
             return (int)TG_OK;
         });
+    };
+    auto wgrad = [&](std::vector<WJ> jobs) -> int {
+        if (overlap || !g_wgrad_grouped) return issue_wgrad(std::move(jobs));      // side streams: start as early as the operands exist
+        pending.insert(pending.end(), jobs.begin(), jobs.end());
+        return TG_OK;
+    };
+    auto flush_wgrad = [&]() -> int {
+        for (size_t i = 0; i < pending.size(); i += 8)
+            TG_TRY(issue_wgrad(std::vector<WJ>(pending.begin() + i, pending.begin() + std::min(pending.size(), i + 8))));
+        pending.clear();
+        return TG_OK;
     };
     // ---- merge layer -------------------------------------------------------------------------------------------------------
     // df1 = (f1 > 0) ? dout W2 : 0 -- the ReLU mask rides in the product's epilogue (one launch less per layer); widths the fused form
@@ -804,6 +820,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         TG_TRY(fork());                       // du and the time-encoder slabs are final
         TG_TRY(wgrad({WJ{Bc.du, hk, (int)hk, Lc.own, Lc.own_ld, dn, dPm, dn, dub}}));                 // dP = du^T own, dub = sum_rows du
+        TG_TRY(flush_wgrad());
         {
             void* stv = wstream;
             hipStream_t st = ws_;
@@ -841,6 +858,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
                 jobs.push_back(WJ{Lc.q + h * hd, dq, hd, Bc.du + (int64_t)h * dk, hk, dk, G.Wk + (int64_t)h * hd * dk, dk, nullptr});
             jobs.push_back(WJ{Bc.dq, dq, dq, Lc.own, Lc.own_ld, dn, G.Wq, dq, vec_dq});                                          // dWq[:, :dn], sum_rows dq
             TG_TRY(wgrad(jobs));
+            TG_TRY(flush_wgrad());
         }
         {
             hipStream_t st = ws_;

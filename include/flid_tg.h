@@ -218,7 +218,7 @@ int tg_gemm_f32_nt_masked(int64_t M, int64_t N, int64_t K, const float* d_A, int
 
 /* ---- grouped weight gradients (split-bf16 MFMA) ------------------------------------------------------
  * replaces the autograd weight / bias gradients of the nn.Linear layers in models/modules.py:54-69,152-163,235 for one layer:
- * up to 6 products C_j[M_j, N_j] += A_j^T B_j over the same `rows` (A_j: rows x M_j, B_j: rows x N_j, row-major) in ONE launch;
+ * up to 8 products C_j[M_j, N_j] += A_j^T B_j over the same `rows` (A_j: rows x M_j, B_j: rows x N_j, row-major) in ONE launch;
  * colsum_A_j[M_j] += column sums of A_j when non-NULL (the bias gradient: A_j is the gradient of the layer's output).
  * C_j and colsum_A_j are ACCUMULATED into with float atomics (zero them, or pass a running gradient).  M_j, N_j, lda, ldb
  * multiples of 4, operands 16-byte aligned; returns TG_EINVAL for other shapes (use tg_gemm_f32 + tg_colsum). */

@@ -43,6 +43,12 @@ def wgrad_groups(R, dev):
     dout, f1, df1, yr, dres, ctx, dctx, agg, du, own = f(R, 172), f(R, 172), f(R, 172), f(R, 444), f(R, 272), f(R, 272), f(R, 272), f(R, 888), f(R, 888), f(R, 172)
     z = lambda *s_: torch.zeros(*s_, device=dev)
     W2, W1, Wr, Wv, dP, b = z(172, 172), z(172, 444), z(272, 272), z(272, 444), z(888, 172), z(888)
+    g = _three_groups(dout, f1, df1, yr, dres, ctx, dctx, agg, du, own, W2, W1, Wr, Wv, dP, b)
+    g["all six of a layer (one launch)"] = (sum((v[0] for v in g.values()), []), sum(v[1] for v in g.values()))
+    return g
+
+
+def _three_groups(dout, f1, df1, yr, dres, ctx, dctx, agg, du, own, W2, W1, Wr, Wv, dP, b):
     return {"merge: dW2, dW1 (+ biases)": ([(dout, f1, W2, b[:172]), (df1, yr, W1, b[:172])], 172 * 172 + 172 * 444),
             "dWr (+ d br), dWv_h x 2": ([(dres, ctx, Wr, b[:272]), (dctx[:, :136], agg[:, :444], Wv[:136], None),
                                          (dctx[:, 136:], agg[:, 444:], Wv[136:], None)], 272 * 272 + 272 * 444),
