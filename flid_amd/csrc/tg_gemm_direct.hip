@@ -122,9 +122,11 @@ bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     if (K <= 0 || K % 4 || lda % 4 || strideA % 4 || !al16(A)) return false;
     if (b_kc ? (ldb % 4 || strideB % 4 || !al16(B)) : K < 8) return false;       // (K x N form: the guard rows 4..7 must exist)
     const int64_t gx = (N + 31) / 32, gy = (M + 31) / 32;
-    // the point of this kernel is a chip that would otherwise be mostly idle: beyond ~8 workgroups per CU the tiled kernels'
-    // operand reuse wins
-    if (gx * gy * nbatch > 2048 || nbatch > 65535 || K > 4096) return false;
+    // the point of this kernel is a chip that would otherwise be mostly idle: beyond ~3 workgroups per CU the tiled split-bf16
+    // kernel's operand reuse wins (1 200 x 888 x 136 in 1 064 tiles: 16 us here, ~9 us there; swept 200 .. 2048: 800 is the step's
+    // optimum, 0.945 -> 0.931 ms)
+    static const int64_t max_tiles = (getenv("FLID_GEMM_TUNE") && getenv("FLID_DIRECT_MAX_TILES")) ? atoll(getenv("FLID_DIRECT_MAX_TILES")) : 800;
+    if (gx * gy * nbatch > max_tiles || nbatch > 65535 || K > 4096) return false;
     const int vec_c = N % 4 == 0 && ldc % 4 == 0 && strideC % 4 == 0 && al16(C) && (!bias || al16(bias)) && (!mask || (al16(mask) && ldm % 4 == 0));
     if (mask && nbatch != 1) return false;
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
