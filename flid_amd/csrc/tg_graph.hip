@@ -461,3 +461,86 @@ extern "C" int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n
     dedupe_lookup_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_pos_ws, d_vals_ws, n, row_offset, d_count_pad, d_out_row);
     return tg::launch_status("dedupe kernels");
 }
+
+#ifndef TG_TRY
+#define TG_TRY(expr) do { int _rc = (expr); if (_rc != TG_OK) return _rc; } while (0)
+#endif
+// ---- graph-only part of one TGN batch in ONE call -----------------------------------------------------------------------------
+// (what MemoryModel.prepare_batch_begin did with ~25 numpy / torch operations: 0.24 ms of host time per 600-edge batch, on a path
+// whose GPU work is 0.55 ms).  Device blob, int32 units unless noted, n edges, m = hi - lo embedded edges (2 m roots):
+//   [ root times (2m f64) | counterpart ids (2n) | edge ids twice (2n) | times twice (2n f32) | root ids (2m) | batch node ids (2n) | neighbor slots (2m k) ]
+//   ^ off[0]               ^ off[1]              ^ off[2]              ^ off[3]              ^ off[4]        ^ off[5]              ^ off[6]      off[7] = end
+// Everything before the neighbor slots is staged in pinned memory and copied with one async copy; the sampler writes the slots
+// right behind, so [root ids | batch node ids | neighbor slots] IS the list whose distinct nodes the memory update touches.
+extern "C" int tg_tgn_prepare_layout(int64_t n, int64_t m, int k, int64_t* off8) {
+    TG_REQUIRE(off8 && n >= 0 && m >= 0 && m <= n && k > 0, "tg_tgn_prepare_layout: arguments");
+    int64_t o = 0;
+    off8[0] = o; o += 2 * (2 * m);          // f64 = two int32 units each
+    off8[1] = o; o += 2 * n;
+    off8[2] = o; o += 2 * n;
+    off8[3] = o; o += 2 * n;
+    off8[4] = o; o += 2 * m;
+    off8[5] = o; o += 2 * n;
+    off8[6] = o; o += 2 * m * k;
+    off8[7] = o;
+    return TG_OK;
+}
+
+extern "C" int tg_tgn_prepare_batch(const tg_graph* g, const int64_t* h_src, const int64_t* h_dst, const double* h_t, const int64_t* h_eid,
+                                    int64_t n, int64_t lo, int64_t hi, int k, int64_t num_nodes, void* h_stage, int32_t* d_blob, int32_t* d_S_eid,
+                                    float* d_S_t, float* d_S_dt, const float* d_zero_t, int64_t capacity, void* d_keys_ws,
+                                    int32_t* d_vals_ws, int32_t* d_pos_ws, int32_t* d_uniq, float* d_uniq_t, int32_t* d_rowmap,
+                                    int32_t* d_count_pad, int32_t* h_count_pad, int64_t* h_uniq_nodes, double* h_last_time, int64_t* h_num_uniq,
+                                    void* stream) {
+    TG_REQUIRE(g && h_src && h_dst && h_t && h_stage && d_blob && d_S_eid && d_S_t && d_S_dt && d_zero_t && d_keys_ws && d_vals_ws && d_pos_ws &&
+               d_uniq && d_uniq_t && d_rowmap && d_count_pad && h_count_pad, "tg_tgn_prepare_batch: null pointer");
+    TG_REQUIRE(k > 0, "Number of sampled neighbors for each node should be greater than 0!");
+    TG_REQUIRE(n > 0 && 0 <= lo && lo < hi && hi <= n, "tg_tgn_prepare_batch: batch / shard bounds");
+    const int64_t m = hi - lo;
+    int64_t off[8];
+    TG_TRY(tg_tgn_prepare_layout(n, m, k, off));
+    for (int64_t i = 0; i < n; ++i)
+        if (h_src[i] < 0 || h_src[i] >= num_nodes || h_dst[i] < 0 || h_dst[i] >= num_nodes) { tg::set_error("list index out of range"); return TG_ERANGE; }
+    int32_t* st = reinterpret_cast<int32_t*>(h_stage);
+    double* rt = reinterpret_cast<double*>(st + off[0]);
+    float* t32 = reinterpret_cast<float*>(st + off[3]);
+    for (int64_t i = 0; i < m; ++i) {
+        rt[i] = h_t[lo + i]; rt[m + i] = h_t[lo + i];
+        st[off[4] + i] = (int32_t)h_src[lo + i]; st[off[4] + m + i] = (int32_t)h_dst[lo + i];
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        st[off[1] + i] = (int32_t)h_dst[i]; st[off[1] + n + i] = (int32_t)h_src[i];            // the counterpart of [src role | dst role]
+        const int32_t e = h_eid ? (int32_t)h_eid[i] : 0;
+        st[off[2] + i] = e; st[off[2] + n + i] = e;
+        t32[i] = (float)h_t[i]; t32[n + i] = (float)h_t[i];
+        st[off[5] + i] = (int32_t)h_src[i]; st[off[5] + n + i] = (int32_t)h_dst[i];
+    }
+    // host mirror of the state advance: the distinct batch nodes (first-seen order) and, per node, the time of its LAST occurrence in
+    // [src role | dst role] order -- the time its pending message will carry (MemoryModel.py:155-180)
+    if (h_uniq_nodes && h_last_time && h_num_uniq) {
+        int64_t cap2 = 64;
+        while (cap2 < 4 * n) cap2 <<= 1;
+        static thread_local std::vector<int64_t> keys, slot;
+        keys.assign((size_t)cap2, -1);
+        slot.assign((size_t)cap2, 0);
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < 2 * n; ++i) {
+            const int64_t v = i < n ? h_src[i] : h_dst[i - n];
+            uint64_t h = ((uint64_t)v * 0x9E3779B97F4A7C15ULL) >> 20;
+            for (;; ++h) {
+                const int64_t j = (int64_t)(h & (uint64_t)(cap2 - 1));
+                if (keys[j] == v) { h_last_time[slot[j]] = h_t[i < n ? i : i - n]; break; }
+                if (keys[j] < 0) { keys[j] = v; slot[j] = cnt; h_uniq_nodes[cnt] = v; h_last_time[cnt] = h_t[i < n ? i : i - n]; ++cnt; break; }
+            }
+        }
+        *h_num_uniq = cnt;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    TG_HIP_CHECK(hipMemcpyAsync(d_blob, h_stage, sizeof(int32_t) * (size_t)off[6], hipMemcpyHostToDevice, s));
+    TG_TRY(tg_sample_recent(g, d_blob + off[4], reinterpret_cast<const double*>(d_blob + off[0]), nullptr, 2 * m, k, d_blob + off[6], d_S_eid, d_S_t,
+                            d_S_dt, nullptr, stream));
+    const int64_t total = off[7] - off[4];
+    TG_TRY(tg_dedupe_pairs(d_blob + off[4], d_zero_t, total, capacity, d_keys_ws, d_vals_ws, d_pos_ws, 0, d_uniq, d_uniq_t, d_rowmap, d_count_pad, stream));
+    TG_HIP_CHECK(hipMemcpyAsync(h_count_pad, d_count_pad, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return TG_OK;
+}

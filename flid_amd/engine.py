@@ -675,6 +675,19 @@ class PreparedFrontier:
 _prefetch_stream = None
 
 
+_event_ring = [None, 0]
+
+
+def _ring_event():
+    """an event from a ring of 32, to be re-recorded: creating one costs ~9 us (hipEventCreate), a prepared batch needs two.  A
+    holder that outlives 32 later records simply waits for later work of the same in-order stream."""
+    if _event_ring[0] is None:
+        _event_ring[0] = [torch.cuda.Event() for _ in range(32)]
+    ev = _event_ring[0][_event_ring[1] % 32]
+    _event_ring[1] += 1
+    return ev
+
+
 def _side_stream():
     global _prefetch_stream
     if _prefetch_stream is None:
@@ -730,7 +743,7 @@ def prepare_begin(graph: TemporalGraph, ids_dev, times_dev, k: int, num_layers: 
         cp = graph.dedupe_pairs_async(S[0][:n].reshape(-1), S[2][:n].reshape(-1), n, ids_all[n:], uniq_t, child)
         job.count_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
         job.count_host.copy_(cp, non_blocking=True)
-        job.count_ready = torch.cuda.Event()
+        job.count_ready = _ring_event()
         job.count_ready.record()
         job.S, job.ids_all, job.uniq_t, job.child = S, ids_all, uniq_t, child
     return job
@@ -750,7 +763,7 @@ def prepare_finish(job: FrontierJob) -> PreparedFrontier:
         fr = Frontier(counts=[n, count], ids_all=job.ids_all[:n + count], S=tuple(x[:n + count] for x in job.S), child=job.child,
                       pad_rows=[pad + n if pad >= 0 else -1])
     with torch.cuda.stream(side):
-        ev = torch.cuda.Event()
+        ev = _ring_event()
         ev.record()
     for t in (fr.ids_all, fr.child) + tuple(fr.S):            # allocated on the side stream, consumed on the main stream
         if t is not None:

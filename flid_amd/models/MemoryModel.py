@@ -353,7 +353,7 @@ class MemoryModel(torch.nn.Module):
             else:
                 rows = h_rows
             base = rows + ops.gather_rows(self.node_raw_features, uniq)
-            fr = engine.Frontier(counts=[m], ids_all=rowmap[:m], S=S, child=None, pad_rows=[], feat_idx0=rowmap[m:m + m * k], pad_row0=job["pad"])
+            fr = engine.Frontier(counts=[m], ids_all=job["row_roots"], S=S, child=None, pad_rows=[], feat_idx0=job["row_nbrs"], pad_row0=job["pad"])
             cfg = dict(n=m, k=k, num_layers=1, num_heads=self.num_heads, dropout=float(self.dropout), training=bool(self.training),
                        edge_table=self.edge_raw_features, table_grad=pending)
             emb, saved = engine._native_forward(cfg, fr, base, te_w, te_b, layer_params)
@@ -392,7 +392,7 @@ class MemoryModel(torch.nn.Module):
         upd = u[bank._has[u]]
         self._check_not_in_the_past(upd)                                                       # reference :485-486
         with torch.no_grad():
-            check(lib().tg_tgn_persist(ops._p(rows.detach()), rows.stride(0), ops._p(rowmap[m + m * k:]), ops._p(batch_d), ops._p(bank._has_dev),
+            check(lib().tg_tgn_persist(ops._p(rows.detach()), rows.stride(0), ops._p(job["row_batch"]), ops._p(batch_d), ops._p(bank._has_dev),
                                        ops._p(bank._msg_time_dev), ops._p(bank.node_memories.data), bank.node_memories.stride(0),
                                        ops._p(bank.node_last_updated_times.data), 2 * n, self.memory_dim, ops._stream()), "tg_tgn_persist")
             msgs = ops.build_messages(bank.node_memories.data, bank.node_last_updated_times.data, batch_d, b_d, t32_d,
@@ -414,57 +414,71 @@ class MemoryModel(torch.nn.Module):
         the ids, the neighbor lookups, and the hash set of distinct touched nodes -- issued on a side stream; the count of distinct
         nodes travels to pinned memory.  prepare_batch_finish(job) (a step later: no wait) yields the object to pass as
         `src_node_ids` of compute_src_dst_node_temporal_embeddings / compute_shard_embeddings_and_advance (dst / times then None)."""
+        import ctypes as C
+        from .._lib import check, lib
         dev = self.node_raw_features.device
-        src_node_ids, dst_node_ids = np.asarray(src_node_ids), np.asarray(dst_node_ids)
-        times = np.asarray(node_interact_times, dtype=np.float64)
-        n, k = len(src_node_ids), int(num_neighbors)
+        src = np.ascontiguousarray(src_node_ids, dtype=np.int64)
+        dst = np.ascontiguousarray(dst_node_ids, dtype=np.int64)
+        times = np.ascontiguousarray(node_interact_times, dtype=np.float64)
+        eid = None if edge_ids is None else np.ascontiguousarray(edge_ids, dtype=np.int64)
+        n, k = len(src), int(num_neighbors)
         assert k > 0, 'Number of sampled neighbors for each node should be greater than 0!'
-        node_ids = np.concatenate([src_node_ids, dst_node_ids])
-        if int(node_ids.max()) >= self.num_nodes or int(node_ids.min()) < 0:
-            raise IndexError("list index out of range")
         lo, hi = (0, n) if shard is None else shard
-        emb_ids = np.concatenate([src_node_ids[lo:hi], dst_node_ids[lo:hi]])
-        emb_t = np.concatenate([times[lo:hi], times[lo:hi]])
-        m = len(emb_ids)
+        m = 2 * (hi - lo)                                      # embedded roots: both roles of the shard's edges
         graph = self.embedding_module.neighbor_sampler.graph
+        off = (C.c_int64 * 8)()
+        check(lib().tg_tgn_prepare_layout(n, hi - lo, k, off), "tg_tgn_prepare_layout")
+        o_t, o_b, o_e, o_t32, o_root, o_batch, o_nbr, o_end = (int(v) for v in off)
+        total = o_end - o_root
         side, main = engine._side_stream(), torch.cuda.current_stream()
-        with torch.cuda.stream(side):
-            eid2 = np.zeros(2 * n, dtype=np.int32) if edge_ids is None else np.concatenate([np.asarray(edge_ids), np.asarray(edge_ids)]).astype(np.int32)
-            ids_d, t_d, batch_d, b_d, t32_d, e_d = ops.h2d([emb_ids.astype(np.int32), emb_t, node_ids.astype(np.int32),
-                                                            np.concatenate([dst_node_ids, src_node_ids]).astype(np.int32),
-                                                            np.concatenate([times, times]).astype(np.float32), eid2], dev)
-            S = graph.sample_recent(ids_d, t_d, k)
-            total = m + m * k + 2 * n
-            all_nodes = torch.empty(total, dtype=torch.int32, device=dev)      # [embedded roots | their sampled neighbors | every batch node]
-            all_nodes[:m].copy_(ids_d)
-            all_nodes[m:m + m * k].copy_(S[0].reshape(-1))
-            all_nodes[m + m * k:].copy_(batch_d)
+        # ONE C call on the side stream: pinned staging of the ids / times, one H2D copy, neighbor lookup, distinct touched nodes, count
+        # to pinned memory.  The device buffer is allocated while the side stream is current (the caching allocator then never hands
+        # out a block that queued main-stream kernels still read); set_stream costs 0.4 us, the `with torch.cuda.stream` form 6.
+        stage = torch.empty(4 * o_nbr + 16, dtype=torch.uint8, pin_memory=True)             # (+ the 2 count words behind the staged blob)
+        torch.cuda.set_stream(side)
+        try:
+            # one allocation: [blob (o_end) | slot edge ids, slot times, query - slot times (3 m k) | distinct ids, their times, row of every entry (3 total) | count, pad]
+            dev_all = torch.empty(o_end + 3 * m * k + 3 * total + 4, dtype=torch.int32, device=dev)
             zt = getattr(self, "_zero_t", None)
             if zt is None or zt.numel() < total:
                 zt = self._zero_t = torch.zeros(total, dtype=torch.float32, device=dev)
-            uniq = torch.empty(total, dtype=torch.int32, device=dev)
-            uniq_t = torch.empty(total, dtype=torch.float32, device=dev)
-            rowmap = torch.empty(total, dtype=torch.int32, device=dev)
-            cp = graph.dedupe_pairs_async(all_nodes, zt[:total], 0, uniq, uniq_t, rowmap)
-            count_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-            count_host.copy_(cp, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        # host side of the state advance: the distinct batch nodes and, per node, its LAST position in [src role | dst role] order
-        u, first_rev = np.unique(node_ids[::-1], return_index=True)
-        last_pos = (2 * n - 1 - first_rev).astype(np.int64)
-        return dict(n=n, m=m, k=k, lo=lo, hi=hi, node_ids=node_ids, times=times, S=S, uniq=uniq, rowmap=rowmap, batch_d=batch_d, b_d=b_d,
-                    t32_d=t32_d, e_d=(e_d if edge_ids is not None else None), u=u, new_t=times[last_pos % n],
-                    count_host=count_host, ready=ev, main=main, graph=graph, keep=(ids_d, t_d, all_nodes, uniq_t))
+            cap, ws = graph._dedupe_ws_for(total, dev)
+        finally:
+            torch.cuda.set_stream(main)
+        blob = dev_all[:o_end]
+        S3 = dev_all[o_end:o_end + 3 * m * k].view(3, m, k)
+        ded = dev_all[o_end + 3 * m * k:o_end + 3 * m * k + 3 * total].view(3, total)
+        base = dev_all.data_ptr()
+        p_S, p_ded = base + 4 * o_end, base + 4 * (o_end + 3 * m * k)
+        count_ptr = stage.data_ptr() + 4 * o_nbr
+        u_buf, t_buf, n_u = np.empty(2 * n, dtype=np.int64), np.empty(2 * n, dtype=np.float64), C.c_int64(0)
+        check(lib().tg_tgn_prepare_batch(graph._h, src.ctypes.data, dst.ctypes.data, times.ctypes.data, None if eid is None else eid.ctypes.data,
+                                         n, lo, hi, k, self.num_nodes, stage.data_ptr(), base, p_S, p_S + 4 * m * k, p_S + 8 * m * k,
+                                         zt.data_ptr(), cap, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(),
+                                         p_ded, p_ded + 4 * total, p_ded + 8 * total, p_ded + 12 * total, count_ptr,
+                                         u_buf.ctypes.data, t_buf.ctypes.data, C.addressof(n_u), side.cuda_stream),
+              "tg_tgn_prepare_batch")
+        ev = engine._ring_event()            # (a new torch.cuda.Event costs 9 us: hipEventCreate)
+        ev.record(side)
+        S = (blob[o_nbr:o_end].view(m, k), S3[0], S3[1].view(torch.float32), S3[2].view(torch.float32))
+        rowmap = ded[2]
+        node_ids = np.concatenate([src, dst])
+        # host side of the state advance (filled by the C call): the distinct batch nodes and, per node, the time of its LAST
+        # occurrence in [src role | dst role] order
+        u, new_t = u_buf[:n_u.value], t_buf[:n_u.value]
+        return dict(n=n, m=m, k=k, lo=lo, hi=hi, node_ids=node_ids, times=times, S=S, uniq=ded[0], rowmap=rowmap,
+                    row_roots=rowmap[:m], row_batch=rowmap[m:m + 2 * n], row_nbrs=rowmap[m + 2 * n:],
+                    batch_d=blob[o_batch:o_batch + 2 * n], b_d=blob[o_b:o_b + 2 * n], t32_d=blob[o_t32:o_t32 + 2 * n].view(torch.float32),
+                    e_d=(blob[o_e:o_e + 2 * n] if eid is not None else None), u=u, new_t=new_t,
+                    count_host=stage[4 * o_nbr:4 * o_nbr + 8].view(torch.int32), ready=ev, main=main, graph=graph,
+                    keep=(stage, dev_all, src, dst, times, eid))
 
     def prepare_batch_finish(self, job):
         job["ready"].synchronize()
         count, pad = job["count_host"].tolist()
         job["uniq"] = job["uniq"][:count]
         job["pad"] = pad
-        for t in (job["uniq"], job["rowmap"], job["batch_d"], job["b_d"], job["t32_d"], job["e_d"]) + tuple(job["S"]):
-            if t is not None:
-                t.record_stream(job["main"])
+        job["keep"][1].record_stream(job["main"])          # the one device allocation every tensor of the job is a view of
         job["finished"] = True
         return job
 
@@ -495,7 +509,7 @@ class MemoryModel(torch.nn.Module):
         else:
             rows = ops.gather_rows(mem, uniq)             # nothing pending anywhere (first batch of an epoch): the GRU is not called (:203-212)
         base = rows + ops.gather_rows(self.node_raw_features, uniq)                                # reference :654-655 on the touched rows
-        fr = engine.Frontier(counts=[m], ids_all=rowmap[:m], S=S, child=None, pad_rows=[], feat_idx0=rowmap[m:m + m * k], pad_row0=job["pad"])
+        fr = engine.Frontier(counts=[m], ids_all=job["row_roots"], S=S, child=None, pad_rows=[], feat_idx0=job["row_nbrs"], pad_row0=job["pad"])
         cfg = dict(n=m, k=k, num_layers=1, num_heads=self.num_heads, dropout=float(self.dropout), training=bool(self.training),
                    edge_table=self.edge_raw_features, table_grad=bool(torch.is_grad_enabled() and rows.requires_grad))
         emb = engine._apply(cfg, fr, base, self.time_encoder.w.weight, self.time_encoder.w.bias, self.embedding_module.layer_params(), None)

@@ -21,6 +21,7 @@ extern "C" {
 #define TG_EINVAL -1   /* bad argument / unsupported shape */
 #define TG_EHIP -2     /* a HIP runtime call failed; tg_last_error() has the text */
 #define TG_ENOMEM -3
+#define TG_ERANGE -4   /* an id beyond the graph: the reference's `IndexError: list index out of range` */
 
 typedef struct tg_graph tg_graph; /* opaque: device CSR of time-sorted incidences */
 
@@ -309,6 +310,24 @@ int tg_tgn_persist(const float* d_rows, int64_t rows_ld, const int32_t* d_row_of
  * d_has[node] = 1 and d_msg_time[node] = t32 of the winning entry.  d_last_idx_ws: (num_nodes) int32, all -1 on entry and on exit. */
 int tg_msg_scatter_last(const int32_t* d_nodes, const float* d_msgs, int64_t msg_ld, const float* d_t32, int64_t count, int width,
                         float* d_table, int64_t table_ld, int32_t* d_has, float* d_msg_time, int32_t* d_last_idx_ws, void* stream);
+
+/* ---- graph-only part of one TGN batch (prefetchable; host arrays in, everything issued on `stream`) ---------------------------
+ * replaces, for a prepared batch, the host-side glue of models/MemoryModel.py:96-131 (ids to the device), the neighbor lookup of
+ * :632-715 for the 2 m embedded roots (edges [lo, hi) of the batch, both roles) and the search for the distinct nodes whose memory
+ * the call touches.  tg_tgn_prepare_layout gives the offsets (int32 units) of the device blob's sections:
+ *   off[0] root times (2m f64) | off[1] counterpart ids (2n) | off[2] edge ids twice (2n) | off[3] times twice (2n f32) |
+ *   off[4] root ids (2m) | off[5] batch node ids [src | dst] (2n) | off[6] neighbor slots (2m, k) | off[7] end
+ * h_stage: pinned, 4 off[6] bytes; d_blob: 4 off[7] bytes.  d_uniq / d_uniq_t / d_rowmap (off[7] - off[4] each), d_count_pad,
+ * the workspaces and `capacity` as tg_dedupe_pairs (over [root ids | batch node ids | neighbor slots], times all zero: d_zero_t);
+ * h_count_pad (pinned, 2 ints) receives (count, padding row) with an async copy.  h_uniq_nodes / h_last_time (2n each, optional): the
+ * distinct batch nodes and the time of each one's last occurrence in [src | dst] order (host mirror of :155-180), *h_num_uniq of them.
+ * TG_ERANGE for an id outside [0, num_nodes). */
+int tg_tgn_prepare_layout(int64_t n, int64_t m, int k, int64_t* off8);
+int tg_tgn_prepare_batch(const tg_graph* g, const int64_t* h_src, const int64_t* h_dst, const double* h_t, const int64_t* h_eid,
+                         int64_t n, int64_t lo, int64_t hi, int k, int64_t num_nodes, void* h_stage, int32_t* d_blob, int32_t* d_S_eid,
+                         float* d_S_t, float* d_S_dt, const float* d_zero_t, int64_t capacity, void* d_keys_ws, int32_t* d_vals_ws,
+                         int32_t* d_pos_ws, int32_t* d_uniq, float* d_uniq_t, int32_t* d_rowmap, int32_t* d_count_pad,
+                         int32_t* h_count_pad, int64_t* h_uniq_nodes, double* h_last_time, int64_t* h_num_uniq, void* stream);
 
 /* ---- DyGFormer sequence side --------------------------------------------------------------------------
  * neighbor co-occurrence counts (models/DyGFormer.py:337-393): for every slot of the source rows (n, wa) and destination
