@@ -100,6 +100,7 @@ SIGNATURES = {
     "tg_gelu_bwd": (C.c_int, [c_void, c_void, c_i64, c_void, c_void]),
     "tg_softmax_fwd": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_void]),
     "tg_softmax_keymask_fwd": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_i64, c_void, c_void]),
+    "tg_tgn_host_advance": (C.c_int, [c_void, c_void, c_i64, c_void, c_void, c_void, c_i64, c_void]),
     "tg_tgn_prepare_layout": (C.c_int, [c_i64, c_i64, C.c_int, c_void]),
     "tg_tgn_prepare_batch": (C.c_int, [c_void] * 5 + [c_i64, c_i64, c_i64, C.c_int, c_i64] + [c_void] * 6 + [c_i64] + [c_void] * 11 + [c_void]),
     "tg_recent_window_mean": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
@@ -148,7 +149,7 @@ def lib():
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().tg_last_error().decode("utf-8", "replace")
-        if rc == -1 and ("greater than 0" in msg or "greater than 1" in msg):
+        if rc == -1 and ("greater than 0" in msg or "greater than 1" in msg or "in the past" in msg):
             raise AssertionError(msg.split("invalid argument: ", 1)[-1])       # reference raises AssertionError there
         if rc == -4:
             raise IndexError("list index out of range")                        # an id beyond the graph, as the reference's list lookup

@@ -159,3 +159,27 @@ extern "C" int tg_build_messages(const float* d_mem, int64_t mem_ld, const float
         d_edge, edge_ld, d_eids, d_te_w, d_te_b, n, d, de, T, d_out);
     return tg::launch_status("build_messages_kernel");
 }
+
+
+// Host mirror of one positive batch's state advance (models/MemoryModel.py:155-180 with the assertion of :485-486): for the distinct
+// batch nodes u[i] (any order) with the time new_t[i] of their last occurrence -- a node that holds a pending message gets it applied
+// (its last-update time becomes the message's), then every node files a new message at new_t[i].  Nothing is changed when the
+// assertion fails (TG_EINVAL, "Trying to update memory to time in the past!").  *next_violation = 1 when a filed message is older
+// than its node's last update: the reference's NEXT get_updated_memories would raise on it.  Pure host code (numpy arrays in place).
+extern "C" int tg_tgn_host_advance(const int64_t* u, const double* new_t, int64_t count, uint8_t* has, double* msg_time, float* last_update,
+                                   int64_t num_nodes, int* next_violation) {
+    TG_REQUIRE(u && new_t && has && msg_time && last_update && next_violation && count >= 0, "tg_tgn_host_advance: arguments");
+    for (int64_t i = 0; i < count; ++i) {
+        const int64_t v = u[i];
+        TG_REQUIRE(v >= 0 && v < num_nodes, "tg_tgn_host_advance: node id out of range");
+        TG_REQUIRE(!(has[v] && last_update[v] > (float)msg_time[v]), "Trying to update memory to time in the past!");
+    }
+    for (int64_t i = 0; i < count; ++i) {
+        const int64_t v = u[i];
+        if (has[v]) last_update[v] = (float)msg_time[v];
+        has[v] = 1;
+        msg_time[v] = new_t[i];
+        if (last_update[v] > (float)new_t[i]) *next_violation = 1;
+    }
+    return TG_OK;
+}

@@ -389,8 +389,14 @@ class MemoryModel(torch.nn.Module):
             assert edge_ids is not None
             e_d, = ops.h2d([np.concatenate([np.asarray(edge_ids), np.asarray(edge_ids)]).astype(np.int32)], dev)
         u, new_t = job["u"], job["new_t"]
-        upd = u[bank._has[u]]
-        self._check_not_in_the_past(upd)                                                       # reference :485-486
+        # host mirrors first (one C call; raises the reference's assertion of :485-486 before anything changes): pending messages of
+        # the batch nodes applied, the new ones filed at the time of each node's last occurrence
+        import ctypes as C
+        viol = C.c_int(0)
+        check(lib().tg_tgn_host_advance(u.ctypes.data, new_t.ctypes.data, len(u), bank._has.ctypes.data, bank._msg_time.ctypes.data,
+                                        bank._h_last.ctypes.data, len(bank._has), C.addressof(viol)), "tg_tgn_host_advance")
+        if viol.value:
+            bank._past_violation = True         # the reference's next get_updated_memories would raise on this message
         with torch.no_grad():
             check(lib().tg_tgn_persist(ops._p(rows.detach()), rows.stride(0), ops._p(job["row_batch"]), ops._p(batch_d), ops._p(bank._has_dev),
                                        ops._p(bank._msg_time_dev), ops._p(bank.node_memories.data), bank.node_memories.stride(0),
@@ -401,12 +407,6 @@ class MemoryModel(torch.nn.Module):
             check(lib().tg_msg_scatter_last(ops._p(batch_d), ops._p(msgs), msgs.stride(0), ops._p(t32_d), 2 * n, self.message_dim,
                                             ops._p(bank._msg), bank._msg.stride(0), ops._p(bank._has_dev), ops._p(bank._msg_time_dev),
                                             ops._p(bank._last_idx_ws), ops._stream()), "tg_msg_scatter_last")
-        if len(upd):
-            bank._h_last[upd] = bank._msg_time[upd].astype(np.float32)
-        bank._has[u] = True
-        bank._msg_time[u] = new_t
-        if np.any(bank._h_last[u] > new_t.astype(np.float32)):
-            bank._past_violation = True         # the reference's next get_updated_memories would raise on this message
 
     # ---- lazy path: graph-only part (prefetchable) ----------------------------------------------------------------------------
     def prepare_batch_begin(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20, shard=None, edge_ids=None):

@@ -322,6 +322,12 @@ int tg_msg_scatter_last(const int32_t* d_nodes, const float* d_msgs, int64_t msg
  * h_count_pad (pinned, 2 ints) receives (count, padding row) with an async copy.  h_uniq_nodes / h_last_time (2n each, optional): the
  * distinct batch nodes and the time of each one's last occurrence in [src | dst] order (host mirror of :155-180), *h_num_uniq of them.
  * TG_ERANGE for an id outside [0, num_nodes). */
+/* host mirror of one positive batch's state advance (models/MemoryModel.py:155-180, assertion of :485-486), numpy arrays in place:
+ * nodes u[i] with a pending message get it applied (last_update = its time), then each files a new message at new_t[i].  TG_EINVAL
+ * ("Trying to update memory to time in the past!") leaves everything unchanged; *next_violation = 1 when a filed message is older
+ * than its node's last update.  No device work. */
+int tg_tgn_host_advance(const int64_t* u, const double* new_t, int64_t count, uint8_t* has, double* msg_time, float* last_update,
+                        int64_t num_nodes, int* next_violation);
 int tg_tgn_prepare_layout(int64_t n, int64_t m, int k, int64_t* off8);
 int tg_tgn_prepare_batch(const tg_graph* g, const int64_t* h_src, const int64_t* h_dst, const double* h_t, const int64_t* h_eid,
                          int64_t n, int64_t lo, int64_t hi, int k, int64_t num_nodes, void* h_stage, int32_t* d_blob, int32_t* d_S_eid,
