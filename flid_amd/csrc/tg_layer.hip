@@ -319,12 +319,23 @@ __global__ void __launch_bounds__(256) merge_weights_kernel(MergeJobs jobs, cons
     __shared__ float As[32][33], Bs[32][33], Cs[32][33];
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     if ((int)blockIdx.x >= jobs.total_tiles) {           // ub[h dk + j] = sum_k Wk[h hd + k, j] qb[h hd + k]
-        const int64_t hj = (int64_t)(blockIdx.x - jobs.total_tiles) * 256 + t;
+        // 32 outputs per workgroup, the contraction split over 8 thread groups whose loads are all in flight at once (one thread per
+        // output walking all hd rows was a chain of ~17 exposed load round trips: 20 us for 0.2 MFLOP)
+        const int64_t hj = (int64_t)(blockIdx.x - jobs.total_tiles) * 32 + tx;
+        const int per = (hd + 7) / 8, k0 = ty * per, k1 = min(hd, k0 + per);
+        float acc = 0.f;
         if (hj < (int64_t)H * dk) {
             const int h = (int)(hj / dk), jj = (int)(hj % dk);
-            float acc = 0.f;
-            for (int k = 0; k < hd; ++k) acc = fmaf(Wk[((int64_t)h * hd + k) * dk + jj], qb[h * hd + k], acc);
-            ub[hj] = acc;
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) acc = fmaf(Wk[((int64_t)h * hd + k) * dk + jj], qb[h * hd + k], acc);
+        }
+        As[ty][tx] = acc;
+        __syncthreads();
+        if (ty == 0 && hj < (int64_t)H * dk) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += As[g][tx];
+            ub[hj] = s;
         }
         return;
     }
@@ -333,16 +344,31 @@ __global__ void __launch_bounds__(256) merge_weights_kernel(MergeJobs jobs, cons
     const MergeJob J = jobs.j[ji];
     const int tile = blockIdx.x - J.tile0, m0 = (tile / J.tiles_n) * 32, n0 = (tile % J.tiles_n) * 32;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < J.K; k0 += 32) {
+    // operand tiles of chunk k0 + 32 are loaded into registers while chunk k0 is multiplied (K = head_dim = 136 is five chunks: without
+    // the look-ahead the kernel was five exposed global round trips, 20 us for 0.1 GFLOP)
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = t + 256 * q;                                   // 1024 elements of each operand tile
             const int am = J.sAm == 1 ? (e & 31) : (e >> 5), ak = J.sAm == 1 ? (e >> 5) : (e & 31);
-            As[ak][am] = (m0 + am < J.M && k0 + ak < J.K) ? J.A[(int64_t)(m0 + am) * J.sAm + (int64_t)(k0 + ak) * J.sAk] : 0.f;
+            ra[q] = (m0 + am < J.M && k0 + ak < J.K) ? J.A[(int64_t)(m0 + am) * J.sAm + (int64_t)(k0 + ak) * J.sAk] : 0.f;
             const int bn = J.sBn == 1 ? (e & 31) : (e >> 5), bk = J.sBn == 1 ? (e >> 5) : (e & 31);
-            Bs[bk][bn] = (n0 + bn < J.N && k0 + bk < J.K) ? J.B[(int64_t)(k0 + bk) * J.sBk + (int64_t)(n0 + bn) * J.sBn] : 0.f;
+            rb[q] = (n0 + bn < J.N && k0 + bk < J.K) ? J.B[(int64_t)(k0 + bk) * J.sBk + (int64_t)(n0 + bn) * J.sBn] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < J.K; k0 += 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + 256 * q;
+            const int am = J.sAm == 1 ? (e & 31) : (e >> 5), ak = J.sAm == 1 ? (e >> 5) : (e & 31);
+            As[ak][am] = ra[q];
+            const int bn = J.sBn == 1 ? (e & 31) : (e >> 5), bk = J.sBn == 1 ? (e >> 5) : (e & 31);
+            Bs[bk][bn] = rb[q];
         }
         __syncthreads();
+        if (k0 + 32 < J.K) fetch(k0 + 32);
 #pragma unroll 8
         for (int k = 0; k < 32; ++k) {
             const float b = Bs[k][tx];
@@ -589,7 +615,7 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
             for (int h = 0; h < H; ++h)         // P_h (dk x dn): A(m = j, k) = Wk[h hd + k, j], B(k, n = i) = Wq[h hd + k, i]
                 add_job(mj, P.Wk + (int64_t)h * hd * dk, P.Wq + (int64_t)h * hd * dq, wt.P + (int64_t)h * dk * dn, wt.PT + (int64_t)h * dk,
                         dk, dn, hd, 1, dk, dq, 1, dn, H * dk, 0);
-            const unsigned blocks = (unsigned)(mj.total_tiles + ((int64_t)H * dk + 255) / 256);
+            const unsigned blocks = (unsigned)(mj.total_tiles + ((int64_t)H * dk + 31) / 32);
             merge_weights_kernel<<<blocks, 256, 0, s>>>(mj, P.Wk, L->qbias, H, hd, dk, wt.ub);
             TG_TRY(tg::launch_status("merge_weights_kernel"));
         }
@@ -710,7 +736,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     };
     // slab regions of `part` (each finished on the side stream while the main chain moves on)
     const int64_t relu_blocks = (R + 15) / 16;
-    const unsigned ln_grid = (unsigned)row_grid(R);
+    // (at most 768 workgroups = 3 per CU walk the rows: every workgroup leaves a slab of 4 dq column sums, and 3 400 of them were
+    // 15 MB for the slab-sum launch to read: 11 us)
+    const unsigned ln_grid = (unsigned)std::min<int64_t>(row_grid(R), 768);
     const int attn_parts = tg_attn_bwd_parts(R);
     float* part_relu = Bw->part;
     float* part_ln = part_relu + relu_blocks * dn;
