@@ -40,7 +40,7 @@ sys.modules["utils.DataLoader"] = _stub
 from utils.utils import get_neighbor_sampler, NegativeEdgeSampler  # noqa: E402
 from models.modules import TimeEncoder, MultiHeadAttention  # noqa: E402
 from models.TGAT import TGAT  # noqa: E402
-from models.MemoryModel import MemoryModel  # noqa: E402
+from models.MemoryModel import MemoryModel, compute_src_dst_node_time_shifts  # noqa: E402
 from models.DyGFormer import DyGFormer  # noqa: E402
 from models.TCL import TCL  # noqa: E402
 from models.GraphMixer import GraphMixer  # noqa: E402
@@ -579,6 +579,16 @@ def gold_mixer_full(num_edges=60000, lo=56000, batch=200, seed=91, scale=0.05):
          **grads_compact({k_: p.grad for k_, p in model.named_parameters() if p.grad is not None}))
 
 
+def gold_time_shifts():
+    """compute_src_dst_node_time_shifts (models/MemoryModel.py:718-751) on two toy streams (integer and fractional stamps, ties)"""
+    out = {}
+    for tag, gs in (("a", 4), ("b", 7)):
+        src, dst, eid, t, _ = toy_graph(gs)
+        out[f"src_{tag}"], out[f"dst_{tag}"], out[f"t_{tag}"] = src, dst, t
+        out[f"shifts_{tag}"] = np.array(compute_src_dst_node_time_shifts(src, dst, t), dtype=np.float64)
+    save("time_shifts", **out)
+
+
 def gold_backbones_small():
     run_tcl("tcl_K5", 8, 6, 4, 2, 2, 5, 9, seed=83, graph_seed=8)
     run_tcl("tcl_K3_uniform", 8, 6, 4, 1, 2, 3, 7, seed=84, graph_seed=8, strategy="uniform")
@@ -587,6 +597,7 @@ def gold_backbones_small():
 
 
 FULL = {
+    "time_shifts": gold_time_shifts,
     "backbones_small": gold_backbones_small,
     "tcl_full": gold_tcl_full,
     "mixer_full": gold_mixer_full,

@@ -110,3 +110,12 @@ def test_negative_edge_sampler_draws_like_the_reference(strategy):
     assert np.array_equal(a, g[f"{strategy}R_s"]) and np.array_equal(b, g[f"{strategy}R_d"])
     with pytest.raises(ValueError, match="Not implemented error for negative_sample_strategy"):
         NegativeEdgeSampler(src, dst, interact_times=t, negative_sample_strategy="nope").sample(3)
+
+
+def test_time_shifts_match_the_reference():
+    """compute_src_dst_node_time_shifts (models/MemoryModel.py:718-751; JODIE's constants, computed and ignored for TGN)"""
+    from flid_amd.models.MemoryModel import compute_src_dst_node_time_shifts
+    g = load_golden("time_shifts")
+    for tag in ("a", "b"):
+        got = np.array(compute_src_dst_node_time_shifts(g[f"src_{tag}"], g[f"dst_{tag}"], g[f"t_{tag}"]))
+        np.testing.assert_allclose(got, g[f"shifts_{tag}"], rtol=1e-12)
