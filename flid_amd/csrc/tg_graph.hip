@@ -442,6 +442,28 @@ extern "C" int tg_recent_window_mean(const tg_graph* g, const int32_t* d_ids, co
     return tg::launch_status("recent_window_mean_kernel");
 }
 
+// Host-side history counts (pure host code over the exported CSR, tg_graph_export): out[q] = number of incidences of ids[q] strictly
+// before times[q] -- what find_neighbors_before (utils/utils.py:130-147) returns the length of.  DyGFormer needs the longest
+// window of a batch BEFORE it can shape its launches (models/DyGFormer.py:196-245 pads to the batch maximum); reading the device
+// kernel's lengths back stalled the host on the whole previous step.
+extern "C" int tg_host_count_before(const int64_t* h_row_ptr, const double* h_t, int64_t num_rows, const int64_t* ids, const double* times,
+                                    int64_t n, int64_t* out) {
+    TG_REQUIRE(h_row_ptr && h_t && ids && times && out && n >= 0, "tg_host_count_before: arguments");
+    for (int64_t q = 0; q < n; ++q) {
+        const int64_t v = ids[q];
+        if (v < 0 || v >= num_rows) { tg::set_error("list index out of range"); return TG_ERANGE; }
+        int64_t lo = h_row_ptr[v], hi = h_row_ptr[v + 1];
+        const int64_t base = lo;
+        const double when = times[q];
+        while (lo < hi) {                                   // searchsorted(side = 'left'): first index with t >= when
+            const int64_t mid = (lo + hi) >> 1;
+            if (h_t[mid] < when) lo = mid + 1; else hi = mid;
+        }
+        out[q] = lo - base;
+    }
+    return TG_OK;
+}
+
 extern "C" int64_t tg_dedupe_capacity(int64_t n) {
     int64_t c = 1024;
     while (c < 2 * n) c <<= 1;

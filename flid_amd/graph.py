@@ -53,6 +53,16 @@ class TemporalGraph:
             self._host = (rp, nb, ei, tt)
         return self._host
 
+    def count_before_host(self, ids: np.ndarray, times: np.ndarray) -> np.ndarray:
+        """history length of every (node, time) query, computed on the host from the exported CSR (no device work, no sync)"""
+        rp, _, _, tt = self.host_csr()
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        out = np.empty(len(ids), dtype=np.int64)
+        check(lib().tg_host_count_before(rp.ctypes.data, tt.ctypes.data, self.num_rows, ids.ctypes.data, times.ctypes.data, len(ids),
+                                         out.ctypes.data), "tg_host_count_before")
+        return out
+
     # ---- device lookups ---------------------------------------------------------------------------
     def sample_recent(self, ids: torch.Tensor, times: torch.Tensor, k: int, out=None, want_dt=True):
         """ids int32 (n,), times float64 or float32 (n,) on the device.  Returns (nbr i32, eid i32, t f32, dt f32|None),

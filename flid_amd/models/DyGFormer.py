@@ -100,8 +100,11 @@ class DyGFormer(nn.Module):
                                            np.ascontiguousarray(dst_node_ids, dtype=np.int32)], dev)
         sides = [self._windows(ids_dev, t_dev) for ids_dev in (src_dev, dst_dev)]
         # the reference pads every side to ITS OWN longest sequence of the batch (+ the node itself, rounded up to a patch
-        # multiple): the unmasked transformer sees the padded positions, so the width is part of the result.  One tiny readback.
-        lens = torch.stack([sides[0][3].max(), sides[1][3].max()]).cpu().tolist() if B else [1, 1]
+        # multiple): the unmasked transformer sees the padded positions, so the width is part of the result.  The lengths come from
+        # the host copy of the adjacency (binary searches in C, ~10 us): reading the device kernel's lengths back made the host wait
+        # for the whole previous step (1.1 of 5.5 ms)
+        L = self.max_input_sequence_length
+        lens = [int(np.minimum(g.count_before_host(ids, node_interact_times), L - 1).max()) + 1 for ids in (src_node_ids, dst_node_ids)] if B else [1, 1]
         widths = [(int(l) + P - 1) // P * P for l in lens]
         seqs = [tuple(t[:, :w].contiguous() for t in side[:3]) for side, w in zip(sides, widths)]
         counts = ops.cooccurrence(seqs[0][0], seqs[1][0])                                 # DyGFormer.py:104-106

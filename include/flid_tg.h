@@ -74,6 +74,10 @@ int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n, int64_t c
  * models/DyGFormer.py:196-245 pad_sequences (cut to the newest max_len-1, self in slot 0, left-aligned).
  * Outputs are (n, width) row-major with width = max_len rounded up to a patch multiple by the caller;
  * d_out_len[i] = 1 + kept neighbors.  Slots beyond d_out_len are (0, 0, 0.0f). */
+/* host-side history lengths over the exported CSR (tg_graph_export): out[q] = number of incidences of ids[q] strictly before
+ * times[q] (the prefix length of utils/utils.py:130-147).  No device work; TG_ERANGE for an id outside [0, num_rows). */
+int tg_host_count_before(const int64_t* h_row_ptr, const double* h_t, int64_t num_rows, const int64_t* ids, const double* times, int64_t n,
+                         int64_t* out);
 int tg_first_hop_window(const tg_graph* g, const int32_t* d_ids, const double* d_times64, int64_t n, int max_len,
                         int width, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, int32_t* d_out_len,
                         void* stream);
