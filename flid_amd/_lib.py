@@ -66,6 +66,8 @@ SIGNATURES = {
     "tg_sample_recent": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "tg_dedupe_capacity": (c_i64, [c_i64]),
     "tg_dedupe_pairs": (C.c_int, [c_void, c_void, c_i64, c_i64, c_void, c_void, c_void, c_i32, c_void, c_void, c_void, c_void, c_void]),
+    "tg_graph_set_time_weights": (C.c_int, [c_void, C.c_double]),
+    "tg_sample_random": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_int, C.c_int, C.c_uint64, c_void, c_void, c_void, c_void, c_void, c_void]),
     "tg_host_count_before": (C.c_int, [c_void, c_void, c_i64, c_void, c_void, c_i64, c_void]),
     "tg_first_hop_window": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void]),
     "tg_time_encode": (C.c_int, [c_void, c_i64, c_void, c_void, C.c_int, C.c_int, c_void, c_void]),

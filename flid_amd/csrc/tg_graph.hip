@@ -4,6 +4,7 @@
 //   tg_first_hop_window  <- utils/utils.py:254-273 + models/DyGFormer.py:196-245
 #include <algorithm>
 #include <numeric>
+#include <math.h>
 #include <vector>
 
 #include <atomic>
@@ -74,6 +75,7 @@ struct tg_graph {
     int64_t num_entries = 0;
     int64_t* d_row_ptr = nullptr;
     tg::Incidence* d_inc = nullptr;
+    double* d_cumw = nullptr;      // per incidence: running sum of the time-interval-aware sampling weights inside its row (tg_graph_set_time_weights)
 };
 
 extern "C" void tg_graph_destroy(tg_graph* g);
@@ -175,6 +177,7 @@ extern "C" void tg_graph_destroy(tg_graph* g) {
     if (!g) return;
     (void)hipFree(g->d_row_ptr);
     (void)hipFree(g->d_inc);
+    (void)hipFree(g->d_cumw);
     delete g;
 }
 extern "C" int64_t tg_graph_num_rows(const tg_graph* g) { return g ? g->num_rows : -1; }
@@ -440,6 +443,124 @@ extern "C" int tg_recent_window_mean(const tg_graph* g, const int32_t* d_ids, co
     recent_window_mean_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g->d_row_ptr, g->d_inc, g->num_rows, d_ids, d_times64, n, window,
                                                                        d_table, table_ld, cols, d_out, out_ld);
     return tg::launch_status("recent_window_mean_kernel");
+}
+
+// ---- random sampling strategies on the device (a NON-bit-exact mode: the reference draws from numpy's RandomState on the host,
+// utils/utils.py:176-199, and the bit-exact path does the same; here a counter-based generator replaces that stream) ------------
+namespace {
+__device__ __forceinline__ double u01(uint64_t seed, uint64_t ctr) {             // splitmix64 of (seed, counter) -> [0, 1)
+    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// 32 lanes per query, k <= 128 slots: draw k indices of the node's strictly-earlier history with replacement -- uniformly, or with
+// the time-interval-aware probabilities softmax(p[:cnt]), p_i = e_i / sum_{j <= i} e_j, e_j = exp(tsf (t_j - t_last)) (utils.py:112-128,
+// :183-186), through the row's running weight sums -- then order the k samples by (float32 time, draw) as the reference re-sorts
+// them by time (:193-199).
+constexpr int RS_KMAX = 128;
+__global__ void __launch_bounds__(256) sample_random_kernel(const int64_t* __restrict__ row_ptr, const tg::Incidence* __restrict__ inc,
+        const double* __restrict__ cumw, int64_t num_rows, const int32_t* __restrict__ ids, const double* __restrict__ t64,
+        const float* __restrict__ t32, int64_t n, int k, uint64_t seed, int32_t* __restrict__ o_nbr, int32_t* __restrict__ o_eid,
+        float* __restrict__ o_t, float* __restrict__ o_dt, int32_t* __restrict__ status) {
+    constexpr int GROUP = 32;
+    __shared__ float s_t[8][RS_KMAX];
+    __shared__ int64_t s_j[8][RS_KMAX];
+    const int lane = threadIdx.x % GROUP, grp = threadIdx.x / GROUP;
+    for (int64_t q0 = (int64_t)blockIdx.x * 8; q0 < n; q0 += (int64_t)gridDim.x * 8) {
+        const int64_t q = q0 + grp;
+        int64_t cnt = 0, lo = 0;
+        double when = 0.0;
+        if (q < n) {
+            const int32_t v = ids[q];
+            when = t64 ? t64[q] : (double)t32[q];
+            if (v < 0 || v >= num_rows) {
+                if (lane == 0 && status) atomicExch(status, 1);
+            } else {
+                lo = row_ptr[v];
+                if (lane == 0) cnt = history_end(inc, lo, row_ptr[v + 1], when);
+                cnt = __shfl(cnt, 0, GROUP);
+            }
+            const double wtot = (cumw && cnt > 0) ? cumw[lo + cnt - 1] : 0.0;
+            for (int s = lane; s < k; s += GROUP) {
+                int64_t j = -1;
+                if (cnt > 0) {
+                    const double u = u01(seed, (uint64_t)q * (uint64_t)k + (uint64_t)s);
+                    if (wtot > 0.0) {                             // first index whose running weight exceeds u * total
+                        const double target = u * wtot;
+                        int64_t a = 0, b = cnt - 1;
+                        while (a < b) {
+                            const int64_t mid = (a + b) >> 1;
+                            if (cumw[lo + mid] > target) b = mid; else a = mid + 1;
+                        }
+                        j = a;
+                    } else {                                      // uniform (also: every weight of the prefix is zero -> softmax is uniform)
+                        j = (int64_t)(u * (double)cnt);
+                        if (j >= cnt) j = cnt - 1;
+                    }
+                }
+                s_j[grp][s] = j;
+                s_t[grp][s] = j >= 0 ? (float)inc[lo + j].t : 0.f;
+            }
+        }
+        __syncthreads();
+        if (q < n) {
+            for (int s = lane; s < k; s += GROUP) {
+                const int64_t j = s_j[grp][s];
+                const float ts = s_t[grp][s];
+                int r = 0;
+                for (int x = 0; x < k; ++x) r += (s_t[grp][x] < ts) || (s_t[grp][x] == ts && x < s);
+                const int64_t o = q * k + (j >= 0 ? r : s);
+                int32_t nb = 0, ed = 0;
+                if (j >= 0) { const tg::Incidence e = inc[lo + j]; nb = e.nbr; ed = e.eid; }
+                o_nbr[o] = nb; o_eid[o] = ed; o_t[o] = ts;
+                if (o_dt) o_dt[o] = t64 ? (float)(when - (double)ts) : (t32[q] - ts);
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" int tg_graph_set_time_weights(tg_graph* g, double time_scaling_factor) {
+    TG_REQUIRE(g, "tg_graph_set_time_weights: null graph");
+    std::vector<int64_t> rp(g->num_rows + 1);
+    std::vector<tg::Incidence> inc(g->num_entries);
+    TG_HIP_CHECK(hipMemcpy(rp.data(), g->d_row_ptr, sizeof(int64_t) * (g->num_rows + 1), hipMemcpyDeviceToHost));
+    if (g->num_entries) TG_HIP_CHECK(hipMemcpy(inc.data(), g->d_inc, sizeof(tg::Incidence) * g->num_entries, hipMemcpyDeviceToHost));
+    std::vector<double> cw(std::max<int64_t>(1, g->num_entries));
+    for (int64_t v = 0; v < g->num_rows; ++v) {
+        const int64_t lo = rp[v], hi = rp[v + 1];
+        if (lo == hi) continue;
+        const double tmax = inc[hi - 1].t;                       // rows are sorted by time: the maximum is the last entry
+        double cum = 0.0, wsum = 0.0;
+        for (int64_t j = lo; j < hi; ++j) {
+            const double e = exp(time_scaling_factor * (inc[j].t - tmax));
+            cum += e;
+            const double pr = e / cum;                           // NaN (0 / 0) -> the reference's -1e10 -> weight 0
+            const double w = (pr != pr) ? 0.0 : exp((double)(float)pr);      // softmax over float32(p): exp(p_i) / sum exp(p_j)
+            wsum += w;
+            cw[j] = wsum;
+        }
+    }
+    if (!g->d_cumw) TG_HIP_CHECK(hipMalloc(&g->d_cumw, sizeof(double) * cw.size()));
+    TG_HIP_CHECK(hipMemcpy(g->d_cumw, cw.data(), sizeof(double) * cw.size(), hipMemcpyHostToDevice));
+    return TG_OK;
+}
+
+extern "C" int tg_sample_random(const tg_graph* g, const int32_t* d_ids, const double* d_times64, const float* d_times32, int64_t n, int k,
+                                int weighted, uint64_t seed, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, float* d_out_dt,
+                                int32_t* d_status, void* stream) {
+    TG_REQUIRE(g && d_ids && (d_times64 || d_times32) && d_out_nbr && d_out_eid && d_out_t, "tg_sample_random: null pointer");
+    TG_REQUIRE(k > 0, "Number of sampled neighbors for each node should be greater than 0!");
+    TG_REQUIRE(k <= RS_KMAX, "tg_sample_random: at most 128 sampled neighbors");
+    TG_REQUIRE(!weighted || g->d_cumw, "tg_sample_random: call tg_graph_set_time_weights first");
+    if (n <= 0) return TG_OK;
+    sample_random_kernel<<<grid_for(n, 8), 256, 0, (hipStream_t)stream>>>(g->d_row_ptr, g->d_inc, weighted ? g->d_cumw : nullptr, g->num_rows,
+        d_ids, d_times64, d_times32, n, k, seed, d_out_nbr, d_out_eid, d_out_t, d_out_dt, d_status);
+    return tg::launch_status("sample_random_kernel");
 }
 
 // Host-side history counts (pure host code over the exported CSR, tg_graph_export): out[q] = number of incidences of ids[q] strictly

@@ -171,6 +171,25 @@ def frontier_from_host_sampler(sampler, ids: np.ndarray, times: np.ndarray, k: i
     return Frontier(counts=counts, ids_all=ids_d, S=S_layers[num_layers], child=child_d, pad_rows=[-1] * (num_layers - 1), S_layers=S_layers)
 
 
+def frontier_from_device_random(sampler, ids_dev: torch.Tensor, times_dev: torch.Tensor, k: int, num_layers: int) -> Frontier:
+    """as frontier_from_host_sampler for a sampler in device_random mode: the same layout (independent samples per layer, rows not
+    shared), every draw on the device (tg_sample_random) -- no per-node host loop, not numpy's stream"""
+    if num_layers > 2:
+        raise NotImplementedError("random sampling strategies: the device engine lays out at most 2 layers of independent samples")
+    n = ids_dev.numel()
+    draw = lambda i, t: sampler.sample_on_device(i.contiguous(), t.contiguous(), k)
+    if num_layers == 1:
+        S1 = draw(ids_dev, times_dev)
+        return Frontier(counts=[n], ids_all=ids_dev, S=S1, child=None, pad_rows=[], S_layers={1: S1})
+    own = draw(ids_dev, times_dev)                                   # layer-1 sample of the roots (their own lower-layer embedding)
+    top = draw(ids_dev, times_dev)                                   # layer-2 sample of the same roots: a fresh draw
+    below = draw(top[0].reshape(-1), top[2].reshape(-1))            # layer-1 sample of the layer-2 neighbors (float32 times)
+    S1 = tuple(torch.cat([own[i], below[i]]) for i in range(4))
+    ids_all = torch.cat([ids_dev, top[0].reshape(-1)])
+    child = torch.arange(n, n + n * k, dtype=torch.int32, device=ids_dev.device)
+    return Frontier(counts=[n, n * k], ids_all=ids_all, S=top, child=child, pad_rows=[-1], S_layers={2: top, 1: S1})
+
+
 class _EmbedFn(torch.autograd.Function):
     """One autograd node for the whole L-layer embedding.  Inputs after the fixed ones: te_w, te_b, then per layer the
     7 attention + 4 merge parameters, then (optionally) the layer-0 base table when it carries gradient (TGN)."""
@@ -808,7 +827,9 @@ def embed(graph: TemporalGraph, table: torch.Tensor, edge_table: torch.Tensor, t
         return torch.zeros((0, table.shape[1]), device=dev)
     if num_layers == 0:
         return ops.gather_rows(table, ids_dev)
-    if host_sampler is not None:          # uniform / time_interval_aware: numpy RandomState stream on the host, kernels unchanged
+    if host_sampler is not None and getattr(host_sampler, "device_random", False):
+        fr = frontier_from_device_random(host_sampler, ids_dev, times_dev, k, num_layers)      # opt-in: counter-based draws on the device
+    elif host_sampler is not None:        # uniform / time_interval_aware: numpy RandomState stream on the host, kernels unchanged
         if torch.is_tensor(ids):
             ids, times = ids.cpu().numpy(), times.cpu().numpy()
         fr = frontier_from_host_sampler(host_sampler, ids, times, k, num_layers, dev, groups)

@@ -82,6 +82,24 @@ class TemporalGraph:
                                      _p(out[3]), C.c_void_p(0), _stream()), "tg_sample_recent")
         return out
 
+    def set_time_weights(self, time_scaling_factor: float):
+        """running sums of the time-interval-aware sampling weights (device random mode of the sampler)"""
+        check(lib().tg_graph_set_time_weights(self._h, float(time_scaling_factor)), "tg_graph_set_time_weights")
+        self._time_weights = float(time_scaling_factor)
+
+    def sample_random(self, ids: torch.Tensor, times: torch.Tensor, k: int, seed: int, weighted: bool = False):
+        """k random historical neighbors per query drawn ON THE DEVICE (counter-based generator; not numpy's stream): same outputs as
+        sample_recent"""
+        n, dev = ids.numel(), ids.device
+        out = (torch.empty((n, k), dtype=torch.int32, device=dev), torch.empty((n, k), dtype=torch.int32, device=dev),
+               torch.empty((n, k), dtype=torch.float32, device=dev), torch.empty((n, k), dtype=torch.float32, device=dev))
+        t64 = times if times.dtype == torch.float64 else None
+        t32 = times if times.dtype == torch.float32 else None
+        assert ids.dtype == torch.int32 and ids.is_contiguous() and times.is_contiguous() and (t64 is not None or t32 is not None)
+        check(lib().tg_sample_random(self._h, _p(ids), _p(t64), _p(t32), n, int(k), int(bool(weighted)), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                     _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), None, _stream()), "tg_sample_random")
+        return out
+
     def first_hop_window(self, ids: torch.Tensor, times: torch.Tensor, max_len: int, width: int):
         n = ids.numel()
         dev = ids.device

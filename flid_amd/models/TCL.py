@@ -39,9 +39,10 @@ class TCL(nn.Module):
         dev = self.node_raw_features.device
         sampler = self.neighbor_sampler
         n = len(node_ids)
-        if sampler.sample_neighbor_strategy == "recent":
+        if sampler.sample_neighbor_strategy == "recent" or getattr(sampler, "device_random", False):
             ids_d, t_d = ops.h2d([np.ascontiguousarray(node_ids, dtype=np.int32), np.ascontiguousarray(times, dtype=np.float64)], dev)
-            nbr, eid, _, dt = sampler.graph.sample_recent(ids_d, t_d, k)
+            nbr, eid, _, dt = (sampler.graph.sample_recent(ids_d, t_d, k) if sampler.sample_neighbor_strategy == "recent"
+                               else sampler.sample_on_device(ids_d, t_d, k))
         else:                                   # uniform / time_interval_aware: the host mirror consumes numpy's stream as the reference does
             nb, ne, nt = sampler.get_historical_neighbors(node_ids, times, k)
             ids_d, nbr, eid, dt = ops.h2d([np.ascontiguousarray(node_ids, dtype=np.int32), nb.astype(np.int32), ne.astype(np.int32),

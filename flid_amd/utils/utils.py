@@ -133,18 +133,33 @@ def _device():
 
 class NeighborSampler:
     def __init__(self, graph: TemporalGraph, sample_neighbor_strategy: str = "uniform", time_scaling_factor: float = 0.0,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, device_random: bool = False):
+        """device_random (not in the reference, opt-in): the `uniform` / `time_interval_aware` strategies draw on the DEVICE from a
+        counter-based generator (tg_sample_random) instead of numpy's RandomState on the host -- the same distributions, not the same
+        stream: no bit-exactness with the reference, no per-node host loop (the host path costs ~20 us per query)."""
         self.graph = graph
         self.sample_neighbor_strategy = sample_neighbor_strategy
         self.time_scaling_factor = time_scaling_factor
         self.seed = seed
         self._probs = None
+        self.device_random = bool(device_random) and sample_neighbor_strategy in ("uniform", "time_interval_aware")
+        self._draws = 0                                                   # calls since the last reset: part of the device generator's key
+        if self.device_random and sample_neighbor_strategy == "time_interval_aware":
+            graph.set_time_weights(time_scaling_factor)
         if self.seed is not None:
             self.random_state = np.random.RandomState(self.seed)          # utils/utils.py:109-110
 
     # -- reference API ------------------------------------------------------------------------------------------
     def reset_random_state(self):
         self.random_state = np.random.RandomState(self.seed)             # utils/utils.py:275-280
+        self._draws = 0
+
+    def sample_on_device(self, ids: torch.Tensor, times: torch.Tensor, num_neighbors: int):
+        """device_random mode: (nbr i32, eid i32, t f32, dt f32), each (n, k), for device ids int32 / times float64 | float32; every call
+        advances the generator's key, reset_random_state() rewinds it"""
+        key = (0x5EED if self.seed is None else int(self.seed)) * 0x9E3779B97F4A7C15 + self._draws * 0xD1B54A32D192ED03
+        self._draws += 1
+        return self.graph.sample_random(ids, times, num_neighbors, key, weighted=self.sample_neighbor_strategy == "time_interval_aware")
 
     def find_neighbors_before(self, node_id: int, interact_time: float, return_sampled_probabilities: bool = False):
         rp, nb, ei, tt = self.graph.host_csr()
@@ -166,6 +181,13 @@ class NeighborSampler:
             nbr, eid, t32, _ = self.graph.sample_recent(ids, times, num_neighbors, want_dt=False)
             return (nbr.cpu().numpy().astype(np.longlong), eid.cpu().numpy().astype(np.longlong), t32.cpu().numpy())
         if self.sample_neighbor_strategy in ("uniform", "time_interval_aware"):
+            if self.device_random and num_neighbors <= 128:          # (tg_sample_random's slot limit; GraphMixer's time_gap draw stays on the host)
+                dev = _device()
+                ids = torch.from_numpy(np.ascontiguousarray(node_ids, dtype=np.int32)).to(dev)
+                tt = np.asarray(node_interact_times)
+                times = torch.from_numpy(np.ascontiguousarray(tt, dtype=np.float32 if tt.dtype == np.float32 else np.float64)).to(dev)
+                nbr, eid, t32, _ = self.sample_on_device(ids, times, num_neighbors)
+                return (nbr.cpu().numpy().astype(np.longlong), eid.cpu().numpy().astype(np.longlong), t32.cpu().numpy())
             return self._random_on_host(node_ids, node_interact_times, num_neighbors)
         raise ValueError(f'Not implemented error for sample_neighbor_strategy {self.sample_neighbor_strategy}!')
 
@@ -220,8 +242,10 @@ class NeighborSampler:
         return on, oe, ot
 
 
-def get_neighbor_sampler(data, sample_neighbor_strategy: str = 'uniform', time_scaling_factor: float = 0.0, seed: int = None):
-    """mirror of utils/utils.py:283-302.  `data` needs src_node_ids, dst_node_ids, edge_ids, node_interact_times."""
+def get_neighbor_sampler(data, sample_neighbor_strategy: str = 'uniform', time_scaling_factor: float = 0.0, seed: int = None,
+                         device_random: bool = False):
+    """mirror of utils/utils.py:283-302.  `data` needs src_node_ids, dst_node_ids, edge_ids, node_interact_times.
+    device_random: see NeighborSampler (opt-in, not in the reference)."""
     _device()
     g = TemporalGraph(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
-    return NeighborSampler(g, sample_neighbor_strategy, time_scaling_factor, seed)
+    return NeighborSampler(g, sample_neighbor_strategy, time_scaling_factor, seed, device_random)

@@ -74,6 +74,16 @@ int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n, int64_t c
  * models/DyGFormer.py:196-245 pad_sequences (cut to the newest max_len-1, self in slot 0, left-aligned).
  * Outputs are (n, width) row-major with width = max_len rounded up to a patch multiple by the caller;
  * d_out_len[i] = 1 + kept neighbors.  Slots beyond d_out_len are (0, 0, 0.0f). */
+/* ---- random sampling strategies on the device: a NON-bit-exact mode (opt-in) ---------------------------------------------
+ * The reference draws from numpy's RandomState on the host (utils/utils.py:176-199); the bit-exact path of the sampler mirror does the
+ * same.  Here a counter-based generator (seed, query index, slot) replaces that stream: k draws with replacement from the node's
+ * strictly-earlier history -- uniform (weighted = 0) or with the time-interval-aware probabilities softmax(p[:cnt]),
+ * p = exp(tsf (t - t_last)) / cumsum(...) (utils.py:112-128, :183-186; tg_graph_set_time_weights(tsf) prepares their running sums) --
+ * re-ordered by time as :193-199.  Nodes without history give all-zero rows.  k <= 128.  Output layout as tg_sample_recent. */
+int tg_graph_set_time_weights(tg_graph* g, double time_scaling_factor);
+int tg_sample_random(const tg_graph* g, const int32_t* d_ids, const double* d_times64, const float* d_times32, int64_t n, int k,
+                     int weighted, uint64_t seed, int32_t* d_out_nbr, int32_t* d_out_eid, float* d_out_t, float* d_out_dt,
+                     int32_t* d_status, void* stream);
 /* host-side history lengths over the exported CSR (tg_graph_export): out[q] = number of incidences of ids[q] strictly before
  * times[q] (the prefix length of utils/utils.py:130-147).  No device work; TG_ERANGE for an id outside [0, num_rows). */
 int tg_host_count_before(const int64_t* h_row_ptr, const double* h_t, int64_t num_rows, const int64_t* ids, const double* times, int64_t n,

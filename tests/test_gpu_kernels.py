@@ -578,3 +578,109 @@ def test_multihead_attention_forward_standalone_matches_reference_golden():
     assert np.all((np.abs(ratio) < 1e-6) | (np.abs(ratio - 2.0) < 1e-4)) and (np.abs(ratio) < 1e-6).any() and (np.abs(ratio - 2.0) < 1e-4).any()
     with pytest.raises(RuntimeError, match="ROCm device only"):
         MultiHeadAttention(dn, de, dt, heads, 0.0)(*(v.detach().cpu() for v in ins.values()), g["ids"])
+
+
+# ---- device-side random sampling (opt-in, non-bit-exact mode of the `uniform` / `time_interval_aware` strategies) ------------------
+def _random_case():
+    from flid_amd.synth import wikipedia_like
+    data = wikipedia_like(num_edges=12000, seed=5)
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    return data, adj
+
+
+@pytest.mark.parametrize("strategy", ["uniform", "time_interval_aware"])
+def test_device_random_sampler_draws_valid_sorted_history(strategy):
+    """every sampled (neighbor, edge, time) triple is an entry of the node's strictly-earlier history, rows are ordered by time, nodes
+    without history give zero rows, the same key gives the same draws, reset_random_state rewinds"""
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data, adj = _random_case()
+    smp = get_neighbor_sampler(data, strategy, time_scaling_factor=1e-5, seed=7, device_random=True)
+    rs = np.random.RandomState(0)
+    pick = rs.choice(len(data.src_node_ids), size=500, replace=False)
+    ids = np.concatenate([data.dst_node_ids[pick], data.src_node_ids[:4]])
+    times = np.concatenate([data.node_interact_times[pick], np.zeros(4)])
+    nb, ne, nt = smp.get_historical_neighbors(ids, times, 20)
+    nb2, ne2, nt2 = smp.get_historical_neighbors(ids, times, 20)
+    assert not np.array_equal(nb, nb2)                                   # the second call draws afresh
+    smp.reset_random_state()
+    nb3, ne3, nt3 = smp.get_historical_neighbors(ids, times, 20)
+    assert np.array_equal(nb, nb3) and np.array_equal(ne, ne3) and np.array_equal(nt, nt3)
+    for i, (v, when) in enumerate(zip(ids, times)):
+        cnt = O.history_end(adj, int(v), when)
+        lo = adj.row_ptr[int(v)]
+        if cnt == 0:
+            assert not nb[i].any() and not ne[i].any() and not nt[i].any()
+            continue
+        hist = {(int(a), int(b), np.float32(c)) for a, b, c in zip(adj.nbr[lo:lo + cnt], adj.eid[lo:lo + cnt], adj.t[lo:lo + cnt])}
+        assert all((int(a), int(b), np.float32(c)) in hist for a, b, c in zip(nb[i], ne[i], nt[i])), i
+        assert np.all(np.diff(nt[i]) >= 0), i
+
+
+@pytest.mark.parametrize("strategy", ["uniform", "time_interval_aware"])
+def test_device_random_sampler_follows_the_reference_distribution(strategy):
+    """40 000 draws for one node with a 60-entry history: empirical frequencies vs the probabilities the reference samples with
+    (uniform, or softmax of exp(tsf dt) / cumsum over the prefix: utils/utils.py:112-128, :183-186), 5 sigma per bin"""
+    from flid_amd.utils.utils import get_neighbor_sampler
+    from flid_amd import ops
+    data, adj = _random_case()
+    deg = np.diff(adj.row_ptr)
+    v = int(np.argmax(deg >= 80))
+    lo = adj.row_ptr[v]
+    cnt = 60
+    when = (adj.t[lo + cnt - 1] + adj.t[lo + cnt]) / 2 if adj.t[lo + cnt] > adj.t[lo + cnt - 1] else adj.t[lo + cnt]
+    cnt = O.history_end(adj, v, when)
+    tsf = 2.0 / max(1.0, adj.t[lo + cnt - 1] - adj.t[lo])
+    smp = get_neighbor_sampler(data, strategy, time_scaling_factor=tsf, seed=3, device_random=True)
+    if strategy == "uniform":
+        p = np.full(cnt, 1.0 / cnt)
+    else:
+        tt = adj.t[lo:adj.row_ptr[v + 1]]
+        ex = np.exp(tsf * (tt - tt.max()))
+        pr = ex / np.cumsum(ex)
+        p = torch.softmax(torch.from_numpy(pr[:cnt]).float(), dim=0).double().numpy()
+    n_q, k = 2000, 20
+    ids_d, t_d = ops.h2d([np.full(n_q, v, dtype=np.int32), np.full(n_q, when, dtype=np.float64)], torch.device("cuda:0"))
+    _, eid, _, _ = smp.sample_on_device(ids_d, t_d, k)
+    eids = eid.cpu().numpy().reshape(-1)
+    pos = {int(e): j for j, e in enumerate(adj.eid[lo:lo + cnt])}
+    if len(pos) < cnt:
+        pytest.skip("duplicate edge ids in the chosen history")
+    counts = np.bincount([pos[int(e)] for e in eids], minlength=cnt)
+    total = n_q * k
+    sigma = np.sqrt(total * p * (1 - p))
+    assert np.all(np.abs(counts - total * p) <= 5 * sigma + 1), (counts, total * p)
+
+
+def test_tgat_on_device_random_draws_matches_oracle_given_the_same_draws():
+    """TGAT with a device_random sampler: the embedding is the oracle's for the SAME sampled neighbor lists (replayed to it in the
+    engine's draw order: own layer-1 sample of the roots, their layer-2 sample, the layer-1 sample of the layer-2 neighbors)"""
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data, adj = _random_case()
+    smp = get_neighbor_sampler(data, "uniform", seed=11, device_random=True)
+    dn = 172
+    torch.manual_seed(0)
+    m = TGAT(data.node_raw_features, data.edge_raw_features, smp, 100, 2, 2, 0.0, "cuda:0").to("cuda:0").eval()
+    sl = slice(9000, 9040)
+    bs, bt = data.src_node_ids[sl], data.node_interact_times[sl]
+    smp.reset_random_state()
+    with torch.no_grad():
+        emb = m.compute_node_temporal_embeddings(bs, bt, 2, 6) if hasattr(m, "compute_node_temporal_embeddings") else None
+    # replay: the same keys give the same draws
+    smp.reset_random_state()
+    draws = []
+    ids32 = torch.from_numpy(bs.astype(np.int32)).cuda()
+    t64 = torch.from_numpy(bt.astype(np.float64)).cuda()
+    own = smp.sample_on_device(ids32, t64, 6)
+    top = smp.sample_on_device(ids32, t64, 6)
+    below = smp.sample_on_device(top[0].reshape(-1).contiguous(), top[2].reshape(-1).contiguous(), 6)
+    host = lambda S: (S[0].cpu().numpy().astype(np.int64), S[1].cpu().numpy().astype(np.int64), S[2].cpu().numpy())
+    # the oracle's recursion asks in this order: layer-1 sample of the roots (inside the own recursion), layer-2 sample of the roots,
+    # layer-1 sample of the layer-2 neighbors
+    queue = [host(own), host(top), host(below)]
+    p = {k_: v.detach().cpu() for k_, v in m.state_dict().items()}
+    orc = O.TGATOracle(torch.from_numpy(data.node_raw_features), torch.from_numpy(data.edge_raw_features), adj, p, 2, 2,
+                       sampler_fn=lambda i, t, kk: queue.pop(0))
+    want = orc.embed(bs, bt, 2, 6)
+    assert not queue
+    np.testing.assert_allclose(emb.cpu().numpy(), want.numpy(), atol=1e-4)
