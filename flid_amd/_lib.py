@@ -31,7 +31,8 @@ class LayerDesc(C.Structure):
     """struct tg_layer_desc"""
     _fields_ = [("attn", AttnDesc), ("params", LayerParams), ("own", c_void), ("own_ld", c_i64), ("raw", c_void), ("raw_ld", c_i64),
                 ("cosb", c_void), ("res_dropout_p", c_f32), ("res_seed", C.c_uint64)] + \
-               [(n, c_void) for n in ("qbias", "q", "u", "agg", "prob", "ctx", "res", "y", "mean", "rstd", "f1", "out", "wT")] + [("y_ld", c_i64)]
+               [(n, c_void) for n in ("qbias", "q", "u", "agg", "prob", "ctx", "res", "y", "mean", "rstd", "f1", "out", "wT")] + [("y_ld", c_i64)] + \
+               [("compute_cosb", C.c_int), ("gather_table", c_void), ("gather_ld", c_i64), ("gather_idx", c_void)]
 
 
 class LayerBwdDesc(C.Structure):

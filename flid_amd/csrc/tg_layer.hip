@@ -265,18 +265,55 @@ __global__ void __launch_bounds__(64) wq_time_kernel(const float* __restrict__ s
     atomicAdd(d_cosb + c, acc);
 }
 
-// up to 10 small matrix transposes in one launch (weights, once per step): dst[c * ldd + r] = src[r * lds + c]; the blocks of
-// one extra grid row (blockIdx.y == n, when mv_y is set) compute the matrix-vector product mv_y[i] = sum_t mv_W[i * mv_ld + t] mv_x[t]
-// (the constant half of the query, qb = Wq[:, dn:] cos b), one wave per output
+// The layer's PRELUDE in one launch: up to 10 small matrix transposes (weights, once per step): dst[c * ldd + r] = src[r * lds + c];
+// grid row n: cos(b) (the time encoding of a zero interval, models/TGAT.py:84-85; written out when cosb_out is set, else read from
+// mv_x) and the matrix-vector product mv_y[i] = sum_t mv_W[i * mv_ld + t] cos(b_t) (the constant half of the query, qb = Wq[:, dn:] cos b),
+// one wave per output; grid rows n + 1 ..: the gather of the layer's raw rows g_out[r] = g_table[g_idx[r]] (utils of TGAT.py:77-79).
 struct TrJob { const float* src; float* dst; int rows, cols; int64_t lds, ldd; };
-struct TrJobs { TrJob j[10]; int n; const float *mv_W, *mv_x; float* mv_y; int mv_rows, mv_cols; int64_t mv_ld; };
+struct TrJobs {
+    TrJob j[10];
+    int n;
+    const float *mv_W, *mv_x;
+    float* mv_y;
+    int mv_rows, mv_cols;
+    int64_t mv_ld;
+    const float* te_b;         // != nullptr: cos(b) is computed here (and stored to cosb_out); else mv_x holds it
+    float* cosb_out;
+    const float* g_table;      // != nullptr: gather job
+    const int32_t* g_idx;
+    float* g_out;
+    int64_t g_tld, g_old, g_n;
+    int g_cols, g_rows_y;      // grid rows that walk the gather
+};
 __global__ void __launch_bounds__(256) transpose_many_kernel(TrJobs jobs) {
     __shared__ float tile[32][33];
-    if ((int)blockIdx.y >= jobs.n) {
+    if ((int)blockIdx.y > jobs.n) {                       // ---- row gather: one wave per row, 16-byte chunks
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int64_t first = ((int64_t)(blockIdx.y - jobs.n - 1) * gridDim.x + blockIdx.x) * 4 + wave;
+        const int64_t stride = (int64_t)jobs.g_rows_y * gridDim.x * 4;
+        const bool vec = (jobs.g_cols & 3) == 0 && (jobs.g_tld & 3) == 0 && (jobs.g_old & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(jobs.g_table) | reinterpret_cast<uintptr_t>(jobs.g_out)) & 15) == 0;
+        for (int64_t r = first; r < jobs.g_n; r += stride) {
+            const float* src = jobs.g_table + (int64_t)jobs.g_idx[r] * jobs.g_tld;
+            float* dst = jobs.g_out + r * jobs.g_old;
+            if (vec) {
+                for (int c = lane * 4; c < jobs.g_cols; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+            } else {
+                for (int c = lane; c < jobs.g_cols; c += 64) dst[c] = src[c];
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.y == jobs.n) {                      // ---- cos(b) and the query bias
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (jobs.cosb_out && blockIdx.x == 0)
+            for (int t = threadIdx.x; t < jobs.mv_cols; t += blockDim.x) jobs.cosb_out[t] = tg::cos_phase(jobs.te_b[t]);
         for (int i = blockIdx.x * 4 + wave; i < jobs.mv_rows; i += gridDim.x * 4) {
             float acc = 0.f;
-            for (int t = lane; t < jobs.mv_cols; t += 64) acc = fmaf(jobs.mv_W[(int64_t)i * jobs.mv_ld + t], jobs.mv_x[t], acc);
+            for (int t = lane; t < jobs.mv_cols; t += 64) {
+                const float cb = jobs.te_b ? tg::cos_phase(jobs.te_b[t]) : jobs.mv_x[t];
+                acc = fmaf(jobs.mv_W[(int64_t)i * jobs.mv_ld + t], cb, acc);
+            }
             acc = tg::wave_sum(acc);
             if (lane == 0) jobs.mv_y[i] = acc;
         }
@@ -590,8 +627,16 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     const WT wt = wt_layout(L->wT, H, dn, dq, dk);
     TG_REQUIRE(H <= 2, "tg_tgat_layer_fwd: the native layer path supports 1 or 2 heads");
     // the constant half of the query, qb = Wq[:, dn:] cos b, rides in the transposes' launch
+    // ... together with cos(b) itself (when the caller asks: compute_cosb) and the gather of the layer's raw rows (gather_table)
+    int gather_rows_y = 0;
     auto with_qbias = [&](TrJobs& jobs) {
         jobs.mv_W = P.Wq + dn; jobs.mv_x = L->cosb; jobs.mv_y = L->qbias; jobs.mv_rows = dq; jobs.mv_cols = T; jobs.mv_ld = dq;
+        jobs.te_b = L->compute_cosb ? a.d_te_b : nullptr;
+        jobs.cosb_out = L->compute_cosb ? const_cast<float*>(L->cosb) : nullptr;
+        jobs.g_table = L->gather_table; jobs.g_idx = L->gather_idx; jobs.g_out = const_cast<float*>(L->raw);
+        jobs.g_tld = L->gather_ld; jobs.g_old = L->raw_ld; jobs.g_n = R; jobs.g_cols = dn;
+        gather_rows_y = L->gather_table ? (int)std::min<int64_t>(32, (R + 255) / 256) : 0;      // 64 workgroups x 4 rows per grid row
+        jobs.g_rows_y = gather_rows_y;
     };
     if (g_merged && R >= kMergedMinRows) {
         // merged QUERY side (u = own P^T + ub: the q intermediate and one product per direction leave the chain); the value side keeps
@@ -606,7 +651,7 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
         jobs.n = n;
         with_qbias(jobs);
-        transpose_many_kernel<<<dim3(64, n + 1), 256, 0, s>>>(jobs);
+        transpose_many_kernel<<<dim3(64, n + 1 + gather_rows_y), 256, 0, s>>>(jobs);
         TG_TRY(tg::launch_status("transpose_many_kernel"));
         {
             MergeJobs mj;
@@ -638,7 +683,7 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         jobs.j[n++] = TrJob{P.Wq, wt.WqL, dq, dn, dq, dq};
         jobs.n = n;
         with_qbias(jobs);
-        transpose_many_kernel<<<dim3(64, n + 1), 256, 0, s>>>(jobs);
+        transpose_many_kernel<<<dim3(64, n + 1 + gather_rows_y), 256, 0, s>>>(jobs);
         TG_TRY(tg::launch_status("transpose_many_kernel"));
         // q = [own | cos b] Wq^T : the constant half is a bias row
         TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));

@@ -375,7 +375,7 @@ class _NativeLayer:
     the Python around them was as long as the GPU work): the saved activations of a layer are ONE allocation addressed by
     offset, the backward scratch is one cached allocation, and only tensors that leave this class are torch views."""
 
-    def __init__(self, attn: ops.AttnArgs, params, own, table, ids, cosb, p_res, seed_res):
+    def __init__(self, attn: ops.AttnArgs, params, own, table, ids, cosb, p_res, seed_res, compute_cosb=False):
         """own = None: the layer's own rows ARE its raw rows (layer 1).  The raw rows are gathered (table[ids]) straight into the
         right part of the saved [y | raw] buffer: the merge layer's torch.cat (modules.py:66) never materialises."""
         from ._lib import LayerDesc, LayerParams, lib
@@ -397,10 +397,11 @@ class _NativeLayer:
         self.out = torch.empty((R, Dn), dtype=torch.float32, device=dev)
         yo = offs[_FWD_FIELDS.index("y")]
         yr = self.act[yo:yo + R * (Dq + Dn)].view(R, Dq + Dn)
-        raw = ops.gather_rows(table, ids, out=yr[:, Dq:])
+        assert ids.dtype == torch.int32 and ids.is_contiguous() and table.dtype == torch.float32
+        raw = yr[:, Dq:]                       # filled by the layer's prelude launch (gather_table / gather_idx below)
         if own is None:
             own = raw
-        self.keep = (params, own, cosb)
+        self.keep = (params, own, cosb, table, ids)
         base = self.act.data_ptr()
         d = LayerDesc()
         d.attn = attn.desc
@@ -411,6 +412,8 @@ class _NativeLayer:
             setattr(d, name, base + 4 * o)
         d.out = self.out.data_ptr()
         d.y_ld = Dq + Dn
+        d.compute_cosb = int(compute_cosb)
+        d.gather_table, d.gather_ld, d.gather_idx = table.data_ptr(), ops._rowmajor_ld(table, "table"), ids.data_ptr()
         self.desc = d
 
     def forward(self):
@@ -486,7 +489,7 @@ def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
     Dn, T = table.shape[1], te_w.numel()
     hd = (Dn + T) // H
     te_w_flat = te_w.reshape(-1)
-    cosb = ops.time_encode(_zero1(dev), te_w_flat, te_b).reshape(-1)
+    cosb = torch.empty(T, dtype=torch.float32, device=dev)         # cos(b): written by the first layer's prelude launch
     p_eff = p_drop if training else 0.0
     layers, H_prev = [], None
     for l in range(1, L + 1):
@@ -498,7 +501,7 @@ def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
         seeds = _next_seeds(2) if p_eff > 0 else [0, 0]
         attn = ops.AttnArgs(feat, feat_idx, edge, S_eid[:R].reshape(-1), S_nbr[:R].reshape(-1), S_dt[:R].reshape(-1),
                             te_w_flat, te_b, k, H, hd ** -0.5, p_eff, seeds[0])
-        lay = _NativeLayer(attn, params, own, table, fr.ids_all[:R], cosb, p_eff, seeds[1])
+        lay = _NativeLayer(attn, params, own, table, fr.ids_all[:R], cosb, p_eff, seeds[1], compute_cosb=(l == 1))
         H_prev = lay.forward()
         layers.append(lay)
     return H_prev, (layers, cosb)

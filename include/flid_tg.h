@@ -173,6 +173,10 @@ typedef struct tg_layer_desc {
     float* wT;   /* tg_tgat_layer_wt_floats(dn, dq, dk) floats: transposed weights, written by fwd, read by bwd of the same step */
     int64_t y_ld; /* row stride of y (0 = dq).  With y_ld = raw_ld = dq + dn and raw = y + dq the merge layer's input [y | raw]
                    * (modules.py:66 torch.cat) is one buffer: fc1 and its weight gradient are one product each instead of two */
+    /* the layer's prelude launch (weight transposes + query bias) can also do, when set: */
+    int compute_cosb;             /* cosb[t] = cos(te_b[t]) (attn.d_te_b), written to `cosb` before anything reads it: the time encoding of
+                                   * a zero interval, models/TGAT.py:84-85 (otherwise the caller filled `cosb`) */
+    const float* gather_table; int64_t gather_ld; const int32_t* gather_idx;   /* raw[r, :dn] = gather_table[gather_idx[r], :dn] (TGAT.py:77-79) */
 } tg_layer_desc;
 /* backward: dout (R, dn) in; this layer's parameter gradients are ADDED into grads.* and into d_cosb / d_tew / d_teb (dt_dim)
  * with float atomics: the caller zeroes them (one fill for the whole gradient block of a step) -- as torch accumulates into
