@@ -208,16 +208,15 @@ SegDst seg1(float* p, int cols) { SegDst d{}; d.p[0] = p; d.end[0] = cols; d.n =
 
 // two slabs in one launch (a layer's LayerNorm slabs and its attention backward's time-encoder slabs)
 struct ColJob { const float* x; int64_t ld, n; int cols; SegDst d; };
-__global__ void __launch_bounds__(256) colsum_seg2_kernel(ColJob a, ColJob b, int groups_a) {
-    __shared__ float red[4][64];
-    const bool first = (int)blockIdx.x < groups_a;
+__device__ __forceinline__ void colsum_seg2_body(const ColJob& a, const ColJob& b, int groups_a, int bx, int by, int ny, float (*red)[64]) {
+    const bool first = bx < groups_a;
     const ColJob& j = first ? a : b;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = ((int)blockIdx.x - (first ? 0 : groups_a)) * 64 + lane;
-    if ((int64_t)blockIdx.y * 4 >= j.n) return;                  // (uniform per workgroup) no rows for this slice
+    const int c = (bx - (first ? 0 : groups_a)) * 64 + lane;
+    if ((int64_t)by * 4 >= j.n) return;                          // (uniform per workgroup) no rows for this slice
     float s = 0.f;
     if (c < j.cols)
-        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < j.n; r += (int64_t)gridDim.y * 4) s += j.x[r * j.ld + c];
+        for (int64_t r = (int64_t)by * 4 + wave; r < j.n; r += (int64_t)ny * 4) s += j.x[r * j.ld + c];
     red[wave][lane] = s;
     __syncthreads();
     if (wave != 0 || c >= j.cols) return;
@@ -230,6 +229,10 @@ __global__ void __launch_bounds__(256) colsum_seg2_kernel(ColJob a, ColJob b, in
         }
         beg = j.d.end[i];
     }
+}
+__global__ void __launch_bounds__(256) colsum_seg2_kernel(ColJob a, ColJob b, int groups_a) {
+    __shared__ float red[4][64];
+    colsum_seg2_body(a, b, groups_a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, red);
 }
 int colsum_seg2(const ColJob& a, const ColJob& b, hipStream_t s) {
     if (a.n == 0) return colsum_seg(b.x, b.ld, b.n, b.cols, b.d, s);
@@ -245,13 +248,12 @@ int colsum_seg2(const ColJob& a, const ColJob& b, hipStream_t s) {
 //   dWq[:, dn:] += sq (x) cos(b)      and      d cos(b) += sq^T Wq[:, dn:].
 // Thread = one time column x 16 rows (independent loads), grid.y walks the rows.
 constexpr int WQT_ROWS = 16;
-__global__ void __launch_bounds__(64) wq_time_kernel(const float* __restrict__ sq, int dq, const float* __restrict__ cosb, int T,
-                                                     const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld,
-                                                     float* __restrict__ d_cosb) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= T) return;
+__device__ __forceinline__ void wq_time_body(int bx, int by, const float* __restrict__ sq, int dq, const float* __restrict__ cosb, int T,
+                                             const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld, float* __restrict__ d_cosb) {
+    const int c = bx * 64 + (int)threadIdx.x;                    // the first 64 threads of the workgroup work
+    if (threadIdx.x >= 64 || c >= T) return;
     const float cb = cosb[c];
-    const int r0 = blockIdx.y * WQT_ROWS;
+    const int r0 = by * WQT_ROWS;
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < WQT_ROWS; ++j) {
@@ -263,6 +265,11 @@ __global__ void __launch_bounds__(64) wq_time_kernel(const float* __restrict__ s
         }
     }
     atomicAdd(d_cosb + c, acc);
+}
+__global__ void __launch_bounds__(64) wq_time_kernel(const float* __restrict__ sq, int dq, const float* __restrict__ cosb, int T,
+                                                     const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld,
+                                                     float* __restrict__ d_cosb) {
+    wq_time_body((int)blockIdx.x, (int)blockIdx.y, sq, dq, cosb, T, Wq_t, dWq_t, ld, d_cosb);
 }
 
 // The layer's PRELUDE in one launch: up to 10 small matrix transposes (weights, once per step): dst[c * ldd + r] = src[r * lds + c];
@@ -442,11 +449,10 @@ inline void add_job(MergeJobs& mj, const float* A, const float* B, float* C, flo
 
 // Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), one workgroup per query row i = h hd + k:
 //   dqb_i = Wk[i, :] . dub_h ;  dWk[i, :] += qb_i dub_h ;  dWq[i, dn:] += dqb_i cos b ;  d cos b += Wq[i, dn:] dqb_i
-__global__ void __launch_bounds__(256) ub_bwd_kernel(const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
+__device__ __forceinline__ void ub_bwd_body(int i, const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
         const float* __restrict__ Wq, const float* __restrict__ cosb, int hd, int dn, int dq, int dk, int T, float* __restrict__ dWk,
-        float* __restrict__ dWq, float* __restrict__ d_cosb) {
-    __shared__ float red[4];
-    const int i = blockIdx.x, h = i / hd;
+        float* __restrict__ dWq, float* __restrict__ d_cosb, float* red) {
+    const int h = i / hd;
     const float* du = dub + (int64_t)h * dk;
     const float qbi = qb[i];
     float part = 0.f;
@@ -463,6 +469,35 @@ __global__ void __launch_bounds__(256) ub_bwd_kernel(const float* __restrict__ d
         dWq[(int64_t)i * dq + dn + t] += dqb * cosb[t];
         atomicAdd(d_cosb + t, Wq[(int64_t)i * dq + dn + t] * dqb);
     }
+}
+__global__ void __launch_bounds__(256) ub_bwd_kernel(const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
+        const float* __restrict__ Wq, const float* __restrict__ cosb, int hd, int dn, int dq, int dk, int T, float* __restrict__ dWk,
+        float* __restrict__ dWq, float* __restrict__ d_cosb) {
+    __shared__ float red[4];
+    ub_bwd_body((int)blockIdx.x, dub, qb, Wk, Wq, cosb, hd, dn, dq, dk, T, dWk, dWq, d_cosb, red);
+}
+
+// The layer's backward TAIL in one launch: three independent finishing steps that used to be a launch each (4.5-12 us apiece for
+// a few hundred KB of work).  Workgroups [0, n_head): the constant-part gradients of the query -- ub_bwd (merged projection,
+// head_mode 1: one workgroup per query row) or wq_time (head_mode 2: (T / 64) x (dq / 16) workgroups); the rest: the slab sums.
+struct TailArgs {
+    int head_mode, n_head, wq_gx;
+    const float *v, *qb, *Wk, *Wq, *cosb;        // v = dub (mode 1) or sum_rows dq (mode 2)
+    int hd, dn, dq, dk, T;
+    float *dWk, *dWq, *d_cosb;
+    ColJob a, b;
+    int groups_a, col_gx, col_ny;
+};
+__global__ void __launch_bounds__(256) layer_tail_kernel(TailArgs t) {
+    __shared__ float red[4][64];
+    const int bid = (int)blockIdx.x;
+    if (bid < t.n_head) {
+        if (t.head_mode == 1) ub_bwd_body(bid, t.v, t.qb, t.Wk, t.Wq, t.cosb, t.hd, t.dn, t.dq, t.dk, t.T, t.dWk, t.dWq, t.d_cosb, &red[0][0]);
+        else wq_time_body(bid % t.wq_gx, bid / t.wq_gx, t.v, t.dq, t.cosb, t.T, t.Wq + t.dn, t.dWq + t.dn, t.dq, t.d_cosb);
+        return;
+    }
+    const int c = bid - t.n_head;
+    colsum_seg2_body(t.a, t.b, t.groups_a, c % t.col_gx, c / t.col_gx, t.col_ny, red);
 }
 
 struct WT { float *Wk, *Wv, *W2, *W1a, *W1b, *Wr, *WqL, *P, *PT, *V, *VT, *ub; };
@@ -862,20 +897,37 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     }
     // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres (= d br, which the
     // weight-gradient launch delivers through its ones column instead)]
-    auto slab_sums = [&]() -> int {         // after the attention backward: LayerNorm slabs + time-encoder slabs, one launch
-        ColJob ln{part_ln, 4 * (int64_t)dq, (int64_t)ln_grid, 3 * dq, SegDst{}};
-        ln.d.n = 5;
-        ln.d.p[0] = G.ln_g;     ln.d.end[0] = dq;
-        ln.d.p[1] = G.ln_b;     ln.d.end[1] = 2 * dq;
-        ln.d.p[2] = nullptr;    ln.d.end[2] = 2 * dq + dn;
-        ln.d.p[3] = Bw->d_cosb; ln.d.end[3] = 3 * dq;
-        ln.d.p[4] = nullptr;    ln.d.end[4] = 4 * dq;
-        ColJob at{part_attn, 2 * (int64_t)T, T > 0 ? (int64_t)attn_parts : 0, 2 * T, SegDst{}};
-        at.d.n = 2;
-        at.d.p[0] = Bw->d_tew; at.d.end[0] = T;
-        at.d.p[1] = Bw->d_teb; at.d.end[1] = 2 * T;
+    // head_mode 1: ub_bwd over dub; 2: wq_time over sum_rows dq (vec_dq); both with the slab sums behind them in the same launch
+    auto tail = [&](int head_mode) -> int {
+        TailArgs t{};
+        t.head_mode = head_mode;
+        t.wq_gx = (T + 63) / 64;
+        t.n_head = head_mode == 1 ? dq : (T > 0 ? t.wq_gx * ((dq + WQT_ROWS - 1) / WQT_ROWS) : 0);
+        t.v = head_mode == 1 ? dub : vec_dq;
+        t.qb = Lc.qbias; t.Wk = P.Wk; t.Wq = P.Wq; t.cosb = Lc.cosb;
+        t.hd = hd; t.dn = dn; t.dq = dq; t.dk = dk; t.T = T;
+        t.dWk = G.Wk; t.dWq = G.Wq; t.d_cosb = Bc.d_cosb;
+        t.a = ColJob{part_ln, 4 * (int64_t)dq, (int64_t)ln_grid, 3 * dq, SegDst{}};
+        t.a.d.n = 5;
+        t.a.d.p[0] = G.ln_g;     t.a.d.end[0] = dq;
+        t.a.d.p[1] = G.ln_b;     t.a.d.end[1] = 2 * dq;
+        t.a.d.p[2] = nullptr;    t.a.d.end[2] = 2 * dq + dn;
+        t.a.d.p[3] = Bw->d_cosb; t.a.d.end[3] = 3 * dq;
+        t.a.d.p[4] = nullptr;    t.a.d.end[4] = 4 * dq;
+        t.b = ColJob{part_attn, 2 * (int64_t)T, T > 0 ? (int64_t)attn_parts : 0, 2 * T, SegDst{}};
+        t.b.d.n = 2;
+        t.b.d.p[0] = Bw->d_tew; t.b.d.end[0] = T;
+        t.b.d.p[1] = Bw->d_teb; t.b.d.end[1] = 2 * T;
+        const int ga = (t.a.cols + 63) / 64, gb = t.b.n > 0 ? (t.b.cols + 63) / 64 : 0;
+        const int64_t max_slices = std::max<int64_t>(64, std::min<int64_t>(512, 2048 / std::max(1, ga + gb)));
+        t.groups_a = ga;
+        t.col_gx = ga + gb;
+        t.col_ny = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, std::max(t.a.n, t.b.n) / 32));
         hipStream_t st = ws_;
-        return side([=] { return colsum_seg2(ln, at, st); });
+        return side([=] {
+            layer_tail_kernel<<<(unsigned)(t.n_head + t.col_gx * t.col_ny), 256, 0, st>>>(t);
+            return tg::launch_status("layer_tail_kernel");
+        });
     };
     if (g_merged && R >= kMergedMinRows) {
         // ---- output projection + value path (the reference's two products; weight gradients in one grouped launch) ------------------
@@ -896,16 +948,11 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(flush_wgrad());
         {
             void* stv = wstream;
-            hipStream_t st = ws_;
             // P_h = Wk_h^T Wq_h[:, :dn] :  dWk_h += Wq_h[:, :dn] dP_h^T ;  dWq_h[:, :dn] += Wk_h dP_h ;  then the constant part (ub)
             TG_TRY(side([=] { return tg_gemm_f32_batched(0, 1, hd, dk, dn, 1.f, P.Wq, dq, (int64_t)hd * dq, dPm, dn, (int64_t)dk * dn, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, stv); }));
             TG_TRY(side([=] { return tg_gemm_f32_batched(0, 0, hd, dn, dk, 1.f, P.Wk, dk, (int64_t)hd * dk, dPm, dn, (int64_t)dk * dn, G.Wq, dq, (int64_t)hd * dq, H, nullptr, 0, 1, stv); }));
-            TG_TRY(side([=] {
-                ub_bwd_kernel<<<dq, 256, 0, st>>>(dub, Lc.qbias, P.Wk, P.Wq, Lc.cosb, hd, dn, dq, dk, T, G.Wk, G.Wq, Bc.d_cosb);
-                return tg::launch_status("ub_bwd_kernel");
-            }));
         }
-        TG_TRY(slab_sums());
+        TG_TRY(tail(1));                      // ub_bwd (after the two products above: it also adds into dWk) + the slab sums
         // ---- key / query path: d own = du P (+ the residual's share) ------------------------------------------------------------------
         if (Bw->d_own) {
             // (the residual's share is already there: ln_res_bwd_kernel)
@@ -933,14 +980,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             TG_TRY(wgrad(jobs));
             TG_TRY(flush_wgrad());
         }
-        {
-            hipStream_t st = ws_;
-            TG_TRY(side([=] {
-                wq_time_kernel<<<dim3((T + 63) / 64, (dq + WQT_ROWS - 1) / WQT_ROWS), 64, 0, st>>>(vec_dq, dq, Lc.cosb, T, P.Wq + dn, G.Wq + dn, dq, Bc.d_cosb);
-                return tg::launch_status("wq_time_kernel");
-            }));
-        }
-        TG_TRY(slab_sums());
+        TG_TRY(tail(2));                          // wq_time (the time half of dWq, d cos b) + the slab sums
         if (Bw->d_own) {
             // (the residual's share is already there: ln_res_bwd_kernel)
             TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
