@@ -828,7 +828,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     float* vec_dq = vec;
     float* dub = vec;
     float* dPm = vec + ((dq + hk + 3) / 4) * 4;                 // gradient of the merged query projection, (H dk, dn)
-    // Weight (and bias) gradients of up to 6 Linear layers in ONE launch on the side stream (tg_wgrad_group: split-bf16 MFMA, bias
+    // Weight (and bias) gradients of up to 8 Linear layers in ONE launch (tg_wgrad_group: split-bf16 MFMA, bias
     // sums through a ones column, partial tiles folded with float atomics); shapes it does not cover fall back to one exact
     // product + one column sum per job.
     struct WJ { const float* A; int64_t lda; int M; const float* B; int64_t ldb; int N; float* C; int64_t ldc; float* cs; };

@@ -184,7 +184,7 @@ typedef struct tg_layer_desc {
  * dfeat / pad_row as in tg_attn_bwd; d_own (R, dn; ld) optional gradient w.r.t. own (accumulated into if d_own_accumulate); d_raw
  * (R, dn) optional gradient w.r.t. raw.
  * scratch: df1 (R,dn), dy/dsum/dres/dctx/dq (R,dq), dagg/du (R,heads,dk), part (tg_tgat_layer_part_floats floats of slabs).
- * All weight / bias gradients of the layer leave in 2-3 grouped launches (tg_wgrad_group) on the side streams;
+ * All weight / bias gradients of the layer leave in ONE grouped launch (tg_wgrad_group) after the attention backward;
  * tg_set_wgrad_grouped(0) restores one exact product + one column sum per gradient (A/B tests). */
 typedef struct tg_layer_bwd_desc {
     tg_layer_grads grads;
