@@ -104,6 +104,8 @@ SIGNATURES = {
     "tg_gelu_bwd": (C.c_int, [c_void, c_void, c_i64, c_void, c_void]),
     "tg_softmax_fwd": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_void]),
     "tg_softmax_keymask_fwd": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_i64, c_void, c_void]),
+    "tg_tgn_rows_fwd": (C.c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, C.c_int, C.c_int] + [c_void] * 4 + [C.c_int] + [c_void] * 6 + [c_void]),
+    "tg_gru_gates_bwd_masked": (C.c_int, [c_void] * 6 + [c_i64, C.c_int, c_void, c_void, c_void]),
     "tg_tgn_host_advance": (C.c_int, [c_void, c_void, c_i64, c_void, c_void, c_void, c_i64, c_void]),
     "tg_tgn_prepare_layout": (C.c_int, [c_i64, c_i64, C.c_int, c_void]),
     "tg_tgn_prepare_batch": (C.c_int, [c_void] * 5 + [c_i64, c_i64, c_i64, C.c_int, c_i64] + [c_void] * 6 + [c_i64] + [c_void] * 11 + [c_void]),

@@ -161,6 +161,105 @@ extern "C" int tg_build_messages(const float* d_mem, int64_t mem_ld, const float
 }
 
 
+// ---- the touched rows of a lazily updated TGN memory in one call (models/MemoryModel.py:117, :191-231, :501-543, :654-655) ------
+// For the U distinct touched nodes uniq[r]: h = memory[uniq], x = pending message[uniq]; GRU cell; rows = has_message ? GRU : h (the
+// updated memory, not persisted); base = rows + raw features (the layer-0 table of the embedding).  gi / gh are kept for backward.
+namespace {
+// two row gathers of different widths in one launch (grid.y = job)
+__global__ void __launch_bounds__(256) gather2_kernel(const float* __restrict__ ta, int64_t lda, int ca, float* __restrict__ oa,
+        const float* __restrict__ tb, int64_t ldb, int cb, float* __restrict__ ob, const int32_t* __restrict__ idx, int64_t n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* t = blockIdx.y ? tb : ta;
+    float* o = blockIdx.y ? ob : oa;
+    const int64_t ld = blockIdx.y ? ldb : lda;
+    const int cols = blockIdx.y ? cb : ca;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        const float* src = t + (int64_t)idx[r] * ld;
+        float* dst = o + r * cols;
+        for (int c = lane; c < cols; c += 64) dst[c] = src[c];
+    }
+}
+// GRU gates + selection + base row: rows = has[uniq] ? (1 - z) n + z h : h ; base = rows + raw[uniq]
+__global__ void __launch_bounds__(256) gru_select_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h,
+        const int32_t* __restrict__ uniq, const int32_t* __restrict__ has, const float* __restrict__ raw, int64_t raw_ld, int64_t n, int d,
+        float* __restrict__ rows, float* __restrict__ base) {
+    const int64_t total = n * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r_ = i / d;
+        const int c = (int)(i - r_ * d);
+        const int32_t node = uniq[r_];
+        float v = h[i];
+        if (gi && has[node] > 0) {
+            const float* a = gi + r_ * 3 * d;
+            const float* b = gh + r_ * 3 * d;
+            const float r = sigmoidf_(a[c] + b[c]);
+            const float z = sigmoidf_(a[d + c] + b[d + c]);
+            const float nn = tanhf(a[2 * d + c] + r * b[2 * d + c]);
+            v = (1.f - z) * nn + z * v;
+        }
+        rows[i] = v;
+        base[i] = v + raw[(int64_t)node * raw_ld + c];
+    }
+}
+}  // namespace
+
+extern "C" int tg_tgn_rows_fwd(const float* d_mem, int64_t mem_ld, const float* d_msg, int64_t msg_ld, const float* d_raw, int64_t raw_ld,
+                               const int32_t* d_uniq, int64_t count, const int32_t* d_has, int d, int msg_dim, const float* d_w_ih,
+                               const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, int pending, float* d_h_rows,
+                               float* d_msg_rows, float* d_gi, float* d_gh, float* d_rows, float* d_base, void* stream) {
+    TG_REQUIRE(d_mem && d_raw && d_uniq && d_has && d_h_rows && d_rows && d_base && count >= 0 && d > 0, "tg_tgn_rows_fwd: arguments");
+    TG_REQUIRE(!pending || (d_msg && d_msg_rows && d_gi && d_gh && d_w_ih && d_w_hh && d_b_ih && d_b_hh && msg_dim > 0), "tg_tgn_rows_fwd: GRU arguments");
+    if (count == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned gb = (unsigned)std::min<int64_t>((count + 3) / 4, tg::kMaxGridBlocks);
+    gather2_kernel<<<dim3(gb, pending ? 2 : 1), 256, 0, s>>>(d_mem, mem_ld, d, d_h_rows, d_msg, msg_ld, msg_dim, d_msg_rows, d_uniq, count);
+    if (pending) {
+        if (int rc = tg_gemm_f32(0, 1, count, 3 * d, msg_dim, 1.f, d_msg_rows, msg_dim, d_w_ih, msg_dim, d_gi, 3 * d, d_b_ih, 0, 0, stream)) return rc;
+        if (int rc = tg_gemm_f32(0, 1, count, 3 * d, d, 1.f, d_h_rows, d, d_w_hh, d, d_gh, 3 * d, d_b_hh, 0, 0, stream)) return rc;
+    }
+    const int64_t blocks = std::min<int64_t>((count * d + 255) / 256, tg::kMaxGridBlocks);
+    gru_select_kernel<<<(unsigned)blocks, 256, 0, s>>>(pending ? d_gi : nullptr, d_gh, d_h_rows, d_uniq, d_has, d_raw, raw_ld, count, d, d_rows, d_base);
+    return tg::launch_status("tg_tgn_rows_fwd");
+}
+
+namespace {
+__global__ void __launch_bounds__(256) gru_gates_bwd_masked_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+        const float* __restrict__ h, const float* __restrict__ dout, const int32_t* __restrict__ uniq, const int32_t* __restrict__ has,
+        int64_t n, int d, float* __restrict__ dgi, float* __restrict__ dgh) {
+    const int64_t total = n * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r_ = i / d;
+        const int c = (int)(i - r_ * d);
+        const float* a = gi + r_ * 3 * d;
+        const float* b = gh + r_ * 3 * d;
+        const float r = sigmoidf_(a[c] + b[c]);
+        const float z = sigmoidf_(a[d + c] + b[d + c]);
+        const float ghn = b[2 * d + c];
+        const float nn = tanhf(a[2 * d + c] + r * ghn);
+        const float g = has[uniq[r_]] > 0 ? dout[i] : 0.f;          // rows without a pending message kept their old memory: no GRU gradient
+        const float dnn = g * (1.f - z);
+        const float dz = g * (h[i] - nn);
+        const float dpn = dnn * (1.f - nn * nn);
+        const float dpr = dpn * ghn * r * (1.f - r);
+        const float dpz = dz * z * (1.f - z);
+        float* da = dgi + r_ * 3 * d;
+        float* db = dgh + r_ * 3 * d;
+        da[c] = dpr; db[c] = dpr;
+        da[d + c] = dpz; db[d + c] = dpz;
+        da[2 * d + c] = dpn; db[2 * d + c] = dpn * r;
+    }
+}
+}  // namespace
+
+extern "C" int tg_gru_gates_bwd_masked(const float* d_gi, const float* d_gh, const float* d_h, const float* d_dout, const int32_t* d_uniq,
+                                       const int32_t* d_has, int64_t n, int d, float* d_dgi, float* d_dgh, void* stream) {
+    TG_REQUIRE(d_gi && d_gh && d_h && d_dout && d_uniq && d_has && d_dgi && d_dgh && n >= 0 && d > 0, "tg_gru_gates_bwd_masked: arguments");
+    if (n == 0) return TG_OK;
+    const int64_t blocks = std::min<int64_t>((n * d + 255) / 256, tg::kMaxGridBlocks);
+    gru_gates_bwd_masked_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_gi, d_gh, d_h, d_dout, d_uniq, d_has, n, d, d_dgi, d_dgh);
+    return tg::launch_status("gru_gates_bwd_masked_kernel");
+}
+
 // Host mirror of one positive batch's state advance (models/MemoryModel.py:155-180 with the assertion of :485-486): for the distinct
 // batch nodes u[i] (any order) with the time new_t[i] of their last occurrence -- a node that holds a pending message gets it applied
 // (its last-update time becomes the message's), then every node files a new message at new_t[i].  Nothing is changed when the

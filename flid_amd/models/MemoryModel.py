@@ -343,16 +343,23 @@ class MemoryModel(torch.nn.Module):
         assert not bank._past_violation, "Trying to update memory to time in the past!"
         with torch.no_grad():
             mem = bank.node_memories.data
-            h_rows = ops.gather_rows(mem, uniq)
             pending = bool(bank._has.any())
-            if pending:
-                msg_rows = ops.gather_rows(bank._msg, uniq)
-                new, gi, gh = ops.gru_cell_fwd(msg_rows, h_rows, w_ih, w_hh, b_ih, b_hh)
-                mask = bank._has_dev[uniq.long()].view(-1, 1)
-                rows = torch.where(mask > 0, new, h_rows)
-            else:
-                rows = h_rows
-            base = rows + ops.gather_rows(self.node_raw_features, uniq)
+            # ONE call: gathers of the touched rows (memory, pending messages), GRU products + gates, selection by has-message, and the
+            # layer-0 table `updated memory + raw features` (one allocation for everything it leaves)
+            U, D, MD = uniq.numel(), self.memory_dim, self.message_dim
+            sizes = (U * D, U * MD if pending else 0, U * 3 * D if pending else 0, U * 3 * D if pending else 0, U * D, U * D)
+            offs_, tot_ = [], 0
+            for sz in sizes:
+                offs_.append(tot_)
+                tot_ += (sz + 3) // 4 * 4
+            buf = torch.empty(max(tot_, 4), dtype=torch.float32, device=dev)
+            bp = buf.data_ptr()
+            h_rows, msg_rows, gi, gh, rows, base = (buf[o:o + sz].view(U, -1) if sz else None for o, sz in zip(offs_, sizes))
+            ptr = lambda i: (bp + 4 * offs_[i]) if sizes[i] else None
+            check(lib().tg_tgn_rows_fwd(mem.data_ptr(), mem.stride(0), bank._msg.data_ptr(), bank._msg.stride(0),
+                                        self.node_raw_features.data_ptr(), self.node_raw_features.stride(0), uniq.data_ptr(), U,
+                                        bank._has_dev.data_ptr(), D, MD, w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(),
+                                        int(pending), ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ops._stream()), "tg_tgn_rows_fwd")
             fr = engine.Frontier(counts=[m], ids_all=job["row_roots"], S=S, child=None, pad_rows=[], feat_idx0=job["row_nbrs"], pad_row0=job["pad"])
             cfg = dict(n=m, k=k, num_layers=1, num_heads=self.num_heads, dropout=float(self.dropout), training=bool(self.training),
                        edge_table=self.edge_raw_features, table_grad=pending)
@@ -364,10 +371,10 @@ class MemoryModel(torch.nn.Module):
             if pending:
                 tail = zeroed[npar:npar + gru_len]
                 gv = [tail[o:o + t.numel()].view(t.shape) for o, t in zip(gru_offs, (w_ih, w_hh, b_ih, b_hh))]
-                dm = (d_table * mask.to(d_table.dtype)).contiguous()
                 dgi, dgh = torch.empty_like(gi), torch.empty_like(gh)
-                check(lib().tg_gru_gates_bwd(ops._p(gi), ops._p(gh), ops._p(h_rows), ops._p(dm), dm.shape[0], dm.shape[1], ops._p(dgi), ops._p(dgh),
-                                             ops._p(None), ops._stream()), "tg_gru_gates_bwd")
+                check(lib().tg_gru_gates_bwd_masked(ops._p(gi), ops._p(gh), ops._p(h_rows), ops._p(d_table), ops._p(uniq), ops._p(bank._has_dev),
+                                                    d_table.shape[0], d_table.shape[1], ops._p(dgi), ops._p(dgh), ops._stream()),
+                      "tg_gru_gates_bwd_masked")
                 ops.wgrad_group([(dgi, msg_rows, gv[0], gv[2]), (dgh, h_rows, gv[1], gv[3])])
             g = zeroed[:npar + gru_len]
             if flat[0].grad is None:

@@ -340,6 +340,17 @@ int tg_msg_scatter_last(const int32_t* d_nodes, const float* d_msgs, int64_t msg
  * h_count_pad (pinned, 2 ints) receives (count, padding row) with an async copy.  h_uniq_nodes / h_last_time (2n each, optional): the
  * distinct batch nodes and the time of each one's last occurrence in [src | dst] order (host mirror of :155-180), *h_num_uniq of them.
  * TG_ERANGE for an id outside [0, num_nodes). */
+/* the touched rows of a lazily updated TGN memory in one call (models/MemoryModel.py:117, :191-231, :501-543, :654-655): for the
+ * `count` distinct touched nodes d_uniq[r]: h = memory[node], x = pending message[node], GRU cell (nn.GRUCell, :531-543),
+ * rows = has_message[node] ? GRU : h (the updated memory, not persisted), base = rows + raw features[node].  pending = 0 skips the GRU
+ * (no node of the graph holds a message).  d_h_rows (count, d), d_msg_rows (count, msg_dim), d_gi / d_gh (count, 3 d) are kept for
+ * backward; tg_gru_gates_bwd_masked is tg_gru_gates_bwd with the upstream gradient zeroed for rows without a message. */
+int tg_tgn_rows_fwd(const float* d_mem, int64_t mem_ld, const float* d_msg, int64_t msg_ld, const float* d_raw, int64_t raw_ld,
+                    const int32_t* d_uniq, int64_t count, const int32_t* d_has, int d, int msg_dim, const float* d_w_ih,
+                    const float* d_w_hh, const float* d_b_ih, const float* d_b_hh, int pending, float* d_h_rows, float* d_msg_rows,
+                    float* d_gi, float* d_gh, float* d_rows, float* d_base, void* stream);
+int tg_gru_gates_bwd_masked(const float* d_gi, const float* d_gh, const float* d_h, const float* d_dout, const int32_t* d_uniq,
+                            const int32_t* d_has, int64_t n, int d, float* d_dgi, float* d_dgh, void* stream);
 /* host mirror of one positive batch's state advance (models/MemoryModel.py:155-180, assertion of :485-486), numpy arrays in place:
  * nodes u[i] with a pending message get it applied (last_update = its time), then each files a new message at new_t[i].  TG_EINVAL
  * ("Trying to update memory to time in the past!") leaves everything unchanged; *next_violation = 1 when a filed message is older
