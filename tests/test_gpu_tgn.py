@@ -272,3 +272,34 @@ def test_tgn_regeneration_sweep_equals_sequential_positive_calls():
             a, b = mb.compute_src_dst_node_temporal_embeddings(g["src"][lo:lo + 12], g["dst"][lo:lo + 12], g["t"][lo:lo + 12], g["eid"][lo:lo + 12], True, k)
             assert float((a - s_store[lo:lo + 12]).abs().max()) < 2e-6 and float((b - d_store[lo:lo + 12]).abs().max()) < 2e-6
     assert torch.allclose(ma.memory_bank.node_memories, mb.memory_bank.node_memories, atol=1e-6)
+
+
+def test_prepare_batch_rejects_ids_beyond_the_graph_and_counts_history_on_the_host():
+    """tg_tgn_prepare_batch raises the reference's IndexError for an id beyond the graph (before anything is launched);
+    TemporalGraph.count_before_host (the host-side binary searches DyGFormer shapes its windows with) equals the oracle's history_end"""
+    from flid_amd.models.MemoryModel import MemoryModel
+    from flid_amd.synth import reddit_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = reddit_like(num_edges=5000, seed=1)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = MemoryModel(data.node_raw_features, data.edge_raw_features, sampler, 100, "TGN", 1, 2, 0.0, device="cuda:0").to("cuda:0").train()
+    m.memory_bank.__init_memory_bank__()
+    sl = slice(3000, 3100)
+    bad = data.src_node_ids[sl].copy()
+    bad[7] = m.num_nodes + 3
+    with pytest.raises(IndexError):
+        m.prepare_batch_begin(bad, data.dst_node_ids[sl], data.node_interact_times[sl], 20, edge_ids=data.edge_ids[sl])
+    job = m.prepare_batch_finish(m.prepare_batch_begin(data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl], 20,
+                                                       edge_ids=data.edge_ids[sl]))
+    torch.cuda.synchronize()
+    both = np.concatenate([data.src_node_ids[sl], data.dst_node_ids[sl]])
+    assert sorted(job["u"].tolist()) == sorted(set(both.tolist()))
+    last = {int(v): t for v, t in zip(both, np.concatenate([data.node_interact_times[sl]] * 2))}
+    assert all(last[int(v)] == t for v, t in zip(job["u"], job["new_t"]))
+    uniq = set(job["uniq"].cpu().tolist())
+    assert set(both.tolist()) <= uniq and set(job["S"][0].cpu().numpy().reshape(-1).tolist()) <= uniq
+    adj = O.build_adjacency(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times)
+    ids = data.dst_node_ids[2000:2600]
+    times = data.node_interact_times[2000:2600]
+    want = np.array([O.history_end(adj, int(v), t) for v, t in zip(ids, times)])
+    assert np.array_equal(sampler.graph.count_before_host(ids, times), want)
