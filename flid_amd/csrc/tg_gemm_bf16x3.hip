@@ -507,14 +507,22 @@ constexpr int WBM = 64, WNT = 128;     // weight-gradient workgroup: 2 waves x (
                                        // 256 / 384 / 256) and 46 KB of LDS lets 3 workgroups share a CU: measured 80 / 99 / 57 us ->
                                        // 52 / 73 / 50 us for the three launches of a 13.6 k-row layer.
 template <int TNW>
-__global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int64_t K, int64_t k_chunk) {
+__global__ void __launch_bounds__(WNT) gemm_bf16x3_wgrad_kernel(WgJobs jobs, int64_t K, int64_t k_chunk, int nslices) {
     constexpr int BNt = 32 * TNW;
     constexpr int FA = WBM * ROW_BYTES, FB = BNt * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
     auto sA = [&](int i) -> char* { return lds + i * (FA + FB); };
     auto sB = [&](int i) -> char* { return lds + i * (FA + FB) + FA; };
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int slice = xcd + 8 * (jj / jobs.total_tiles), t = jj % jobs.total_tiles;
+    int slice, t;
+    if (nslices >= 8) {                     // slices in multiples of 8: slice s lives on XCD s % 8
+        slice = xcd + 8 * (jj / jobs.total_tiles);
+        t = jj % jobs.total_tiles;
+    } else {                                // 1, 2 or 4 slices: 8 / nslices tiles of the same slice side by side on as many XCDs
+        slice = xcd % nslices;
+        t = jj * (8 / nslices) + xcd / nslices;
+        if (t >= jobs.total_tiles) return;
+    }
     int ji = 0;
 #pragma unroll
     for (int q = 1; q < 8; ++q) if (q < jobs.n && t >= jobs.j[q].tile0) ji = q;
@@ -678,10 +686,13 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
     const int64_t per = 700 / std::max<int64_t>(1, tiles_c[best_tnw - 2]);
     int64_t best_slices = per >= 10 ? std::max<int64_t>(16, per / 8 * 8) : 8;
     if (best_slices > max_slices) best_slices = max_slices;
+    // few rows (the root layer's 1 200): 8 slices are 5 stages each and an 8-fold atomic fold -- 2 or 4 slices of >= 256 rows, their
+    // tiles spread over the XCDs instead (all six gradients of a 1 200-row layer: 42.9 us with 8 slices, 29.3 with 4, 28.6 with 2)
+    if (rows < 2048) best_slices = rows >= 1024 ? 4 : (rows >= 512 ? 2 : 1);
     static const bool tuning = getenv("FLID_GEMM_TUNE") != nullptr;          // overrides are read only in tuning mode (tools/)
     if (tuning) {
         if (const char* e = getenv("FLID_WG_TNW")) { const int v = atoi(e); if (v == 2 || v == 3) best_tnw = v; }
-        if (const char* e = getenv("FLID_WG_SLICES")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0) best_slices = v; }
+        if (const char* e = getenv("FLID_WG_SLICES")) { const int v = atoi(e); if ((v >= 8 && v % 8 == 0) || v == 4 || v == 2 || v == 1) best_slices = v; }
         if (getenv("FLID_WG_VERBOSE")) fprintf(stderr, "[wgrad] jobs=%d rows=%lld tnw=%d slices=%lld\n", njobs, (long long)rows, best_tnw, (long long)best_slices);
     }
     const int tnw = best_tnw;
@@ -703,13 +714,13 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
     const int64_t slices = best_slices;
     int64_t k_chunk = ((rows + slices - 1) / slices + BK - 1) / BK * BK;
     if (k_chunk < BK) k_chunk = BK;
-    const int64_t blocks = (int64_t)wj.total_tiles * slices;
+    const int64_t blocks = slices >= 8 ? (int64_t)wj.total_tiles * slices : ((wj.total_tiles + 8 / slices - 1) / (8 / slices)) * 8;
     if (blocks >= ((int64_t)1 << 31)) return false;
     for (int i = 0; i < njobs; ++i)          // a K slice of either operand is addressed with 32-bit byte offsets (buffer loads)
         if ((k_chunk + 4 * BK) * std::max(jobs[i].lda, jobs[i].ldb) * 4 >= ((int64_t)1 << 31)) return false;
     ProfScope prof("gemm", flops, s);
-    if (tnw == 3) gemm_bf16x3_wgrad_kernel<3><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk);
-    else gemm_bf16x3_wgrad_kernel<2><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk);
+    if (tnw == 3) gemm_bf16x3_wgrad_kernel<3><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk, (int)slices);
+    else gemm_bf16x3_wgrad_kernel<2><<<(unsigned)blocks, WNT, 0, s>>>(wj, rows, k_chunk, (int)slices);
     return true;
 }
 

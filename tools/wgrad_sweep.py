@@ -20,7 +20,7 @@ for R in (int(v) for v in (sys.argv[1:] or ["13622", "1200"])):
         out = [f"{name[:14]:14s} R={R:6d} model {base:6.1f} |"]
         for tnw in (2, 3):
             os.environ["FLID_WG_TNW"] = str(tnw)
-            for sl in (8, 16, 24, 32, 40, 48, 64):
+            for sl in (2, 4, 8, 16, 24, 32):
                 if sl * 128 > R:
                     continue
                 os.environ["FLID_WG_SLICES"] = str(sl)
