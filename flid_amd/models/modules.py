@@ -66,8 +66,9 @@ class _LinearFn(torch.autograd.Function):
             # when the shapes allow it; otherwise one exact product + one column sum
             n_out, n_in = w.shape
             if n_out % 4 == 0 and n_in % 4 == 0 and dy2.shape[0] >= 256 and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0:
-                dw = torch.zeros_like(w)
-                db = torch.zeros(n_out, device=w.device) if need_b else None
+                zb = torch.zeros(n_out * n_in + (n_out if need_b else 0), device=w.device)       # one fill for both gradients
+                dw = zb[:n_out * n_in].view(n_out, n_in)
+                db = zb[n_out * n_in:] if need_b else None
                 ops.wgrad_group([(dy2, x2, dw, db)])
                 need_b = False
             else:
