@@ -43,6 +43,12 @@ class LayerBwdDesc(C.Structure):
                 ("d_own_accumulate", C.c_int), ("d_raw", c_void), ("defer_join", C.c_int)]
 
 
+class PackJob(C.Structure):
+    """struct tg_pack_job"""
+    _fields_ = [("src", c_void), ("ld", c_i64), ("N", C.c_int), ("K", C.c_int), ("trans", C.c_int), ("dst", c_void)] + \
+               [(n, C.c_int) for n in ("src_N", "src_K", "n_len", "n_pad", "k_len", "k_pad")]
+
+
 class WgradJob(C.Structure):
     """struct tg_wgrad_job"""
     _fields_ = [("A", c_void), ("lda", c_i64), ("M", C.c_int), ("B", c_void), ("ldb", c_i64), ("N", C.c_int), ("C", c_void), ("ldc", c_i64),
@@ -90,7 +96,11 @@ SIGNATURES = {
     "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
                               c_void, C.c_int, C.c_int, c_void]),
     "tg_gemm_f32_nt_masked": (C.c_int, [c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void]),
+    "tg_packed_floats": (c_i64, [C.c_int, C.c_int]),
+    "tg_pack_weights": (C.c_int, [C.c_int, C.POINTER(PackJob), c_void]),
+    "tg_gemm_rows_nt": (C.c_int, [c_i64, C.c_int, C.c_int, c_void, c_i64, c_void, c_void, c_i64, c_void, C.c_int, C.c_int, c_void, c_i64, c_void]),
     "tg_wgrad_group": (C.c_int, [C.c_int, C.POINTER(WgradJob), c_i64, c_void]),
+    "tg_set_wgrad_form": (None, [C.c_int]),
     "tg_set_gemm_mode": (None, [C.c_int]),
     "tg_get_gemm_mode": (C.c_int, []),
     "tg_gemm_f32_batched": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_void,

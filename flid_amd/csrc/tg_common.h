@@ -67,6 +67,13 @@ inline int64_t attn_grid_blocks(int64_t m) {
     const int64_t b = (m + 3) / 4;
     return b < 1 ? 1 : (b > kAttnMaxBlocks ? kAttnMaxBlocks : b);
 }
+// tg_gemm_rows.hip: products on packed weights (false = shape / alignment not covered, nothing launched)
+int64_t packed_floats(int N, int K);
+int pack_weights(int njobs, const tg_pack_job* jobs, hipStream_t s);
+bool gemm_rows_nt(int64_t R, int N, int K, const float* A, int64_t lda, int64_t strideA, const void* packed, int64_t packed_stride_floats,
+                  float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate, const float* mask,
+                  int64_t ldm, hipStream_t s);
+bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);  // tg_wgrad.hip: big tiles + transposing LDS reads + slice fold
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);   // tg_gemm_bf16x3.hip; false = shapes not covered
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,

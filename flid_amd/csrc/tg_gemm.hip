@@ -569,7 +569,7 @@ extern "C" int tg_gemm_f32_nt_masked(int64_t M, int64_t N, int64_t K, const floa
 extern "C" int tg_wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, void* stream) {
     TG_REQUIRE(jobs && njobs >= 1 && njobs <= 8 && rows >= 0, "tg_wgrad_group: arguments");
     if (rows == 0) return TG_OK;
-    if (!tg::wgrad_group(njobs, jobs, rows, (hipStream_t)stream)) {
+    if (!tg::wgrad_group2(njobs, jobs, rows, (hipStream_t)stream) && !tg::wgrad_group(njobs, jobs, rows, (hipStream_t)stream)) {
         tg::set_error("invalid argument: tg_wgrad_group: shape / alignment not covered (M, N, lda, ldb multiples of 4, 16-byte aligned operands)");
         return TG_EINVAL;
     }

@@ -844,7 +844,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             tg_wgrad_job q[8];
             const int n = (int)jobs.size();
             for (int i = 0; i < n; ++i) q[i] = tg_wgrad_job{jobs[i].A, jobs[i].lda, jobs[i].M, jobs[i].B, jobs[i].ldb, jobs[i].N, jobs[i].C, jobs[i].ldc, jobs[i].cs};
-            if (g_wgrad_grouped && tg::wgrad_group(n, q, R, st)) return tg::launch_status("gemm_bf16x3_wgrad_kernel");
+            if (g_wgrad_grouped && (tg::wgrad_group2(n, q, R, st) || tg::wgrad_group(n, q, R, st))) return tg::launch_status("wgrad kernel");
             for (int i = 0; i < n; ++i) {
                 TG_TRY(tg_gemm_f32(1, 0, q[i].M, q[i].N, R, 1.f, q[i].A, q[i].lda, q[i].B, q[i].ldb, q[i].C, q[i].ldc, nullptr, 0, 1, stv));
                 if (q[i].colsum_A) TG_TRY(colsum_seg(q[i].A, q[i].lda, R, q[i].M, seg1(q[i].colsum_A, q[i].M), st));

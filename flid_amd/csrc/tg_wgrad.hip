@@ -1,0 +1,406 @@
+// Weight gradients of a layer, second form:  C_j[M_j, N_j] += A_j^T B_j  (A_j: rows x M_j, B_j: rows x N_j, row-major fp32; the
+// contraction index is the ROW index of both operands), up to 8 products over the same rows in ONE launch + one fold launch.
+//
+// replaces: the autograd weight / bias gradients of every nn.Linear of a temporal-attention layer (models/modules.py:54-69, :152-163,
+//           :235) -- same contract as the first form (gemm_bf16x3_wgrad_kernel in tg_gemm_bf16x3.hip), which stays as the fall-back.
+//
+// What the first form paid for (profiles/r02: 117 us for the six gradients of a 13.6 k-row layer, matrix pipe 15 % busy):
+//   * 64 x 64 output tiles: every operand element was staged (and split fp32 -> bf16 hi / lo) by 3-7 different workgroups;
+//   * a 4 x 4 register transpose per micro-tile, because the MFMA wants 8 consecutive k per lane and the operands are k-major;
+//   * 16 K slices folded with float atomics: 16 x 600 k atomic adds per launch at the chip's ~1.3 TB/s atomic rate.
+// Here
+//   * a workgroup owns a 192 x 256 output tile (8 waves as 2 x 4, each 96 x 64 = six 32 x 32 accumulators): the five products of a
+//     layer are 16 tiles, each operand element is staged 1-3 times;
+//   * operands go to LDS as they lie in memory ([k][column] bf16 hi / lo planes, 8-byte stores of 4 consecutive columns) and come
+//     back through ds_read_b64_tr_b16, the transposing LDS read of gfx950: no register transpose, no VALU besides the split;
+//   * K slices write their partial tiles with plain stores into a workspace; a second, tiny launch adds the slices in fixed order
+//     into C (deterministic, no atomics).  The bias gradient rides along as before: a column of ones appended to B.
+// Split-bf16 arithmetic as in tg_gemm_bf16x3.hip: hi*hi + hi*lo + lo*hi in v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <mutex>
+
+#include "tg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TMB = 6, TNB = 8;                 // tile extent in 32-blocks
+constexpr int TM = 32 * TMB, TN = 32 * TNB;     // 192 x 256
+constexpr int CK = 32;                          // contraction rows per chunk
+constexpr int WNT = 512;
+constexpr int AST = TM * 2 + 64, BST = TN * 2 + 64;      // LDS row strides (bytes): +64 spreads the 4 rows of a transposed read over all banks
+constexpr int A_PLANE = CK * AST, B_PLANE = CK * BST;
+constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+constexpr int NA = TM / 4 * CK / WNT, NB = TN / 4 * CK / WNT;      // float4 per thread and chunk: 3 + 4
+static_assert(TM / 4 * CK % WNT == 0 && TN / 4 * CK % WNT == 0, "staging must tile the workgroup");
+#ifndef FLID_WG2_SCHED
+#define FLID_WG2_SCHED 1
+#endif
+#ifndef FLID_WG2_EXP
+#define FLID_WG2_EXP 0   // timing experiments only (results wrong): 1 no steady-state loads, 2 no MFMAs, 3 no LDS stores
+#endif
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float bf16_lo_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
+__device__ __forceinline__ float bf16_hi_to_f32(uint32_t packed) { return __builtin_bit_cast(float, packed & 0xFFFF0000u); }
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+    hi.x = pack_bf16(v.x, v.y);
+    hi.y = pack_bf16(v.z, v.w);
+    lo.x = pack_bf16(v.x - bf16_lo_to_f32(hi.x), v.y - bf16_hi_to_f32(hi.x));
+    lo.y = pack_bf16(v.z - bf16_lo_to_f32(hi.y), v.w - bf16_hi_to_f32(hi.y));
+}
+
+struct WTile {
+    const float *A, *B;         // operand columns of this tile: A + m0, B + n0
+    int64_t lda, ldb;
+    int mext, next;             // valid columns of A / B in the tile (multiples of 4)
+    int ones_col;               // column of the B tile that reads as 1.0 (the bias gradient), or -1
+    int nw;                     // stored width = next (+ 4 if ones_col >= 0)
+    int64_t slab_off;           // floats, inside one slice of the workspace
+    float* C; int64_t ldc;      // fold: C[m0.., n0..] += ...; colsum[m0..] += column ones_col
+    float* colsum;
+};
+constexpr int MAX_TILES = 24;
+struct WTiles { WTile t[MAX_TILES]; int n; };
+
+// 8 bf16 of one MFMA operand fragment from a [k][column] image: two transposing reads (k = 8 h + 0..3, 8 h + 4..7)
+__device__ __forceinline__ bf16x8 frag_tr(const char* p, int stride) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * stride));
+    const s16x8 v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ void __launch_bounds__(WNT, 2) wgrad2_kernel(WTiles tiles, int64_t R, int64_t rows_per_slice, int nslices, float* __restrict__ ws,
+                                                         int64_t slice_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int t, slice;
+    if ((nslices & 7) == 0) {                       // all tiles of a K slice on one XCD: its L2 pulls that row range of the operands once
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        t = j % tiles.n;
+        slice = xcd + 8 * (j / tiles.n);
+    } else {
+        t = blockIdx.x % tiles.n;
+        slice = blockIdx.x / tiles.n;
+    }
+    const WTile T = tiles.t[t];
+    const int64_t kbeg = (int64_t)slice * rows_per_slice;
+    const int64_t kend = kbeg + rows_per_slice < R ? kbeg + rows_per_slice : R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunks = kend > kbeg ? (int)((kend - kbeg + CK - 1) / CK) : 0;
+
+    // ---- staging map: A float4 f = tid + 512 i -> (row f / 48, chunk f % 48); B f -> (row f >> 6, chunk f & 63)
+    const float* pa[NA];
+    const float* pb[NB];
+    int ra_row[NA], rb_row[NB], la[NA], lb[NB];
+    bool ca_ok[NA], cb_ok[NB], ones[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + WNT * i, row = f / (TM / 4), c4 = f % (TM / 4);
+        ra_row[i] = row;
+        ca_ok[i] = 4 * c4 < T.mext;
+        la[i] = row * AST + c4 * 8;
+        pa[i] = T.A + (ca_ok[i] ? 4 * c4 : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = tid + WNT * i, row = f / (TN / 4), c4 = f % (TN / 4);
+        rb_row[i] = row;
+        cb_ok[i] = 4 * c4 < T.next;
+        ones[i] = 4 * c4 == T.ones_col;
+        lb[i] = row * BST + c4 * 8;
+        pb[i] = T.B + (cb_ok[i] ? 4 * c4 : 0);
+    }
+    auto load = [&](float4 (&xa)[NA], float4 (&xb)[NB], int c) {
+        const int64_t k0 = kbeg + (int64_t)c * CK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int64_t k = k0 + ra_row[i];
+            if (k > R - 1) k = R - 1;
+            xa[i] = *reinterpret_cast<const float4*>(pa[i] + k * T.lda);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int64_t k = k0 + rb_row[i];
+            if (k > R - 1) k = R - 1;
+            xb[i] = *reinterpret_cast<const float4*>(pb[i] + k * T.ldb);
+        }
+    };
+    // one staging unit = one float4 of the next chunk: mask, split, two 8-byte LDS stores (u < NA: operand A, else B)
+    auto store_unit = [&](char* base, const float4 (&xa)[NA], const float4 (&xb)[NB], int64_t k0, int u) {
+        if (u < NA) {
+            const int i = u;
+            const bool ok = ca_ok[i] && k0 + ra_row[i] < kend;
+            const float4 v = make_float4(ok ? xa[i].x : 0.f, ok ? xa[i].y : 0.f, ok ? xa[i].z : 0.f, ok ? xa[i].w : 0.f);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            if (FLID_WG2_EXP != 3) {
+                *reinterpret_cast<uint2*>(base + la[i]) = hi;
+                *reinterpret_cast<uint2*>(base + A_PLANE + la[i]) = lo;
+            }
+        } else {
+            const int i = u - NA;
+            const bool rok = k0 + rb_row[i] < kend;
+            const bool ok = cb_ok[i] && rok;
+            float4 v = make_float4(ok ? xb[i].x : 0.f, ok ? xb[i].y : 0.f, ok ? xb[i].z : 0.f, ok ? xb[i].w : 0.f);
+            if (ones[i]) v.x = rok ? 1.f : 0.f;
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            if (FLID_WG2_EXP != 3) {
+                *reinterpret_cast<uint2*>(base + 2 * A_PLANE + lb[i]) = hi;
+                *reinterpret_cast<uint2*>(base + 2 * A_PLANE + B_PLANE + lb[i]) = lo;
+            }
+        }
+    };
+    auto store = [&](int stage, const float4 (&xa)[NA], const float4 (&xb)[NB], int c) {
+        const int64_t k0 = kbeg + (int64_t)c * CK;
+#pragma unroll
+        for (int u = 0; u < NA + NB; ++u) store_unit(lds + stage * STAGE, xa, xb, k0, u);
+    };
+
+    // ---- fragments: wave (wm, wn) owns blocks [3 wm, 3 wm + 3) x [2 wn, 2 wn + 2)
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, h = g >> 1, mh = g & 1, q = (lane & 15) >> 2, p = lane & 3;
+    const int fa = (8 * h + q) * AST + (32 * 3 * wm + 16 * mh + 4 * p) * 2;
+    const int fb = (8 * h + q) * BST + (32 * 2 * wn + 16 * mh + 4 * p) * 2;
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // One half of the chunk pipeline (see gemm_rows_kernel: what a half waits for was issued a whole half earlier), ONE basic block
+    // (a chunk past the end stores zeros and multiplies them), scheduled by hand: the 36 MFMAs of chunk c (stage `cur`) in 12 groups
+    // of three; under 7 of the groups one staging unit of chunk c + 1 (~26 VALU instructions + 2 LDS stores into stage `nxt`), under
+    // the others the loads of chunk c + 3 into the registers the units have freed.  The two waves of a SIMD leave every barrier
+    // together: with all staging ahead of all products they used the vector and the matrix pipe in turn (68 us for a 13.6 k-row layer).
+    auto half = [&](int cur, int nxt, float4 (&xa)[NA], float4 (&xb)[NB], int c_next, int c_load) {
+        const char* base = lds + cur * STAGE;
+        char* nbase = lds + nxt * STAGE;
+        const int64_t k0n = kbeg + (int64_t)c_next * CK;
+        const int64_t k0l = kbeg + (int64_t)c_load * CK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[3], al[3], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ah[i] = frag_tr(base + fa + ks * 16 * AST + i * 64, AST);
+                al[i] = frag_tr(base + A_PLANE + fa + ks * 16 * AST + i * 64, AST);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = frag_tr(base + 2 * A_PLANE + fb + ks * 16 * BST + j * 64, BST);
+                bl[j] = frag_tr(base + 2 * A_PLANE + B_PLANE + fb + ks * 16 * BST + j * 64, BST);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int grp = 0; grp < 6; ++grp) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const int mm = grp * 3 + e, term = mm / 6, i = (mm % 6) / 2, j = mm % 2;
+                    if (FLID_WG2_EXP == 2) {
+                        const float4 x = __builtin_bit_cast(float4, ah[i]), y = __builtin_bit_cast(float4, bh[j]);
+                        const float4 z = __builtin_bit_cast(float4, al[i]), w = __builtin_bit_cast(float4, bl[j]);
+                        acc[i][j][term] += x.x + y.y + z.z + w.w;
+                    } else if (term == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    else if (term == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+                const int slot = ks * 6 + grp;                  // 0..11
+                if (slot < NA + NB) {
+                    store_unit(nbase, xa, xb, k0n, slot);
+#if FLID_WG2_SCHED
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+#endif
+                } else if (FLID_WG2_EXP != 1) {
+                    // loads of chunk c_load: NA + NB float4 over the remaining 12 - (NA + NB) groups
+                    constexpr int REM = 12 - (NA + NB);
+                    const int r = slot - (NA + NB);
+#pragma unroll
+                    for (int u = 0; u < NA + NB; ++u) {
+                        if (u * REM / (NA + NB) != r) continue;
+                        if (u < NA) {
+                            int64_t k = k0l + ra_row[u];
+                            if (k > R - 1) k = R - 1;
+                            xa[u] = *reinterpret_cast<const float4*>(pa[u] + k * T.lda);
+                        } else {
+                            int64_t k = k0l + rb_row[u - NA];
+                            if (k > R - 1) k = R - 1;
+                            xb[u - NA] = *reinterpret_cast<const float4*>(pb[u - NA] + k * T.ldb);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    float4 xa0[NA], xb0[NB], xa1[NA], xb1[NB];
+    if (nchunks > 0) {
+        load(xa0, xb0, 0);
+        load(xa1, xb1, 1);
+        store(0, xa0, xb0, 0);
+        load(xa0, xb0, 2);
+        __syncthreads();
+        for (int c = 0; c < nchunks; c += 2) {
+            half(0, 1, xa1, xb1, c + 1, c + 3);
+            __syncthreads();
+            half(1, 0, xa0, xb0, c + 2, c + 4);
+            __syncthreads();
+        }
+    }
+    // ---- partial tile -> workspace (plain stores, 128 contiguous bytes per half wave)
+    float* dst = ws + (int64_t)slice * slice_stride + T.slab_off;
+    const int col = lane & 31, rh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = 32 * (2 * wn + j) + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * (3 * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * rh;
+                if (m < T.mext && n < T.nw) dst[(int64_t)m * T.nw + n] = acc[i][j][r];
+            }
+        }
+}
+
+// C += sum over slices (fixed order); the ones column lands in colsum.  One element per thread, the slices' loads independent.
+__global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, int nslices, const float* __restrict__ ws, int64_t slice_stride) {
+    const WTile T = tiles.t[blockIdx.y];
+    const int64_t total = (int64_t)T.mext * T.nw;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int m = (int)(e / T.nw), n = (int)(e - (int64_t)m * T.nw);
+    if (n >= T.next && n != T.ones_col) return;
+    const float* p = ws + T.slab_off + e;
+    float s = 0.f;
+    int sl = 0;
+    for (; sl + 8 <= nslices; sl += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(sl + q) * slice_stride];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; sl < nslices; ++sl) s += p[(int64_t)sl * slice_stride];
+    if (n < T.next) T.C[(int64_t)m * T.ldc + n] += s;
+    else if (T.colsum) T.colsum[m] += s;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct Ws { hipStream_t stream; float* p; size_t floats; };
+Ws g_ws[4] = {};
+std::mutex g_ws_mutex;
+float* workspace(size_t need, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    Ws* w = nullptr;
+    for (auto& c : g_ws) if (c.p && c.stream == s) { w = &c; break; }
+    if (!w) for (auto& c : g_ws) if (!c.p) { w = &c; w->stream = s; break; }
+    if (!w) return nullptr;
+    if (need > w->floats) {
+        if (w->p) { if (hipStreamSynchronize(s) != hipSuccess) return nullptr; (void)hipFree(w->p); w->p = nullptr; w->floats = 0; }
+        const size_t want = need + need / 4;
+        if (hipMalloc(&w->p, want * sizeof(float)) != hipSuccess) { w->p = nullptr; (void)hipGetLastError(); return nullptr; }
+        w->floats = want;
+    }
+    return w->p;
+}
+
+bool g_wgrad2 = true;
+
+}  // namespace
+
+namespace tg {
+
+// false = a job's shape / alignment is not covered or no workspace (nothing launched): the caller takes the first form
+bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s) {
+    if (!g_wgrad2 || njobs < 1 || njobs > 8 || rows < 1) return false;
+    WTiles wt;
+    wt.n = 0;
+    int64_t slab = 0;
+    double flops = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const tg_wgrad_job& q = jobs[i];
+        if (!(q.A && q.B && q.C && q.M >= 4 && q.N >= 4 && q.M % 4 == 0 && q.N % 4 == 0 && q.lda % 4 == 0 && q.ldb % 4 == 0 && al16(q.A) && al16(q.B)))
+            return false;
+        if (q.lda < q.M || q.ldb < q.N || q.ldc < q.N) return false;
+        const int nfull = q.N + (q.colsum_A ? 4 : 0);                       // the ones column takes a 4-column slot of its own
+        const int mb = (q.M + 31) / 32, nb = (nfull + 31) / 32;
+        const int gm = (mb + TMB - 1) / TMB, gn = (nb + TNB - 1) / TNB;
+        const int em = (mb + gm - 1) / gm * 32, en = (nb + gn - 1) / gn * 32;   // balanced extents (multiples of 32)
+        for (int a = 0; a < gm; ++a)
+            for (int b = 0; b < gn; ++b) {
+                if (wt.n >= MAX_TILES) return false;
+                WTile& T = wt.t[wt.n++];
+                const int m0 = a * em, n0 = b * en;
+                T.A = q.A + m0; T.B = q.B + n0; T.lda = q.lda; T.ldb = q.ldb;
+                T.mext = std::min(em, q.M - m0);
+                T.next = std::max(0, std::min(en, q.N - n0));
+                const bool has_ones = q.colsum_A && q.N >= n0 && q.N < n0 + en;
+                T.ones_col = has_ones ? q.N - n0 : -1;
+                T.nw = T.next + (has_ones ? 4 : 0);
+                if (T.mext <= 0 || T.nw <= 0) { --wt.n; continue; }
+                T.slab_off = slab;
+                slab += (int64_t)T.mext * T.nw;
+                T.C = q.C + (int64_t)m0 * q.ldc + n0; T.ldc = q.ldc;
+                T.colsum = has_ones ? q.colsum_A + m0 : nullptr;
+            }
+        flops += 2.0 * q.M * q.N * rows;
+    }
+    slab = (slab + 3) / 4 * 4;
+    // K slices: ~256 workgroups (one per CU: 128 KB of LDS each); a multiple of 8 pins each slice to an XCD
+    int64_t slices = std::max<int64_t>(1, 256 / wt.n);
+    if (slices >= 8) slices = slices / 8 * 8;
+    const int64_t max_slices = std::max<int64_t>(1, rows / (2 * CK));
+    if (slices > max_slices) slices = max_slices;
+    static const bool tuning = getenv("FLID_GEMM_TUNE") != nullptr;
+    if (tuning) if (const char* e = getenv("FLID_WG2_SLICES")) { const int v = atoi(e); if (v >= 1) slices = v; }
+    int64_t rps = ((rows + slices - 1) / slices + CK - 1) / CK * CK;
+    slices = (rows + rps - 1) / rps;
+    if (slices >= 8 && slices % 8) {                    // keep the XCD pinning: round the slice count up to a multiple of 8 (empty tails are legal)
+        slices = (slices + 7) / 8 * 8;
+    }
+    float* ws = workspace((size_t)(slices * slab), s);
+    if (!ws) return false;
+    ProfScope prof("gemm", flops, s);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
+    wgrad2_kernel<<<(unsigned)(wt.n * slices), WNT, 2 * STAGE, s>>>(wt, rows, rps, (int)slices, ws, slab);
+    if (hipGetLastError() != hipSuccess) return false;
+    wgrad2_fold_kernel<<<dim3((TM * (TN + 4) + 255) / 256, (unsigned)wt.n), 256, 0, s>>>(wt, (int)slices, ws, slab);
+    return true;
+}
+
+}  // namespace tg
+
+extern "C" void tg_set_wgrad_form(int form) { g_wgrad2 = form != 1; }

@@ -235,6 +235,26 @@ int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, float scale, 
 int tg_gemm_f32_nt_masked(int64_t M, int64_t N, int64_t K, const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
                           const float* d_Y, int64_t ldy, void* stream);
 
+/* ---- row-block products on PACKED weights (split-bf16 MFMA, tg_gemm_rows.hip) -----------------------------
+ * replaces the aten::mm / addmm calls behind the nn.Linear layers of models/modules.py:54-69,152-163,199-235 (and their input
+ * gradients) for the tall-times-small products of a layer: C[R,N] = A[R,K] W^T (+ bias[N]) (+ C) (ReLU) (keep where mask > 0).
+ * W is given PACKED: tg_pack_weights splits an (N x K) fp32 weight into bf16 hi / lo and stores it in MFMA fragment order,
+ * tg_packed_floats(N, K) floats per weight, once per optimizer step (weights change only there).
+ *   trans = 0: W[n][k] = src[n * ld + k];  trans = 1: W[n][k] = src[k * ld + n] (the transposed weight of an input gradient).
+ * Constraints of tg_gemm_rows_nt: N, K, lda, ldc multiples of 4, 16-byte aligned operands (else TG_EINVAL: use
+ * tg_gemm_f32 on the unpacked weight). */
+typedef struct tg_pack_job {
+    const float* src; int64_t ld; int N, K, trans; void* dst;
+    /* optional index maps (0 = identity): packed row n' -> source row (n' / n_pad) * n_len + n' % n_pad, zero where n' % n_pad >= n_len or
+     * the source row >= src_N (0 = N); the same for columns with k_len / k_pad / src_K.  They let a fused chain keep an intermediate
+     * in a padded layout (per-head blocks rounded up to MFMA tiles, [y | raw] with each part rounded up to 32) */
+    int src_N, src_K, n_len, n_pad, k_len, k_pad;
+} tg_pack_job;
+int64_t tg_packed_floats(int N, int K);
+int tg_pack_weights(int njobs, const tg_pack_job* jobs, void* stream);
+int tg_gemm_rows_nt(int64_t R, int N, int K, const float* d_A, int64_t lda, const void* d_packed, float* d_C, int64_t ldc,
+                    const float* d_bias, int relu, int accumulate, const float* d_mask, int64_t ldm, void* stream);
+
 /* ---- grouped weight gradients (split-bf16 MFMA) ------------------------------------------------------
  * replaces the autograd weight / bias gradients of the nn.Linear layers in models/modules.py:54-69,152-163,235 for one layer:
  * up to 8 products C_j[M_j, N_j] += A_j^T B_j over the same `rows` (A_j: rows x M_j, B_j: rows x N_j, row-major) in ONE launch;
@@ -248,6 +268,9 @@ typedef struct tg_wgrad_job {
     float* colsum_A;
 } tg_wgrad_job;
 int tg_wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, void* stream);
+/* 2 (default): 192 x 256 output tiles, transposing LDS reads, K slices folded in fixed order by a second launch (deterministic);
+ * 1: the first form (64 x 64 tiles, float-atomic fold) -- A/B tests and the fall-back for shapes form 2 does not cover */
+void tg_set_wgrad_form(int form);
 
 /* ---- synthetic feature tables (measurement only) ---------------------------
  * out[r, c] = f(row0 + r, c, seed), uniform with unit variance, row 0 = 0; the stand-in for the node / edge feature blobs
