@@ -7,7 +7,9 @@ on the Wikipedia-shape synthetic graph (BASELINE.json configs[1]: batch 600, 20 
 
 A step = one pass of the hot path over one batch of 600 edges per GPU (weak scaling: rank r of N takes batch step*N + r of
 the chronological stream), a scalar loss on both outputs, backward to every backbone parameter, the RCCL gradient all-reduce
-when N > 1, and the Adam update.  Batch ids/times are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+when N > 1, and the Adam update.  The feature tables and the graph are resident in HBM; a batch's ids / times enter each call as the
+reference's trainers hand them over -- host numpy int64 / float64 -- and their host-side cast, pinned staging and H2D copy are INSIDE
+the timed region (on the prefetch stream, like the rest of the sampler work).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -22,6 +24,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md chip table
+DTYPE = "f32 (products as split-bf16x3 MFMA: hi*hi + hi*lo + lo*hi, fp32 accumulate; everything else fp32)"
 MFMA_F32_PEAK = 157.3e12     # FLOP/s dense f32-input MFMA
 BATCH, K, L, H, DN, DE, DT = 600, 20, 2, 2, 172, 172, 100
 
@@ -36,15 +39,18 @@ def tgat_bytes_per_edge(k=K, layers=L, dn=DN, de=DE):
     return 2 * root * 2
 
 
-def attn_bytes_per_instance(k=K, heads=H, dn=DN, de=DE, dt=DT, backward=False):
-    """algorithmic HBM bytes of ONE attention instance in tg_attn_fwd / tg_attn_bwd: k neighbor rows (node + edge, fp32),
-    k x 16 B of slot metadata (feat idx, edge idx, nbr id, dt), u in + agg out (+ prob).  Backward: + dagg, agg in, du out."""
+def attn_bytes_per_instance(k=K, heads=H, dn=DN, de=DE, dt=DT, backward=False, activations=False):
+    """HBM bytes of ONE attention instance in tg_attn_fwd / tg_attn_bwd.
+    activations=False: the ALGORITHMIC bytes of SURVEY.md 8(d) -- what any implementation of the reference's gather has to move:
+    k neighbor rows (node + edge, fp32) + k x 16 B of slot lists (feat idx, edge idx, nbr id, dt) = 27 840 B at k = 20, 172 / 172.
+    activations=True: what this design moves on top (its own intermediates, not part of the algorithmic figure): u in + agg out
+    (+ prob); backward: u, agg, dagg in, du out (+ prob)."""
     dk = dn + de + dt
     rows = k * 4 * (dn + de) + k * 16
+    if not activations:
+        return rows
     vec = heads * dk * 4
-    if not backward:
-        return rows + 2 * vec + heads * k * 4
-    return rows + 4 * vec + heads * k * 4
+    return (4 if backward else 2) * vec + heads * k * 4
 
 
 def main():
@@ -172,13 +178,17 @@ def main():
         b = first + (step * world + rank) % span
         return slice(b * BATCH, (b + 1) * BATCH)
 
-    # inputs resident in HBM before the timed region
-    dev_batches = []
+    # a batch enters the timed region as host numpy (int64 ids, float64 times), as the reference's trainers pass it
+    # (PTCL/EM_warmup.py:128-130); --mode lp keeps its three id lists resident (it concatenates them on the device)
+    host_batches, dev_batches = [], []
     for s in range(total_steps + n_prefetch):          # the last timed step still prefetches like every other
         sl = batch_slice(s)
-        dev_batches.append((torch.from_numpy(data.src_node_ids[sl].astype(np.int32)).to(dev),
-                            torch.from_numpy(data.dst_node_ids[sl].astype(np.int32)).to(dev),
-                            torch.from_numpy(data.node_interact_times[sl]).to(dev)))
+        host_batches.append((np.ascontiguousarray(data.src_node_ids[sl], dtype=np.int64), np.ascontiguousarray(data.dst_node_ids[sl], dtype=np.int64),
+                             np.ascontiguousarray(data.node_interact_times[sl], dtype=np.float64)))
+        if args.mode == "lp":
+            dev_batches.append((torch.from_numpy(data.src_node_ids[sl].astype(np.int32)).to(dev),
+                                torch.from_numpy(data.dst_node_ids[sl].astype(np.int32)).to(dev),
+                                torch.from_numpy(data.node_interact_times[sl]).to(dev)))
     rw = torch.randn(2, BATCH, DN, device=dev)
     # the scalar loss of a step: mean over the batch of (src_emb . rw[0] + dst_emb . rw[1]) -- as a fused-step loss function
     # (value from one HIP reduction, gradient w.r.t. the embedding block = rw / (B Dn), a constant)
@@ -217,7 +227,7 @@ def main():
         args.roofline_kernel = "attn_fwd"
 
     def begin(s_):
-        return begin_lp(s_) if args.mode == "lp" else model.prepare_batch_begin(*dev_batches[s_], K)
+        return begin_lp(s_) if args.mode == "lp" else model.prepare_batch_begin(*host_batches[s_], K)
 
     def finish(job):
         from flid_amd import engine as _e
@@ -228,9 +238,9 @@ def main():
         batch s+1's second half (its distinct-row count was copied to pinned memory a step ago: no wait), batch s+2's first half"""
         if s not in prepared:                                      # cold start
             prepared[s] = finish(jobs.pop(s) if s in jobs else begin(s))
-        if s + 1 < len(dev_batches) and s + 1 not in prepared:
+        if s + 1 < len(host_batches) and s + 1 not in prepared:
             prepared[s + 1] = finish(jobs.pop(s + 1) if s + 1 in jobs else begin(s + 1))
-        if s + 2 < len(dev_batches) and s + 2 not in jobs:
+        if s + 2 < len(host_batches) and s + 2 not in jobs:
             jobs[s + 2] = begin(s + 2)
 
     def step_lp(s):
@@ -317,6 +327,30 @@ def main():
 
     edges = args.steps * BATCH * world
     value = edges / elapsed
+    from flid_amd._lib import lib as _lib_
+    gemm_mode_now = int(_lib_().tg_get_gemm_mode())
+    # the reference's own row-for-row recursion (no sharing of repeated (node, time) rows, so every occurrence draws its own dropout
+    # mask): a short extra run, reported beside the headline
+    dedupe_off = None
+    if args.mode == "train" and world == 1 and not args.no_breakdown:
+        from flid_amd import engine as _eng
+        _eng.DEDUPE = False
+        try:
+            prepared.clear(); jobs.clear()
+            n_off = min(20, args.steps)
+            for s in range(args.warmup, args.warmup + 3):
+                step(s)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(args.warmup, args.warmup + n_off):
+                step(s)
+            torch.cuda.synchronize()
+            dt_off = time.perf_counter() - t1
+            dedupe_off = {"value": round(n_off * BATCH / dt_off, 1), "ms_per_step": round(dt_off / n_off * 1e3, 4), "steps": n_off,
+                          "note": "engine.DEDUPE = False: 24 000 layer-1 instances per step instead of the ~13 k distinct ones"}
+        finally:
+            _eng.DEDUPE = True
+            prepared.clear(); jobs.clear()
     # fwd = half of fwd+bwd; the link-prediction step embeds 3 roots per edge instead of 2
     bpe = {"train": tgat_bytes_per_edge(), "fwd": tgat_bytes_per_edge() // 2, "lp": tgat_bytes_per_edge() * 3 // 2}[args.mode]
 
@@ -330,13 +364,19 @@ def main():
                 "avg_launch_ms": round(ms / max(1, cnt), 4), "flops_per_step": units / args.steps}
     else:
         bwd = args.roofline_kernel == "attn_bwd"
+        # `units` counts instances x (algorithmic + activation) bytes on the C side; the roofline is priced on the ALGORITHMIC bytes
+        # of SURVEY 8(d) alone (27 840 B per instance), the activation traffic of this design is listed beside it
+        alg, act = attn_bytes_per_instance(backward=bwd), attn_bytes_per_instance(backward=bwd, activations=True)
+        inst = units / (alg + act)
         roof = {"bound": "hbm", "kernel": ("attn_bwd_fast_kernel<2,2,*> (tg_attn_fast.hip; layer-1 + root launch)" if bwd else
                            "attn_fwd_fast_kernel<2,2> (layer 1) + attn_fwd_kernel (root)"),
-                "achieved": round(units / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": round(units / secs / HBM_PEAK, 4), "traffic": None, "launches": cnt,
-                "avg_launch_ms": round(ms / max(1, cnt), 4), "bytes_per_instance": attn_bytes_per_instance(backward=bwd),
-                "bytes_per_launch_avg": round(units / max(1, cnt), 1)}
-        tr = os.path.join(REPO, "profiles", "traffic_r02.json")     # PMC passes of the same command (tools/traffic_from_pmc.py)
+                "achieved": round(inst * alg / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(inst * alg / secs / HBM_PEAK, 4), "traffic": None, "launches": cnt,
+                "avg_launch_ms": round(ms / max(1, cnt), 4), "bytes_per_instance": alg,
+                "bytes_per_launch_avg": round(inst * alg / max(1, cnt), 1),
+                "activation_bytes_per_instance": act, "achieved_incl_activations": round(units / secs / 1e9, 1),
+                "instances_per_launch_avg": round(inst / max(1, cnt), 1)}
+        tr = os.path.join(REPO, "profiles", "traffic_r03.json")     # PMC passes of the same command (tools/traffic_from_pmc.py)
         if os.path.exists(tr) and args.workload == "wikipedia" and args.mode == "train":
             try:
                 roof["traffic"] = json.load(open(tr)).get(args.roofline_kernel)
@@ -350,7 +390,7 @@ def main():
                   "edges/sec (temporal-embedding %s), TGAT 10M-node / 100M-edge scale graph" % ("fwd+bwd" if args.mode == "train" else "fwd only, eval"),
         "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": DTYPE if gemm_mode_now != 0 else "f32 (exact f32-input MFMA products)", "data": "synthetic",
         "config": {"workload": workload + " + TGAT L=2 H=2 T=100, batch 600 edges/GPU, 20 recent neighbors, dropout %.2f, %s"
                                % (args.dropout, {"train": "fwd+bwd+Adam (%s)" % ("fused step" if fused else "autograd"), "fwd": "fwd (eval)",
                                                  "lp": "link-prediction step"}[args.mode]),
@@ -361,6 +401,8 @@ def main():
         "roofline": roof,
         "breakdown_ms": breakdown,
     }
+    if dedupe_off is not None:
+        out["row_sharing_off"] = dedupe_off
     if "gemm" in fam and args.roofline_kernel != "gemm" and fam["gemm"][2] > 0:
         # the dense projections are priced against the f32-input MFMA peak "alongside" (untimed second pass; all
         # product launches of a step: split-bf16, direct and tiled kernels; flops = 2 M N K as the reference's fp32 mm would do)
@@ -404,7 +446,7 @@ def bench_sweep(args, data, node_tab, edge_tab, workload, dev, rank, world):
     bpe = tgat_bytes_per_edge() // 2
     out = {"metric": "edges/sec (embedding-regeneration sweep, fwd only, eval), TGAT Wikipedia", "value": round(E / elapsed, 1), "unit": "edges/s",
            "n_gpus": world, "steps": chunks, "warmup": args.warmup, "ms_per_step": round(elapsed / chunks * 1e3, 4), "higher_is_better": True,
-           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
            "config": {"workload": workload + f" + TGAT L=2 H=2 T=100, 20 recent neighbors, whole stream ({E} edges) in chunks of {args.chunk_edges}, "
                                              "full-graph sampler, eval mode, stores (E, 172) x 2 resident", "parallelism": f"dp{world}"},
            "path_roofline": {"bytes_per_edge_fwd": bpe, "hbm_frac": round(E / elapsed / world * bpe / HBM_PEAK, 4),
@@ -575,7 +617,7 @@ def bench_memory_or_sequence_model(args):
         metric = "edges/sec (temporal-embedding fwd+bwd), %s Reddit, 1/2/4/8 MI355X" % {"dygformer": "DyGFormer", "tcl": "TCL", "graphmixer": "GraphMixer"}[args.model]
     out = {"metric": metric, "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": DTYPE, "data": "synthetic",
            "config": {"workload": f"Reddit-shape synthetic (10984 nodes, 672447 edges, 172-d edge feats) + {desc}, batch 600 edges/GPU, "
                                   f"dropout {args.dropout:.2f}, host numpy ids per call, fwd+bwd+Adam ({'fused step' if fused else 'autograd'})",
                       "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}"},

@@ -92,6 +92,7 @@ SIGNATURES = {
     "tg_set_merged_min_rows": (None, [c_i64]),
     "tg_side_join": (C.c_int, [c_void]),
     "tg_set_layer_merged": (None, [C.c_int]),
+    "tg_set_layer_chain": (None, [C.c_int]),
     "tg_tgat_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(LayerBwdDesc), c_void]),
     "tg_gemm_f32": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_void, c_i64, c_void, c_i64,
                               c_void, C.c_int, C.c_int, c_void]),

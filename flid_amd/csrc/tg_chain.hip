@@ -17,9 +17,10 @@
 //     of two 32-deep steps each, the set for steps s+2, s+3 in flight while s, s+1 multiply;
 //   * the MFMA is issued with the WEIGHT fragment as operand A: the accumulator then holds, per lane, 4 consecutive output columns
 //     of one row -- a float4 for the HBM store and an 8-byte hi / lo pair for the LDS image of the next product;
-//   * the first product of a chain streams its rows from HBM through a two-buffer ring (as gemm_rows_kernel); later products read
-//     the whole K from the panel the previous epilogue wrote.  LDS: 15 chunks x (64 rows x 32 k x hi|lo) panel + ring + reductions
-//     = 160 128 B -- one workgroup per CU.
+//   * the first product of a chain streams its rows from HBM through a two-buffer ring (as gemm_rows_kernel) that lives in the
+//     still empty panel; later products read the whole K from the panel the previous epilogue wrote.  LDS: 15 chunks x (64 rows x
+//     32 k x hi|lo) + reductions = 126 848 B -- one workgroup per CU.  Few rows (the 1 200-row root layer) take 16-row blocks:
+//     the weights are streamed per workgroup whatever its height (~1.3 MB at ~65 GB/s per CU), so more, shorter blocks only add CUs.
 #include <math.h>
 #include <stdlib.h>
 
@@ -28,47 +29,58 @@
 #include "tg_common.h"
 #include "tg_split.h"
 
+#ifndef FLID_CHAIN_STAMPS
+#define FLID_CHAIN_STAMPS 0
+#endif
+#ifndef FLID_CHAIN_X4
+#define FLID_CHAIN_X4 1   // keep the lo * lo term (see step()); 0: three terms, as the launch-per-product kernels
+#endif
+#ifndef FLID_CHAIN_EXP
+#define FLID_CHAIN_EXP 0   // timing experiments only (results wrong): 1 no steady-state weight loads, 2 no MFMAs, 3 all fragment reads from one chunk
+#endif
+
 namespace {
 
 using namespace tgs;
 
-constexpr int NTH = 256, ROWS = 64, RB = 4;
-constexpr int CHS = ROWS * 64 + 64;          // one plane of one 32-k chunk (+64: the chunk stores of one row spread over banks)
-constexpr int CHUNK = 2 * CHS;               // hi plane | lo plane
+constexpr int NTH = 256;
 constexpr int NCH = 15;                      // panel chunks: [y (9) | raw (6)] of the merge layer is the widest operand
-constexpr int PANEL = NCH * CHUNK;
-constexpr int RING_BUF = 2 * CHUNK;          // one ring buffer = one group of two steps
-constexpr int RED_OFF = PANEL + 2 * RING_BUF;
-constexpr int LDS_BYTES = RED_OFF + 2 * 4 * ROWS * 4;
-static_assert(LDS_BYTES <= 163840, "one workgroup must fit the CU's LDS");
-
-__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p) {      // as ln_res_fwd/bwd_kernel (tg_layer.hip)
-    if (p <= 0.f) return 1.f;
-    const float u = (float)(tg::mix32(seed ^ ((uint64_t)idx * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
-    return u >= p ? 1.f / (1.f - p) : 0.f;
-}
+template <int RB>
+struct Geo {
+    static constexpr int ROWS = 16 * RB;
+    static constexpr int CHS = ROWS * 64 + 64;       // one plane of one 32-k chunk (+64: the chunk stores of one row spread over banks)
+    static constexpr int CHUNK = 2 * CHS;            // hi plane | lo plane
+    static constexpr int PANEL = NCH * CHUNK;
+    static constexpr int RED_OFF = PANEL;
+    static constexpr int LDS_BYTES = RED_OFF + 2 * 4 * ROWS * 4;
+    static constexpr int PER = RB;                   // float4 per thread, head and group when a product streams its rows (16 per row)
+};
+static_assert(Geo<4>::LDS_BYTES <= 163840, "one workgroup must fit the CU's LDS");
 
 // state of one wave inside a chain
-template <int NTW>
+template <int NTW, int RB>
 struct Wave {
+    using G = Geo<RB>;
     char* lds;
     int lane, wave;
     int64_t row0, R;
     f32x4 acc[RB][NTW];
     bf16x8 b0h[2][NTW], b0l[2][NTW], b1h[2][NTW], b1l[2][NTW];
     const uint4* bptr[NTW];
-    int S, t0, tcnt;          // current product: steps, first tile of this wave, tiles it owns
+    int S, t0, tcnt;          // current product: steps, first tile of this wave (inside its operand), tiles it owns
 
-    __device__ __forceinline__ void begin(const void* packed, int nt, int steps) {
+    // the product's nt column tiles are dealt in blocks to waves [w0, w0 + nw); `packed` = that operand
+    __device__ __forceinline__ void begin(const void* packed, int nt, int steps, int w0 = 0, int nw = 4) {
         S = steps;
-        const int cpw = (nt + 3) >> 2;
-        t0 = wave * cpw;
+        const int cpw = (nt + nw - 1) / nw;
+        t0 = (wave - w0) * cpw;
         tcnt = nt - t0 < cpw ? nt - t0 : cpw;
-        if (tcnt < 0) tcnt = 0;
+        if (tcnt < 0 || wave < w0 || wave >= w0 + nw) tcnt = 0;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             int t = t0 + j;
             if (t > nt - 1) t = nt - 1;
+            if (t < 0) t = 0;
             bptr[j] = reinterpret_cast<const uint4*>(packed) + (int64_t)t * S * 128 + lane;
         }
 #pragma unroll
@@ -76,125 +88,161 @@ struct Wave {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // NT = tiles a wave owns in the current product (<= NTW): the loops below run over NT, not over the register arrays' NTW
+    template <int NT>
     __device__ __forceinline__ void loadB(bf16x8 (&bh)[2][NTW], bf16x8 (&bl)[2][NTW], int g) {
+        if (FLID_CHAIN_EXP == 1 && g > 0) return;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             const int s = 2 * g + sl;
             const int sc = s < S ? s : S - 1;
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 bh[sl][j] = __builtin_bit_cast(bf16x8, bptr[j][sc * 128]);
                 bl[sl][j] = __builtin_bit_cast(bf16x8, bptr[j][sc * 128 + 64]);
             }
         }
     }
-    // one 32-deep step: A fragments of the four row blocks from the chunk at `chunk`, against step sl of a B set
+    // one 32-deep step: A fragments of the row blocks from the chunk at `chunk`, against one step of a B set
+    template <int NT>
     __device__ __forceinline__ void step(const char* chunk, const bf16x8 (&bh)[NTW], const bf16x8 (&bl)[NTW]) {
-        const char* p = chunk + frag_off(lane);
+        const char* p = (FLID_CHAIN_EXP == 3 ? lds : chunk) + frag_off(lane);
         bf16x8 ah[RB], al[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             ah[rb] = *reinterpret_cast<const bf16x8*>(p + rb * 1024);
-            al[rb] = *reinterpret_cast<const bf16x8*>(p + CHS + rb * 1024);
+            al[rb] = *reinterpret_cast<const bf16x8*>(p + G::CHS + rb * 1024);
+        }
+        if (FLID_CHAIN_EXP == 2) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const float4 x = __builtin_bit_cast(float4, ah[rb]), y = __builtin_bit_cast(float4, bh[j]);
+                    const float4 z = __builtin_bit_cast(float4, al[rb]), w = __builtin_bit_cast(float4, bl[j]);
+                    acc[rb][j][0] += x.x + y.y + z.z + w.w;
+                }
+            return;
         }
         // weight fragment as operand A: acc[rb][j][r] = C[row 16 rb + (lane & 15)][column 16 (t0 + j) + 4 (lane >> 4) + r]
+        // The chain keeps the lo * lo term too (4 MFMAs per fragment pair): its launches are bound by the weight stream and by latency,
+        // not by the matrix pipe (PMC: 23 % busy), and with three terms the realistic full-size fixture showed hundreds of gradient
+        // entries off by 1e-3 of the tensor's largest (ReLU units of the merge layer flipping; tools/kink_probe.py) where four show none.
+        if (RB == 1 || FLID_CHAIN_X4) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], al[rb], acc[rb][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[rb], acc[rb][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[rb], acc[rb][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[rb], acc[rb][j], 0, 0, 0);
     }
 
     // ---- product whose rows come from the LDS panel: chunks [chunk0, chunk0 + S).  No barrier inside.
+    template <int NT>
     __device__ __forceinline__ void run_panel(int chunk0) {
         const int ngroups = (S + 1) >> 1;
-        const char* base = lds + chunk0 * CHUNK;
-        loadB(b0h, b0l, 0);
+        const char* base = lds + chunk0 * G::CHUNK;
+        loadB<NT>(b0h, b0l, 0);
         for (int g = 0; g < ngroups; g += 2) {
-            loadB(b1h, b1l, g + 1);
-            step(base + (2 * g) * CHUNK, b0h[0], b0l[0]);
-            if (2 * g + 1 < S) step(base + (2 * g + 1) * CHUNK, b0h[1], b0l[1]);
-            loadB(b0h, b0l, g + 2);
-            if (2 * g + 2 < S) step(base + (2 * g + 2) * CHUNK, b1h[0], b1l[0]);
-            if (2 * g + 3 < S) step(base + (2 * g + 3) * CHUNK, b1h[1], b1l[1]);
+            loadB<NT>(b1h, b1l, g + 1);
+            step<NT>(base + (2 * g) * G::CHUNK, b0h[0], b0l[0]);
+            if (2 * g + 1 < S) step<NT>(base + (2 * g + 1) * G::CHUNK, b0h[1], b0l[1]);
+            loadB<NT>(b0h, b0l, g + 2);
+            if (2 * g + 2 < S) step<NT>(base + (2 * g + 2) * G::CHUNK, b1h[0], b1l[0]);
+            if (2 * g + 3 < S) step<NT>(base + (2 * g + 3) * G::CHUNK, b1h[1], b1l[1]);
         }
     }
 
-    // ---- product whose rows stream from HBM (fp32, split here) through the two ring buffers behind the panel.  Ends with a barrier.
-    __device__ __forceinline__ void run_stream(const float* __restrict__ A, int64_t lda, int K) {
+    // ---- product whose rows stream from HBM (fp32, split here): HH operands side by side (the heads of the value projection: operand
+    // hh = columns [hh a_stride, hh a_stride + K) of A), this wave multiplies operand `mine`.  Ring: operand hh, buffer b, step sl at
+    // panel chunk (2 hh + b) * 2 + sl -- the panel is still empty when a chain's first product runs.  Half h multiplies group h
+    // (buffer h & 1, B set h & 1) while group h + 1 goes registers -> LDS and the rows of group h + 3 start their trip from HBM; loads
+    // are unconditional (past the end of K they re-read k = 0 and are stored as zeros).  Ends with a barrier.
+    template <int NT, int HH>
+    __device__ __forceinline__ void run_stream(const float* __restrict__ A, int64_t lda, int64_t a_stride, int K, int mine) {
         const int tid = wave * 64 + lane;
-        const int c4 = tid & 15, r16 = tid >> 4;           // 16 float4 per row and group, 16 rows per pass
-        const float* aptr[4];
-        bool rok[4];
-        int aoff[4];
+        const int c4 = tid & 15, r16 = tid >> 4;           // 16 float4 per row, operand and group; 16 rows per pass
+        constexpr int PER = G::PER;
+        const float* aptr[PER];
+        bool rok[PER];
+        int aoff[PER];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PER; ++i) {
             const int r = r16 + 16 * i;
             int64_t rg = row0 + r;
             rok[i] = rg < R;
             if (rg > R - 1) rg = R - 1;
             aptr[i] = A + rg * lda;
-            aoff[i] = (c4 >> 3) * CHUNK + chunk_off(r, (c4 & 7) * 4);
+            aoff[i] = (c4 >> 3) * G::CHUNK + chunk_off(r, (c4 & 7) * 4);
         }
-        auto loadA = [&](float4 (&ra)[4], int g) {
+        auto loadA = [&](float4 (&ra)[HH][PER], int g) {
             const int k = 64 * g + 4 * c4;
             const int ko = k < K ? k : 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(aptr[i] + ko);
+            for (int hh = 0; hh < HH; ++hh)
+#pragma unroll
+                for (int i = 0; i < PER; ++i) ra[hh][i] = *reinterpret_cast<const float4*>(aptr[i] + hh * a_stride + ko);
         };
-        auto writeA = [&](int buf, const float4 (&ra)[4], int g) {
-            char* base = lds + PANEL + buf * RING_BUF;
+        auto writeA = [&](int buf, const float4 (&ra)[HH][PER], int g) {
             const bool kok = 64 * g + 4 * c4 < K;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = kok && rok[i];
-                const float4 v = make_float4(ok ? ra[i].x : 0.f, ok ? ra[i].y : 0.f, ok ? ra[i].z : 0.f, ok ? ra[i].w : 0.f);
-                uint2 hi, lo;
-                split4(v, hi, lo);
-                *reinterpret_cast<uint2*>(base + aoff[i]) = hi;
-                *reinterpret_cast<uint2*>(base + CHS + aoff[i]) = lo;
+            for (int hh = 0; hh < HH; ++hh) {
+                char* base = lds + ((2 * hh + buf) * 2) * G::CHUNK;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) {
+                    const bool ok = kok && rok[i];
+                    const float4 v = make_float4(ok ? ra[hh][i].x : 0.f, ok ? ra[hh][i].y : 0.f, ok ? ra[hh][i].z : 0.f, ok ? ra[hh][i].w : 0.f);
+                    uint2 hi, lo;
+                    split4(v, hi, lo);
+                    *reinterpret_cast<uint2*>(base + aoff[i]) = hi;
+                    *reinterpret_cast<uint2*>(base + G::CHS + aoff[i]) = lo;
+                }
             }
         };
         const int ngroups = (S + 1) >> 1;
-        float4 ra0[4], ra1[4];
+        float4 ra0[HH][PER], ra1[HH][PER];
         loadA(ra0, 0);
-        loadB(b0h, b0l, 0);
+        loadB<NT>(b0h, b0l, 0);
         loadA(ra1, 1);
         writeA(0, ra0, 0);
         loadA(ra0, 2);
         __syncthreads();
-        const char* r0 = lds + PANEL, *r1 = lds + PANEL + RING_BUF;
+        const char* r0 = lds + (2 * mine) * 2 * G::CHUNK, *r1 = r0 + 2 * G::CHUNK;
         for (int g = 0; g < ngroups; g += 2) {
             writeA(1, ra1, g + 1);
             loadA(ra1, g + 3);
-            loadB(b1h, b1l, g + 1);
-            step(r0, b0h[0], b0l[0]);
-            step(r0 + CHUNK, b0h[1], b0l[1]);               // (a step past the end of K multiplies zero rows)
+            loadB<NT>(b1h, b1l, g + 1);
+            step<NT>(r0, b0h[0], b0l[0]);
+            step<NT>(r0 + G::CHUNK, b0h[1], b0l[1]);        // (a step past the end of K multiplies zero rows)
             __syncthreads();
             writeA(0, ra0, g + 2);
             loadA(ra0, g + 4);
-            loadB(b0h, b0l, g + 2);
-            if (g + 1 < ngroups) { step(r1, b1h[0], b1l[0]); step(r1 + CHUNK, b1h[1], b1l[1]); }
+            loadB<NT>(b0h, b0l, g + 2);
+            if (g + 1 < ngroups) { step<NT>(r1, b1h[0], b1l[0]); step<NT>(r1 + G::CHUNK, b1h[1], b1l[1]); }
             __syncthreads();
         }
     }
-    // coordinates of acc[rb][j]: row (inside the block) and first of its 4 columns
+    // coordinates of acc[rb][j]: row (inside the block) and first of its 4 columns (inside the wave's operand)
     __device__ __forceinline__ int out_row(int rb) const { return rb * 16 + (lane & 15); }
     __device__ __forceinline__ int out_col(int j) const { return (t0 + j) * 16 + 4 * (lane >> 4); }
     // 4 columns [col, col + 4) of `row` into the panel image whose column 0 sits at chunk `chunk0`
     __device__ __forceinline__ void panel_store(int chunk0, int row, int col, const float4& v) {
         uint2 hi, lo;
         split4(v, hi, lo);
-        char* p = lds + (chunk0 + (col >> 5)) * CHUNK + chunk_off(row, col & 31);
+        char* p = lds + (chunk0 + (col >> 5)) * G::CHUNK + chunk_off(row, col & 31);
         *reinterpret_cast<uint2*>(p) = hi;
-        *reinterpret_cast<uint2*>(p + CHS) = lo;
+        *reinterpret_cast<uint2*>(p + G::CHS) = lo;
     }
 };
 
@@ -202,6 +250,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4(const f32x4& a) { return make_float4(a[0], a[1], a[2], a[3]); }
 __device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (they hold the other column groups of the same row)
 __device__ __forceinline__ float quad_rows_sum(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -222,6 +271,7 @@ struct ChainFwdArgs {
     int H, dn, T, de;                 // dq = dn + T, hd = dq / H, dk = dn + de + T
     int hp;                           // per-head block of ctx inside the panel (hd rounded up to 16)
     const float* agg;                 // (R, H dk)
+    int64_t packed_bytes;             // pWv .. end of pW2: one contiguous block (L2 warm-up)
     const void *pWv, *pWr, *pW1, *pW2;   // packed: Wv heads back to back (tg_packed_floats(hd, dk) apart), Wr with K = H hp, W1 with K = [y | raw] padded
     const float *br, *b1, *b2, *ln_g, *ln_b, *cosb;
     const float* own; int64_t own_ld;
@@ -231,24 +281,35 @@ struct ChainFwdArgs {
     float* y; int64_t y_ld;           // (R, dq) inside the [y | raw] buffer
     const float* raw; int64_t raw_ld; // (R, dn)
     float *mean, *rstd, *f1, *out;
+    unsigned long long* dbg;          // diagnostic builds only: 16 stamps per workgroup
 };
 
-// tiles a wave can own: dq <= 320 -> 5
+// tiles a wave can own: dq <= 320 -> 5.  HH = heads (1 or 2)
+template <int RB, int HH>
 __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
+    using G = Geo<RB>;
+    constexpr int ROWS = G::ROWS;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Wave<5> w;
+    Wave<5, RB> w;
     w.lds = lds;
     w.lane = threadIdx.x & 63;
     w.wave = threadIdx.x >> 6;
     w.row0 = (int64_t)blockIdx.x * ROWS;
     w.R = a.R;
     const int lane = w.lane, tid = threadIdx.x;
-    const int dq = a.dn + a.T, hd = dq / a.H, dk = a.dn + a.de + a.T;
+    const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
     const int ychunks = (dq + 31) >> 5, rchunks = (a.dn + 31) >> 5;
-    float* red = reinterpret_cast<float*>(lds + RED_OFF);
+    float* red = reinterpret_cast<float*>(lds + G::RED_OFF);
+#if FLID_CHAIN_STAMPS
+    int stamp_i = 0;
+#define STAMP() do { if (a.dbg && tid == 0) a.dbg[blockIdx.x * 16 + stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
 
     // ---- the merge layer's raw rows: in flight now, into the panel (behind y) after the first product
-    constexpr int RAWN = 3;                                   // float4 per thread: 64 rows x 192 columns / 256 threads / 4
+    constexpr int RAWN = ROWS * 48 / NTH;                     // float4 per thread: ROWS x 192 columns
     float4 rawv[RAWN];
     const int rcols4 = a.dn >> 2;
 #pragma unroll
@@ -259,20 +320,19 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
         rawv[i] = ld4(a.raw + rg * a.raw_ld + (c < rcols4 ? 4 * c : 0));
     }
 
-    // ---- ctx_h = agg_h Wv_h^T, head by head (all four waves on one head: they share its rows of agg)
-    const int ht = (hd + 15) >> 4;                            // tiles per head
-    const int64_t wv_stride = tg::packed_floats(1, 1) * 0 + (int64_t)((hd + 15) / 16) * ((dk + 31) / 32) * 512;   // floats per packed head
-    for (int h = 0; h < a.H; ++h) {
-        w.begin(reinterpret_cast<const float*>(a.pWv) + h * wv_stride, ht, (dk + 31) >> 5);
-        w.run_stream(a.agg + (int64_t)h * dk, (int64_t)a.H * dk, dk);
-        if (h == 0) {
+    // ---- ctx_h = agg_h Wv_h^T: both heads at once, waves [0, 2) on head 0 and [2, 4) on head 1 (one head: all four waves)
+    {
+        const int ht = (hd + 15) >> 4;                        // tiles per head
+        const int64_t wv_stride = (int64_t)((hd + 15) / 16) * ((dk + 31) / 32) * 512;   // floats per packed head (tg_packed_floats(hd, dk))
+        const int mine = HH == 2 ? w.wave >> 1 : 0;
+        w.begin(reinterpret_cast<const float*>(a.pWv) + mine * wv_stride, ht, (dk + 31) >> 5, HH == 2 ? 2 * mine : 0, 4 / HH);
+        w.template run_stream<5, HH>(a.agg, (int64_t)HH * dk, dk, dk, mine);
+        STAMP();
 #pragma unroll
-            for (int i = 0; i < RAWN; ++i) {
-                const int f = tid + NTH * i, r = f / 48, c = f % 48;
-                const bool ok = c < rcols4 && w.row0 + r < a.R;
-                const float4 v = ok ? rawv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (4 * c < 32 * rchunks) w.panel_store(ychunks, r, 4 * c, v);
-            }
+        for (int i = 0; i < RAWN; ++i) {
+            const int f = tid + NTH * i, r = f / 48, c = f % 48;
+            const bool ok = c < rcols4 && w.row0 + r < a.R;
+            if (4 * c < 32 * rchunks) w.panel_store(ychunks, r, 4 * c, ok ? rawv[i] : zero4());
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -282,18 +342,23 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
             for (int rb = 0; rb < RB; ++rb) {
                 const int r = w.out_row(rb);
                 const float4 v = f4(w.acc[rb][j]);
-                w.panel_store(0, r, h * a.hp + col, v);       // columns >= hd of the block are zero (zero rows of the packed weight)
-                if (col < hd && w.row0 + r < a.R) st4(a.ctx + (w.row0 + r) * dq + h * hd + col, v);
+                w.panel_store(0, r, mine * a.hp + col, v);    // columns >= hd of the block are zero (zero rows of the packed weight)
+                if (col < hd && w.row0 + r < a.R) st4(a.ctx + (w.row0 + r) * dq + mine * hd + col, v);
             }
         }
+    }
+    if ((HH * a.hp) & 31) {                                    // tail of the ctx panel's last chunk: multiplies zero columns of Wr, must be finite
+        const int c0 = HH * a.hp, per = (32 - (c0 & 31)) >> 2;
+        for (int f = tid; f < ROWS * per; f += NTH) w.panel_store(0, f / per, c0 + 4 * (f % per), zero4());
     }
     __syncthreads();
 
     // ---- res = ctx Wr^T + br ;  y = LayerNorm(dropout(res) + [own | cos b]) * g + b
     {
-        const int kc = (a.H * a.hp + 31) >> 5;
+        const int kc = (HH * a.hp + 31) >> 5;
+        STAMP();
         w.begin(a.pWr, (dq + 15) >> 4, kc);
-        w.run_panel(0);
+        // the residual's rows [own | cos b] for this wave's columns: in flight under the product
         f32x4 x[RB][5];
         float s1[RB];
         bool rok[RB];
@@ -301,8 +366,28 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
         for (int rb = 0; rb < RB; ++rb) { s1[rb] = 0.f; rok[rb] = w.row0 + w.out_row(rb) < a.R; }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
+            const int col = w.out_col(j);
+            const bool cok = j < w.tcnt && col < dq;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                int64_t rg = w.row0 + w.out_row(rb);
+                if (rg > a.R - 1) rg = a.R - 1;
+                const float* src = !cok ? a.cosb : (col < a.dn ? a.own + rg * a.own_ld + col : a.cosb + (col - a.dn));
+                const float4 o = ld4(src);
+                x[rb][j] = f32x4{o.x, o.y, o.z, o.w};
+            }
+        }
+        w.template run_panel<5>(0);
+        STAMP();
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);
+            if (col >= dq) {                                   // columns past dq in the last tile (lane-wise): not part of the row
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) x[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             const float4 b4 = ld4(a.br + col);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -310,12 +395,12 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
                 if (rg > a.R - 1) rg = a.R - 1;
                 float4 v = add4(f4(w.acc[rb][j]), b4);
                 if (rok[rb]) st4(a.res + rg * dq + col, v);
-                const float4 o = col < a.dn ? ld4(a.own + rg * a.own_ld + col) : ld4(a.cosb + (col - a.dn));
-                const int64_t e = rg * dq + col;
-                v.x = v.x * keep_scale(a.seed, e, a.p_res) + o.x;
-                v.y = v.y * keep_scale(a.seed, e + 1, a.p_res) + o.y;
-                v.z = v.z * keep_scale(a.seed, e + 2, a.p_res) + o.z;
-                v.w = v.w * keep_scale(a.seed, e + 3, a.p_res) + o.w;
+                float ks[4];
+                tg::res_keep_scale4(a.seed, rg * dq + col, a.p_res, ks);
+                v.x = v.x * ks[0] + x[rb][j][0];
+                v.y = v.y * ks[1] + x[rb][j][1];
+                v.z = v.z * ks[2] + x[rb][j][2];
+                v.w = v.w * ks[3] + x[rb][j][3];
                 x[rb][j] = f32x4{v.x, v.y, v.z, v.w};
                 s1[rb] += (v.x + v.y) + (v.z + v.w);
             }
@@ -336,6 +421,7 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             if (j >= w.tcnt) break;
+            if (w.out_col(j) >= dq) continue;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -359,6 +445,7 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
         for (int j = 0; j < 5; ++j) {
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);
+            if (col >= dq) continue;                           // (the zero fill below covers the panel's tail)
             const float4 g4 = ld4(a.ln_g + col), be4 = ld4(a.ln_b + col);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -368,32 +455,32 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
                 v.y = (x[rb][j][1] - mu[rb]) * rs[rb] * g4.y + be4.y;
                 v.z = (x[rb][j][2] - mu[rb]) * rs[rb] * g4.z + be4.z;
                 v.w = (x[rb][j][3] - mu[rb]) * rs[rb] * g4.w + be4.w;
-                if (!rok[rb]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!rok[rb]) v = zero4();
                 w.panel_store(0, r, col, v);
                 if (rok[rb]) st4(a.y + (w.row0 + r) * a.y_ld + col, v);
             }
         }
         // the tail of y's last chunk (columns dq .. 32 ychunks) multiplies zero columns of the packed W1 but must be finite
         if (32 * ychunks > dq) {
-            for (int f = tid; f < ROWS * ((32 * ychunks - dq) >> 2); f += NTH) {
-                const int per = (32 * ychunks - dq) >> 2, r = f / per, c = dq + 4 * (f % per);
-                w.panel_store(0, r, c, make_float4(0.f, 0.f, 0.f, 0.f));
-            }
+            const int per = (32 * ychunks - dq) >> 2;
+            for (int f = tid; f < ROWS * per; f += NTH) w.panel_store(0, f / per, dq + 4 * (f % per), zero4());
         }
     }
     __syncthreads();
 
     // ---- f1 = relu([y | raw] W1^T + b1)
+    STAMP();
     w.begin(a.pW1, (a.dn + 15) >> 4, ychunks + rchunks);
-    w.run_panel(0);
+    w.template run_panel<3>(0);
+    STAMP();
     __syncthreads();                                           // every wave is done with [y | raw]: f1 takes its place
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 3; ++j) {
         if (j >= w.tcnt) break;
         const int col = w.out_col(j);
         if (col >= a.dn) {                                     // padding columns of the last tile: zeros for the next product
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) w.panel_store(0, w.out_row(rb), col, make_float4(0.f, 0.f, 0.f, 0.f));
+            for (int rb = 0; rb < RB; ++rb) w.panel_store(0, w.out_row(rb), col, zero4());
             continue;
         }
         const float4 b4 = ld4(a.b1 + col);
@@ -409,10 +496,12 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
     __syncthreads();
 
     // ---- out = f1 W2^T + b2
+    STAMP();
     w.begin(a.pW2, (a.dn + 15) >> 4, rchunks);
-    w.run_panel(0);
+    w.template run_panel<3>(0);
+    STAMP();
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 3; ++j) {
         if (j >= w.tcnt) break;
         const int col = w.out_col(j);
         if (col >= a.dn) continue;
@@ -423,9 +512,23 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
             if (w.row0 + r < a.R) st4(a.out + (w.row0 + r) * a.dn + col, add4(f4(w.acc[rb][j]), b4));
         }
     }
+    STAMP();
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+unsigned long long* g_chain_dbg = nullptr;
+
+template <int RB, int HH>
+int launch_fwd(const ChainFwdArgs& a, hipStream_t s) {
+    using G = Geo<RB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_kernel<RB, HH>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr_set = true;
+    }
+    chain_fwd_kernel<RB, HH><<<(unsigned)((a.R + G::ROWS - 1) / G::ROWS), NTH, G::LDS_BYTES, s>>>(a);
+    return tg::launch_status("chain_fwd_kernel");
+}
 
 }  // namespace
 
@@ -437,19 +540,21 @@ bool chain_shape_ok(int H, int dn, int T, int de) {
     const int dq = dn + T, dk = dn + de + T;
     if (dq % H || (dq / H) % 4) return false;
     const int hd = dq / H, hp = (hd + 15) / 16 * 16;
-    if (dq > 320 || dn > 192 || H * hp > 32 * 10) return false;               // tiles per wave <= 5; raw = 6 chunks; ctx panel
+    // tiles per wave: res <= 5, ctx (4 / H waves per head) <= 5, fc1 / fc2 <= 3; panel: ctx <= 8 chunks beside nothing, [y | raw] <= 15
+    if (dq > 320 || dn > 192 || hp / 16 > 5 * (4 / H) || H * hp > 32 * NCH) return false;
     if ((dq + 31) / 32 + (dn + 31) / 32 > NCH || dk > 32 * 64) return false;
     return true;
 }
 int chain_hp(int H, int dn, int T) { const int hd = (dn + T) / H; return (hd + 15) / 16 * 16; }
 
-int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const void* pW1, const void* pW2, hipStream_t s) {
+int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const void* pW1, const void* pW2, int64_t packed_bytes, hipStream_t s) {
     const tg_attn_desc& at = L->attn;
     ChainFwdArgs a;
     a.R = at.m; a.H = at.heads; a.dn = at.dn; a.T = at.dt_dim; a.de = at.de;
     a.hp = chain_hp(at.heads, at.dn, at.dt_dim);
     a.agg = L->agg;
     a.pWv = pWv; a.pWr = pWr; a.pW1 = pW1; a.pW2 = pW2;
+    a.packed_bytes = packed_bytes;
     const tg_layer_params& P = L->params;
     a.br = P.br; a.b1 = P.b1; a.b2 = P.b2; a.ln_g = P.ln_g; a.ln_b = P.ln_b; a.cosb = L->cosb;
     a.own = L->own; a.own_ld = L->own_ld;
@@ -457,16 +562,18 @@ int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const vo
     a.ctx = L->ctx; a.res = L->res; a.y = L->y; a.y_ld = L->y_ld ? L->y_ld : at.dn + at.dt_dim;
     a.raw = L->raw; a.raw_ld = L->raw_ld;
     a.mean = L->mean; a.rstd = L->rstd; a.f1 = L->f1; a.out = L->out;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    a.dbg = g_chain_dbg;
     const int dq = at.dn + at.dt_dim, dk = at.dn + at.de + at.dt_dim;
     const double macs = (double)dk * dq + (double)dq * dq + (double)(dq + at.dn) * at.dn + (double)at.dn * at.dn;
     ProfScope prof("gemm", 2.0 * at.m * macs, s);
-    chain_fwd_kernel<<<(unsigned)((at.m + ROWS - 1) / ROWS), NTH, LDS_BYTES, s>>>(a);
-    return launch_status("chain_fwd_kernel");
+    // 64-row blocks once they fill the chip; fewer rows take 16-row blocks (a workgroup streams all the weights whatever its height)
+    static const bool force_rb1 = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_CHAIN_RB1") != nullptr;
+    const bool tall = at.m >= 64 * 128 && !force_rb1;
+    if (at.heads == 2) return tall ? launch_fwd<4, 2>(a, s) : launch_fwd<1, 2>(a, s);
+    return tall ? launch_fwd<4, 1>(a, s) : launch_fwd<1, 1>(a, s);
 }
 
 }  // namespace tg
+
+// diagnostic builds (-DFLID_CHAIN_STAMPS=1): the chain kernels write 16 s_memtime stamps per workgroup here (null = off)
+extern "C" void tg_chain_debug_buffer(void* p) { g_chain_dbg = reinterpret_cast<unsigned long long*>(p); }

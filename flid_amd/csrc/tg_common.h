@@ -73,6 +73,10 @@ int pack_weights(int njobs, const tg_pack_job* jobs, hipStream_t s);
 bool gemm_rows_nt(int64_t R, int N, int K, const float* A, int64_t lda, int64_t strideA, const void* packed, int64_t packed_stride_floats,
                   float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate, const float* mask,
                   int64_t ldm, hipStream_t s);
+// tg_chain.hip: everything behind the attention of a layer's forward as one launch
+bool chain_shape_ok(int H, int dn, int T, int de);
+int chain_hp(int H, int dn, int T);
+int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const void* pW1, const void* pW2, int64_t packed_bytes, hipStream_t s);
 bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);  // tg_wgrad.hip: big tiles + transposing LDS reads + slice fold
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);   // tg_gemm_bf16x3.hip; false = shapes not covered
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
@@ -147,6 +151,30 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ uint32_t mix32(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return (uint32_t)(x >> 11);
+}
+// Dropout of the residual path (models/modules.py:235): ONE 64-bit hash serves the 4 consecutive elements [4 g, 4 g + 4) of the
+// flattened (row, column) index, 16 bits each (the keep probability is 1 - round(65536 p) / 65536: 0.899994 at p = 0.1).  The same
+// function in the LayerNorm kernels (tg_layer.hip, element form) and in the chain kernels (tg_chain.hip, float4 form), forward and backward.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ void res_keep_scale4(uint64_t seed, int64_t idx4, float p, float (&k)[4]) {      // idx4 % 4 == 0
+    if (p <= 0.f) { k[0] = k[1] = k[2] = k[3] = 1.f; return; }
+    const uint64_t h = mix64(seed ^ ((uint64_t)(idx4 >> 2) * 0x9E3779B97F4A7C15ULL));
+    const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+    const float s = 1.f / (1.f - p);
+    const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+    k[0] = (lo & 0xFFFFu) >= thr ? s : 0.f;
+    k[1] = (lo >> 16) >= thr ? s : 0.f;
+    k[2] = (hi & 0xFFFFu) >= thr ? s : 0.f;
+    k[3] = (hi >> 16) >= thr ? s : 0.f;
+}
+__device__ __forceinline__ float res_keep_scale(uint64_t seed, int64_t idx, float p) {
+    if (p <= 0.f) return 1.f;
+    const uint64_t h = mix64(seed ^ ((uint64_t)(idx >> 2) * 0x9E3779B97F4A7C15ULL));
+    const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+    return (uint32_t)((h >> (16 * (idx & 3))) & 0xFFFFu) >= thr ? 1.f / (1.f - p) : 0.f;
 }
 __device__ __forceinline__ float dropout_keep_scale(uint64_t seed, int64_t row, int head, int slot, float p) {
     if (p <= 0.f) return 1.f;

@@ -26,11 +26,7 @@ __host__ __device__ inline int64_t row_grid(int64_t n) {
     return b < 1 ? 1 : (b > tg::kMaxGridBlocks ? tg::kMaxGridBlocks : b);
 }
 
-__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p) {
-    if (p <= 0.f) return 1.f;
-    const float u = (float)(tg::mix32(seed ^ ((uint64_t)idx * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
-    return u >= p ? 1.f / (1.f - p) : 0.f;
-}
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p) { return tg::res_keep_scale(seed, idx, p); }
 
 // y = LayerNorm(dropout(res) + [own | cosb]) * gamma + beta        (modules.py:235-238 with residual = cat[node, time(0)])
 template <int MAXC>
@@ -521,6 +517,27 @@ inline WT wt_layout(float* base, int H, int dn, int dq, int dk) {
     return w;
 }
 
+// Packed weights of the chain kernels (tg_chain.hip), behind the transposed copies in the layer's wT block
+struct PK { float *Wv, *Wr, *W1, *W2; int64_t total; };
+inline int64_t r4(int64_t n) { return (n + 3) / 4 * 4; }
+inline PK pk_layout(float* base, int H, int dn, int dq, int dk) {
+    PK k;
+    const int hd = dq / H, hp = (hd + 15) / 16 * 16;
+    const int yc = (dq + 31) / 32, rc = (dn + 31) / 32;
+    float* p = base;
+    k.Wv = p; p += H * tg::packed_floats(hd, dk);
+    k.Wr = p; p += tg::packed_floats(dq, H * hp);
+    k.W1 = p; p += tg::packed_floats(dn, 32 * (yc + rc));
+    k.W2 = p; p += tg::packed_floats(dn, dn);
+    k.total = p - base;
+    return k;
+}
+inline int64_t wt_floats_plain(int dn, int dq, int dk) {
+    const int64_t H = 2;
+    return 2 * (int64_t)dk * dq + 2 * (int64_t)dn * dn + 2 * (int64_t)dq * dn + (int64_t)dq * dq + 2 * H * dk * dn + 2 * H * dk * dq + H * dk + 16;
+}
+bool g_chain = true;       // fused row-block chains (tg_chain.hip) where the layer's geometry allows
+
 inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, tg::kMaxGridBlocks)); }
 
 #define TG_TRY(expr) do { int _rc = (expr); if (_rc != TG_OK) return _rc; } while (0)
@@ -661,6 +678,24 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     // backward): with them EVERY product of the main chain has two k-contiguous operands and runs on the split-bf16 kernel.
     const WT wt = wt_layout(L->wT, H, dn, dq, dk);
     TG_REQUIRE(H <= 2, "tg_tgat_layer_fwd: the native layer path supports 1 or 2 heads");
+    // everything behind the attention as ONE launch (tg_chain.hip) when the geometry and the alignment allow: its weights are packed here
+    const PK pk = pk_layout(L->wT + r4(wt_floats_plain(dn, dq, dk)), H, dn, dq, dk);
+    const int64_t ldy_c = L->y_ld ? L->y_ld : dq;
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool use_chain = g_chain && tg_get_gemm_mode() != 0 && tg::chain_shape_ok(H, dn, T, a.de) && a16(L->agg) && a16(L->ctx) && a16(L->res) && a16(L->y) && a16(L->raw) &&
+                           a16(L->own) && a16(L->f1) && a16(L->out) && a16(L->cosb) && a16(P.br) && a16(P.b1) && a16(P.b2) && a16(P.ln_g) && a16(P.ln_b) &&
+                           a16(L->wT) && L->own_ld % 4 == 0 && L->raw_ld % 4 == 0 && ldy_c % 4 == 0;
+    if (use_chain) {
+        const int hp = tg::chain_hp(H, dn, T), yc = (dq + 31) / 32, rc = (dn + 31) / 32;
+        tg_pack_job jobs[5];
+        int n = 0;
+        for (int h = 0; h < H; ++h)
+            jobs[n++] = tg_pack_job{P.Wv + (int64_t)h * hd * dk, dk, hd, dk, 0, pk.Wv + h * tg::packed_floats(hd, dk), 0, 0, 0, 0, 0, 0};
+        jobs[n++] = tg_pack_job{P.Wr, dq, dq, H * hp, 0, pk.Wr, 0, dq, 0, 0, hd, hp};                       // K = per-head blocks of hp
+        jobs[n++] = tg_pack_job{P.W1, (int64_t)dq + dn, dn, 32 * (yc + rc), 0, pk.W1, 0, dq + dn, 0, 0, dq, 32 * yc};   // K = [y | raw], each part padded to 32
+        jobs[n++] = tg_pack_job{P.W2, dn, dn, dn, 0, pk.W2, 0, 0, 0, 0, 0, 0};
+        TG_TRY(tg::pack_weights(n, jobs, s));
+    }
     // the constant half of the query, qb = Wq[:, dn:] cos b, rides in the transposes' launch
     // ... together with cos(b) itself (when the caller asks: compute_cosb) and the gather of the layer's raw rows (gather_table)
     int gather_rows_y = 0;
@@ -726,6 +761,7 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, L->q, dq, hd, wt.Wk, hd, (int64_t)dk * hd, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
         TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
     }
+    if (use_chain) return tg::chain_fwd(L, pk.Wv, pk.Wr, pk.W1, pk.W2, pk.total * 4, s);
     // ctx_h = Wv_h agg_h ; res = ctx Wr^T + br
     TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, L->agg, (int64_t)H * dk, dk, P.Wv, dk, (int64_t)hd * dk, L->ctx, dq, hd, H, nullptr, 0, 0, stream));
     TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, L->ctx, dq, P.Wr, dq, L->res, dq, P.br, 0, 0, stream));
@@ -748,9 +784,12 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
 }
 
 extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
-    const int64_t H = 2;                                              // the native layer path supports 1 or 2 heads
-    return 2 * (int64_t)dk * dq + 2 * (int64_t)dn * dn + 2 * (int64_t)dq * dn + (int64_t)dq * dq +
-           2 * H * dk * dn + 2 * H * dk * dq + H * dk + 16;
+    // transposed copies + merged projections (the native layer path supports 1 or 2 heads: sized for 2), then the packed weights of
+    // the chain kernels (largest for H = 1: one head block of dq rows)
+    const int64_t plain = r4(wt_floats_plain(dn, dq, dk));
+    int64_t pk = 0;
+    for (int H = 1; H <= 2; ++H) if (dq % H == 0) pk = std::max(pk, pk_layout(nullptr, H, dn, dq, dk).total);
+    return plain + pk + 16;
 }
 
 extern "C" int64_t tg_tgat_layer_vec_floats(int dn, int dq, int dk, int heads) {
@@ -844,7 +883,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             tg_wgrad_job q[8];
             const int n = (int)jobs.size();
             for (int i = 0; i < n; ++i) q[i] = tg_wgrad_job{jobs[i].A, jobs[i].lda, jobs[i].M, jobs[i].B, jobs[i].ldb, jobs[i].N, jobs[i].C, jobs[i].ldc, jobs[i].cs};
-            if (g_wgrad_grouped && (tg::wgrad_group2(n, q, R, st) || tg::wgrad_group(n, q, R, st))) return tg::launch_status("wgrad kernel");
+            if (g_wgrad_grouped && ((tg_get_gemm_mode() != 0 && tg::wgrad_group2(n, q, R, st)) || tg::wgrad_group(n, q, R, st))) return tg::launch_status("wgrad kernel");
             for (int i = 0; i < n; ++i) {
                 TG_TRY(tg_gemm_f32(1, 0, q[i].M, q[i].N, R, 1.f, q[i].A, q[i].lda, q[i].B, q[i].ldb, q[i].C, q[i].ldc, nullptr, 0, 1, stv));
                 if (q[i].colsum_A) TG_TRY(colsum_seg(q[i].A, q[i].lda, R, q[i].M, seg1(q[i].colsum_A, q[i].M), st));
@@ -866,7 +905,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // ---- merge layer -------------------------------------------------------------------------------------------------------
     // df1 = (f1 > 0) ? dout W2 : 0 -- the ReLU mask rides in the product's epilogue (one launch less per layer); widths the fused form
     // does not cover take the product and the mask kernel separately.  (db1 = sum_rows df1 comes out of the weight-gradient launch.)
-    if (dn % 4 == 0 && (reinterpret_cast<uintptr_t>(Bw->dout) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->f1) & 15) == 0) {
+    if (tg_get_gemm_mode() != 0 && dn % 4 == 0 && (reinterpret_cast<uintptr_t>(Bw->dout) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->f1) & 15) == 0) {   // (the fused mask lives in the split-bf16 kernel)
         TG_TRY(tg_gemm_f32_nt_masked(R, dn, dn, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, L->f1, dn, stream));
     } else {
         TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
@@ -994,6 +1033,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     return TG_OK;
 }
 
+extern "C" void tg_set_layer_chain(int on) { g_chain = on != 0; }
 extern "C" void tg_set_overlap(int on) { g_overlap = (on & 1) != 0; g_issue_thread = (on & 2) == 0; }
 extern "C" void tg_set_layer_merged(int on) { g_merged = on != 0; }
 extern "C" void tg_set_wgrad_grouped(int on) { g_wgrad_grouped = on != 0; }

@@ -96,6 +96,19 @@ class TGAT(nn.Module):
         """First half of prepare_batch for a trainer that knows its batches two steps ahead: issues the level-0 lookups and the
         row sharing on the side stream and returns at once; prepare_batch_finish(job) one step later reads the (by then
         complete) distinct-row count without waiting and issues the rest."""
+        if not torch.is_tensor(src_node_ids):
+            # host numpy int64 ids / float64 times, as the reference's trainers hand them over (PTCL/EM_warmup.py:128-130): one pinned
+            # staging block, one asynchronous copy ON THE SIDE STREAM (the main stream is a step behind and must not be waited for)
+            from .. import ops
+            ids = [np.asarray(src_node_ids), np.asarray(dst_node_ids)]
+            graph = self.neighbor_sampler.graph
+            for a in ids:
+                if len(a) and (int(a.max()) >= graph.num_rows or int(a.min()) < 0):
+                    raise IndexError("list index out of range")                      # what utils/utils.py:141 raises
+            with torch.cuda.stream(engine._side_stream()):
+                src_node_ids, dst_node_ids, node_interact_times = ops.h2d(
+                    [np.ascontiguousarray(ids[0], dtype=np.int32), np.ascontiguousarray(ids[1], dtype=np.int32),
+                     np.ascontiguousarray(node_interact_times, dtype=np.float64)], self.node_raw_features.device)
         job = engine.prepare_begin(self.neighbor_sampler.graph, [src_node_ids, dst_node_ids], [node_interact_times, node_interact_times],
                                    num_neighbors, self.num_layers)
         job.nsrc = src_node_ids.numel()

@@ -212,6 +212,9 @@ void tg_set_overlap(int on);
  * u_h = own (Wk_h^T Wq_h[:, :dn])^T + ub_h and res = agg (Wr[:, h] Wv_h)^T + br -- two products fewer per direction on the main
  * chain, same function up to fp32 reassociation; 0: the reference's q / u / ctx / res products.  Set before forward, keep for its backward. */
 void tg_set_layer_merged(int on);
+/* 1 (default): everything behind the attention of a layer's forward runs as ONE launch (tg_chain.hip: row blocks handed from product
+ * to product through LDS) when the layer's geometry allows; 0: one launch per product / LayerNorm (A/B tests, and the fall-back) */
+void tg_set_layer_chain(int on);
 /* `stream` waits for everything tg_tgat_layer_bwd(defer_join = 1) put on the side streams (drains the helper thread first) */
 int tg_side_join(void* stream);
 
