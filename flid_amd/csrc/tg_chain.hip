@@ -515,6 +515,242 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
     STAMP();
 }
 
+struct ChainBwdArgs {
+    int64_t R;
+    int H, dn, T, de;
+    int hpb;                          // per-head block of dctx inside the panel (hd rounded up to 32: a head's block starts on a chunk)
+    const float* dout;                // (R, dn)
+    const float* f1;                  // (R, dn) forward activations (ReLU mask)
+    const void *pW2T, *pW1aT, *pWrT, *pWvT;   // packed transposed weights; pWvT: heads back to back (tg_packed_floats(dk, hd) apart)
+    const float *ln_g, *cosb;
+    const float* own; int64_t own_ld;
+    const float* res;                 // (R, dq)
+    const float *mean, *rstd;
+    float p_res; uint64_t seed;
+    float* df1;                       // (R, dn)
+    float* dres;                      // (R, dq)   dropout-masked LayerNorm input gradient
+    float* dctx;                      // (R, dq)
+    float* dagg;                      // (R, H dk)
+    float* d_own; int64_t d_own_ld; int d_own_acc;      // optional: (+)= the residual's share dsum[:, :dn]
+    float* part;                      // (workgroups, 4 dq): [sum dy xhat | sum dy | sum dsum | sum dres] per workgroup
+    unsigned long long* dbg;
+};
+
+template <int RB, int HH>
+__global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
+    using G = Geo<RB>;
+    constexpr int ROWS = G::ROWS;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    Wave<5, RB> w;
+    w.lds = lds;
+    w.lane = threadIdx.x & 63;
+    w.wave = threadIdx.x >> 6;
+    w.row0 = (int64_t)blockIdx.x * ROWS;
+    w.R = a.R;
+    const int lane = w.lane, tid = threadIdx.x;
+    const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
+    const int nchunks_dn = (a.dn + 31) >> 5, nchunks_dq = (dq + 31) >> 5;
+    float* red = reinterpret_cast<float*>(lds + G::RED_OFF);
+    bool rok[RB];
+    int64_t rgc[RB];                                           // this lane's global rows, clamped
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t rg = w.row0 + w.out_row(rb);
+        rok[rb] = rg < a.R;
+        rgc[rb] = rg < a.R ? rg : a.R - 1;
+    }
+
+    // ---- df1 = (dout W2) * (f1 > 0)
+    {
+        w.begin(a.pW2T, (a.dn + 15) >> 4, nchunks_dn);
+        f32x4 m[RB][3];                                        // the forward activations of this wave's columns: in flight under the product
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = w.out_col(j);
+            const bool cok = j < w.tcnt && col < a.dn;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float4 v = ld4(a.f1 + (cok ? rgc[rb] * a.dn + col : 0));
+                m[rb][j] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+        w.template run_stream<3, 1>(a.dout, a.dn, 0, a.dn, 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= w.tcnt) break;
+            const int col = w.out_col(j);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int r = w.out_row(rb);
+                float4 v = f4(w.acc[rb][j]);
+                if (col >= a.dn) v = zero4();                  // padding columns of the last tile: zeros for the next product
+                else {
+                    v.x = m[rb][j][0] > 0.f ? v.x : 0.f; v.y = m[rb][j][1] > 0.f ? v.y : 0.f;
+                    v.z = m[rb][j][2] > 0.f ? v.z : 0.f; v.w = m[rb][j][3] > 0.f ? v.w : 0.f;
+                    if (rok[rb]) st4(a.df1 + rgc[rb] * a.dn + col, v);
+                    else v = zero4();
+                }
+                w.panel_store(0, r, col, v);
+            }
+        }
+        if ((16 * ((a.dn + 15) >> 4)) & 31) {                  // second half of the last chunk when dn's tiles end mid-chunk
+            const int c0 = 16 * ((a.dn + 15) >> 4);
+            for (int f = tid; f < ROWS * 4; f += NTH) w.panel_store(0, f >> 2, c0 + 4 * (f & 3), zero4());
+        }
+    }
+    __syncthreads();
+
+    // ---- dy = df1 W1[:, :dq] ;  LayerNorm backward: dsum, dres = dsum * dropout mask, the workgroup's column sums
+    {
+        w.begin(a.pW1aT, (dq + 15) >> 4, nchunks_dn);
+        f32x4 xh[RB][5];                                       // LayerNorm's normalised input, recomputed from res / own / mean / rstd
+        float mu[RB], rs[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) { mu[rb] = a.mean[rgc[rb]]; rs[rb] = a.rstd[rgc[rb]]; }
+        unsigned km[RB][5];                                    // dropout keep bits of each float4 (bit e = element e kept)
+        const float kscale = a.p_res > 0.f ? 1.f / (1.f - a.p_res) : 1.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int col = w.out_col(j);
+            const bool cok = j < w.tcnt && col < dq;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float4 rv = ld4(a.res + (cok ? rgc[rb] * dq + col : 0));
+                const float* src = !cok ? a.cosb : (col < a.dn ? a.own + rgc[rb] * a.own_ld + col : a.cosb + (col - a.dn));
+                const float4 o = ld4(src);
+                float ks[4];
+                tg::res_keep_scale4(a.seed, rgc[rb] * dq + (cok ? col : 0), a.p_res, ks);
+                km[rb][j] = (ks[0] > 0.f ? 1u : 0u) | (ks[1] > 0.f ? 2u : 0u) | (ks[2] > 0.f ? 4u : 0u) | (ks[3] > 0.f ? 8u : 0u);
+                xh[rb][j] = f32x4{rv.x * ks[0] + o.x, rv.y * ks[1] + o.y, rv.z * ks[2] + o.z, rv.w * ks[3] + o.w};
+            }
+        }
+        w.template run_panel<5>(0);
+        float s1[RB], s2[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) s1[rb] = s2[rb] = 0.f;
+        f32x4 gg[RB][5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int col = w.out_col(j);
+            const bool cok = j < w.tcnt && col < dq;
+            const float4 g4 = cok ? ld4(a.ln_g + col) : zero4();
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                if (!cok) { gg[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[rb][j] = gg[rb][j]; continue; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xh[rb][j][e] = (xh[rb][j][e] - mu[rb]) * rs[rb];
+                const f32x4 d = w.acc[rb][j];
+                gg[rb][j] = f32x4{d[0] * g4.x, d[1] * g4.y, d[2] * g4.z, d[3] * g4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[rb] += gg[rb][j][e]; s2[rb] = fmaf(gg[rb][j][e], xh[rb][j][e], s2[rb]); }
+            }
+        }
+        float* red2 = red + 4 * ROWS;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            s1[rb] = quad_rows_sum(s1[rb]);
+            s2[rb] = quad_rows_sum(s2[rb]);
+            if (lane < 16) { red[w.wave * ROWS + rb * 16 + lane] = s1[rb]; red2[w.wave * ROWS + rb * 16 + lane] = s2[rb]; }
+        }
+        __syncthreads();                                       // (also: every wave is done reading the df1 panel)
+        float m1[RB], m2[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int r = w.out_row(rb);
+            m1[rb] = (red[r] + red[ROWS + r] + red[2 * ROWS + r] + red[3 * ROWS + r]) / dq;
+            m2[rb] = (red2[r] + red2[ROWS + r] + red2[2 * ROWS + r] + red2[3 * ROWS + r]) / dq;
+        }
+        float* part = a.part + (int64_t)blockIdx.x * 4 * dq;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (j >= w.tcnt) break;
+            const int col = w.out_col(j);
+            if (col >= dq) continue;
+            float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f}, c3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int r = w.out_row(rb);
+                float dx[4], dr[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dx[e] = rs[rb] * (gg[rb][j][e] - m1[rb] - xh[rb][j][e] * m2[rb]);
+                    dr[e] = ((km[rb][j] >> e) & 1u) ? dx[e] * kscale : 0.f;
+                    if (!rok[rb]) { dx[e] = 0.f; dr[e] = 0.f; }
+                    else { c0[e] = fmaf(w.acc[rb][j][e], xh[rb][j][e], c0[e]); c1[e] += w.acc[rb][j][e]; c2[e] += dx[e]; c3[e] += dr[e]; }
+                }
+                const float4 drv = make_float4(dr[0], dr[1], dr[2], dr[3]);
+                w.panel_store(0, r, col, drv);
+                if (rok[rb]) {
+                    st4(a.dres + rgc[rb] * dq + col, drv);
+                    if (a.d_own && col < a.dn) {
+                        float* o = a.d_own + rgc[rb] * a.d_own_ld + col;
+                        float4 dv = make_float4(dx[0], dx[1], dx[2], dx[3]);
+                        if (a.d_own_acc) dv = add4(dv, ld4(o));
+                        st4(o, dv);
+                    }
+                }
+            }
+            // column sums over the workgroup's rows: the 16 lanes with the same l >> 4 hold the same columns
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { c0[e] = rows16_sum(c0[e]); c1[e] = rows16_sum(c1[e]); c2[e] = rows16_sum(c2[e]); c3[e] = rows16_sum(c3[e]); }
+            if ((lane & 15) == 0) {
+                st4(part + col, make_float4(c0[0], c0[1], c0[2], c0[3]));
+                st4(part + dq + col, make_float4(c1[0], c1[1], c1[2], c1[3]));
+                st4(part + 2 * dq + col, make_float4(c2[0], c2[1], c2[2], c2[3]));
+                st4(part + 3 * dq + col, make_float4(c3[0], c3[1], c3[2], c3[3]));
+            }
+        }
+        if (32 * nchunks_dq > dq) {                            // tail of dres's last chunk
+            const int per = (32 * nchunks_dq - dq) >> 2;
+            for (int f = tid; f < ROWS * per; f += NTH) w.panel_store(0, f / per, dq + 4 * (f % per), zero4());
+        }
+    }
+    __syncthreads();
+
+    // ---- dctx = dres Wr   (columns laid out in per-head blocks of hpb for the next product)
+    {
+        const int ntile = (HH * a.hpb) >> 4;
+        w.begin(a.pWrT, ntile, nchunks_dq);
+        w.template run_panel<5>(0);
+        __syncthreads();                                       // every wave is done with the dres panel
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (j >= w.tcnt) break;
+            const int col = w.out_col(j);                      // padded column: head col / hpb, column col % hpb inside the head
+            const int h = col / a.hpb, ch = col - h * a.hpb;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float4 v = f4(w.acc[rb][j]);
+                if (!rok[rb]) v = zero4();
+                w.panel_store(0, w.out_row(rb), col, v);       // (columns >= hd of a block are zero: zero rows of the packed weight)
+                if (rok[rb] && ch < hd) st4(a.dctx + rgc[rb] * dq + h * hd + ch, v);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- dagg_h = dctx_h Wv_h : dk columns per head, 20 tiles (5 per wave) per pass
+    {
+        const int ht = (dk + 15) >> 4, hs = a.hpb >> 5;
+        const int64_t wv_stride = (int64_t)ht * hs * 512;      // floats per packed head (tg_packed_floats(dk, hd), hd padded to hpb)
+        for (int h = 0; h < HH; ++h)
+            for (int tb = 0; tb < ht; tb += 20) {
+                const int nt = ht - tb < 20 ? ht - tb : 20;
+                w.begin(reinterpret_cast<const float*>(a.pWvT) + h * wv_stride + (int64_t)tb * hs * 512, nt, hs);
+                w.template run_panel<5>(h * hs);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if (j >= w.tcnt) break;
+                    const int col = 16 * tb + w.out_col(j);
+                    if (col >= dk) continue;
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+                        if (rok[rb]) st4(a.dagg + rgc[rb] * ((int64_t)HH * dk) + h * dk + col, f4(w.acc[rb][j]));
+                }
+            }
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 unsigned long long* g_chain_dbg = nullptr;
 
@@ -530,6 +766,18 @@ int launch_fwd(const ChainFwdArgs& a, hipStream_t s) {
     return tg::launch_status("chain_fwd_kernel");
 }
 
+template <int RB, int HH>
+int launch_bwd(const ChainBwdArgs& a, hipStream_t s) {
+    using G = Geo<RB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_kernel<RB, HH>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr_set = true;
+    }
+    chain_bwd_kernel<RB, HH><<<(unsigned)((a.R + G::ROWS - 1) / G::ROWS), NTH, G::LDS_BYTES, s>>>(a);
+    return tg::launch_status("chain_bwd_kernel");
+}
+
 }  // namespace
 
 namespace tg {
@@ -543,6 +791,8 @@ bool chain_shape_ok(int H, int dn, int T, int de) {
     // tiles per wave: res <= 5, ctx (4 / H waves per head) <= 5, fc1 / fc2 <= 3; panel: ctx <= 8 chunks beside nothing, [y | raw] <= 15
     if (dq > 320 || dn > 192 || hp / 16 > 5 * (4 / H) || H * hp > 32 * NCH) return false;
     if ((dq + 31) / 32 + (dn + 31) / 32 > NCH || dk > 32 * 64) return false;
+    const int hpb = (hd + 31) / 32 * 32;
+    if (H * hpb > 320) return false;                                          // dctx: 20 tiles, 10 chunks
     return true;
 }
 int chain_hp(int H, int dn, int T) { const int hd = (dn + T) / H; return (hd + 15) / 16 * 16; }
@@ -571,6 +821,34 @@ int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const vo
     const bool tall = at.m >= 64 * 128 && !force_rb1;
     if (at.heads == 2) return tall ? launch_fwd<4, 2>(a, s) : launch_fwd<1, 2>(a, s);
     return tall ? launch_fwd<4, 1>(a, s) : launch_fwd<1, 1>(a, s);
+}
+
+int chain_hpb(int H, int dn, int T) { const int hd = (dn + T) / H; return (hd + 31) / 32 * 32; }
+// workgroups of a chain launch over `rows` rows (= slabs of column sums the backward chain leaves in `part`)
+int64_t chain_blocks(int64_t rows) { return rows >= 64 * 128 ? (rows + 63) / 64 : (rows + 15) / 16; }
+
+int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, float* part, const void* pW2T, const void* pW1aT,
+              const void* pWrT, const void* pWvT, hipStream_t s) {
+    const tg_attn_desc& at = L->attn;
+    ChainBwdArgs a;
+    a.R = at.m; a.H = at.heads; a.dn = at.dn; a.T = at.dt_dim; a.de = at.de;
+    a.hpb = chain_hpb(at.heads, at.dn, at.dt_dim);
+    a.dout = Bw->dout; a.f1 = L->f1;
+    a.pW2T = pW2T; a.pW1aT = pW1aT; a.pWrT = pWrT; a.pWvT = pWvT;
+    a.ln_g = L->params.ln_g; a.cosb = L->cosb;
+    a.own = L->own; a.own_ld = L->own_ld;
+    a.res = L->res; a.mean = L->mean; a.rstd = L->rstd;
+    a.p_res = L->res_dropout_p; a.seed = L->res_seed;
+    a.df1 = Bw->df1; a.dres = dres; a.dctx = Bw->dctx; a.dagg = Bw->dagg;
+    a.d_own = Bw->d_own; a.d_own_ld = Bw->d_own_ld; a.d_own_acc = Bw->d_own_accumulate;
+    a.part = part;
+    a.dbg = nullptr;
+    const int dq = at.dn + at.dt_dim, dk = at.dn + at.de + at.dt_dim;
+    const double macs = (double)at.dn * at.dn + (double)dq * at.dn + (double)dq * dq + (double)dk * dq;
+    ProfScope prof("gemm", 2.0 * at.m * macs, s);
+    const bool tall = at.m >= 64 * 128;
+    if (at.heads == 2) return tall ? launch_bwd<4, 2>(a, s) : launch_bwd<1, 2>(a, s);
+    return tall ? launch_bwd<4, 1>(a, s) : launch_bwd<1, 1>(a, s);
 }
 
 }  // namespace tg

@@ -77,6 +77,10 @@ bool gemm_rows_nt(int64_t R, int N, int K, const float* A, int64_t lda, int64_t 
 bool chain_shape_ok(int H, int dn, int T, int de);
 int chain_hp(int H, int dn, int T);
 int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const void* pW1, const void* pW2, int64_t packed_bytes, hipStream_t s);
+int chain_hpb(int H, int dn, int T);
+int64_t chain_blocks(int64_t rows);
+int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, float* part, const void* pW2T, const void* pW1aT,
+              const void* pWrT, const void* pWvT, hipStream_t s);
 bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);  // tg_wgrad.hip: big tiles + transposing LDS reads + slice fold
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);   // tg_gemm_bf16x3.hip; false = shapes not covered
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered

@@ -518,7 +518,7 @@ inline WT wt_layout(float* base, int H, int dn, int dq, int dk) {
 }
 
 // Packed weights of the chain kernels (tg_chain.hip), behind the transposed copies in the layer's wT block
-struct PK { float *Wv, *Wr, *W1, *W2; int64_t total; };
+struct PK { float *Wv, *Wr, *W1, *W2, *W2T, *W1aT, *WrT, *WvT; int64_t total; };
 inline int64_t r4(int64_t n) { return (n + 3) / 4 * 4; }
 inline PK pk_layout(float* base, int H, int dn, int dq, int dk) {
     PK k;
@@ -529,6 +529,11 @@ inline PK pk_layout(float* base, int H, int dn, int dq, int dk) {
     k.Wr = p; p += tg::packed_floats(dq, H * hp);
     k.W1 = p; p += tg::packed_floats(dn, 32 * (yc + rc));
     k.W2 = p; p += tg::packed_floats(dn, dn);
+    const int hpb = (hd + 31) / 32 * 32;                 // backward: dctx in per-head blocks that start on a 32-k chunk
+    k.W2T = p; p += tg::packed_floats(dn, dn);
+    k.W1aT = p; p += tg::packed_floats(dq, dn);
+    k.WrT = p; p += tg::packed_floats(H * hpb, dq);
+    k.WvT = p; p += H * tg::packed_floats(dk, hpb);
     k.total = p - base;
     return k;
 }
@@ -687,13 +692,20 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
                            a16(L->wT) && L->own_ld % 4 == 0 && L->raw_ld % 4 == 0 && ldy_c % 4 == 0;
     if (use_chain) {
         const int hp = tg::chain_hp(H, dn, T), yc = (dq + 31) / 32, rc = (dn + 31) / 32;
-        tg_pack_job jobs[5];
+        tg_pack_job jobs[12];
         int n = 0;
         for (int h = 0; h < H; ++h)
             jobs[n++] = tg_pack_job{P.Wv + (int64_t)h * hd * dk, dk, hd, dk, 0, pk.Wv + h * tg::packed_floats(hd, dk), 0, 0, 0, 0, 0, 0};
         jobs[n++] = tg_pack_job{P.Wr, dq, dq, H * hp, 0, pk.Wr, 0, dq, 0, 0, hd, hp};                       // K = per-head blocks of hp
         jobs[n++] = tg_pack_job{P.W1, (int64_t)dq + dn, dn, 32 * (yc + rc), 0, pk.W1, 0, dq + dn, 0, 0, dq, 32 * yc};   // K = [y | raw], each part padded to 32
         jobs[n++] = tg_pack_job{P.W2, dn, dn, dn, 0, pk.W2, 0, 0, 0, 0, 0, 0};
+        // backward operands (the transposed weights its input-gradient products multiply with; weights change only at the optimizer step)
+        const int hpb = tg::chain_hpb(H, dn, T);
+        jobs[n++] = tg_pack_job{P.W2, dn, dn, dn, 1, pk.W2T, 0, 0, 0, 0, 0, 0};                                      // df1 = dout W2
+        jobs[n++] = tg_pack_job{P.W1, (int64_t)dq + dn, dq, dn, 1, pk.W1aT, 0, 0, 0, 0, 0, 0};                      // dy = df1 W1[:, :dq]
+        jobs[n++] = tg_pack_job{P.Wr, dq, H * hpb, dq, 1, pk.WrT, dq, 0, hd, hpb, 0, 0};                             // dctx = dres Wr, columns in head blocks
+        for (int h = 0; h < H; ++h)                                                                                  // dagg_h = dctx_h Wv_h
+            jobs[n++] = tg_pack_job{P.Wv + (int64_t)h * hd * dk, dk, dk, hd, 1, pk.WvT + h * tg::packed_floats(dk, hpb), 0, 0, 0, 0, 0, 0};
         TG_TRY(tg::pack_weights(n, jobs, s));
     }
     // the constant half of the query, qb = Wq[:, dn:] cos b, rides in the transposes' launch
@@ -820,6 +832,17 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const int64_t w1ld = dq + dn;
     float* vec = Bw->vec;
     const WT wt = wt_layout(L->wT, H, dn, dq, dk);                 // filled by the forward call of this step
+    // the products and the LayerNorm backward ahead of the attention as ONE launch (tg_chain.hip) -- under the same conditions as the
+    // forward chain, whose prelude packed the transposed weights
+    const PK pk = pk_layout(L->wT + r4(wt_floats_plain(dn, dq, dk)), H, dn, dq, dk);
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    float* dres_c = L->res_dropout_p > 0.f ? Bw->dres : Bw->dsum;
+    const bool use_chain = g_chain && tg_get_gemm_mode() != 0 && tg::chain_shape_ok(H, dn, T, a.de) && a16(L->agg) && a16(L->ctx) && a16(L->res) &&
+                           a16(L->y) && a16(L->raw) && a16(L->own) && a16(L->f1) && a16(L->out) && a16(L->cosb) && a16(P.br) && a16(P.b1) &&
+                           a16(P.b2) && a16(P.ln_g) && a16(P.ln_b) && a16(L->wT) && L->own_ld % 4 == 0 && L->raw_ld % 4 == 0 &&
+                           (L->y_ld ? L->y_ld : dq) % 4 == 0 &&                                  // (= the forward's decision)
+                           a16(Bw->dout) && a16(Bw->df1) && a16(dres_c) && a16(Bw->dctx) && a16(Bw->dagg) && a16(Bw->part) &&
+                           (!Bw->d_own || (a16(Bw->d_own) && Bw->d_own_ld % 4 == 0));
     const bool overlap = g_overlap && g_side.init();
     // where everything that only feeds parameter gradients goes: re-pointed by every fork()
     void* wstream = stream;
@@ -857,7 +880,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const int64_t relu_blocks = (R + 15) / 16;
     // (at most 768 workgroups = 3 per CU walk the rows: every workgroup leaves a slab of 4 dq column sums, and 3 400 of them were
     // 15 MB for the slab-sum launch to read: 11 us)
-    const unsigned ln_grid = (unsigned)std::min<int64_t>(row_grid(R), 768);
+    const unsigned ln_grid = use_chain ? (unsigned)tg::chain_blocks(R) : (unsigned)std::min<int64_t>(row_grid(R), 768);
     const int attn_parts = tg_attn_bwd_parts(R);
     float* part_relu = Bw->part;
     float* part_ln = part_relu + relu_blocks * dn;
@@ -905,7 +928,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // ---- merge layer -------------------------------------------------------------------------------------------------------
     // df1 = (f1 > 0) ? dout W2 : 0 -- the ReLU mask rides in the product's epilogue (one launch less per layer); widths the fused form
     // does not cover take the product and the mask kernel separately.  (db1 = sum_rows df1 comes out of the weight-gradient launch.)
-    if (tg_get_gemm_mode() != 0 && dn % 4 == 0 && (reinterpret_cast<uintptr_t>(Bw->dout) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->f1) & 15) == 0) {   // (the fused mask lives in the split-bf16 kernel)
+    if (use_chain) {
+        TG_TRY(tg::chain_bwd(L, Bw, dres_c, part_ln, pk.W2T, pk.W1aT, pk.WrT, pk.WvT, s));
+    } else if (tg_get_gemm_mode() != 0 && dn % 4 == 0 && (reinterpret_cast<uintptr_t>(Bw->dout) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->f1) & 15) == 0) {   // (the fused mask lives in the split-bf16 kernel)
         TG_TRY(tg_gemm_f32_nt_masked(R, dn, dn, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, L->f1, dn, stream));
     } else {
         TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, nullptr, 0, 0, stream));
@@ -923,11 +948,11 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(wgrad({WJ{Bc.dout, dn, dn, Lc.f1, dn, dn, G.W2, dn, G.b2},
                       WJ{Bc.df1, dn, dn, Lc.y, ldy, dq, G.W1, w1ld, G.b1},
                       WJ{Bc.df1, dn, dn, Lc.raw, Lc.raw_ld, dn, G.W1 + dq, w1ld, nullptr}}));
-    TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
+    if (!use_chain) TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
     if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
-    float* dres = L->res_dropout_p > 0.f ? Bw->dres : Bw->dsum;
-    {
+    float* dres = dres_c;
+    if (!use_chain) {
         const size_t lds = sizeof(float) * ROW_WAVES * 4 * dq;
         if (dq <= 64) ln_res_bwd_kernel<1><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln, Bw->d_own, Bw->d_own_ld, Bw->d_own_accumulate);
         else if (dq <= 320) ln_res_bwd_kernel<5><<<ln_grid, 256, lds, s>>>(L->res, L->own, L->own_ld, L->cosb, Bw->dy, R, dn, dq, L->res_dropout_p, L->res_seed, P.ln_g, L->mean, L->rstd, Bw->dsum, dres, part_ln, Bw->d_own, Bw->d_own_ld, Bw->d_own_accumulate);
@@ -970,8 +995,10 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     };
     if (g_merged && R >= kMergedMinRows) {
         // ---- output projection + value path (the reference's two products; weight gradients in one grouped launch) ------------------
-        TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
-        TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, hk, dk, H, nullptr, 0, 0, stream));
+        if (!use_chain) {
+            TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
+            TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, hk, dk, H, nullptr, 0, 0, stream));
+        }
         TG_TRY(fork());                       // dres / dsum, dctx and the LayerNorm slabs are final
         {
             std::vector<WJ> jobs;
@@ -1000,9 +1027,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     } else {
         TG_TRY(fork());                           // dres / dsum and the LayerNorm slabs are final
         // ---- output projection ------------------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
+        if (!use_chain) TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
         // ---- value path -------------------------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, hk, dk, H, nullptr, 0, 0, stream));
+        if (!use_chain) TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, Bw->dctx, dq, hd, wt.Wv, hd, (int64_t)dk * hd, Bw->dagg, hk, dk, H, nullptr, 0, 0, stream));
         // ---- fused attention backward -------------------------------------------------------------------------------------------------
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         // ---- key / query path --------------------------------------------------------------------------------------------------------
