@@ -43,24 +43,31 @@ namespace {
 
 using namespace tgs;
 
-constexpr int NTH = 256;
 constexpr int NCH = 15;                      // panel chunks: [y (9) | raw (6)] of the merge layer is the widest operand
-template <int RB>
+// RB row blocks of 16; NW waves (4, or 8 = two per SIMD).  Measured on the 13.6 k-row layer: 8 waves run the chain in the same time as
+// 4 (112.8 k vs 115 k cycles per workgroup) -- every product moves its weights at ~20-27 B / cycle / CU whatever the wave count: the
+// launch is bound by the CU's path to L2, not by issue slots -- and spill registers; the launchers instantiate 4.
+template <int RB, int NW>
 struct Geo {
     static constexpr int ROWS = 16 * RB;
+    static constexpr int NTH = 64 * NW;
     static constexpr int CHS = ROWS * 64 + 64;       // one plane of one 32-k chunk (+64: the chunk stores of one row spread over banks)
     static constexpr int CHUNK = 2 * CHS;            // hi plane | lo plane
     static constexpr int PANEL = NCH * CHUNK;
     static constexpr int RED_OFF = PANEL;
-    static constexpr int LDS_BYTES = RED_OFF + 2 * 4 * ROWS * 4;
-    static constexpr int PER = RB;                   // float4 per thread, head and group when a product streams its rows (16 per row)
+    static constexpr int LDS_BYTES = RED_OFF + 2 * NW * ROWS * 4;
+    static constexpr int RPP = 4 * NW;               // rows per pass when a product streams its rows (16 float4 per row and group)
+    static constexpr int PER = ROWS / RPP;           // float4 per thread, operand and group
+    static constexpr int NTW = NW == 8 ? 3 : 5;      // most column tiles a wave owns in any product of a chain
+    static_assert(ROWS % RPP == 0, "row passes must tile the block");
 };
-static_assert(Geo<4>::LDS_BYTES <= 163840, "one workgroup must fit the CU's LDS");
+static_assert(Geo<4, 8>::LDS_BYTES <= 163840, "one workgroup must fit the CU's LDS");
 
 // state of one wave inside a chain
-template <int NTW, int RB>
+template <int RB, int NW>
 struct Wave {
-    using G = Geo<RB>;
+    using G = Geo<RB, NW>;
+    static constexpr int NTW = G::NTW;
     char* lds;
     int lane, wave;
     int64_t row0, R;
@@ -70,7 +77,7 @@ struct Wave {
     int S, t0, tcnt;          // current product: steps, first tile of this wave (inside its operand), tiles it owns
 
     // the product's nt column tiles are dealt in blocks to waves [w0, w0 + nw); `packed` = that operand
-    __device__ __forceinline__ void begin(const void* packed, int nt, int steps, int w0 = 0, int nw = 4) {
+    __device__ __forceinline__ void begin(const void* packed, int nt, int steps, int w0 = 0, int nw = NW) {
         S = steps;
         const int cpw = (nt + nw - 1) / nw;
         t0 = (wave - w0) * cpw;
@@ -172,14 +179,14 @@ struct Wave {
     template <int NT, int HH>
     __device__ __forceinline__ void run_stream(const float* __restrict__ A, int64_t lda, int64_t a_stride, int K, int mine) {
         const int tid = wave * 64 + lane;
-        const int c4 = tid & 15, r16 = tid >> 4;           // 16 float4 per row, operand and group; 16 rows per pass
+        const int c4 = tid & 15, r16 = tid >> 4;           // 16 float4 per row, operand and group; RPP rows per pass
         constexpr int PER = G::PER;
         const float* aptr[PER];
         bool rok[PER];
         int aoff[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int r = r16 + 16 * i;
+            const int r = r16 + G::RPP * i;
             int64_t rg = row0 + r;
             rok[i] = rg < R;
             if (rg > R - 1) rg = R - 1;
@@ -284,13 +291,14 @@ struct ChainFwdArgs {
     unsigned long long* dbg;          // diagnostic builds only: 16 stamps per workgroup
 };
 
-// tiles a wave can own: dq <= 320 -> 5.  HH = heads (1 or 2)
-template <int RB, int HH>
-__global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
-    using G = Geo<RB>;
-    constexpr int ROWS = G::ROWS;
+// HH = heads (1 or 2); NW = waves.  Tiles per wave (compile-time loop bounds): the widest product (res, dq <= 16 NTW NW columns)
+// takes NTW, the merge layer's (dn columns) NTF.
+template <int RB, int HH, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs a) {
+    using G = Geo<RB, NW>;
+    constexpr int ROWS = G::ROWS, NTH = G::NTH, NTW = G::NTW, NTF = NW == 8 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Wave<5, RB> w;
+    Wave<RB, NW> w;
     w.lds = lds;
     w.lane = threadIdx.x & 63;
     w.wave = threadIdx.x >> 6;
@@ -324,9 +332,9 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
     {
         const int ht = (hd + 15) >> 4;                        // tiles per head
         const int64_t wv_stride = (int64_t)((hd + 15) / 16) * ((dk + 31) / 32) * 512;   // floats per packed head (tg_packed_floats(hd, dk))
-        const int mine = HH == 2 ? w.wave >> 1 : 0;
-        w.begin(reinterpret_cast<const float*>(a.pWv) + mine * wv_stride, ht, (dk + 31) >> 5, HH == 2 ? 2 * mine : 0, 4 / HH);
-        w.template run_stream<5, HH>(a.agg, (int64_t)HH * dk, dk, dk, mine);
+        const int mine = HH == 2 ? w.wave / (NW / 2) : 0;
+        w.begin(reinterpret_cast<const float*>(a.pWv) + mine * wv_stride, ht, (dk + 31) >> 5, HH == 2 ? (NW / 2) * mine : 0, NW / HH);
+        w.template run_stream<NTW, HH>(a.agg, (int64_t)HH * dk, dk, dk, mine);
         STAMP();
 #pragma unroll
         for (int i = 0; i < RAWN; ++i) {
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
             if (4 * c < 32 * rchunks) w.panel_store(ychunks, r, 4 * c, ok ? rawv[i] : zero4());
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);                     // inside the head's block
 #pragma unroll
@@ -359,13 +367,13 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
         STAMP();
         w.begin(a.pWr, (dq + 15) >> 4, kc);
         // the residual's rows [own | cos b] for this wave's columns: in flight under the product
-        f32x4 x[RB][5];
+        f32x4 x[RB][NTW];
         float s1[RB];
         bool rok[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) { s1[rb] = 0.f; rok[rb] = w.row0 + w.out_row(rb) < a.R; }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int col = w.out_col(j);
             const bool cok = j < w.tcnt && col < dq;
 #pragma unroll
@@ -377,10 +385,10 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
                 x[rb][j] = f32x4{o.x, o.y, o.z, o.w};
             }
         }
-        w.template run_panel<5>(0);
+        w.template run_panel<NTW>(0);
         STAMP();
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);
             if (col >= dq) {                                   // columns past dq in the last tile (lane-wise): not part of the row
@@ -415,11 +423,14 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int r = w.out_row(rb);
-            mu[rb] = (red[r] + red[ROWS + r] + red[2 * ROWS + r] + red[3 * ROWS + r]) / dq;
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) t += red[q * ROWS + r];
+            mu[rb] = t / dq;
             s2[rb] = 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             if (j >= w.tcnt) break;
             if (w.out_col(j) >= dq) continue;
 #pragma unroll
@@ -427,7 +438,7 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = x[rb][j][e] - mu[rb]; s2[rb] = fmaf(d, d, s2[rb]); }
         }
-        float* red2 = red + 4 * ROWS;
+        float* red2 = red + NW * ROWS;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             s2[rb] = quad_rows_sum(s2[rb]);
@@ -438,11 +449,14 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int r = w.out_row(rb);
-            rs[rb] = rsqrtf((red2[r] + red2[ROWS + r] + red2[2 * ROWS + r] + red2[3 * ROWS + r]) / dq + 1e-5f);
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) t += red2[q * ROWS + r];
+            rs[rb] = rsqrtf(t / dq + 1e-5f);
             if (w.wave == 0 && lane < 16 && rok[rb]) { a.mean[w.row0 + r] = mu[rb]; a.rstd[w.row0 + r] = rs[rb]; }
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);
             if (col >= dq) continue;                           // (the zero fill below covers the panel's tail)
@@ -471,11 +485,11 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
     // ---- f1 = relu([y | raw] W1^T + b1)
     STAMP();
     w.begin(a.pW1, (a.dn + 15) >> 4, ychunks + rchunks);
-    w.template run_panel<3>(0);
+    w.template run_panel<NTF>(0);
     STAMP();
     __syncthreads();                                           // every wave is done with [y | raw]: f1 takes its place
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NTF; ++j) {
         if (j >= w.tcnt) break;
         const int col = w.out_col(j);
         if (col >= a.dn) {                                     // padding columns of the last tile: zeros for the next product
@@ -498,10 +512,10 @@ __global__ void __launch_bounds__(NTH, 1) chain_fwd_kernel(ChainFwdArgs a) {
     // ---- out = f1 W2^T + b2
     STAMP();
     w.begin(a.pW2, (a.dn + 15) >> 4, rchunks);
-    w.template run_panel<3>(0);
+    w.template run_panel<NTF>(0);
     STAMP();
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NTF; ++j) {
         if (j >= w.tcnt) break;
         const int col = w.out_col(j);
         if (col >= a.dn) continue;
@@ -536,12 +550,12 @@ struct ChainBwdArgs {
     unsigned long long* dbg;
 };
 
-template <int RB, int HH>
-__global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
-    using G = Geo<RB>;
-    constexpr int ROWS = G::ROWS;
+template <int RB, int HH, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs a) {
+    using G = Geo<RB, NW>;
+    constexpr int ROWS = G::ROWS, NTH = G::NTH, NTW = G::NTW, NTF = NW == 8 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Wave<5, RB> w;
+    Wave<RB, NW> w;
     w.lds = lds;
     w.lane = threadIdx.x & 63;
     w.wave = threadIdx.x >> 6;
@@ -563,9 +577,9 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
     // ---- df1 = (dout W2) * (f1 > 0)
     {
         w.begin(a.pW2T, (a.dn + 15) >> 4, nchunks_dn);
-        f32x4 m[RB][3];                                        // the forward activations of this wave's columns: in flight under the product
+        f32x4 m[RB][NTF];                                        // the forward activations of this wave's columns: in flight under the product
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NTF; ++j) {
             const int col = w.out_col(j);
             const bool cok = j < w.tcnt && col < a.dn;
 #pragma unroll
@@ -574,9 +588,9 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
                 m[rb][j] = f32x4{v.x, v.y, v.z, v.w};
             }
         }
-        w.template run_stream<3, 1>(a.dout, a.dn, 0, a.dn, 0);
+        w.template run_stream<NTF, 1>(a.dout, a.dn, 0, a.dn, 0);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NTF; ++j) {
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);
 #pragma unroll
@@ -603,14 +617,14 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
     // ---- dy = df1 W1[:, :dq] ;  LayerNorm backward: dsum, dres = dsum * dropout mask, the workgroup's column sums
     {
         w.begin(a.pW1aT, (dq + 15) >> 4, nchunks_dn);
-        f32x4 xh[RB][5];                                       // LayerNorm's normalised input, recomputed from res / own / mean / rstd
+        f32x4 xh[RB][NTW];                                       // LayerNorm's normalised input, recomputed from res / own / mean / rstd
         float mu[RB], rs[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) { mu[rb] = a.mean[rgc[rb]]; rs[rb] = a.rstd[rgc[rb]]; }
-        unsigned km[RB][5];                                    // dropout keep bits of each float4 (bit e = element e kept)
+        unsigned km[RB][NTW];                                    // dropout keep bits of each float4 (bit e = element e kept)
         const float kscale = a.p_res > 0.f ? 1.f / (1.f - a.p_res) : 1.f;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int col = w.out_col(j);
             const bool cok = j < w.tcnt && col < dq;
 #pragma unroll
@@ -624,13 +638,13 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
                 xh[rb][j] = f32x4{rv.x * ks[0] + o.x, rv.y * ks[1] + o.y, rv.z * ks[2] + o.z, rv.w * ks[3] + o.w};
             }
         }
-        w.template run_panel<5>(0);
+        w.template run_panel<NTW>(0);
         float s1[RB], s2[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) s1[rb] = s2[rb] = 0.f;
-        f32x4 gg[RB][5];
+        f32x4 gg[RB][NTW];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             const int col = w.out_col(j);
             const bool cok = j < w.tcnt && col < dq;
             const float4 g4 = cok ? ld4(a.ln_g + col) : zero4();
@@ -645,7 +659,7 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
                 for (int e = 0; e < 4; ++e) { s1[rb] += gg[rb][j][e]; s2[rb] = fmaf(gg[rb][j][e], xh[rb][j][e], s2[rb]); }
             }
         }
-        float* red2 = red + 4 * ROWS;
+        float* red2 = red + NW * ROWS;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             s1[rb] = quad_rows_sum(s1[rb]);
@@ -657,12 +671,15 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int r = w.out_row(rb);
-            m1[rb] = (red[r] + red[ROWS + r] + red[2 * ROWS + r] + red[3 * ROWS + r]) / dq;
-            m2[rb] = (red2[r] + red2[ROWS + r] + red2[2 * ROWS + r] + red2[3 * ROWS + r]) / dq;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) { t1 += red[q * ROWS + r]; t2 += red2[q * ROWS + r]; }
+            m1[rb] = t1 / dq;
+            m2[rb] = t2 / dq;
         }
         float* part = a.part + (int64_t)blockIdx.x * 4 * dq;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);
             if (col >= dq) continue;
@@ -711,10 +728,10 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
     {
         const int ntile = (HH * a.hpb) >> 4;
         w.begin(a.pWrT, ntile, nchunks_dq);
-        w.template run_panel<5>(0);
+        w.template run_panel<NTW>(0);
         __syncthreads();                                       // every wave is done with the dres panel
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);                      // padded column: head col / hpb, column col % hpb inside the head
             const int h = col / a.hpb, ch = col - h * a.hpb;
@@ -729,17 +746,17 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
     }
     __syncthreads();
 
-    // ---- dagg_h = dctx_h Wv_h : dk columns per head, 20 tiles (5 per wave) per pass
+    // ---- dagg_h = dctx_h Wv_h : dk columns per head, NTW NW tiles per pass
     {
         const int ht = (dk + 15) >> 4, hs = a.hpb >> 5;
         const int64_t wv_stride = (int64_t)ht * hs * 512;      // floats per packed head (tg_packed_floats(dk, hd), hd padded to hpb)
         for (int h = 0; h < HH; ++h)
-            for (int tb = 0; tb < ht; tb += 20) {
-                const int nt = ht - tb < 20 ? ht - tb : 20;
+            for (int tb = 0; tb < ht; tb += NTW * NW) {
+                const int nt = ht - tb < NTW * NW ? ht - tb : NTW * NW;
                 w.begin(reinterpret_cast<const float*>(a.pWvT) + h * wv_stride + (int64_t)tb * hs * 512, nt, hs);
-                w.template run_panel<5>(h * hs);
+                w.template run_panel<NTW>(h * hs);
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
+                for (int j = 0; j < NTW; ++j) {
                     if (j >= w.tcnt) break;
                     const int col = 16 * tb + w.out_col(j);
                     if (col >= dk) continue;
@@ -754,27 +771,27 @@ __global__ void __launch_bounds__(NTH, 1) chain_bwd_kernel(ChainBwdArgs a) {
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 unsigned long long* g_chain_dbg = nullptr;
 
-template <int RB, int HH>
+template <int RB, int HH, int NW>
 int launch_fwd(const ChainFwdArgs& a, hipStream_t s) {
-    using G = Geo<RB>;
+    using G = Geo<RB, NW>;
     static bool attr_set = false;
     if (!attr_set) {
-        TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_kernel<RB, HH>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_kernel<RB, HH, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         attr_set = true;
     }
-    chain_fwd_kernel<RB, HH><<<(unsigned)((a.R + G::ROWS - 1) / G::ROWS), NTH, G::LDS_BYTES, s>>>(a);
+    chain_fwd_kernel<RB, HH, NW><<<(unsigned)((a.R + G::ROWS - 1) / G::ROWS), G::NTH, G::LDS_BYTES, s>>>(a);
     return tg::launch_status("chain_fwd_kernel");
 }
 
-template <int RB, int HH>
+template <int RB, int HH, int NW>
 int launch_bwd(const ChainBwdArgs& a, hipStream_t s) {
-    using G = Geo<RB>;
+    using G = Geo<RB, NW>;
     static bool attr_set = false;
     if (!attr_set) {
-        TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_kernel<RB, HH>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_kernel<RB, HH, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         attr_set = true;
     }
-    chain_bwd_kernel<RB, HH><<<(unsigned)((a.R + G::ROWS - 1) / G::ROWS), NTH, G::LDS_BYTES, s>>>(a);
+    chain_bwd_kernel<RB, HH, NW><<<(unsigned)((a.R + G::ROWS - 1) / G::ROWS), G::NTH, G::LDS_BYTES, s>>>(a);
     return tg::launch_status("chain_bwd_kernel");
 }
 
@@ -819,8 +836,8 @@ int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const vo
     // 64-row blocks once they fill the chip; fewer rows take 16-row blocks (a workgroup streams all the weights whatever its height)
     static const bool force_rb1 = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_CHAIN_RB1") != nullptr;
     const bool tall = at.m >= 64 * 128 && !force_rb1;
-    if (at.heads == 2) return tall ? launch_fwd<4, 2>(a, s) : launch_fwd<1, 2>(a, s);
-    return tall ? launch_fwd<4, 1>(a, s) : launch_fwd<1, 1>(a, s);
+    if (at.heads == 2) return tall ? launch_fwd<4, 2, 4>(a, s) : launch_fwd<1, 2, 4>(a, s);
+    return tall ? launch_fwd<4, 1, 4>(a, s) : launch_fwd<1, 1, 4>(a, s);
 }
 
 int chain_hpb(int H, int dn, int T) { const int hd = (dn + T) / H; return (hd + 31) / 32 * 32; }
@@ -847,8 +864,8 @@ int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, 
     const double macs = (double)at.dn * at.dn + (double)dq * at.dn + (double)dq * dq + (double)dk * dq;
     ProfScope prof("gemm", 2.0 * at.m * macs, s);
     const bool tall = at.m >= 64 * 128;
-    if (at.heads == 2) return tall ? launch_bwd<4, 2>(a, s) : launch_bwd<1, 2>(a, s);
-    return tall ? launch_bwd<4, 1>(a, s) : launch_bwd<1, 1>(a, s);
+    if (at.heads == 2) return tall ? launch_bwd<4, 2, 4>(a, s) : launch_bwd<1, 2, 4>(a, s);
+    return tall ? launch_bwd<4, 1, 4>(a, s) : launch_bwd<1, 1, 4>(a, s);
 }
 
 }  // namespace tg
