@@ -270,7 +270,13 @@ def main():
             return
         opt.zero_grad(set_to_none=True)
         if fused:
-            model.train_step(prepared.pop(s), mean_loss, K)          # forward, loss, backward: no autograd graph
+            # forward, loss, backward: no autograd graph; N > 1: the root layer's gradient block starts its all-reduce as soon as that
+            # layer's backward is queued, under the lower layer's backward
+            model.train_step(prepared.pop(s), mean_loss, K, grad_ready=reducer.segment_ready if reducer is not None else None)
+            if reducer is not None:
+                reducer.finish()
+            opt.step()
+            return
         else:
             se, de_ = model.compute_src_dst_node_temporal_embeddings(prepared.pop(s), None, None, K)
             loss = torch.addcmul(se * rw[0], de_, rw[1]).mean()      # the same scalar through torch autograd
@@ -319,10 +325,26 @@ def main():
             step(s)
         fam.update({tag: ops.profile_collect(tag) for tag in others})
     ops.profile_enable(False)
+    dist_info = None
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        elapsed = max(per_rank)
+        # the collective alone: the flat gradient (one bucket) reduced 20 times back to back
+        gbuf = torch.zeros(sum(p.numel() for p in train_params), device=dev)
+        for _ in range(3):
+            torch.distributed.all_reduce(gbuf)
+        torch.cuda.synchronize()
+        t_ar = time.perf_counter()
+        for _ in range(20):
+            torch.distributed.all_reduce(gbuf)
+        torch.cuda.synchronize()
+        dist_info = {"rccl_ranks": world, "backend": torch.distributed.get_backend(),
+                     "per_rank_ms_per_step": [round(e / args.steps * 1e3, 4) for e in per_rank],
+                     "allreduce_ms": round((time.perf_counter() - t_ar) / 20 * 1e3, 4), "allreduce_floats": int(gbuf.numel()),
+                     "overlap": "root-layer block reduced under the layer-1 backward (GradAllReducer.segment_ready)" if fused else "none"}
     breakdown = {k_: round(v[0] / args.steps, 4) for k_, v in fam.items()}
 
     edges = args.steps * BATCH * world
@@ -403,6 +425,8 @@ def main():
     }
     if dedupe_off is not None:
         out["row_sharing_off"] = dedupe_off
+    if dist_info is not None:
+        out["distributed"] = dist_info
     if "gemm" in fam and args.roofline_kernel != "gemm" and fam["gemm"][2] > 0:
         # the dense projections are priced against the f32-input MFMA peak "alongside" (untimed second pass; all
         # product launches of a step: split-bf16, direct and tiled kernels; flops = 2 M N K as the reference's fp32 mm would do)
@@ -588,10 +612,26 @@ def bench_memory_or_sequence_model(args):
     elapsed = time.perf_counter() - t0
     ms, units, cnt = ops.profile_collect(fam_name)
     ops.profile_enable(False)
+    dist_info = None
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        elapsed = max(per_rank)
+        # the collective alone: the flat gradient (one bucket) reduced 20 times back to back
+        gbuf = torch.zeros(sum(p.numel() for p in train_params), device=dev)
+        for _ in range(3):
+            torch.distributed.all_reduce(gbuf)
+        torch.cuda.synchronize()
+        t_ar = time.perf_counter()
+        for _ in range(20):
+            torch.distributed.all_reduce(gbuf)
+        torch.cuda.synchronize()
+        dist_info = {"rccl_ranks": world, "backend": torch.distributed.get_backend(),
+                     "per_rank_ms_per_step": [round(e / args.steps * 1e3, 4) for e in per_rank],
+                     "allreduce_ms": round((time.perf_counter() - t_ar) / 20 * 1e3, 4), "allreduce_floats": int(gbuf.numel()),
+                     "overlap": "root-layer block reduced under the layer-1 backward (GradAllReducer.segment_ready)" if fused else "none"}
     value = args.steps * BATCH * world / elapsed
     secs = max(ms * 1e-3, 1e-12)
     if args.model == "tgn":

@@ -3,7 +3,10 @@
 The reference has no distributed code; the temporal embedding shards naturally: every rank
 holds the graph, the feature tables and the weights, embeds its own slice of the edge batch, and the only exchange is one
 sum all-reduce of the ~1 M fp32 gradients (4 MB, latency-bound on 7 x 153 GB/s links) in a single flat bucket, weighted so
-that a mean-reduced loss equals its single-GPU value.  TGN additionally all-gathers its new raw messages (tgn_exchange)."""
+that a mean-reduced loss equals its single-GPU value.  In the fused step the bucket is cut in two: the root layer's block is
+reduced on RCCL's stream as soon as its backward is queued (GradAllReducer.segment_ready), under the lower layer's backward; the
+rest follows at the end (finish).  TGN needs no data exchange at all: every rank advances the replicated memory / message state
+with the whole batch's (identical) update (MemoryModel.compute_shard_embeddings_and_advance)."""
 import os
 from typing import Iterable, List, Optional
 
@@ -50,6 +53,49 @@ class GradAllReducer:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+
+    # ---- bucketed form for the fused step: segments of the (single, flat) gradient as they become final
+    def segment_ready(self, seg: torch.Tensor, weight: float = None):
+        """start the all-reduce of a finished segment of the flat gradient (a view of it) without blocking the stream that
+        produced it: the collective runs on the backend's own stream, ordered behind everything queued so far"""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return
+        w = (1.0 / world) if weight is None else float(weight)
+        if w != 1.0:
+            seg.mul_(w)
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg.data_ptr(), seg.numel()))
+
+    def finish(self, weight: float = None):
+        """reduce whatever segment_ready has not covered (flat-parameter mode: one gradient tensor) and make the current stream
+        wait for every collective in flight"""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return
+        pend = getattr(self, "_pending", [])
+        self._pending = []
+        if not pend:
+            return self.reduce(weight)
+        assert len(self.params) == 1 and self.params[0].grad is not None, "segment_ready is for the flat-parameter mode"
+        g = self.params[0].grad
+        w = (1.0 / world) if weight is None else float(weight)
+        esz = g.element_size()
+        done = sorted(((p - g.data_ptr()) // esz, n) for _, p, n in pend)
+        pos, rest = 0, []
+        for lo, n in done:                      # the complement of the segments already in flight
+            if lo > pos:
+                rest.append(g[pos:lo])
+            pos = max(pos, lo + n)
+        if pos < g.numel():
+            rest.append(g[pos:])
+        works = [wk for wk, _, _ in pend]
+        for r in rest:
+            if w != 1.0:
+                r.mul_(w)
+            works.append(dist.all_reduce(r, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for wk in works:
+            wk.wait()                           # (device backends: the current stream waits; the host does not block)
 
     def reduce(self, weight: float = None):
         """Gather the gradients into the flat bucket (one multi-tensor copy), scale, ONE all-reduce, and hand the bucket's views

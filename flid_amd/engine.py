@@ -507,7 +507,7 @@ def _native_forward(cfg, fr, table, te_w, te_b, layer_params):
     return H_prev, (layers, cosb)
 
 
-def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_floats: int = 0):
+def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_floats: int = 0, grad_ready=None):
     """every layer = one native backward call; returns (d_table or None, gradient block, offsets of [te_w, te_b, *layer_params]
     inside it, number of gradient floats).  The block is laid out like TGAT.flatten_parameters()' flat parameter."""
     layers, cosb = saved
@@ -564,6 +564,12 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_
                 else:
                     d_own += d_raw
                     ops.scatter_add_rows(d_own, fr.ids_all[:R], d_table)
+            if grad_ready is not None and l >= 2:
+                # layer l's own parameter gradients are final once its backward is queued (the time encoder's block keeps
+                # accumulating until layer 1): a data-parallel caller can start reducing this segment under the lower layers' backward
+                lo_ = offs[2 + (l - 1) * 11]
+                hi_ = offs[2 + l * 11] if l < L else npar
+                grad_ready(zeroed[lo_:hi_])
             dH = dH_prev
     finally:
         check(lib().tg_side_join(ops._stream()), "tg_side_join")
@@ -623,18 +629,23 @@ class _EmbedFnNative(torch.autograd.Function):
         return (None, None, d_table, *grads)
 
 
-def forward_backward(cfg, fr, table, flat, loss_fn):
+def forward_backward(cfg, fr, table, flat, loss_fn, grad_ready=None):
     """Fused-trainer form of one step: forward, the caller's loss on the embeddings, backward -- with no autograd
     graph in between.  flat = (flat parameter, views) of TGAT.flatten_parameters(); loss_fn(emb) -> (loss, d loss / d emb) sees the
     (n, Dn) embeddings detached.  Returns (embeddings, loss); the gradient is ADDED to flat[0].grad (set if None), exactly what
-    loss.backward() through embed() would have left there."""
+    loss.backward() through embed() would have left there.
+    grad_ready(segment): called with each upper layer's block of the NEW gradient as soon as that layer's backward is queued (the
+    segments are views of the gradient block; the rest -- time encoder + layer 1 -- is final when this returns).  With it the
+    gradient is SET, not added (flat[0].grad must be None: the segments handed out are the .grad storage itself)."""
     views = flat[1]
     te_w, te_b, layer_params = views[0], views[1], views[2:]
     with torch.no_grad():
         out, saved = _native_forward(cfg, fr, table, te_w, te_b, layer_params)
     loss, d_out = loss_fn(out)
     with torch.no_grad():
-        _, zeroed, _, npar = _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, d_out)
+        if grad_ready is not None and flat[0].grad is not None:
+            raise RuntimeError("forward_backward(grad_ready=...): zero_grad(set_to_none=True) first")
+        _, zeroed, _, npar = _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, d_out, grad_ready=grad_ready)
         g = zeroed[:npar]
         if flat[0].grad is None:
             flat[0].grad = g

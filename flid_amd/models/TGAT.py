@@ -119,7 +119,7 @@ class TGAT(nn.Module):
         pf.nsrc = job.nsrc
         return pf
 
-    def train_step(self, prepared, loss_fn, num_neighbors: int = 20):
+    def train_step(self, prepared, loss_fn, num_neighbors: int = 20, grad_ready=None):
         """Fused-trainer step (not in the reference): forward of the prepared batch, `loss_fn(emb) -> (loss, d_emb)` on
         the detached (2 B, Dn) embedding block [src rows | dst rows], backward -- without an autograd graph.  Needs
         flatten_parameters(); the gradient lands in the flat parameter's .grad exactly as loss.backward() would leave it."""
@@ -136,7 +136,7 @@ class TGAT(nn.Module):
                    training=bool(self.training), edge_table=self.edge_raw_features, table_grad=False)
         if self.num_heads > 2 or not engine.NATIVE:
             raise NotImplementedError("train_step runs the one-call-per-layer path (1 or 2 heads)")
-        return engine.forward_backward(cfg, pf.frontier, self.node_raw_features, flat, loss_fn)
+        return engine.forward_backward(cfg, pf.frontier, self.node_raw_features, flat, loss_fn, grad_ready=grad_ready)
 
     def compute_node_temporal_embeddings(self, node_ids: np.ndarray, node_interact_times: np.ndarray,
                                          current_layer_num: int, num_neighbors: int = 20, _groups=None):

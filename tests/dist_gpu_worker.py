@@ -1,0 +1,99 @@
+"""One rank of tests/test_00_gpu_dist.py (started by torch.distributed.run; also usable by hand on one GPU for plumbing:
+FLID_BENCH_SHARE_GPU=1 FLID_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 tests/dist_gpu_worker.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from flid_amd import dist as fdist                                   # noqa: E402
+from flid_amd import ops                                             # noqa: E402
+from flid_amd._lib import lib                                        # noqa: E402
+
+
+def flat_grad(model, flat, data, sl, k, weight, reducer=None):
+    """one fused step's gradient on edges `sl` (loss = sum over the slice of emb . r / n_global)"""
+    n = sl.stop - sl.start
+    rs = np.random.RandomState(5)
+    r_all = torch.from_numpy(rs.standard_normal((2, 600, data.node_raw_features.shape[1])).astype(np.float32)).cuda()
+    lo = sl.start - 2000
+    r = torch.cat([r_all[0, lo:lo + n], r_all[1, lo:lo + n]]).contiguous()
+
+    def loss_fn(emb):
+        return (emb * r).sum() / n, r / n                           # mean over the LOCAL slice (the reducer's weight rescales it)
+    flat.grad = None
+    pf = model.prepare_batch_finish(model.prepare_batch_begin(data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl], k))
+    model.train_step(pf, loss_fn, k, grad_ready=(lambda seg: reducer.segment_ready(seg, weight)) if reducer is not None else None)
+    if reducer is not None:
+        reducer.finish(weight)
+    torch.cuda.synchronize()
+    return flat.grad.clone()
+
+
+def main():
+    rank, world, local = fdist.init_from_env()
+    if os.environ.get("FLID_BENCH_SHARE_GPU"):
+        local = 0
+    torch.cuda.set_device(local)
+    from flid_amd.models.MemoryModel import MemoryModel
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.sweep import regenerate_embeddings
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+    dev = f"cuda:{local}"
+    data = wikipedia_like(num_edges=6000, seed=0, zero_node_feat=False)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+
+    # ---- (i) TGAT gradient: 2 shards of 300 edges + weighted all-reduce == one process on the 600 edges
+    for mode, tol in ((0, 3e-6), (1, 1e-4)):
+        lib().tg_set_gemm_mode(mode)
+        torch.manual_seed(0)
+        model = TGAT(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, num_layers=2, num_heads=2, dropout=0.0,
+                     device=dev).to(dev).train()
+        fdist.broadcast_parameters(model)
+        flat = model.flatten_parameters()
+        reducer = fdist.GradAllReducer([flat])
+        lo, hi = fdist.shard_bounds(600, rank, world)
+        g_dp = flat_grad(model, flat, data, slice(2000 + lo, 2000 + hi), 10, (hi - lo) / 600.0, reducer)
+        g_one = flat_grad(model, flat, data, slice(2000, 2600), 10, 1.0)
+        err = float((g_dp - g_one).abs().max()) / max(1e-12, float(g_one.abs().max()))
+        assert err <= tol, f"rank {rank} mode {mode}: reduced gradient differs from the full-batch gradient by {err:.2e} of its largest entry"
+    lib().tg_set_gemm_mode(1)
+
+    # ---- (ii) TGN: replicas stay bit-identical over 5 sharded steps
+    torch.manual_seed(0)
+    tgn = MemoryModel(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, model_name="TGN", num_layers=1,
+                      num_heads=2, dropout=0.0, device=dev).to(dev).train()
+    fdist.broadcast_parameters(tgn)
+    tgn.memory_bank.__init_memory_bank__()
+    for b in range(5):
+        sl = slice(b * 200, (b + 1) * 200)
+        with torch.no_grad():
+            tgn.compute_shard_embeddings_and_advance(data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl],
+                                                     data.edge_ids[sl], fdist.shard_bounds(200, rank, world), True, 10)
+    state = torch.cat([tgn.memory_bank.node_memories.data.reshape(-1), tgn.memory_bank.node_last_updated_times.data.reshape(-1)])
+    both = [torch.empty_like(state) for _ in range(world)]
+    dist.all_gather(both, state)
+    assert all(torch.equal(both[0], b_) for b_ in both[1:]), "TGN replicas diverged"
+
+    # ---- (iii) regeneration sweep: rank-interleaved chunks + all-gather == one rank
+    torch.manual_seed(0)
+    m2 = TGAT(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, num_layers=2, num_heads=2, dropout=0.1,
+              device=dev).to(dev)
+    fdist.broadcast_parameters(m2)
+    s_dp, d_dp = regenerate_embeddings(m2, data, 200, 10, chunk_edges=512, rank=rank, world=world)
+    s_1, d_1 = regenerate_embeddings(m2, data, 200, 10, chunk_edges=512, rank=0, world=1)
+    assert float((s_dp - s_1).abs().max()) < 2e-5 and float((d_dp - d_1).abs().max()) < 2e-5, "sharded sweep != single-rank stores"
+
+    dist.barrier()
+    if rank == 0:
+        print("DIST-GPU-OK", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,3 +80,36 @@ def test_shard_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _seg_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    fdist.init_from_env(backend="gloo")
+    p = torch.nn.Parameter(torch.zeros(37))
+    p.grad = torch.arange(37, dtype=torch.float32) * (rank + 1)        # rank r holds (r + 1) * [0..36]
+    red = fdist.GradAllReducer([p])
+    w = 0.25 if rank == 0 else 0.75
+    red.segment_ready(p.grad[20:30], w)                                 # an upper layer's block, early
+    red.segment_ready(p.grad[30:37], w)
+    red.finish(w)                                                       # the rest: [0, 20)
+    q.put((rank, p.grad.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_segmented_allreduce_covers_the_flat_gradient_once():
+    """GradAllReducer.segment_ready + finish (the bucketed, overlapped form of the fused step): every element of the flat gradient
+    is scaled and reduced exactly once, whatever the segments handed in early"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_seg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    want = np.arange(37, dtype=np.float32) * (0.25 * 1 + 0.75 * 2)
+    for _, g in out:
+        assert np.allclose(g, want, atol=1e-6)
