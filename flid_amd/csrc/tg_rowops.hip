@@ -314,6 +314,33 @@ extern "C" int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, fl
     return tg::launch_status("weighted_sum_kernel");
 }
 
+// loss[0] = mean_i BCE(sigmoid(z_i), y_i) with y_i = 1 for i < n_pos else 0, dz_i = (sigmoid(z_i) - y_i) / n: the link-prediction
+// warm-up's sigmoid + nn.BCELoss (PTCL/EM_warmup.py:212-222) and its gradient w.r.t. the logits, one workgroup (n = 2 x batch).
+// BCELoss clamps log() at -100; softplus(+-z) saturates the same way far beyond any logit a trained head produces.
+__global__ void __launch_bounds__(256) bce_logits_kernel(const float* __restrict__ z, int64_t n_pos, int64_t n, float* __restrict__ loss,
+                                                         float* __restrict__ dz) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const float inv = 1.f / (float)n;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float v = z[i], y = i < n_pos ? 1.f : 0.f;
+        const float sp = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));        // softplus(v) = -log(1 - sigmoid(v))
+        float l = sp - y * v;                                             // = -[y log p + (1 - y) log(1 - p)]
+        if (l > 100.f) l = 100.f;
+        s += l;
+        dz[i] = (1.f / (1.f + expf(-v)) - y) * inv;
+    }
+    s = tg::wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv;
+}
+extern "C" int tg_bce_logits(const float* d_z, int64_t n_pos, int64_t n, float* d_loss, float* d_dz, void* stream) {
+    TG_REQUIRE(d_z && d_loss && d_dz && n > 0 && n_pos >= 0 && n_pos <= n, "tg_bce_logits: arguments");
+    bce_logits_kernel<<<1, 256, 0, (hipStream_t)stream>>>(d_z, n_pos, n, d_loss, d_dz);
+    return tg::launch_status("bce_logits_kernel");
+}
+
 extern "C" int tg_rowop_parts(int64_t n) { return (int)row_grid(n); }
 
 extern "C" int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols, float* d_out,

@@ -1,0 +1,78 @@
+"""Caller-side heads + losses of the trainers in fused-step form: `loss_fn(emb) -> (loss, d loss / d emb)` objects for
+TGAT.train_step / MemoryModel.train_step, so that a whole trainer step -- backbone forward, head, loss, head backward, backbone
+backward -- runs without an autograd graph.
+
+replaces: PTCL/EM_warmup.py:212-231 (MergeLayer link predictor -> sigmoid -> nn.BCELoss -> backward) and, through
+`AutogradHeadLoss`, PTCL/M_step.py:285-318 (MLPClassifier -> masked / weighted cross entropy) and NPL/NPL.py:280-307."""
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+
+def _acc_grad(p, g):
+    p.grad = g if p.grad is None else p.grad + g
+
+
+class LinkPredictionLoss:
+    """The link-prediction warm-up's head and loss on an embedding block [src | dst | negative dst] (3 B rows):
+        p+ = sigmoid(head(src, dst)), p- = sigmoid(head(src, neg)),  loss = BCELoss(cat[p+, p-], cat[1, 0])      (EM_warmup.py:212-222)
+    with head = MergeLayer(D, D, H, 1) = fc2(relu(fc1(cat[a, b]))) (models/modules.py:58-69).  Forward and backward are explicit
+    products on the library's kernels (no autograd); the head's parameter gradients are ADDED to their .grad, the gradient w.r.t. the
+    embedding block is returned -- the source rows collect both uses, as in the reference, which embeds them twice.  The reference
+    computes the positive and the negative pair in two backbone calls (4 roots per edge); here the sources are embedded once."""
+
+    def __init__(self, head):
+        self.head = head
+        self.loss_out = None
+
+    def __call__(self, emb: torch.Tensor):
+        fc1, fc2 = self.head.fc1, self.head.fc2
+        n3, D = emb.shape
+        B = n3 // 3
+        assert n3 == 3 * B and fc1.weight.shape[1] == 2 * D and fc2.weight.shape[0] == 1
+        H = fc1.weight.shape[0]
+        dev = emb.device
+        src, dst, neg = emb[:B], emb[B:2 * B], emb[2 * B:]
+        X = torch.cat([torch.cat([src, dst], 1), torch.cat([src, neg], 1)], 0)                 # (2 B, 2 D): positive pairs, negative pairs
+        h = torch.empty((2 * B, H), device=dev)
+        ops.gemm(X, fc1.weight.detach(), h, tb=True, bias=fc1.bias.detach(), relu=True)
+        z = torch.empty((2 * B, 1), device=dev)
+        ops.gemm(h, fc2.weight.detach(), z, tb=True, bias=fc2.bias.detach())
+        if self.loss_out is None or self.loss_out.device != dev:
+            self.loss_out = torch.zeros(1, device=dev)
+        dz = torch.empty((2 * B, 1), device=dev)
+        check(lib().tg_bce_logits(ops._p(z), B, 2 * B, ops._p(self.loss_out), ops._p(dz), ops._stream()), "tg_bce_logits")
+        # backward
+        dW2 = torch.empty_like(fc2.weight)
+        ops.gemm(dz, h, dW2, ta=True)                                                            # (1, H)
+        dh = torch.empty((2 * B, H), device=dev)
+        ops.gemm(dz, fc2.weight.detach(), dh)                                                    # (2 B, 1) x (1, H)
+        ops.relu_bwd_(dh, h)
+        dW1 = torch.empty_like(fc1.weight)
+        ops.gemm(dh, X, dW1, ta=True)
+        dX = torch.empty((2 * B, 2 * D), device=dev)
+        ops.gemm(dh, fc1.weight.detach(), dX)
+        _acc_grad(fc2.weight, dW2)
+        _acc_grad(fc2.bias, ops.colsum(dz))
+        _acc_grad(fc1.weight, dW1)
+        _acc_grad(fc1.bias, ops.colsum(dh))
+        d_emb = torch.cat([dX[:B, :D] + dX[B:, :D], dX[:B, D:], dX[B:, D:]], 0)
+        return self.loss_out, d_emb
+
+
+class AutogradHeadLoss:
+    """Any head + loss written with torch ops (the M-step's MLPClassifier with its ground-truth / pseudo-label masks and per-sample
+    weights, PTCL/M_step.py:285-318): the head runs as a small autograd island on the detached embedding block; its parameters get
+    their .grad as usual, the backbone receives d loss / d emb and runs its backward without a graph.
+    `fn(emb) -> scalar loss` (emb requires grad)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, emb: torch.Tensor):
+        x = emb.detach().requires_grad_(True)
+        with torch.enable_grad():
+            loss = self.fn(x)
+            loss.backward()
+        return loss.detach(), x.grad

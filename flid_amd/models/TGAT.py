@@ -68,8 +68,11 @@ class TGAT(nn.Module):
         return flat_param
 
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray,
-                                                 node_interact_times: np.ndarray, num_neighbors: int = 20):
+                                                 node_interact_times: np.ndarray, num_neighbors: int = 20, roots: str = "both"):
         # both sides share one device pass: rows are independent (reference computes them one after the other, :61-65)
+        # roots = "src" (not in the reference): only the source embeddings are wanted (PTCL/M_step.py:285) -> (src_emb, None)
+        if roots == "src" and not isinstance(src_node_ids, engine.PreparedFrontier):
+            return self.compute_node_temporal_embeddings(src_node_ids, node_interact_times, self.num_layers, num_neighbors), None
         if isinstance(src_node_ids, engine.PreparedFrontier):
             emb = self.compute_node_temporal_embeddings(src_node_ids, None, self.num_layers, num_neighbors)
             return engine.split_rows(emb, src_node_ids.nsrc)
@@ -92,10 +95,13 @@ class TGAT(nn.Module):
         pf.nsrc = src_node_ids.numel()
         return pf
 
-    def prepare_batch_begin(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20):
+    def prepare_batch_begin(self, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20, roots: str = "both"):
         """First half of prepare_batch for a trainer that knows its batches two steps ahead: issues the level-0 lookups and the
         row sharing on the side stream and returns at once; prepare_batch_finish(job) one step later reads the (by then
         complete) distinct-row count without waiting and issues the rest."""
+        # roots = "src": embed the source nodes only -- single-way datasets' M-step classifies `batch_src_node_embeddings` alone
+        # (PTCL/M_step.py:285: the destination rows the reference computes there are never read), half the roots of a step
+        assert roots in ("both", "src")
         if not torch.is_tensor(src_node_ids):
             # host numpy int64 ids / float64 times, as the reference's trainers hand them over (PTCL/EM_warmup.py:128-130): one pinned
             # staging block, one asynchronous copy ON THE SIDE STREAM (the main stream is a step behind and must not be waited for)
@@ -109,9 +115,29 @@ class TGAT(nn.Module):
                 src_node_ids, dst_node_ids, node_interact_times = ops.h2d(
                     [np.ascontiguousarray(ids[0], dtype=np.int32), np.ascontiguousarray(ids[1], dtype=np.int32),
                      np.ascontiguousarray(node_interact_times, dtype=np.float64)], self.node_raw_features.device)
-        job = engine.prepare_begin(self.neighbor_sampler.graph, [src_node_ids, dst_node_ids], [node_interact_times, node_interact_times],
-                                   num_neighbors, self.num_layers)
+        if roots == "src":
+            job = engine.prepare_begin(self.neighbor_sampler.graph, [src_node_ids], [node_interact_times], num_neighbors, self.num_layers)
+        else:
+            job = engine.prepare_begin(self.neighbor_sampler.graph, [src_node_ids, dst_node_ids], [node_interact_times, node_interact_times],
+                                       num_neighbors, self.num_layers)
         job.nsrc = src_node_ids.numel()
+        return job
+
+    def prepare_roots_begin(self, id_lists, node_interact_times, num_neighbors: int = 20):
+        """as prepare_batch_begin for any number of root lists that share the batch's interaction times -- the link-prediction warm-up's
+        [src, dst, negative dst] (PTCL/EM_warmup.py:128-153; the reference embeds the sources twice, once per pair).  Host numpy
+        int64 / float64 in; the embedding block of the prepared batch is the lists' rows one after the other."""
+        from .. import ops
+        graph = self.neighbor_sampler.graph
+        arrs = [np.asarray(a) for a in id_lists]
+        for a in arrs:
+            if len(a) and (int(a.max()) >= graph.num_rows or int(a.min()) < 0):
+                raise IndexError("list index out of range")
+        with torch.cuda.stream(engine._side_stream()):
+            dev = ops.h2d([np.ascontiguousarray(a, dtype=np.int32) for a in arrs] + [np.ascontiguousarray(node_interact_times, dtype=np.float64)],
+                          self.node_raw_features.device)
+        job = engine.prepare_begin(graph, dev[:-1], [dev[-1]] * len(arrs), num_neighbors, self.num_layers)
+        job.nsrc = len(arrs[0])
         return job
 
     def prepare_batch_finish(self, job):

@@ -232,6 +232,10 @@ int tg_time_bias_finish(float* d_teb, const float* d_b, const float* d_cosb, int
  * stand-in for the reduction of PTCL/EM_warmup.py:222 / M_step.py:297-306).  Operands 16-byte aligned. */
 int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, float scale, float* d_out, void* stream);
 
+/* d_loss[0] = mean_i BCE(sigmoid(z_i), y_i), y_i = 1 for i < n_pos else 0; d_dz[i] = (sigmoid(z_i) - y_i) / n.
+ * replaces `.sigmoid()` + nn.BCELoss + its backward in the link-prediction warm-up (PTCL/EM_warmup.py:212-222). */
+int tg_bce_logits(const float* d_z, int64_t n_pos, int64_t n, float* d_loss, float* d_dz, void* stream);
+
 /* C[M,N] = (Y > 0) ? A[M,K] B[N,K]^T : 0   -- the input gradient of `relu(x W^T)` with the ReLU mask applied in the product's
  * epilogue (Y = the forward output; models/modules.py:68 `self.act(self.fc1(...))` differentiated).  Operands 16-byte aligned,
  * lda / ldb / K multiples of 4. */

@@ -596,7 +596,62 @@ def gold_backbones_small():
     run_mixer("mixer_K4_uniform", 8, 4, 1, 4, 5, 7, seed=94, graph_seed=9, strategy="uniform")
 
 
+def gold_tgat_lp3(num_edges=30000, lo=20000, batch=200, steps=3, seed=48, scale=0.05, lr=1e-4, neg_seed=7):
+    """The trainer's call sequence on TGAT (PTCL/EM_warmup.py:126-231), run on the reference classes: `steps` consecutive batches of
+    the link-prediction warm-up -- seeded NegativeEdgeSampler draw, positive and negative embeddings, MergeLayer link predictor,
+    sigmoid, BCELoss, optimizer.zero_grad / backward / Adam step over nn.Sequential(backbone, head).  Recorded: the negative draws,
+    every step's loss, and the parameters after the last step (compacted like the gradients of the other fixtures)."""
+    from flid_amd.synth import wikipedia_like
+    from models.modules import MergeLayer
+    from utils.utils import create_optimizer
+    import torch.nn as nn
+    data = wikipedia_like(num_edges=num_edges, seed=0, zero_node_feat=False)
+    ns = get_neighbor_sampler(Data(data.src_node_ids, data.dst_node_ids, data.node_interact_times, data.edge_ids), "recent", seed=0)
+    backbone = TGAT(data.node_raw_features, data.edge_raw_features, ns, time_feat_dim=100, num_layers=2, num_heads=2, dropout=0.0)
+    head = MergeLayer(input_dim1=172, input_dim2=172, hidden_dim=172, output_dim=1)
+    shapes = {k_: tuple(v.shape) for k_, v in backbone.state_dict().items()}
+    params = O.seeded_like(shapes, seed=seed, scale=scale)
+    O.kink_free_(params)
+    backbone.load_state_dict(params)
+    hshapes = {k_: tuple(v.shape) for k_, v in head.state_dict().items()}
+    hparams = O.seeded_like(hshapes, seed=seed + 1, scale=scale)
+    head.load_state_dict(hparams)
+    model = nn.Sequential(backbone, head)
+    model.train()
+    optimizer = create_optimizer(model=model, optimizer_name="Adam", learning_rate=lr, weight_decay=0.0)      # EM_warmup.py:99-100
+    neg = NegativeEdgeSampler(src_node_ids=data.src_node_ids[:lo + batch * steps], dst_node_ids=data.dst_node_ids[:lo + batch * steps], seed=neg_seed)
+    loss_func = nn.BCELoss()
+    losses, negs = [], []
+    model[0].set_neighbor_sampler(ns)
+    for b in range(steps):
+        sl = slice(lo + b * batch, lo + (b + 1) * batch)
+        bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+        _, bn = neg.sample(size=len(bs))                                                             # :132
+        se, de = model[0].compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=bd, node_interact_times=bt, num_neighbors=20)
+        nse, nde = model[0].compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=bn, node_interact_times=bt, num_neighbors=20)
+        pos = model[1](input_1=se, input_2=de).squeeze(dim=-1).sigmoid()                              # :212-215
+        ngp = model[1](input_1=nse, input_2=nde).squeeze(dim=-1).sigmoid()
+        predicts = torch.cat([pos, ngp], dim=0)
+        labels = torch.cat([torch.ones_like(pos), torch.zeros_like(ngp)], dim=0)
+        loss = loss_func(input=predicts, target=labels)                                              # :222
+        losses.append(float(loss.item()))
+        negs.append(np.asarray(bn, dtype=np.int64))
+        optimizer.zero_grad()
+        loss.backward()
+        if b == 0:      # the first step's gradients: which entries carry a gradient above rounding level (Adam moves ALL by ~lr)
+            first = {"g1:" + k_[2:]: v for k_, v in grads_compact({k_: p.grad for k_, p in model[0].named_parameters()}).items() if k_.startswith("g:")}
+        optimizer.step()                                                                             # :229-231
+    final = {"p:" + k_[2:]: v for k_, v in grads_compact({k_: p for k_, p in model[0].named_parameters()}).items() if k_.startswith("g:")}
+    final.update({"ps:" + k_[3:]: v for k_, v in grads_compact({k_: p for k_, p in model[0].named_parameters()}).items() if k_.startswith("gs:")})
+    hfinal = {"h:" + k_: p.detach().numpy().copy() for k_, p in model[1].named_parameters()}
+    save("tgat_lp3", num_edges=np.int64(num_edges), lo=np.int64(lo), batch=np.int64(batch), steps=np.int64(steps), seed=np.int64(seed),
+         scale=np.float64(scale), lr=np.float64(lr), neg_seed=np.int64(neg_seed), losses=np.asarray(losses, dtype=np.float64),
+         neg=np.stack(negs), crc=_crc(data.src_node_ids, data.dst_node_ids, data.node_interact_times, data.edge_raw_features[:64]),
+         **final, **hfinal, **first)
+
+
 FULL = {
+    "tgat_lp3": gold_tgat_lp3,
     "time_shifts": gold_time_shifts,
     "backbones_small": gold_backbones_small,
     "tcl_full": gold_tcl_full,

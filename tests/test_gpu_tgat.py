@@ -542,3 +542,68 @@ def test_regeneration_sweep_fills_the_stores_like_the_per_batch_loop():
         os_, od_ = orc.src_dst(data.src_node_ids[pick], data.dst_node_ids[pick], data.node_interact_times[pick], 7)
     np.testing.assert_allclose(s_store.cpu().numpy()[pick], os_.numpy(), atol=TOL)
     np.testing.assert_allclose(d_store.cpu().numpy()[pick], od_.numpy(), atol=TOL)
+
+
+def test_link_prediction_warmup_three_steps_match_reference_golden():
+    """The trainer's call sequence on TGAT (PTCL/EM_warmup.py:126-231) against values captured from the reference classes
+    (tests/golden/make_golden.py::gold_tgat_lp3): seeded NegativeEdgeSampler draws, then per batch the fused step -- [src | dst | neg]
+    embedded in one call, MergeLayer head + sigmoid + BCE (flid_amd.heads.LinkPredictionLoss), backward, Adam on backbone (FlatAdam,
+    flat parameter) and head -- three batches in a row: every loss, and the parameters after the third update."""
+    from conftest import grads_compact_np, load_golden
+    from flid_amd.heads import LinkPredictionLoss
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.models.modules import MergeLayer
+    from flid_amd.optim import FlatAdam
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.utils.utils import NegativeEdgeSampler, get_neighbor_sampler
+    g = load_golden("tgat_lp3")
+    E, lo, B, steps, lr = int(g["num_edges"]), int(g["lo"]), int(g["batch"]), int(g["steps"]), float(g["lr"])
+    data = wikipedia_like(num_edges=E, seed=0, zero_node_feat=False)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, num_layers=2, num_heads=2, dropout=0.0, device="cuda:0")
+    p = O.seeded_like({k_: tuple(v.shape) for k_, v in m.state_dict().items()}, int(g["seed"]), float(g["scale"]))
+    O.kink_free_(p)
+    m.load_state_dict(p)
+    m = m.to("cuda:0").train()
+    head = MergeLayer(172, 172, 172, 1).to("cuda:0")
+    hp = O.seeded_like({k_: tuple(v.shape) for k_, v in head.state_dict().items()}, int(g["seed"]) + 1, float(g["scale"]))
+    head.load_state_dict(hp)
+    p0 = {k_: v.detach().clone() for k_, v in m.state_dict().items()}
+    flat = m.flatten_parameters()
+    opt, hopt = FlatAdam([flat], lr=lr), FlatAdam(list(head.parameters()), lr=lr)
+    lp = LinkPredictionLoss(head)
+    neg = NegativeEdgeSampler(src_node_ids=data.src_node_ids[:lo + B * steps], dst_node_ids=data.dst_node_ids[:lo + B * steps], seed=int(g["neg_seed"]))
+    for b in range(steps):
+        sl = slice(lo + b * B, lo + (b + 1) * B)
+        bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+        _, bn = neg.sample(size=B)
+        assert np.array_equal(np.asarray(bn), g["neg"][b])                                        # the seeded draw is the reference's
+        pf = m.prepare_batch_finish(m.prepare_roots_begin([bs, bd, bn], bt, 20))
+        opt.zero_grad(set_to_none=True)
+        hopt.zero_grad(set_to_none=True)
+        _, loss = m.train_step(pf, lp, 20)
+        opt.step()
+        hopt.step()
+        # (first step: the same weights, 2e-5; later steps run on weights that two Adam updates have moved by ~lr per entry, with the
+        # sign of rounding-level gradient entries free -- the north-star tolerance)
+        assert abs(float(loss) - float(g["losses"][b])) <= (2e-5 if b == 0 else 1e-4), (b, float(loss), float(g["losses"][b]))
+    # parameters after three Adam updates.  Adam's first steps move EVERY entry by ~lr whatever its gradient's size, so an entry whose
+    # gradient is at rounding level takes either sign, in the reference as here: the updates are compared where the reference's
+    # first-step gradient is above 1e-3 of its tensor's largest entry (the fixture records it) -- there, 95 % within a quarter of a step
+    mine = grads_compact_np({k_: v.detach().cpu().numpy() for k_, v in m.named_parameters()})
+    init = grads_compact_np({k_: p0[k_].cpu().numpy() for k_, _ in m.named_parameters()})
+    for k_ in [k for k in g if k.startswith("p:")]:
+        name = "g:" + k_[2:]
+        g1 = g["g1:" + k_[2:]]
+        # (the time encoder's gradient entries are cancelling sums of terms scaled by intervals of up to 2.7e6 s: accurate to ~1e-2 of the
+        # tensor's largest entry in fp32, in the reference as here -- tests/conftest.py)
+        sig = np.abs(g1) >= (5e-2 if "time_encoder" in k_ else 1e-3) * np.abs(g1).max()
+        if sig.sum() < 8:
+            continue
+        upd_ref, upd_mine = (g[k_] - init[name])[sig], (mine[name] - init[name])[sig]
+        bad = np.abs(upd_mine - upd_ref) > 0.25 * lr          # (a step taken with the other sign would differ by >= 0.67 lr)
+        assert bad.mean() <= (0.1 if "time_encoder" in k_ else 0.05), (k_, float(bad.mean()), int(sig.sum()))
+    for n_, prm in head.named_parameters():
+        upd_ref, upd_mine = g["h:" + n_] - hp[n_].numpy(), prm.detach().cpu().numpy() - hp[n_].numpy()
+        big = np.abs(upd_ref) >= 2.5 * lr                       # entries the reference moved three times the same way
+        assert not big.any() or (np.abs(upd_mine - upd_ref)[big] > 0.25 * lr).mean() <= 0.05, n_
