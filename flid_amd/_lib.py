@@ -105,6 +105,7 @@ SIGNATURES = {
     "tg_set_wgrad_form": (None, [C.c_int]),
     "tg_set_gemm_mode": (None, [C.c_int]),
     "tg_get_gemm_mode": (C.c_int, []),
+    "tg_set_gemm_mode_thread": (None, [C.c_int]),
     "tg_gemm_f32_batched": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_void,
                                       c_i64, c_i64, C.c_int, c_void, C.c_int, C.c_int, c_void]),
     "tg_gemm_f32_batched2": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64,
@@ -148,6 +149,10 @@ class TgError(RuntimeError):
     pass
 
 
+class TgShapeNotCovered(TgError):
+    """TG_ESHAPE: the entry point does not cover this (valid) shape / alignment and launched nothing -- take the general form"""
+
+
 def lib():
     """Load (once) and return the CDLL with typed entry points.  Raises if the HIP extension was not built."""
     global _lib
@@ -169,6 +174,8 @@ def check(rc: int, what: str = ""):
         msg = lib().tg_last_error().decode("utf-8", "replace")
         if rc == -1 and ("greater than 0" in msg or "greater than 1" in msg or "in the past" in msg):
             raise AssertionError(msg.split("invalid argument: ", 1)[-1])       # reference raises AssertionError there
+        if rc == -5:
+            raise TgShapeNotCovered(f"{what or 'libflid_tg'}: {msg}")
         if rc == -4:
             raise IndexError("list index out of range")                        # an id beyond the graph, as the reference's list lookup
         raise TgError(f"{what or 'libflid_tg'} failed (rc={rc}): {msg}")

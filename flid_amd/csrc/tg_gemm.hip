@@ -40,6 +40,10 @@ namespace {
 // 1 = row-times-weight products (A as M x K, B as N x K) run on the split-bf16 kernel (tg_gemm_bf16x3.hip); 0 = everything on
 // the exact f32-input MFMA kernel below.
 int g_gemm_mode = 1;
+// per-thread override (-1 = none): a caller that wants exact products for ONE call (models/modules.py _exact_products) sets it around
+// that call on its own thread -- flipping the process-wide mode raced with every other issuing thread (side-stream issuer, loaders)
+thread_local int t_gemm_mode = -1;
+inline int gemm_mode() { return t_gemm_mode >= 0 ? t_gemm_mode : g_gemm_mode; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -427,7 +431,7 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     // X W with a small W (K x N): transpose W once into a per-stream scratch and take the k-contiguous kernels (direct / split-bf16):
     // the f32-input tile kernel runs such products at 131 TFLOP/s at best, the split-bf16 one at 230 (DyGFormer's 38 400-row
     // input gradients, TGN's GRU).  Not for batched calls, nor when W is as large as the activations.
-    if (g_gemm_mode >= 1 && a_kc && !b_kc && inner == 1 && nbatch == 1 && alpha == 1.f && K % 4 == 0 && M >= 4 * N && K * N <= ((int64_t)4 << 20)) {
+    if (gemm_mode() >= 1 && a_kc && !b_kc && inner == 1 && nbatch == 1 && alpha == 1.f && K % 4 == 0 && M >= 4 * N && K * N <= ((int64_t)4 << 20)) {
         if (float* bt = transpose_workspace((size_t)K * N, s)) {
             transpose_kn_kernel<<<dim3((unsigned)((N + 31) / 32), (unsigned)((K + 31) / 32)), 256, 0, s>>>(d_B, ldb, K, N, bt);
             return gemm_impl(0, 1, M, N, K, alpha, d_A, lda, 0, bt, K, 0, d_C, ldc, 0, 1, d_bias, relu, accumulate, s);
@@ -438,7 +442,7 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     if (!no_direct && a_kc && inner == 1 && alpha == 1.f && (b_kc || !d_mask) &&
         tg::gemm_direct_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s, d_mask, ldm, b_kc))
         return tg::launch_status("gemm_direct_nt_kernel");
-    if (g_gemm_mode >= 1 && a_kc && b_kc && inner == 1 && alpha == 1.f &&
+    if (gemm_mode() >= 1 && a_kc && b_kc && inner == 1 && alpha == 1.f &&
         tg::gemm_bf16x3_nt(M, N, K, d_A, lda, strideA, d_B, ldb, strideB, d_C, ldc, strideC, nbatch, d_bias, relu, accumulate, s, d_mask, ldm))
         return tg::launch_status("gemm_bf16x3_nt_kernel");
     TG_REQUIRE(!d_mask, "tg_gemm_f32_nt_masked: operands must be 16-byte aligned with leading dimensions / K multiples of 4");
@@ -466,7 +470,7 @@ int gemm_impl(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, cons
     int64_t splits = 1;
     // tiles the split is sized for: the split-bf16 weight-gradient kernel (mode 2) works on 128 x 96 / 128 x 64 tiles
     // mode 1 takes it for the larger outputs only (dP 888 x 172: 71 -> 57 us, dV 272 x 888: 102 -> 84 us; 172 x 272 and smaller lose)
-    const bool tn_bf16 = (g_gemm_mode == 2 || (g_gemm_mode == 1 && M * N >= 65536)) && ta && !tb && inner == 1 && alpha == 1.f && !d_bias &&
+    const bool tn_bf16 = (gemm_mode() == 2 || (gemm_mode() == 1 && M * N >= 65536)) && ta && !tb && inner == 1 && alpha == 1.f && !d_bias &&
                          !relu && M % 4 == 0 && N % 4 == 0;
     const int64_t tiles_for_split = tn_bf16 ? ((M + 127) / 128) * std::min((N + 95) / 96, (N + 63) / 64) : gx * gy;
     if (!relu && ta && tiles_for_split * nbatch < 512 && K >= 2 * BK) {
@@ -570,11 +574,12 @@ extern "C" int tg_wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows,
     TG_REQUIRE(jobs && njobs >= 1 && njobs <= 8 && rows >= 0, "tg_wgrad_group: arguments");
     if (rows == 0) return TG_OK;
     if (!tg::wgrad_group2(njobs, jobs, rows, (hipStream_t)stream) && !tg::wgrad_group(njobs, jobs, rows, (hipStream_t)stream)) {
-        tg::set_error("invalid argument: tg_wgrad_group: shape / alignment not covered (M, N, lda, ldb multiples of 4, 16-byte aligned operands)");
-        return TG_EINVAL;
+        tg::set_error("tg_wgrad_group: shape / alignment not covered (M, N, lda, ldb multiples of 4, 16-byte aligned operands)");
+        return TG_ESHAPE;
     }
     return tg::launch_status("gemm_bf16x3_wgrad_kernel");
 }
 
 extern "C" void tg_set_gemm_mode(int mode) { g_gemm_mode = mode; }
-extern "C" int tg_get_gemm_mode(void) { return g_gemm_mode; }
+extern "C" int tg_get_gemm_mode(void) { return gemm_mode(); }
+extern "C" void tg_set_gemm_mode_thread(int mode) { t_gemm_mode = mode; }

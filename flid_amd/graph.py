@@ -120,20 +120,26 @@ class TemporalGraph:
         return out
 
     def _dedupe_ws_for(self, n, dev):
+        """hash-set workspace of the CALLING STREAM: the prefetch path runs on a side stream while a plain call (a validation forward,
+        a negative-sample forward) may use the same sampler on the main stream -- one shared workspace let the two corrupt each
+        other's row maps, and a regrow could free it under the other stream's kernels"""
         cap = int(lib().tg_dedupe_capacity(n))
-        ws = getattr(self, "_dedupe_ws", None)
-        if ws is None or ws[0].numel() < cap or ws[2].numel() < n or ws[0].device != dev:
+        if not isinstance(getattr(self, "_dedupe_ws", None), dict):
+            self._dedupe_ws = {}
+        key = (str(dev), int(_stream() or 0))
+        ws = self._dedupe_ws.get(key)
+        if ws is None or ws[0].numel() < cap or ws[2].numel() < n:
             ws = (torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
                   torch.empty(max(n, 1), dtype=torch.int32, device=dev))
-            self._dedupe_ws = ws
+            self._dedupe_ws[key] = ws
         return cap, ws
 
     def dedupe_pairs_async(self, ids: torch.Tensor, t32: torch.Tensor, row_offset: int, out_ids: torch.Tensor, out_t: torch.Tensor,
                            row: torch.Tensor):
         """distinct (id, float32 time) pairs of a sampled level, written into caller buffers (each at least len(ids) long):
         out_ids / out_t = the pairs in arrival order, row[i] = row_offset + index of slot i's pair.  Returns the DEVICE tensor
-        (count, index of the padding pair or -1): nothing is read back here.  The hash-set workspace is per graph object and is
-        reused by the next call on the same stream (calls on one graph must not run concurrently on two streams)."""
+        (count, index of the padding pair or -1): nothing is read back here.  The hash-set workspace is per graph object AND per
+        stream (calls on two streams do not share it)."""
         n, dev = ids.numel(), ids.device
         cap, ws = self._dedupe_ws_for(n, dev)
         cp = torch.empty(2, dtype=torch.int32, device=dev)

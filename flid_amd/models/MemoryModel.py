@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine, ops
+from .._lib import TgShapeNotCovered
 from ..utils.utils import NeighborSampler
 from .modules import MergeLayer, MultiHeadAttention, TimeEncoder
 
@@ -213,7 +214,7 @@ class _GRURowsMaskedFn(torch.autograd.Function):
         db_hh = torch.zeros(w_hh.shape[0], device=dout.device)
         try:
             ops.wgrad_group([(dgi, msg_rows, dw_ih, db_ih), (dgh, h_rows, dw_hh, db_hh)])
-        except Exception:                      # widths that are not multiples of 4: one exact product + one column sum each
+        except TgShapeNotCovered:              # widths that are not multiples of 4: one exact product + one column sum each
             ops.gemm(dgi, msg_rows, dw_ih, ta=True)
             ops.gemm(dgh, h_rows, dw_hh, ta=True)
             db_ih, db_hh = ops.colsum(dgi), ops.colsum(dgh)

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .._lib import TgShapeNotCovered
 
 
 class _exact_products:
@@ -21,13 +22,12 @@ class _exact_products:
     def __enter__(self):
         if self.on:
             from .._lib import lib
-            self.prev = lib().tg_get_gemm_mode()
-            lib().tg_set_gemm_mode(0)
+            lib().tg_set_gemm_mode_thread(0)        # this thread's calls only: other issuing threads keep the process-wide mode
 
     def __exit__(self, *exc):
         if self.on:
             from .._lib import lib
-            lib().tg_set_gemm_mode(self.prev)
+            lib().tg_set_gemm_mode_thread(-1)
         return False
 
 
@@ -69,8 +69,12 @@ class _LinearFn(torch.autograd.Function):
                 zb = torch.zeros(n_out * n_in + (n_out if need_b else 0), device=w.device)       # one fill for both gradients
                 dw = zb[:n_out * n_in].view(n_out, n_in)
                 db = zb[n_out * n_in:] if need_b else None
-                ops.wgrad_group([(dy2, x2, dw, db)])
-                need_b = False
+                try:
+                    ops.wgrad_group([(dy2, x2, dw, db)])
+                    need_b = False
+                except TgShapeNotCovered:                # (e.g. operands beyond the kernel's 32-bit offsets): the general product + a column sum
+                    dw = torch.empty_like(w)
+                    ops.gemm(dy2, x2, dw, ta=True)
             else:
                 dw = torch.empty_like(w)
                 ops.gemm(dy2, x2, dw, ta=True)

@@ -24,7 +24,7 @@ import torch
 
 def regenerate_embeddings(backbone, data, batch_size: int = 200, num_neighbors: int = 20, chunk_edges: int = 4096,
                           out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, first_edge: int = 0, num_edges: Optional[int] = None,
-                          rank: int = 0, world: int = 1):
+                          rank: int = 0, world: int = 1, time_gap: int = 2000):
     """Fill (and return) the two stores with the embeddings of edges [first_edge, first_edge + num_edges) of `data` (chronological
     order, row = position in `data`, as the reference's full_idx_data_loader walks it).  The backbone's current neighbor sampler is
     used (the callers set the full-graph sampler first, M_step.py:458); TGN's memory bank must have been reset by the caller
@@ -78,10 +78,22 @@ def regenerate_embeddings(backbone, data, batch_size: int = 200, num_neighbors: 
                         s, d = backbone.compute_src_dst_node_temporal_embeddings(ready.pop(i), None, None, num_neighbors)
                         src_store[lo:hi].copy_(s)
                         dst_store[lo:hi].copy_(d)
+                elif isinstance(backbone, DyGFormer):
+                    # DyGFormer pads both sides to the longest history IN THE BATCH, its transformer is unmasked and the mean runs
+                    # over the padded patches (models/DyGFormer.py:196-245, :185-187): an edge's embedding depends on which edges
+                    # share its batch.  The stores must therefore be filled batch by batch exactly as the reference's loop walks them
+                    # (`batch_size` edges, M_step.py:456-509) -- ranks take whole batches, never a different grouping.
+                    B = int(batch_size)
+                    batches = [(lo, min(lo + B, first_edge + num_edges)) for lo in range(first_edge, first_edge + num_edges, B)]
+                    for lo, hi in batches[rank::world]:
+                        s, d = backbone.compute_src_dst_node_temporal_embeddings(src[lo:hi], dst[lo:hi], t[lo:hi])
+                        src_store[lo:hi].copy_(s)
+                        dst_store[lo:hi].copy_(d)
                 else:
+                    from .models.GraphMixer import GraphMixer
                     for lo, hi in mine:
-                        if isinstance(backbone, DyGFormer):
-                            s, d = backbone.compute_src_dst_node_temporal_embeddings(src[lo:hi], dst[lo:hi], t[lo:hi])
+                        if isinstance(backbone, GraphMixer):        # (its node encoder looks `time_gap` neighbors back: args.time_gap, M_step.py:487)
+                            s, d = backbone.compute_src_dst_node_temporal_embeddings(src[lo:hi], dst[lo:hi], t[lo:hi], num_neighbors, time_gap)
                         else:
                             s, d = backbone.compute_src_dst_node_temporal_embeddings(src[lo:hi], dst[lo:hi], t[lo:hi], num_neighbors)
                         src_store[lo:hi].copy_(s)

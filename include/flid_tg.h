@@ -22,6 +22,7 @@ extern "C" {
 #define TG_EHIP -2     /* a HIP runtime call failed; tg_last_error() has the text */
 #define TG_ENOMEM -3
 #define TG_ERANGE -4   /* an id beyond the graph: the reference's `IndexError: list index out of range` */
+#define TG_ESHAPE -5   /* a valid request whose shape / alignment this entry point does not cover: nothing was launched, take the general form */
 
 typedef struct tg_graph tg_graph; /* opaque: device CSR of time-sorted incidences */
 
@@ -267,7 +268,7 @@ int tg_gemm_rows_nt(int64_t R, int N, int K, const float* d_A, int64_t lda, cons
  * up to 8 products C_j[M_j, N_j] += A_j^T B_j over the same `rows` (A_j: rows x M_j, B_j: rows x N_j, row-major) in ONE launch;
  * colsum_A_j[M_j] += column sums of A_j when non-NULL (the bias gradient: A_j is the gradient of the layer's output).
  * C_j and colsum_A_j are ACCUMULATED into with float atomics (zero them, or pass a running gradient).  M_j, N_j, lda, ldb
- * multiples of 4, operands 16-byte aligned; returns TG_EINVAL for other shapes (use tg_gemm_f32 + tg_colsum). */
+ * multiples of 4, operands 16-byte aligned; returns TG_ESHAPE for other shapes (nothing launched: use tg_gemm_f32 + tg_colsum). */
 typedef struct tg_wgrad_job {
     const float* A; int64_t lda; int M;
     const float* B; int64_t ldb; int N;
@@ -302,6 +303,9 @@ int tg_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, co
  * mode 0 = exact fp32 (f32-input MFMA) everywhere. */
 void tg_set_gemm_mode(int mode);
 int tg_get_gemm_mode(void);
+/* override for the CALLING THREAD only (mode as tg_set_gemm_mode; -1 = follow the process-wide mode): per-call precision without
+ * touching what other issuing threads see */
+void tg_set_gemm_mode_thread(int mode);
 
 /* strided-batched form: problem b uses A + b*stride_a, B + b*stride_b, C + b*stride_c (bias + b*N).  One launch for the
  * per-head products of models/modules.py:186-197 (head h = column / row block h of the projection weights). */
