@@ -32,6 +32,9 @@
 #ifndef FLID_CHAIN_STAMPS
 #define FLID_CHAIN_STAMPS 0
 #endif
+#ifndef FLID_CHAIN_SCHED
+#define FLID_CHAIN_SCHED 1
+#endif
 #ifndef FLID_CHAIN_X4
 #define FLID_CHAIN_X4 1   // keep the lo * lo term (see step()); 0: three terms, as the launch-per-product kernels
 #endif
@@ -64,10 +67,10 @@ struct Geo {
 static_assert(Geo<4, 8>::LDS_BYTES <= 163840, "one workgroup must fit the CU's LDS");
 
 // state of one wave inside a chain
-template <int RB, int NW>
+template <int RB, int NW, int NTW_ = Geo<RB, NW>::NTW>
 struct Wave {
     using G = Geo<RB, NW>;
-    static constexpr int NTW = G::NTW;
+    static constexpr int NTW = NTW_;
     char* lds;
     int lane, wave;
     int64_t row0, R;
@@ -75,6 +78,18 @@ struct Wave {
     bf16x8 b0h[2][NTW], b0l[2][NTW], b1h[2][NTW], b1l[2][NTW];
     const uint4* bptr[NTW];
     int S, t0, tcnt;          // current product: steps, first tile of this wave (inside its operand), tiles it owns
+#if FLID_CHAIN_STAMPS == 2
+    unsigned long long* fine = nullptr;     // diagnostic: stamps inside run_panel (one product only)
+    int fine_i = 0;
+    __device__ __forceinline__ void fstamp() {
+        __builtin_amdgcn_sched_barrier(0);
+        if (fine && threadIdx.x == 0 && fine_i < 16) fine[fine_i] = __builtin_amdgcn_s_memtime();
+        ++fine_i;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    __device__ __forceinline__ void fstamp() {}
+#endif
 
     // the product's nt column tiles are dealt in blocks to waves [w0, w0 + nw); `packed` = that operand
     __device__ __forceinline__ void begin(const void* packed, int nt, int steps, int w0 = 0, int nw = NW) {
@@ -155,19 +170,47 @@ struct Wave {
             for (int rb = 0; rb < RB; ++rb) acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[rb], acc[rb][j], 0, 0, 0);
     }
 
+    // Scheduling hint for a block that issues NV vector loads and then one step's 4 RB NT MFMAs: the fragment reads first, then one
+    // load behind every RB MFMAs.  Issued back to back, a group's 4 NT weight loads (1 KiB each: 16 cycles of the CU's address
+    // path apiece, times four waves) held the wave's in-order issue for 400-1 450 cycles before its first MFMA (stamps inside the res
+    // product: steps 1 100 cycles, load blocks 400-1 450) -- spread out, they cost no issue time at all.
+    template <int NT, int NV>
+    __device__ __forceinline__ void spread_loads() {
+#if FLID_CHAIN_SCHED
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RB, 0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (4 * RB * NT) / NV > 0 ? (4 * RB * NT) / NV : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#endif
+    }
+
     // ---- product whose rows come from the LDS panel: chunks [chunk0, chunk0 + S).  No barrier inside.
     template <int NT>
     __device__ __forceinline__ void run_panel(int chunk0) {
         const int ngroups = (S + 1) >> 1;
         const char* base = lds + chunk0 * G::CHUNK;
+        fstamp();
         loadB<NT>(b0h, b0l, 0);
+        fstamp();
         for (int g = 0; g < ngroups; g += 2) {
             loadB<NT>(b1h, b1l, g + 1);
+            fstamp();
             step<NT>(base + (2 * g) * G::CHUNK, b0h[0], b0l[0]);
+            spread_loads<NT, 4 * NT>();
+            fstamp();
             if (2 * g + 1 < S) step<NT>(base + (2 * g + 1) * G::CHUNK, b0h[1], b0l[1]);
-            loadB<NT>(b0h, b0l, g + 2);
-            if (2 * g + 2 < S) step<NT>(base + (2 * g + 2) * G::CHUNK, b1h[0], b1l[0]);
+            fstamp();
+            fstamp();
+            if (2 * g + 2 < S) {                                 // (uniform; the loads of group g + 2 inside the block whose MFMAs hide them)
+                loadB<NT>(b0h, b0l, g + 2);
+                step<NT>(base + (2 * g + 2) * G::CHUNK, b1h[0], b1l[0]);
+                spread_loads<NT, 4 * NT>();
+            }
+            fstamp();
             if (2 * g + 3 < S) step<NT>(base + (2 * g + 3) * G::CHUNK, b1h[1], b1l[1]);
+            fstamp();
         }
     }
 
@@ -231,12 +274,17 @@ struct Wave {
             loadA(ra1, g + 3);
             loadB<NT>(b1h, b1l, g + 1);
             step<NT>(r0, b0h[0], b0l[0]);
+            spread_loads<NT, 4 * NT + HH * PER>();
             step<NT>(r0 + G::CHUNK, b0h[1], b0l[1]);        // (a step past the end of K multiplies zero rows)
             __syncthreads();
             writeA(0, ra0, g + 2);
-            loadA(ra0, g + 4);
-            loadB<NT>(b0h, b0l, g + 2);
-            if (g + 1 < ngroups) { step<NT>(r1, b1h[0], b1l[0]); step<NT>(r1 + G::CHUNK, b1h[1], b1l[1]); }
+            if (g + 1 < ngroups) {                              // (uniform; past the last group nothing more is needed)
+                loadA(ra0, g + 4);
+                loadB<NT>(b0h, b0l, g + 2);
+                step<NT>(r1, b1h[0], b1l[0]);
+                spread_loads<NT, 4 * NT + HH * PER>();
+                step<NT>(r1 + G::CHUNK, b1h[1], b1l[1]);
+            }
             __syncthreads();
         }
     }
@@ -264,12 +312,13 @@ __device__ __forceinline__ float quad_rows_sum(float v) {
     v += __shfl_xor(v, 32, 64);
     return v;
 }
-// sum over the 16 lanes that share l >> 4 (they hold the same columns of the block's 16 rows)
+// sum over the 16 lanes that share l >> 4 (they hold the same columns of the block's 16 rows): DPP inside the VALU, every lane of the
+// row ends up with the row's sum (the first four steps of tg::wave_sum)
 __device__ __forceinline__ float rows16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v = tg::dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
+    v = tg::dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
+    v = tg::dpp_add<0x141>(v);         // row_half_mirror
+    v = tg::dpp_add<0x140>(v);         // row_mirror
     return v;
 }
 
@@ -308,7 +357,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
     const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
     const int ychunks = (dq + 31) >> 5, rchunks = (a.dn + 31) >> 5;
     float* red = reinterpret_cast<float*>(lds + G::RED_OFF);
-#if FLID_CHAIN_STAMPS
+#if FLID_CHAIN_STAMPS == 1
     int stamp_i = 0;
 #define STAMP() do { if (a.dbg && tid == 0) a.dbg[blockIdx.x * 16 + stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
 #else
@@ -385,7 +434,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
                 x[rb][j] = f32x4{o.x, o.y, o.z, o.w};
             }
         }
+#if FLID_CHAIN_STAMPS == 2
+        w.fine = a.dbg ? a.dbg + blockIdx.x * 16 : nullptr;
+        w.fine_i = 0;
+#endif
         w.template run_panel<NTW>(0);
+#if FLID_CHAIN_STAMPS == 2
+        w.fine = nullptr;
+#endif
         STAMP();
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -402,7 +458,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
                 int64_t rg = w.row0 + w.out_row(rb);
                 if (rg > a.R - 1) rg = a.R - 1;
                 float4 v = add4(f4(w.acc[rb][j]), b4);
-                if (rok[rb]) st4(a.res + rg * dq + col, v);
                 float ks[4];
                 tg::res_keep_scale4(a.seed, rg * dq + col, a.p_res, ks);
                 v.x = v.x * ks[0] + x[rb][j][0];
@@ -464,14 +519,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int r = w.out_row(rb);
-                float4 v;
-                v.x = (x[rb][j][0] - mu[rb]) * rs[rb] * g4.x + be4.x;
-                v.y = (x[rb][j][1] - mu[rb]) * rs[rb] * g4.y + be4.y;
-                v.z = (x[rb][j][2] - mu[rb]) * rs[rb] * g4.z + be4.z;
-                v.w = (x[rb][j][3] - mu[rb]) * rs[rb] * g4.w + be4.w;
+                // the normalised input is what the backward needs of this stage: it is saved in the `res` buffer (with the chain, `res`
+                // holds xhat = (dropout(res) + [own | cos b] - mean) * rstd, not the projection's raw output)
+                const float4 xn = make_float4((x[rb][j][0] - mu[rb]) * rs[rb], (x[rb][j][1] - mu[rb]) * rs[rb],
+                                              (x[rb][j][2] - mu[rb]) * rs[rb], (x[rb][j][3] - mu[rb]) * rs[rb]);
+                float4 v = make_float4(xn.x * g4.x + be4.x, xn.y * g4.y + be4.y, xn.z * g4.z + be4.z, xn.w * g4.w + be4.w);
                 if (!rok[rb]) v = zero4();
                 w.panel_store(0, r, col, v);
-                if (rok[rb]) st4(a.y + (w.row0 + r) * a.y_ld + col, v);
+                if (rok[rb]) { st4(a.y + (w.row0 + r) * a.y_ld + col, v); st4(a.res + (w.row0 + r) * dq + col, xn); }
             }
         }
         // the tail of y's last chunk (columns dq .. 32 ychunks) multiplies zero columns of the packed W1 but must be finite
@@ -554,8 +609,9 @@ template <int RB, int HH, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs a) {
     using G = Geo<RB, NW>;
     constexpr int ROWS = G::ROWS, NTH = G::NTH, NTW = G::NTW, NTF = NW == 8 ? 2 : 3;
+    constexpr int NTD = NW == 8 ? 4 : 7;                       // tiles per wave of the widest product (dagg_h: dk columns in one pass)
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    Wave<RB, NW> w;
+    Wave<RB, NW, NTD> w;
     w.lds = lds;
     w.lane = threadIdx.x & 63;
     w.wave = threadIdx.x >> 6;
@@ -574,6 +630,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
         rgc[rb] = rg < a.R ? rg : a.R - 1;
     }
 
+#if FLID_CHAIN_STAMPS == 1
+    int stamp_i = 0;
+#endif
+    STAMP();
     // ---- df1 = (dout W2) * (f1 > 0)
     {
         w.begin(a.pW2T, (a.dn + 15) >> 4, nchunks_dn);
@@ -588,7 +648,31 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
                 m[rb][j] = f32x4{v.x, v.y, v.z, v.w};
             }
         }
-        w.template run_stream<NTF, 1>(a.dout, a.dn, 0, a.dn, 0);
+        // dout is narrow (dn <= 192 columns): the whole block goes into the panel at once (one trip to HBM, no ring, no barriers in
+        // the product) -- streamed in three 64-k groups it took 18 k cycles for 4.6 k cycles of MFMA work
+        {
+            constexpr int DN4 = 48;                            // float4 per row (192 columns)
+            constexpr int NL = ROWS * DN4 / NTH;
+            float4 dv[NL];
+            const int c4n = a.dn >> 2;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int f = tid + NTH * i, r = f / DN4, c = f % DN4;
+                int64_t rg = w.row0 + r;
+                if (rg > a.R - 1) rg = a.R - 1;
+                dv[i] = ld4(a.dout + rg * a.dn + (c < c4n ? 4 * c : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int f = tid + NTH * i, r = f / DN4, c = f % DN4;
+                const bool ok = c < c4n && w.row0 + r < a.R;
+                if (4 * c < 32 * nchunks_dn) w.panel_store(0, r, 4 * c, ok ? dv[i] : zero4());
+            }
+        }
+        __syncthreads();
+        w.template run_panel<NTF>(0);
+        STAMP();
+        __syncthreads();                                       // every wave is done reading dout: df1 takes its place
 #pragma unroll
         for (int j = 0; j < NTF; ++j) {
             if (j >= w.tcnt) break;
@@ -613,50 +697,49 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
         }
     }
     __syncthreads();
+    STAMP();
 
     // ---- dy = df1 W1[:, :dq] ;  LayerNorm backward: dsum, dres = dsum * dropout mask, the workgroup's column sums
     {
         w.begin(a.pW1aT, (dq + 15) >> 4, nchunks_dn);
-        f32x4 xh[RB][NTW];                                       // LayerNorm's normalised input, recomputed from res / own / mean / rstd
-        float mu[RB], rs[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) { mu[rb] = a.mean[rgc[rb]]; rs[rb] = a.rstd[rgc[rb]]; }
-        unsigned km[RB][NTW];                                    // dropout keep bits of each float4 (bit e = element e kept)
+        f32x4 xh[RB][NTW];                                     // LayerNorm's normalised input, saved by the forward chain in `res`
+        unsigned km[RB][NTW];                                  // dropout keep bits of each float4 (bit e = element e kept)
         const float kscale = a.p_res > 0.f ? 1.f / (1.f - a.p_res) : 1.f;
+        float rs[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) rs[rb] = a.rstd[rgc[rb]];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int col = w.out_col(j);
             const bool cok = j < w.tcnt && col < dq;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const float4 rv = ld4(a.res + (cok ? rgc[rb] * dq + col : 0));
-                const float* src = !cok ? a.cosb : (col < a.dn ? a.own + rgc[rb] * a.own_ld + col : a.cosb + (col - a.dn));
-                const float4 o = ld4(src);
+                const float4 xv = ld4(a.res + (cok ? rgc[rb] * dq + col : 0));
+                xh[rb][j] = f32x4{xv.x, xv.y, xv.z, xv.w};
                 float ks[4];
                 tg::res_keep_scale4(a.seed, rgc[rb] * dq + (cok ? col : 0), a.p_res, ks);
                 km[rb][j] = (ks[0] > 0.f ? 1u : 0u) | (ks[1] > 0.f ? 2u : 0u) | (ks[2] > 0.f ? 4u : 0u) | (ks[3] > 0.f ? 8u : 0u);
-                xh[rb][j] = f32x4{rv.x * ks[0] + o.x, rv.y * ks[1] + o.y, rv.z * ks[2] + o.z, rv.w * ks[3] + o.w};
             }
         }
         w.template run_panel<NTW>(0);
+        STAMP();
+        // g = dy * gamma (in place in the accumulators); row sums of g and g * xhat
         float s1[RB], s2[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) s1[rb] = s2[rb] = 0.f;
-        f32x4 gg[RB][NTW];
+        float4 gam[NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int col = w.out_col(j);
             const bool cok = j < w.tcnt && col < dq;
-            const float4 g4 = cok ? ld4(a.ln_g + col) : zero4();
+            gam[j] = cok ? ld4(a.ln_g + col) : zero4();
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                if (!cok) { gg[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[rb][j] = gg[rb][j]; continue; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xh[rb][j][e] = (xh[rb][j][e] - mu[rb]) * rs[rb];
+                if (!cok) { xh[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
                 const f32x4 d = w.acc[rb][j];
-                gg[rb][j] = f32x4{d[0] * g4.x, d[1] * g4.y, d[2] * g4.z, d[3] * g4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s1[rb] += gg[rb][j][e]; s2[rb] = fmaf(gg[rb][j][e], xh[rb][j][e], s2[rb]); }
+                s1[rb] += (d[0] * gam[j].x + d[1] * gam[j].y) + (d[2] * gam[j].z + d[3] * gam[j].w);
+                s2[rb] = fmaf(d[0] * gam[j].x, xh[rb][j][0], fmaf(d[1] * gam[j].y, xh[rb][j][1],
+                         fmaf(d[2] * gam[j].z, xh[rb][j][2], fmaf(d[3] * gam[j].w, xh[rb][j][3], s2[rb]))));
             }
         }
         float* red2 = red + NW * ROWS;
@@ -683,6 +766,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);
             if (col >= dq) continue;
+            const float gm[4] = {gam[j].x, gam[j].y, gam[j].z, gam[j].w};
             float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f}, c3[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -690,10 +774,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
                 float dx[4], dr[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    dx[e] = rs[rb] * (gg[rb][j][e] - m1[rb] - xh[rb][j][e] * m2[rb]);
+                    const float d = w.acc[rb][j][e];
+                    dx[e] = rs[rb] * (d * gm[e] - m1[rb] - xh[rb][j][e] * m2[rb]);
                     dr[e] = ((km[rb][j] >> e) & 1u) ? dx[e] * kscale : 0.f;
                     if (!rok[rb]) { dx[e] = 0.f; dr[e] = 0.f; }
-                    else { c0[e] = fmaf(w.acc[rb][j][e], xh[rb][j][e], c0[e]); c1[e] += w.acc[rb][j][e]; c2[e] += dx[e]; c3[e] += dr[e]; }
+                    else { c0[e] = fmaf(d, xh[rb][j][e], c0[e]); c1[e] += d; c2[e] += dx[e]; c3[e] += dr[e]; }
                 }
                 const float4 drv = make_float4(dr[0], dr[1], dr[2], dr[3]);
                 w.panel_store(0, r, col, drv);
@@ -723,12 +808,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
         }
     }
     __syncthreads();
+    STAMP();
 
     // ---- dctx = dres Wr   (columns laid out in per-head blocks of hpb for the next product)
     {
         const int ntile = (HH * a.hpb) >> 4;
         w.begin(a.pWrT, ntile, nchunks_dq);
         w.template run_panel<NTW>(0);
+        STAMP();
         __syncthreads();                                       // every wave is done with the dres panel
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -745,18 +832,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
         }
     }
     __syncthreads();
+    STAMP();
 
     // ---- dagg_h = dctx_h Wv_h : dk columns per head, NTW NW tiles per pass
     {
         const int ht = (dk + 15) >> 4, hs = a.hpb >> 5;
         const int64_t wv_stride = (int64_t)ht * hs * 512;      // floats per packed head (tg_packed_floats(dk, hd), hd padded to hpb)
+        const int npass = (ht + NTD * NW - 1) / (NTD * NW);   // passes per head (dk = 444: 28 tiles = one pass of 7 per wave)
+        const int tpp = (ht + npass - 1) / npass;
         for (int h = 0; h < HH; ++h)
-            for (int tb = 0; tb < ht; tb += NTW * NW) {
-                const int nt = ht - tb < NTW * NW ? ht - tb : NTW * NW;
+            for (int tb = 0; tb < ht; tb += tpp) {
+                const int nt = ht - tb < tpp ? ht - tb : tpp;
                 w.begin(reinterpret_cast<const float*>(a.pWvT) + h * wv_stride + (int64_t)tb * hs * 512, nt, hs);
-                w.template run_panel<NTW>(h * hs);
+                w.template run_panel<NTD>(h * hs);
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
+                for (int j = 0; j < NTD; ++j) {
                     if (j >= w.tcnt) break;
                     const int col = 16 * tb + w.out_col(j);
                     if (col >= dk) continue;
@@ -766,10 +856,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
                 }
             }
     }
+    STAMP();
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 unsigned long long* g_chain_dbg = nullptr;
+unsigned long long* g_chain_dbg_bwd = nullptr;
 
 template <int RB, int HH, int NW>
 int launch_fwd(const ChainFwdArgs& a, hipStream_t s) {
@@ -859,7 +951,7 @@ int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, 
     a.df1 = Bw->df1; a.dres = dres; a.dctx = Bw->dctx; a.dagg = Bw->dagg;
     a.d_own = Bw->d_own; a.d_own_ld = Bw->d_own_ld; a.d_own_acc = Bw->d_own_accumulate;
     a.part = part;
-    a.dbg = nullptr;
+    a.dbg = g_chain_dbg_bwd;
     const int dq = at.dn + at.dt_dim, dk = at.dn + at.de + at.dt_dim;
     const double macs = (double)at.dn * at.dn + (double)dq * at.dn + (double)dq * dq + (double)dk * dq;
     ProfScope prof("gemm", 2.0 * at.m * macs, s);
@@ -872,3 +964,4 @@ int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, 
 
 // diagnostic builds (-DFLID_CHAIN_STAMPS=1): the chain kernels write 16 s_memtime stamps per workgroup here (null = off)
 extern "C" void tg_chain_debug_buffer(void* p) { g_chain_dbg = reinterpret_cast<unsigned long long*>(p); }
+extern "C" void tg_chain_debug_buffer_bwd(void* p) { g_chain_dbg_bwd = reinterpret_cast<unsigned long long*>(p); }

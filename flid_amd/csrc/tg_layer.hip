@@ -840,9 +840,11 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     const bool use_chain = g_chain && tg_get_gemm_mode() != 0 && tg::chain_shape_ok(H, dn, T, a.de) && a16(L->agg) && a16(L->ctx) && a16(L->res) &&
                            a16(L->y) && a16(L->raw) && a16(L->own) && a16(L->f1) && a16(L->out) && a16(L->cosb) && a16(P.br) && a16(P.b1) &&
                            a16(P.b2) && a16(P.ln_g) && a16(P.ln_b) && a16(L->wT) && L->own_ld % 4 == 0 && L->raw_ld % 4 == 0 &&
-                           (L->y_ld ? L->y_ld : dq) % 4 == 0 &&                                  // (= the forward's decision)
-                           a16(Bw->dout) && a16(Bw->df1) && a16(dres_c) && a16(Bw->dctx) && a16(Bw->dagg) && a16(Bw->part) &&
-                           (!Bw->d_own || (a16(Bw->d_own) && Bw->d_own_ld % 4 == 0));
+                           (L->y_ld ? L->y_ld : dq) % 4 == 0;                                    // = the forward's decision
+    // (the forward chain leaves the NORMALISED LayerNorm input in `res`, which only the backward chain reads that way)
+    TG_REQUIRE(!use_chain || (a16(Bw->dout) && a16(Bw->df1) && a16(dres_c) && a16(Bw->dctx) && a16(Bw->dagg) && a16(Bw->part) &&
+                              (!Bw->d_own || (a16(Bw->d_own) && Bw->d_own_ld % 4 == 0))),
+               "tg_tgat_layer_bwd: backward buffers must be 16-byte aligned (the layer's forward ran the chain kernel)");
     const bool overlap = g_overlap && g_side.init();
     // where everything that only feeds parameter gradients goes: re-pointed by every fork()
     void* wstream = stream;

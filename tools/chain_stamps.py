@@ -17,10 +17,12 @@ from flid_amd._lib import lib                 # noqa: E402
 def main():
     h = C.CDLL(os.environ["FLID_TG_LIB"])
     buf = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda:0")
-    h.tg_chain_debug_buffer.argtypes = [C.c_void_p]
     sys.argv = [sys.argv[0], "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-breakdown"]
     lib()
-    h.tg_chain_debug_buffer(buf.data_ptr())
+    which = os.environ.get("CHAIN", "fwd")
+    fn = h.tg_chain_debug_buffer if which == "fwd" else h.tg_chain_debug_buffer_bwd
+    fn.argtypes = [C.c_void_p]
+    fn(buf.data_ptr())
     bench.main()
     torch.cuda.synchronize()
     st = buf.cpu().numpy().reshape(-1, 16)
