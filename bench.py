@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-flat", action="store_true", help="per-tensor parameters / gradients / Adam as in the reference's trainers")
     ap.add_argument("--gemm-mode", type=int, default=None, help="tg_set_gemm_mode override (experiments)")
     ap.add_argument("--trace-steps", action="store_true", help="per-step GPU times (events) to stderr")
+    ap.add_argument("--event-every", type=int, default=4, help="HIP events around the roofline kernel's launches in every n-th timed step "
+                    "(an event pair costs ~12 us of stream idle time per launch; 1 = every step)")
+    ap.add_argument("--host-profile", action="store_true", help="host issue cost per phase of a fused step (GPU idle at each step start) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the untimed per-family profiling pass")
     ap.add_argument("--cpu-sample-edges", type=int, default=1800)
@@ -295,13 +298,22 @@ def main():
     torch.cuda.synchronize()
     # timed region: HIP events (C side, on the launch stream) around the roofline kernel's launches only -- 2 per step for the
     # attention kernels; timing every GEMM launch as well costs ~15 % wall, so the per-family breakdown is a second, untimed pass
+    # the events sit on the launch stream and each costs a few us of idle time around the launch they bracket: every
+    # --event-every-th step of the timed region carries them, the others run as the product does
     ops.profile_enable(args.roofline_kernel)
     ops.profile_collect(args.roofline_kernel)
+    ops.profile_enable(False)
     barrier()
     marks = []
+    every = max(1, args.event_every)
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
-        step(s)
+        if every == 1 or (s - args.warmup) % every == 0:
+            ops.profile_enable(args.roofline_kernel)
+            step(s)
+            ops.profile_enable(False)
+        else:
+            step(s)
         if args.trace_steps:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -315,6 +327,24 @@ def main():
         host = [marks[i][1] - marks[i - 1][1] for i in range(1, len(marks))]
         print("[bench] per-step GPU ms :", " ".join(f"{x:.2f}" for x in gpu), file=sys.stderr)
         print("[bench] per-step host ms:", " ".join(f"{x * 1e3:.2f}" for x in host), file=sys.stderr)
+    if args.host_profile and fused and rank == 0:
+        # what the HOST spends issuing one step when nothing is queued ahead of it (the GPU can only be as fast as this)
+        acc = {"prefetch": 0.0, "train_step": 0.0, "adam": 0.0}
+        prepared.clear()
+        jobs.clear()
+        for s in range(args.warmup, total_steps):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            prefetch(s)
+            b = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            model.train_step(prepared.pop(s), mean_loss, K)
+            c = time.perf_counter()
+            opt.step()
+            d = time.perf_counter()
+            if s > args.warmup:
+                acc["prefetch"] += b - a; acc["train_step"] += c - b; acc["adam"] += d - c
+        print("[bench] host issue us/step (idle GPU): " + ", ".join(f"{k} {v / (args.steps - 1) * 1e6:.0f}" for k, v in acc.items()), file=sys.stderr)
     fam = {args.roofline_kernel: ops.profile_collect(args.roofline_kernel)}
     others = [t for t in ("attn_fwd", "attn_bwd", "gemm") if t != args.roofline_kernel]
     if not args.no_breakdown:
@@ -345,7 +375,8 @@ def main():
                      "per_rank_ms_per_step": [round(e / args.steps * 1e3, 4) for e in per_rank],
                      "allreduce_ms": round((time.perf_counter() - t_ar) / 20 * 1e3, 4), "allreduce_floats": int(gbuf.numel()),
                      "overlap": "root-layer block reduced under the layer-1 backward (GradAllReducer.segment_ready)" if fused else "none"}
-    breakdown = {k_: round(v[0] / args.steps, 4) for k_, v in fam.items()}
+    breakdown = {k_: round(v[0] / (len(range(0, args.steps, max(1, args.event_every))) if k_ == args.roofline_kernel else args.steps), 4)
+                 for k_, v in fam.items()}
 
     edges = args.steps * BATCH * world
     value = edges / elapsed
@@ -379,11 +410,12 @@ def main():
     # roofline of the selected kernel family: HIP events on its launch stream over the timed region
     ms, units, cnt = fam[args.roofline_kernel]
     secs = max(ms * 1e-3, 1e-12)
+    sampled_steps = len(range(0, args.steps, every))
     if args.roofline_kernel == "gemm":
         roof = {"bound": "mfma", "kernel": "gemm_tile_kernel (tg_gemm_f32*, all shapes of a step)",
                 "achieved": round(units / secs / 1e12, 3), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
                 "frac": round(units / secs / MFMA_F32_PEAK, 4), "traffic": None, "launches": cnt,
-                "avg_launch_ms": round(ms / max(1, cnt), 4), "flops_per_step": units / args.steps}
+                "avg_launch_ms": round(ms / max(1, cnt), 4), "flops_per_step": units / sampled_steps}
     else:
         bwd = args.roofline_kernel == "attn_bwd"
         # `units` counts instances x (algorithmic + activation) bytes on the C side; the roofline is priced on the ALGORITHMIC bytes
@@ -420,7 +452,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "path_roofline": {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4),
                           "edges_per_s_at_100pct": round(HBM_PEAK / bpe, 1)},
-        "roofline": roof,
+        "roofline": dict(roof, timed_steps=f"{sampled_steps} of {args.steps} (every {every}th step of the timed region carries the HIP events)"),
         "breakdown_ms": breakdown,
     }
     if dedupe_off is not None:
@@ -602,7 +634,7 @@ def bench_memory_or_sequence_model(args):
     torch.cuda.synchronize()
     fam_name = "attn_bwd" if args.model == "tgn" else "gemm"
     ops.profile_enable(fam_name)
-    ops.profile_collect(fam_name)
+    ops.profile_collect(fam_name)  
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):

@@ -726,11 +726,17 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         // main chain but needed a (dq x H dk) gradient product over all rows (89 us) plus a weight-space chain behind it
         TrJobs jobs;
         int n = 0;
-        jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
-        jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
+        // (with the chain kernels the backward's transposed weights are PACKED by the launch above; only W1b -- the raw rows' input
+        // gradient of a trainable base table, a launch of its own -- still wants a plain transposed copy)
+        if (!use_chain) {
+            jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
+            jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
+        }
         jobs.j[n++] = TrJob{P.W1 + dq, wt.W1b, dn, dn, (int64_t)dq + dn, dn};
-        for (int h = 0; h < H; ++h) jobs.j[n++] = TrJob{P.Wv + (int64_t)h * hd * dk, wt.Wv + (int64_t)h * dk * hd, hd, dk, dk, hd};
-        jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
+        if (!use_chain) {
+            for (int h = 0; h < H; ++h) jobs.j[n++] = TrJob{P.Wv + (int64_t)h * hd * dk, wt.Wv + (int64_t)h * dk * hd, hd, dk, dk, hd};
+            jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
+        }
         jobs.n = n;
         with_qbias(jobs);
         transpose_many_kernel<<<dim3(64, n + 1 + gather_rows_y), 256, 0, s>>>(jobs);
@@ -757,11 +763,13 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         for (int h = 0; h < H && n < 4; ++h) {
             jobs.j[n++] = TrJob{P.Wk + (int64_t)h * hd * dk, wt.Wk + (int64_t)h * dk * hd, hd, dk, dk, hd};
         }
-        for (int h = 0; h < H; ++h) jobs.j[n++] = TrJob{P.Wv + (int64_t)h * hd * dk, wt.Wv + (int64_t)h * dk * hd, hd, dk, dk, hd};
-        jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
-        jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
+        if (!use_chain) {
+            for (int h = 0; h < H; ++h) jobs.j[n++] = TrJob{P.Wv + (int64_t)h * hd * dk, wt.Wv + (int64_t)h * dk * hd, hd, dk, dk, hd};
+            jobs.j[n++] = TrJob{P.W2, wt.W2, dn, dn, dn, dn};
+            jobs.j[n++] = TrJob{P.W1, wt.W1a, dn, dq, (int64_t)dq + dn, dn};
+        }
         jobs.j[n++] = TrJob{P.W1 + dq, wt.W1b, dn, dn, (int64_t)dq + dn, dn};
-        jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
+        if (!use_chain) jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
         jobs.j[n++] = TrJob{P.Wq, wt.WqL, dq, dn, dq, dq};
         jobs.n = n;
         with_qbias(jobs);

@@ -31,6 +31,12 @@ def family(name):
         return "attn_fwd"
     if "attn_bwd" in name:
         return "attn_bwd"
+    if "chain_fwd" in name:
+        return "chain_fwd"
+    if "chain_bwd" in name:
+        return "chain_bwd"
+    if "wgrad2_kernel" in name:
+        return "wgrad2"
     if "gemm" in name:
         return "gemm"
     return None
