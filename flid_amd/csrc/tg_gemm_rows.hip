@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "tg_common.h"
+#include "tg_pack.h"
 
 namespace {
 
@@ -50,45 +51,9 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-// Packed operand of B (N x K, "row n = output column n"): [tile t = n / 16][step s = k / 32][plane hi, lo][lane 0..63][8 bf16]
-// lane l of (t, s) holds B[16 t + (l & 15)][32 s + 8 (l >> 4) + 0..7]  -- the B fragment of v_mfma_f32_16x16x32_bf16 --
-// zero beyond N or K.  trans = 0: B[n][k] = src[n * ld + k];  trans = 1: B[n][k] = src[k * ld + n] (the transposed weight that the
-// input-gradient products multiply with).
-struct PackJobs { tg_pack_job j[24]; int frag0[25]; int n; };
-
-__global__ void __launch_bounds__(NTH) pack_weights_kernel(PackJobs jobs) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int total = jobs.frag0[jobs.n];
-    for (int f = blockIdx.x * 4 + wave; f < total; f += gridDim.x * 4) {
-        int ji = 0;
-        while (ji + 1 < jobs.n && f >= jobs.frag0[ji + 1]) ++ji;
-        const tg_pack_job J = jobs.j[ji];
-        const int S = (J.K + 31) / 32;
-        const int fl = f - jobs.frag0[ji], t = fl / S, s = fl - t * S;
-        const int np = 16 * t + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
-        int n = np;
-        bool nok = np < J.N;
-        if (J.n_pad > 0) { const int r = np % J.n_pad; nok = nok && r < J.n_len; n = (np / J.n_pad) * J.n_len + r; }
-        nok = nok && n < (J.src_N > 0 ? J.src_N : J.N);
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int kp = k0 + q;
-            int k = kp;
-            bool ok = nok && kp < J.K;
-            if (J.k_pad > 0) { const int r = kp % J.k_pad; ok = ok && r < J.k_len; k = (kp / J.k_pad) * J.k_len + r; }
-            ok = ok && k < (J.src_K > 0 ? J.src_K : J.K);
-            const int64_t o = J.trans ? (int64_t)k * J.ld + n : (int64_t)n * J.ld + k;
-            v[q] = ok ? J.src[o] : 0.f;
-        }
-        uint2 h0, l0, h1, l1;
-        split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
-        split4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
-        uint4* dst = reinterpret_cast<uint4*>(J.dst) + ((int64_t)fl * 2) * 64 + lane;
-        dst[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        dst[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-    }
-}
+// (layout and body: tg_pack.h -- the layer prelude launch of tg_layer.hip runs the same body beside its other roles)
+using tgs::PackJobs;
+__global__ void __launch_bounds__(NTH) pack_weights_kernel(PackJobs jobs) { tgs::pack_body(jobs, (int)blockIdx.x, (int)gridDim.x); }
 
 // ------------------------------------------------------------------------------------------------ the product
 // GS = 32-deep steps per group (the barrier interval).  The k loop runs over HALVES: half h multiplies group h while everything group
@@ -333,15 +298,8 @@ int pack_weights(int njobs, const tg_pack_job* jobs, hipStream_t s) {
     TG_REQUIRE(njobs >= 0 && njobs <= 24, "tg_pack_weights: at most 24 jobs per launch");
     if (njobs == 0) return TG_OK;
     PackJobs pj;
-    pj.n = njobs;
-    int total = 0;
-    for (int i = 0; i < njobs; ++i) {
-        TG_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].N > 0 && jobs[i].K > 0 && al16(jobs[i].dst), "tg_pack_weights: bad job");
-        pj.j[i] = jobs[i];
-        pj.frag0[i] = total;
-        total += ((jobs[i].N + 15) / 16) * ((jobs[i].K + 31) / 32);
-    }
-    pj.frag0[njobs] = total;
+    const int total = tgs::pack_jobs_fill(pj, njobs, jobs);
+    TG_REQUIRE(total >= 0, "tg_pack_weights: bad job");
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 3) / 4, 2048);
     pack_weights_kernel<<<blocks, NTH, 0, s>>>(pj);
     return launch_status("pack_weights_kernel");

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "tg_common.h"
+#include "tg_pack.h"
 
 namespace {
 
@@ -288,12 +289,21 @@ struct TrJobs {
     int64_t g_tld, g_old, g_n;
     int g_cols, g_rows_y;      // grid rows that walk the gather
 };
-__global__ void __launch_bounds__(256) transpose_many_kernel(TrJobs jobs) {
-    __shared__ float tile[32][33];
-    if ((int)blockIdx.y > jobs.n) {                       // ---- row gather: one wave per row, 16-byte chunks
+// one wave: qb_i = sum_t Wq[i, dn + t] cos(b_t) (every lane returns the sum)
+__device__ __forceinline__ float query_bias_row(const TrJobs& jobs, int i, int lane) {
+    float acc = 0.f;
+    for (int t = lane; t < jobs.mv_cols; t += 64) {
+        const float cb = jobs.te_b ? tg::cos_phase(jobs.te_b[t]) : jobs.mv_x[t];
+        acc = fmaf(jobs.mv_W[(int64_t)i * jobs.mv_ld + t], cb, acc);
+    }
+    return tg::wave_sum(acc);
+}
+// (bx, by) of a (gx, n + 1 + g_rows_y) grid of 256-thread workgroups
+__device__ __forceinline__ void transpose_many_body(const TrJobs& jobs, int bx, int by, int gx, float (*tile)[33]) {
+    if (by > jobs.n) {                                    // ---- row gather: one wave per row, 16-byte chunks
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int64_t first = ((int64_t)(blockIdx.y - jobs.n - 1) * gridDim.x + blockIdx.x) * 4 + wave;
-        const int64_t stride = (int64_t)jobs.g_rows_y * gridDim.x * 4;
+        const int64_t first = ((int64_t)(by - jobs.n - 1) * gx + bx) * 4 + wave;
+        const int64_t stride = (int64_t)jobs.g_rows_y * gx * 4;
         const bool vec = (jobs.g_cols & 3) == 0 && (jobs.g_tld & 3) == 0 && (jobs.g_old & 3) == 0 &&
                          ((reinterpret_cast<uintptr_t>(jobs.g_table) | reinterpret_cast<uintptr_t>(jobs.g_out)) & 15) == 0;
         for (int64_t r = first; r < jobs.g_n; r += stride) {
@@ -307,24 +317,19 @@ __global__ void __launch_bounds__(256) transpose_many_kernel(TrJobs jobs) {
         }
         return;
     }
-    if ((int)blockIdx.y == jobs.n) {                      // ---- cos(b) and the query bias
+    if (by == jobs.n) {                                   // ---- cos(b) and the query bias
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (jobs.cosb_out && blockIdx.x == 0)
+        if (jobs.cosb_out && bx == 0)
             for (int t = threadIdx.x; t < jobs.mv_cols; t += blockDim.x) jobs.cosb_out[t] = tg::cos_phase(jobs.te_b[t]);
-        for (int i = blockIdx.x * 4 + wave; i < jobs.mv_rows; i += gridDim.x * 4) {
-            float acc = 0.f;
-            for (int t = lane; t < jobs.mv_cols; t += 64) {
-                const float cb = jobs.te_b ? tg::cos_phase(jobs.te_b[t]) : jobs.mv_x[t];
-                acc = fmaf(jobs.mv_W[(int64_t)i * jobs.mv_ld + t], cb, acc);
-            }
-            acc = tg::wave_sum(acc);
+        for (int i = bx * 4 + wave; i < jobs.mv_rows; i += gx * 4) {
+            const float acc = query_bias_row(jobs, i, lane);
             if (lane == 0) jobs.mv_y[i] = acc;
         }
         return;
     }
-    const TrJob jb = jobs.j[blockIdx.y];
+    const TrJob jb = jobs.j[by];
     const int tiles_c = (jb.cols + 31) / 32, tiles_r = (jb.rows + 31) / 32;
-    for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+    for (int t = bx; t < tiles_c * tiles_r; t += gx) {
         const int tr = t / tiles_c, tc = t % tiles_c;
         const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
         __syncthreads();
@@ -354,14 +359,14 @@ struct MergeJobs { MergeJob j[4]; int n, total_tiles; };
 // Small weight-space products, up to 4 jobs per launch (the merged projections forward, their gradient chains backward):
 // 32 x 32 output tile per workgroup, K in LDS chunks of 32; thread (ty, tx) owns rows ty, ty+8, ty+16, ty+24 of column tx.
 // Operand tiles are loaded along whichever index is contiguous in memory.  Blocks past the tiles compute ub (forward only).
-__global__ void __launch_bounds__(256) merge_weights_kernel(MergeJobs jobs, const float* __restrict__ Wk, const float* __restrict__ qb,
-                                                            int H, int hd, int dk, float* __restrict__ ub) {
-    __shared__ float As[32][33], Bs[32][33], Cs[32][33];
+// bx: workgroup index inside the role; qb: the query bias in LDS (computed by this workgroup: the launch that writes it to memory is this one)
+__device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx, const float* __restrict__ Wk, const float* qb, int H, int hd,
+                                                   int dk, float* __restrict__ ub, float (*As)[33], float (*Bs)[33], float (*Cs)[33]) {
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
-    if ((int)blockIdx.x >= jobs.total_tiles) {           // ub[h dk + j] = sum_k Wk[h hd + k, j] qb[h hd + k]
+    if (bx >= jobs.total_tiles) {                        // ub[h dk + j] = sum_k Wk[h hd + k, j] qb[h hd + k]
         // 32 outputs per workgroup, the contraction split over 8 thread groups whose loads are all in flight at once (one thread per
         // output walking all hd rows was a chain of ~17 exposed load round trips: 20 us for 0.2 MFLOP)
-        const int64_t hj = (int64_t)(blockIdx.x - jobs.total_tiles) * 32 + tx;
+        const int64_t hj = (int64_t)(bx - jobs.total_tiles) * 32 + tx;
         const int per = (hd + 7) / 8, k0 = ty * per, k1 = min(hd, k0 + per);
         float acc = 0.f;
         if (hj < (int64_t)H * dk) {
@@ -380,9 +385,9 @@ __global__ void __launch_bounds__(256) merge_weights_kernel(MergeJobs jobs, cons
         return;
     }
     int ji = 0;
-    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].tile0) ++ji;
+    while (ji + 1 < jobs.n && bx >= jobs.j[ji + 1].tile0) ++ji;
     const MergeJob J = jobs.j[ji];
-    const int tile = blockIdx.x - J.tile0, m0 = (tile / J.tiles_n) * 32, n0 = (tile % J.tiles_n) * 32;
+    const int tile = bx - J.tile0, m0 = (tile / J.tiles_n) * 32, n0 = (tile % J.tiles_n) * 32;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // operand tiles of chunk k0 + 32 are loaded into registers while chunk k0 is multiplied (K = head_dim = 136 is five chunks: without
     // the look-ahead the kernel was five exposed global round trips, 20 us for 0.1 GFLOP)
@@ -441,6 +446,66 @@ inline void add_job(MergeJobs& mj, const float* A, const float* B, float* C, flo
     MergeJob& J = mj.j[mj.n++];
     J = MergeJob{A, B, C, CT, M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, (N + 31) / 32, mj.total_tiles, accumulate};
     mj.total_tiles += ((M + 31) / 32) * J.tiles_n;
+}
+
+// Everything of a layer that depends on the WEIGHTS alone (and the raw-row gather), in one launch of three kinds of workgroups:
+//   [0, nb_merge)         the merged query projection P_h = Wk_h^T Wq_h[:, :dn] and its constant part ub (merge_weights_body)
+//   [.., + nb_pack)       the packed split-bf16 operands of the chain kernels (tg_pack.h)
+//   the rest (64 tr_gy)   transposed copies, cos(b), the query bias, the raw-row gather (transpose_many_body)
+// (three launches before: 6.5 + 8.4 + 12.5 us for the 13.6 k-row layer, 5 + 5.4 us for the root layer).  The ub workgroups need the
+// query bias this same launch produces, so each recomputes it into LDS with the arithmetic of the workgroups that store it.
+struct PreludeArgs {
+    tgs::PackJobs pk;
+    TrJobs tr;
+    MergeJobs mj;
+    int nb_pack, tr_gy, nb_merge;
+    const float* Wk;
+    int H, hd, dk;
+    float* ub;
+};
+__global__ void __launch_bounds__(256) layer_prelude_kernel(PreludeArgs a) {
+    __shared__ float sm[3][32][33];
+    __shared__ float qbs[1024];
+    // (the merge tiles are the longest dependent chains of the launch: they take the lowest workgroup numbers and start first)
+    int b = (int)blockIdx.x - a.nb_merge;
+    if (b >= 0) {
+        if (b < a.nb_pack) { tgs::pack_body(a.pk, b, a.nb_pack); return; }
+        b -= a.nb_pack;
+        transpose_many_body(a.tr, b & 63, b >> 6, 64, sm[0]);
+        return;
+    }
+    b = (int)blockIdx.x;
+    if (b >= a.mj.total_tiles) {
+        // the query-bias rows of the head(s) this workgroup's 32 outputs belong to; 8 rows of a wave in flight at a time (one row at a
+        // time was 68 exposed load round trips: the launch took 35 us longer than the three it replaced)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int64_t j0 = (int64_t)(b - a.mj.total_tiles) * 32;
+        const int h0 = (int)(j0 / a.dk), h1 = (int)min<int64_t>((j0 + 31) / a.dk, a.H - 1);
+        const int i_lo = h0 * a.hd, i_hi = (h1 + 1) * a.hd;
+        float* cbs = &sm[0][0][0];                       // cos(b_t), T <= 1024 (host-checked: dq <= 1024)
+        for (int t = threadIdx.x; t < a.tr.mv_cols; t += 256) cbs[t] = a.tr.te_b ? tg::cos_phase(a.tr.te_b[t]) : a.tr.mv_x[t];
+        __syncthreads();
+        for (int i = i_lo + 8 * wave; i < i_hi; i += 32) {
+            float acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+            for (int t = lane; t < a.tr.mv_cols; t += 64) {
+                const float cb = cbs[t];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int ir = min(i + r, i_hi - 1);
+                    acc[r] = fmaf(a.tr.mv_W[(int64_t)ir * a.tr.mv_ld + t], cb, acc[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float v = tg::wave_sum(acc[r]);
+                if (lane == 0 && i + r < i_hi) qbs[i + r] = v;
+            }
+        }
+        __syncthreads();
+    }
+    merge_weights_body(a.mj, b, a.Wk, qbs, a.H, a.hd, a.dk, a.ub, sm[0], sm[1], sm[2]);
 }
 
 // Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), one workgroup per query row i = h hd + k:
@@ -637,7 +702,7 @@ private:
 };
 SideIssuer g_issuer;
 bool g_issue_thread = true;
-bool g_merged = true;      // merged projections (merge_weights_kernel); false = the reference's four separate products per layer
+bool g_merged = true;      // merged projections (merge_weights_body); false = the reference's four separate products per layer
 // the weight-space work of the merged form (one merge kernel forward, ~6 small launches backward) is a fixed cost per layer call:
 // it pays from a few thousand rows on (TGAT layer 1: 12 k rows), not for the 1 200-row root layer or a TGN batch
 int64_t kMergedMinRows = 4096;
@@ -690,6 +755,17 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     const bool use_chain = g_chain && tg_get_gemm_mode() != 0 && tg::chain_shape_ok(H, dn, T, a.de) && a16(L->agg) && a16(L->ctx) && a16(L->res) && a16(L->y) && a16(L->raw) &&
                            a16(L->own) && a16(L->f1) && a16(L->out) && a16(L->cosb) && a16(P.br) && a16(P.b1) && a16(P.b2) && a16(P.ln_g) && a16(P.ln_b) &&
                            a16(L->wT) && L->own_ld % 4 == 0 && L->raw_ld % 4 == 0 && ldy_c % 4 == 0;
+    PreludeArgs pa;                          // one launch for everything that depends on the weights alone
+    pa.pk.n = 0; pa.pk.frag0[0] = 0; pa.nb_pack = 0;
+    pa.mj.n = 0; pa.mj.total_tiles = 0;
+    pa.Wk = P.Wk; pa.H = H; pa.hd = hd; pa.dk = dk; pa.ub = wt.ub;
+    auto launch_prelude = [&](int n_tr, int gather_y, bool with_ub) -> int {
+        pa.tr_gy = n_tr + 1 + gather_y;
+        pa.nb_merge = pa.mj.total_tiles + (with_ub ? (int)(((int64_t)H * dk + 31) / 32) : 0);
+        const int64_t blocks = (int64_t)pa.nb_merge + pa.nb_pack + 64 * pa.tr_gy;
+        layer_prelude_kernel<<<(unsigned)blocks, 256, 0, s>>>(pa);
+        return tg::launch_status("layer_prelude_kernel");
+    };
     if (use_chain) {
         const int hp = tg::chain_hp(H, dn, T), yc = (dq + 31) / 32, rc = (dn + 31) / 32;
         tg_pack_job jobs[12];
@@ -706,7 +782,9 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         jobs[n++] = tg_pack_job{P.Wr, dq, H * hpb, dq, 1, pk.WrT, dq, 0, hd, hpb, 0, 0};                             // dctx = dres Wr, columns in head blocks
         for (int h = 0; h < H; ++h)                                                                                  // dagg_h = dctx_h Wv_h
             jobs[n++] = tg_pack_job{P.Wv + (int64_t)h * hd * dk, dk, dk, hd, 1, pk.WvT + h * tg::packed_floats(dk, hpb), 0, 0, 0, 0, 0, 0};
-        TG_TRY(tg::pack_weights(n, jobs, s));
+        const int frags = tgs::pack_jobs_fill(pa.pk, n, jobs);
+        TG_REQUIRE(frags >= 0, "tg_tgat_layer_fwd: packed-weight job table");
+        pa.nb_pack = (int)std::min<int64_t>((frags + 3) / 4, 2048);
     }
     // the constant half of the query, qb = Wq[:, dn:] cos b, rides in the transposes' launch
     // ... together with cos(b) itself (when the caller asks: compute_cosb) and the gather of the layer's raw rows (gather_table)
@@ -739,19 +817,11 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         }
         jobs.n = n;
         with_qbias(jobs);
-        transpose_many_kernel<<<dim3(64, n + 1 + gather_rows_y), 256, 0, s>>>(jobs);
-        TG_TRY(tg::launch_status("transpose_many_kernel"));
-        {
-            MergeJobs mj;
-            mj.n = 0;
-            mj.total_tiles = 0;
-            for (int h = 0; h < H; ++h)         // P_h (dk x dn): A(m = j, k) = Wk[h hd + k, j], B(k, n = i) = Wq[h hd + k, i]
-                add_job(mj, P.Wk + (int64_t)h * hd * dk, P.Wq + (int64_t)h * hd * dq, wt.P + (int64_t)h * dk * dn, wt.PT + (int64_t)h * dk,
-                        dk, dn, hd, 1, dk, dq, 1, dn, H * dk, 0);
-            const unsigned blocks = (unsigned)(mj.total_tiles + ((int64_t)H * dk + 31) / 32);
-            merge_weights_kernel<<<blocks, 256, 0, s>>>(mj, P.Wk, L->qbias, H, hd, dk, wt.ub);
-            TG_TRY(tg::launch_status("merge_weights_kernel"));
-        }
+        pa.tr = jobs;
+        for (int h = 0; h < H; ++h)             // P_h (dk x dn): A(m = j, k) = Wk[h hd + k, j], B(k, n = i) = Wq[h hd + k, i]
+            add_job(pa.mj, P.Wk + (int64_t)h * hd * dk, P.Wq + (int64_t)h * hd * dq, wt.P + (int64_t)h * dk * dn, wt.PT + (int64_t)h * dk,
+                    dk, dn, hd, 1, dk, dq, 1, dn, H * dk, 0);
+        TG_TRY(launch_prelude(n, gather_rows_y, true));
         // u = own P^T + ub   (all heads in one product, K = dn)
         TG_TRY(tg_gemm_f32(0, 1, R, H * dk, dn, 1.f, L->own, L->own_ld, wt.P, dn, L->u, (int64_t)H * dk, wt.ub, 0, 0, stream));
         TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
@@ -773,8 +843,8 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         jobs.j[n++] = TrJob{P.Wq, wt.WqL, dq, dn, dq, dq};
         jobs.n = n;
         with_qbias(jobs);
-        transpose_many_kernel<<<dim3(64, n + 1 + gather_rows_y), 256, 0, s>>>(jobs);
-        TG_TRY(tg::launch_status("transpose_many_kernel"));
+        pa.tr = jobs;
+        TG_TRY(launch_prelude(n, gather_rows_y, false));
         // q = [own | cos b] Wq^T : the constant half is a bias row
         TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
         // u_h = Wk_h^T q_h
