@@ -58,7 +58,8 @@ struct Geo {
     static constexpr int CHUNK = 2 * CHS;            // hi plane | lo plane
     static constexpr int PANEL = NCH * CHUNK;
     static constexpr int RED_OFF = PANEL;
-    static constexpr int LDS_BYTES = RED_OFF + 2 * NW * ROWS * 4;
+    static constexpr int PAR_OFF = RED_OFF + 2 * NW * ROWS * 4;   // bias / LayerNorm vectors of the layer (forward chain): 3 x 320 + 2 x 192 floats
+    static constexpr int LDS_BYTES = PAR_OFF + (3 * 320 + 2 * 192) * 4;
     static constexpr int RPP = 4 * NW;               // rows per pass when a product streams its rows (16 float4 per row and group)
     static constexpr int PER = ROWS / RPP;           // float4 per thread, operand and group
     static constexpr int NTW = NW == 8 ? 3 : 5;      // most column tiles a wave owns in any product of a chain
@@ -364,6 +365,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
 #define STAMP() do {} while (0)
 #endif
     STAMP();
+    // the layer's bias and LayerNorm vectors into LDS (visible behind the first product's barriers): read from memory inside an epilogue
+    // each of them was an exposed round trip to L2 with nothing else for the wave to do
+    float* par = reinterpret_cast<float*>(lds + G::PAR_OFF);
+    float *p_br = par, *p_g = par + 320, *p_b = par + 640, *p_b1 = par + 960, *p_b2 = par + 1152;
+    for (int i = tid; i < dq; i += NTH) { p_br[i] = a.br[i]; p_g[i] = a.ln_g[i]; p_b[i] = a.ln_b[i]; }
+    for (int i = tid; i < a.dn; i += NTH) { p_b1[i] = a.b1[i]; p_b2[i] = a.b2[i]; }
 
     // ---- the merge layer's raw rows: in flight now, into the panel (behind y) after the first product
     constexpr int RAWN = ROWS * 48 / NTH;                     // float4 per thread: ROWS x 192 columns
@@ -452,7 +459,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
                 for (int rb = 0; rb < RB; ++rb) x[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 continue;
             }
-            const float4 b4 = ld4(a.br + col);
+            const float4 b4 = ld4(p_br + col);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 int64_t rg = w.row0 + w.out_row(rb);
@@ -515,7 +522,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
             if (j >= w.tcnt) break;
             const int col = w.out_col(j);
             if (col >= dq) continue;                           // (the zero fill below covers the panel's tail)
-            const float4 g4 = ld4(a.ln_g + col), be4 = ld4(a.ln_b + col);
+            const float4 g4 = ld4(p_g + col), be4 = ld4(p_b + col);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int r = w.out_row(rb);
@@ -552,7 +559,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
             for (int rb = 0; rb < RB; ++rb) w.panel_store(0, w.out_row(rb), col, zero4());
             continue;
         }
-        const float4 b4 = ld4(a.b1 + col);
+        const float4 b4 = ld4(p_b1 + col);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int r = w.out_row(rb);
@@ -574,7 +581,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
         if (j >= w.tcnt) break;
         const int col = w.out_col(j);
         if (col >= a.dn) continue;
-        const float4 b4 = ld4(a.b2 + col);
+        const float4 b4 = ld4(p_b2 + col);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int r = w.out_row(rb);

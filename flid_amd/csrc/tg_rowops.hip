@@ -262,7 +262,8 @@ extern "C" int tg_time_bias_finish(float* d_teb, const float* d_b, const float* 
 
 // out[0] = scale * sum_i a[i] * w[i]: the scalar of a weighted-mean loss over an embedding block.  64 workgroups leave partial sums in
 // a small workspace; the last one to arrive (agent-scope ticket) folds them in fixed order and re-arms the ticket -- one launch,
-// deterministic, ~5 us (a single workgroup walking the block took 27 us: pure load latency).
+// deterministic (a single workgroup walking the block took 27 us: pure load latency; the last workgroup reading the 64 partial sums
+// one after the other, 5 of this kernel's 10 us).
 constexpr int WS_BLOCKS = 64;
 __global__ void __launch_bounds__(256) weighted_sum_kernel(const float* __restrict__ a, const float* __restrict__ w, int64_t n, float scale,
                                                            float* __restrict__ out, float* __restrict__ part, unsigned int* __restrict__ ticket) {
@@ -287,10 +288,13 @@ __global__ void __launch_bounds__(256) weighted_sum_kernel(const float* __restri
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = t == gridDim.x - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            float t2 = 0.f;
-            for (int i = 0; i < (int)gridDim.x; ++i) t2 += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {                            // the partial sums in one load per lane, folded by a fixed tree
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float t2 = (int)threadIdx.x < (int)gridDim.x ? __hip_atomic_load(part + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        t2 = tg::wave_sum(t2);
+        if (threadIdx.x == 0) {
             out[0] = t2 * scale;
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch (stream order)
         }

@@ -25,13 +25,25 @@ def main():
     fn(buf.data_ptr())
     bench.main()
     torch.cuda.synchronize()
-    st = buf.cpu().numpy().reshape(-1, 16)
+    st = buf.cpu().numpy().reshape(-1, 16).astype(np.int64)
     st = st[st[:, 0] != 0]
-    d = np.diff(st.astype(np.int64), axis=1)
-    n = int((st[0] != 0).sum())
-    print("workgroups stamped (last launch):", len(st), "stamps:", n)
-    print("mean interval between stamps (memtime ticks):", np.round(d[:, :n - 1].mean(0), 0))
-    print("total:", float((st[:, n - 1] - st[:, 0]).mean()))
+    n = int((st[-1] != 0).sum())
+    # the root layer's launch (16-row workgroups: ceil(1200 / 16) = 75) ran last and overwrote the first rows: the rows behind them
+    # still hold the 13.6 k-row launch of the same step
+    small = int(os.environ.get("SMALL_BLOCKS", "75"))
+    for name, blk in (("root launch", st[:small]), ("tall launch", st[small:])):
+        if len(blk) == 0:
+            continue
+        nn = int((blk[0] != 0).sum())
+        d = np.diff(blk, axis=1)[:, :nn - 1]
+        tot = blk[:, nn - 1] - blk[:, 0]
+        print(f"{name}: {len(blk)} workgroups, {nn} stamps")
+        print("  mean interval between stamps (cycles):", np.round(d.mean(0), 0))
+        print("  max  interval between stamps (cycles):", d.max(0))
+        print(f"  per-workgroup total: mean {tot.mean():.0f}  min {tot.min()}  p50 {np.percentile(tot, 50):.0f}  p90 {np.percentile(tot, 90):.0f}  max {tot.max()}")
+        print(f"  first start -> last end: {blk[:, nn - 1].max() - blk[:, 0].min()}   start skew: {blk[:, 0].max() - blk[:, 0].min()}")
+        per_xcd = [tot[i::8].mean() for i in range(8)]
+        print("  mean total by workgroup number % 8:", np.round(per_xcd, 0))
 
 
 if __name__ == "__main__":
