@@ -161,6 +161,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise TgError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       f"or `make -C flid_amd/csrc`.  flid_amd has no CPU fallback.")
+    # torch first: it brings its own libamdhip64, and the library must bind to THAT runtime -- loaded before torch it pulls in the
+    # system's copy, the process then holds two HIP runtimes and the second one finds "no ROCm-capable device"
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)      # AttributeError if the library does not export a declared symbol

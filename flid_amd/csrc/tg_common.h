@@ -81,7 +81,15 @@ int chain_hpb(int H, int dn, int T);
 int64_t chain_blocks(int64_t rows);
 int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, float* part, const void* pW2T, const void* pW1aT,
               const void* pWrT, const void* pWvT, hipStream_t s);
-bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);  // tg_wgrad.hip: big tiles + transposing LDS reads + slice fold
+// Column sums of tall slab matrices added (float atomics) into up to 6 destination vectors: column c belongs to the first segment with
+// c < end[i] and lands at p[i][c - begin_i]; a null p[i] drops the segment (device body: tg_colsum.h)
+struct SegDst { float* p[6]; int end[6]; int n; };
+struct ColJob { const float* x; int64_t ld, n; int cols; SegDst d; };
+// two slab matrices summed by extra workgroups of another launch: a (col_gx x col_ny) grid of 256-thread workgroups, the first groups_a
+// grid columns on `a`
+struct ColExtra { ColJob a, b; int groups_a, col_gx, col_ny; };
+// tg_wgrad.hip: big tiles + transposing LDS reads + slice fold; `extra` (optional): slab sums that ride in the fold launch
+bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s, const ColExtra* extra = nullptr);
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);   // tg_gemm_bf16x3.hip; false = shapes not covered
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,

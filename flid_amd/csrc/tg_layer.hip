@@ -16,6 +16,7 @@
 
 #include "tg_common.h"
 #include "tg_pack.h"
+#include "tg_colsum.h"
 
 namespace {
 
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(256) relu_bwd_colsum_kernel(float* __restrict_
 // Column sums of a tall matrix added (float atomics) into up to 6 destination vectors: column c belongs to the first segment
 // with c < end[i] and lands at p[i][c - begin_i]; a null p[i] drops the segment.  One launch finishes a bias / LayerNorm /
 // time-encoder gradient that used to take two reduction passes plus copies.
-struct SegDst { float* p[6]; int end[6]; int n; };
+using tg::SegDst;
 __global__ void __launch_bounds__(256) colsum_seg_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int cols, SegDst d) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -204,29 +205,8 @@ int colsum_seg(const float* x, int64_t ld, int64_t n, int cols, const SegDst& d,
 SegDst seg1(float* p, int cols) { SegDst d{}; d.p[0] = p; d.end[0] = cols; d.n = 1; return d; }
 
 // two slabs in one launch (a layer's LayerNorm slabs and its attention backward's time-encoder slabs)
-struct ColJob { const float* x; int64_t ld, n; int cols; SegDst d; };
-__device__ __forceinline__ void colsum_seg2_body(const ColJob& a, const ColJob& b, int groups_a, int bx, int by, int ny, float (*red)[64]) {
-    const bool first = bx < groups_a;
-    const ColJob& j = first ? a : b;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = (bx - (first ? 0 : groups_a)) * 64 + lane;
-    if ((int64_t)by * 4 >= j.n) return;                          // (uniform per workgroup) no rows for this slice
-    float s = 0.f;
-    if (c < j.cols)
-        for (int64_t r = (int64_t)by * 4 + wave; r < j.n; r += (int64_t)ny * 4) s += j.x[r * j.ld + c];
-    red[wave][lane] = s;
-    __syncthreads();
-    if (wave != 0 || c >= j.cols) return;
-    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    int beg = 0;
-    for (int i = 0; i < j.d.n; ++i) {
-        if (c < j.d.end[i]) {
-            if (j.d.p[i]) atomicAdd(j.d.p[i] + (c - beg), t);
-            return;
-        }
-        beg = j.d.end[i];
-    }
-}
+using tg::ColJob;
+using tg::colsum_seg2_body;
 __global__ void __launch_bounds__(256) colsum_seg2_kernel(ColJob a, ColJob b, int groups_a) {
     __shared__ float red[4][64];
     colsum_seg2_body(a, b, groups_a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, red);
@@ -353,6 +333,7 @@ struct MergeJob {            // C[m, n] (+)= sum_k A(m, k) B(k, n); optionally a
     const float *A, *B;
     float *C, *CT;
     int M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, tiles_n, tile0, accumulate;
+    const float *r1_m, *r1_n;     // optional rank-1 term of the epilogue: C[m, n] += r1_m[m] r1_n[n]
 };
 struct MergeJobs { MergeJob j[4]; int n, total_tiles; };
 
@@ -428,7 +409,9 @@ __device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx
         Cs[ty + 8 * q][tx] = acc[q];
         if (m < J.M && n < J.N) {
             float* c = J.C + (int64_t)m * J.ldc + n;
-            *c = J.accumulate ? *c + acc[q] : acc[q];
+            float v = acc[q];
+            if (J.r1_m) v = fmaf(J.r1_m[m], J.r1_n[n], v);
+            *c = J.accumulate ? *c + v : v;
         }
     }
     if (!J.CT) return;                                                   // (uniform per workgroup)
@@ -444,7 +427,7 @@ __device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx
 inline void add_job(MergeJobs& mj, const float* A, const float* B, float* C, float* CT, int M, int N, int K, int sAm, int sAk, int sBk,
                     int sBn, int ldc, int ldct, int accumulate) {
     MergeJob& J = mj.j[mj.n++];
-    J = MergeJob{A, B, C, CT, M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, (N + 31) / 32, mj.total_tiles, accumulate};
+    J = MergeJob{A, B, C, CT, M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, (N + 31) / 32, mj.total_tiles, accumulate, nullptr, nullptr};
     mj.total_tiles += ((M + 31) / 32) * J.tiles_n;
 }
 
@@ -508,39 +491,50 @@ __global__ void __launch_bounds__(256) layer_prelude_kernel(PreludeArgs a) {
     merge_weights_body(a.mj, b, a.Wk, qbs, a.H, a.hd, a.dk, a.ub, sm[0], sm[1], sm[2]);
 }
 
-// Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), one workgroup per query row i = h hd + k:
+// Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), UBR query rows i = h hd + k per workgroup:
 //   dqb_i = Wk[i, :] . dub_h ;  dWk[i, :] += qb_i dub_h ;  dWq[i, dn:] += dqb_i cos b ;  d cos b += Wq[i, dn:] dqb_i
-__device__ __forceinline__ void ub_bwd_body(int i, const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
+// (one workgroup per row was 272 workgroups adding into the same T addresses of d cos b: 17 us of serialised float atomics; here the
+// rows of a workgroup are summed first and the launch makes dq / UBR adds per address)
+constexpr int UBR = 8;
+__device__ __forceinline__ void ub_bwd_body(int blk, const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
         const float* __restrict__ Wq, const float* __restrict__ cosb, int hd, int dn, int dq, int dk, int T, float* __restrict__ dWk,
         float* __restrict__ dWq, float* __restrict__ d_cosb, float* red) {
-    const int h = i / hd;
-    const float* du = dub + (int64_t)h * dk;
-    const float qbi = qb[i];
-    float part = 0.f;
-    for (int j = threadIdx.x; j < dk; j += blockDim.x) {
-        const float d = du[j];
-        part = fmaf(Wk[(int64_t)i * dk + j], d, part);
-        dWk[(int64_t)i * dk + j] += qbi * d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blk * UBR;
+    for (int r = wave; r < UBR; r += 4) {                     // a wave per row: dqb_i, and the rank-1 update of dWk's row
+        const int i = i0 + r;
+        if (i >= dq) break;                                    // (wave-uniform)
+        const float* du = dub + (int64_t)(i / hd) * dk;
+        const float qbi = qb[i];
+        float part = 0.f;
+        for (int j = lane; j < dk; j += 64) {
+            const float d = du[j];
+            part = fmaf(Wk[(int64_t)i * dk + j], d, part);
+            dWk[(int64_t)i * dk + j] += qbi * d;
+        }
+        part = tg::wave_sum(part);
+        if (lane == 0) red[r] = part;
     }
-    part = tg::wave_sum(part);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    const float dqb = red[0] + red[1] + red[2] + red[3];
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        dWq[(int64_t)i * dq + dn + t] += dqb * cosb[t];
-        atomicAdd(d_cosb + t, Wq[(int64_t)i * dq + dn + t] * dqb);
+        const float cb = cosb[t];
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < UBR; ++r) {
+            const int i = i0 + r;
+            if (i < dq) {
+                const float dqb = red[r];
+                dWq[(int64_t)i * dq + dn + t] += dqb * cb;
+                acc = fmaf(Wq[(int64_t)i * dq + dn + t], dqb, acc);
+            }
+        }
+        atomicAdd(d_cosb + t, acc);
     }
-}
-__global__ void __launch_bounds__(256) ub_bwd_kernel(const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
-        const float* __restrict__ Wq, const float* __restrict__ cosb, int hd, int dn, int dq, int dk, int T, float* __restrict__ dWk,
-        float* __restrict__ dWq, float* __restrict__ d_cosb) {
-    __shared__ float red[4];
-    ub_bwd_body((int)blockIdx.x, dub, qb, Wk, Wq, cosb, hd, dn, dq, dk, T, dWk, dWq, d_cosb, red);
 }
 
 // The layer's backward TAIL in one launch: three independent finishing steps that used to be a launch each (4.5-12 us apiece for
 // a few hundred KB of work).  Workgroups [0, n_head): the constant-part gradients of the query -- ub_bwd (merged projection,
-// head_mode 1: one workgroup per query row) or wq_time (head_mode 2: (T / 64) x (dq / 16) workgroups); the rest: the slab sums.
+// head_mode 1: one workgroup per UBR query rows) or wq_time (head_mode 2: (T / 64) x (dq / 16) workgroups); the rest: the slab sums.
 struct TailArgs {
     int head_mode, n_head, wq_gx;
     const float *v, *qb, *Wk, *Wq, *cosb;        // v = dub (mode 1) or sum_rows dq (mode 2)
@@ -979,14 +973,19 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // three launches per layer were 72 us of fixed cost for 93 us of work.  Their operands (dout, f1, df1, [y | raw], dres, ctx,
     // dctx, agg, du, own) are all distinct buffers that stay untouched until the call returns.
     std::vector<WJ> pending;
-    auto issue_wgrad = [&](std::vector<WJ> jobs) -> int {
+    // extra (optional): the layer's slab sums, as extra workgroups of the fold launch when the second form takes the jobs, else a launch
+    auto issue_wgrad = [&](std::vector<WJ> jobs, const tg::ColExtra* extra = nullptr) -> int {
         hipStream_t st = ws_;
         void* stv = wstream;
+        const bool has_extra = extra != nullptr;
+        const tg::ColExtra ex = has_extra ? *extra : tg::ColExtra{};
         return side([=] {
             tg_wgrad_job q[8];
             const int n = (int)jobs.size();
             for (int i = 0; i < n; ++i) q[i] = tg_wgrad_job{jobs[i].A, jobs[i].lda, jobs[i].M, jobs[i].B, jobs[i].ldb, jobs[i].N, jobs[i].C, jobs[i].ldc, jobs[i].cs};
-            if (g_wgrad_grouped && ((tg_get_gemm_mode() != 0 && tg::wgrad_group2(n, q, R, st)) || tg::wgrad_group(n, q, R, st))) return tg::launch_status("wgrad kernel");
+            if (g_wgrad_grouped && tg_get_gemm_mode() != 0 && tg::wgrad_group2(n, q, R, st, has_extra ? &ex : nullptr)) return tg::launch_status("wgrad kernel");
+            if (has_extra) TG_TRY(colsum_seg2(ex.a, ex.b, st));
+            if (g_wgrad_grouped && tg::wgrad_group(n, q, R, st)) return tg::launch_status("wgrad kernel");
             for (int i = 0; i < n; ++i) {
                 TG_TRY(tg_gemm_f32(1, 0, q[i].M, q[i].N, R, 1.f, q[i].A, q[i].lda, q[i].B, q[i].ldb, q[i].C, q[i].ldc, nullptr, 0, 1, stv));
                 if (q[i].colsum_A) TG_TRY(colsum_seg(q[i].A, q[i].lda, R, q[i].M, seg1(q[i].colsum_A, q[i].M), st));
@@ -999,9 +998,10 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         pending.insert(pending.end(), jobs.begin(), jobs.end());
         return TG_OK;
     };
-    auto flush_wgrad = [&]() -> int {
+    auto flush_wgrad = [&](const tg::ColExtra* extra = nullptr) -> int {
         for (size_t i = 0; i < pending.size(); i += 8)
-            TG_TRY(issue_wgrad(std::vector<WJ>(pending.begin() + i, pending.begin() + std::min(pending.size(), i + 8))));
+            TG_TRY(issue_wgrad(std::vector<WJ>(pending.begin() + i, pending.begin() + std::min(pending.size(), i + 8)),
+                               i + 8 >= pending.size() ? extra : nullptr));
         pending.clear();
         return TG_OK;
     };
@@ -1042,31 +1042,35 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // slab columns: [dgamma | dbeta | sum dsum (node half unused, time half = d cos(b) of the residual) | sum dres (= d br, which the
     // weight-gradient launch delivers through its ones column instead)]
     // head_mode 1: ub_bwd over dub; 2: wq_time over sum_rows dq (vec_dq); both with the slab sums behind them in the same launch
-    auto tail = [&](int head_mode) -> int {
+    auto slab_jobs = [&](ColJob& ja, ColJob& jb, int& groups_a, int& col_gx, int& col_ny) {
+        ja = ColJob{part_ln, 4 * (int64_t)dq, (int64_t)ln_grid, 3 * dq, SegDst{}};
+        ja.d.n = 5;
+        ja.d.p[0] = G.ln_g;     ja.d.end[0] = dq;
+        ja.d.p[1] = G.ln_b;     ja.d.end[1] = 2 * dq;
+        ja.d.p[2] = nullptr;    ja.d.end[2] = 2 * dq + dn;
+        ja.d.p[3] = Bw->d_cosb; ja.d.end[3] = 3 * dq;
+        ja.d.p[4] = nullptr;    ja.d.end[4] = 4 * dq;
+        jb = ColJob{part_attn, 2 * (int64_t)T, T > 0 ? (int64_t)attn_parts : 0, 2 * T, SegDst{}};
+        jb.d.n = 2;
+        jb.d.p[0] = Bw->d_tew; jb.d.end[0] = T;
+        jb.d.p[1] = Bw->d_teb; jb.d.end[1] = 2 * T;
+        const int ga = (ja.cols + 63) / 64, gb = jb.n > 0 ? (jb.cols + 63) / 64 : 0;
+        const int64_t max_slices = std::max<int64_t>(64, std::min<int64_t>(512, 2048 / std::max(1, ga + gb)));
+        groups_a = ga;
+        col_gx = ga + gb;
+        col_ny = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, std::max(ja.n, jb.n) / 32));
+    };
+    auto tail = [&](int head_mode, bool with_slab_sums = true) -> int {
         TailArgs t{};
         t.head_mode = head_mode;
         t.wq_gx = (T + 63) / 64;
-        t.n_head = head_mode == 1 ? dq : (T > 0 ? t.wq_gx * ((dq + WQT_ROWS - 1) / WQT_ROWS) : 0);
+        t.n_head = head_mode == 1 ? (dq + UBR - 1) / UBR : (T > 0 ? t.wq_gx * ((dq + WQT_ROWS - 1) / WQT_ROWS) : 0);
         t.v = head_mode == 1 ? dub : vec_dq;
         t.qb = Lc.qbias; t.Wk = P.Wk; t.Wq = P.Wq; t.cosb = Lc.cosb;
         t.hd = hd; t.dn = dn; t.dq = dq; t.dk = dk; t.T = T;
         t.dWk = G.Wk; t.dWq = G.Wq; t.d_cosb = Bc.d_cosb;
-        t.a = ColJob{part_ln, 4 * (int64_t)dq, (int64_t)ln_grid, 3 * dq, SegDst{}};
-        t.a.d.n = 5;
-        t.a.d.p[0] = G.ln_g;     t.a.d.end[0] = dq;
-        t.a.d.p[1] = G.ln_b;     t.a.d.end[1] = 2 * dq;
-        t.a.d.p[2] = nullptr;    t.a.d.end[2] = 2 * dq + dn;
-        t.a.d.p[3] = Bw->d_cosb; t.a.d.end[3] = 3 * dq;
-        t.a.d.p[4] = nullptr;    t.a.d.end[4] = 4 * dq;
-        t.b = ColJob{part_attn, 2 * (int64_t)T, T > 0 ? (int64_t)attn_parts : 0, 2 * T, SegDst{}};
-        t.b.d.n = 2;
-        t.b.d.p[0] = Bw->d_tew; t.b.d.end[0] = T;
-        t.b.d.p[1] = Bw->d_teb; t.b.d.end[1] = 2 * T;
-        const int ga = (t.a.cols + 63) / 64, gb = t.b.n > 0 ? (t.b.cols + 63) / 64 : 0;
-        const int64_t max_slices = std::max<int64_t>(64, std::min<int64_t>(512, 2048 / std::max(1, ga + gb)));
-        t.groups_a = ga;
-        t.col_gx = ga + gb;
-        t.col_ny = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, std::max(t.a.n, t.b.n) / 32));
+        slab_jobs(t.a, t.b, t.groups_a, t.col_gx, t.col_ny);
+        if (!with_slab_sums) t.col_ny = 0;
         hipStream_t st = ws_;
         return side([=] {
             layer_tail_kernel<<<(unsigned)(t.n_head + t.col_gx * t.col_ny), 256, 0, st>>>(t);
@@ -1091,6 +1095,22 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         TG_TRY(fork());                       // du and the time-encoder slabs are final
         TG_TRY(wgrad({WJ{Bc.du, hk, (int)hk, Lc.own, Lc.own_ld, dn, dPm, dn, dub}}));                 // dP = du^T own, dub = sum_rows du
+        if (!overlap && g_wgrad_grouped) {
+            // everything left is weight space.  The slab sums ride in the weight gradients' fold launch (they were the larger part of the
+            // tail launch, which could only start after the weight-space products although it does not depend on them).
+            tg::ColExtra ce{};
+            slab_jobs(ce.a, ce.b, ce.groups_a, ce.col_gx, ce.col_ny);
+            TG_TRY(flush_wgrad(&ce));
+            // P_h = Wk_h^T Wq_h[:, :dn] :  dWk_h += Wq_h[:, :dn] dP_h^T ;  dWq_h[:, :dn] += Wk_h dP_h ;  then the constant part (ub_bwd, which
+            // also adds into dWk).  (One launch of 32 x 32 fp32 tiles for both products and ub_bwd was measured: 42 us against 7 + 9 + 5 --
+            // its K = 444 product is 14 dependent chunk round trips per tile.)
+            TG_TRY(tg_gemm_f32_batched(0, 1, hd, dk, dn, 1.f, P.Wq, dq, (int64_t)hd * dq, dPm, dn, (int64_t)dk * dn, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, stream));
+            TG_TRY(tg_gemm_f32_batched(0, 0, hd, dn, dk, 1.f, P.Wk, dk, (int64_t)hd * dk, dPm, dn, (int64_t)dk * dn, G.Wq, dq, (int64_t)hd * dq, H, nullptr, 0, 1, stream));
+            TG_TRY(tail(1, false));
+            if (Bw->d_own) TG_TRY(tg_gemm_f32(0, 1, R, dn, hk, 1.f, Bw->du, hk, wt.PT, hk, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
+            drain_guard.on = false;
+            return TG_OK;
+        }
         TG_TRY(flush_wgrad());
         {
             void* stv = wstream;
@@ -1124,9 +1144,16 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
                 jobs.push_back(WJ{Lc.q + h * hd, dq, hd, Bc.du + (int64_t)h * dk, hk, dk, G.Wk + (int64_t)h * hd * dk, dk, nullptr});
             jobs.push_back(WJ{Bc.dq, dq, dq, Lc.own, Lc.own_ld, dn, G.Wq, dq, vec_dq});                                          // dWq[:, :dn], sum_rows dq
             TG_TRY(wgrad(jobs));
-            TG_TRY(flush_wgrad());
         }
-        TG_TRY(tail(2));                          // wq_time (the time half of dWq, d cos b) + the slab sums
+        if (!overlap && g_wgrad_grouped) {        // the slab sums ride in the weight gradients' fold launch
+            tg::ColExtra ce{};
+            slab_jobs(ce.a, ce.b, ce.groups_a, ce.col_gx, ce.col_ny);
+            TG_TRY(flush_wgrad(&ce));
+            TG_TRY(tail(2, false));               // wq_time (the time half of dWq, d cos b)
+        } else {
+            TG_TRY(flush_wgrad());
+            TG_TRY(tail(2));                      // wq_time + the slab sums
+        }
         if (Bw->d_own) {
             // (the residual's share is already there: ln_res_bwd_kernel)
             TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));

@@ -23,6 +23,7 @@
 #include <mutex>
 
 #include "tg_common.h"
+#include "tg_colsum.h"
 
 namespace {
 
@@ -288,7 +289,15 @@ __global__ void __launch_bounds__(WNT, 2) wgrad2_kernel(WTiles tiles, int64_t R,
 }
 
 // C += sum over slices (fixed order); the ones column lands in colsum.  One element per thread, the slices' loads independent.
-__global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, int nslices, const float* __restrict__ ws, int64_t slice_stride) {
+// Grid rows behind the tiles' (blockIdx.y >= tiles.n) are the caller's slab sums (tg::ColExtra): independent of the fold, they used to
+// be a part of the layer's tail launch that could only start after it.
+__global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, int nslices, const float* __restrict__ ws, int64_t slice_stride, tg::ColExtra ex) {
+    if ((int)blockIdx.y >= tiles.n) {
+        __shared__ float red[4][64];
+        const int c = ((int)blockIdx.y - tiles.n) * (int)gridDim.x + (int)blockIdx.x;
+        if (c < ex.col_gx * ex.col_ny) tg::colsum_seg2_body(ex.a, ex.b, ex.groups_a, c % ex.col_gx, c / ex.col_gx, ex.col_ny, red);
+        return;
+    }
     const WTile T = tiles.t[blockIdx.y];
     const int64_t total = (int64_t)T.mext * T.nw;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -337,7 +346,7 @@ bool g_wgrad2 = true;
 namespace tg {
 
 // false = a job's shape / alignment is not covered or no workspace (nothing launched): the caller takes the first form
-bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s) {
+bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s, const ColExtra* extra) {
     if (!g_wgrad2 || njobs < 1 || njobs > 8 || rows < 1) return false;
     WTiles wt;
     wt.n = 0;
@@ -397,7 +406,11 @@ bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t
     }
     wgrad2_kernel<<<(unsigned)(wt.n * slices), WNT, 2 * STAGE, s>>>(wt, rows, rps, (int)slices, ws, slab);
     if (hipGetLastError() != hipSuccess) return false;
-    wgrad2_fold_kernel<<<dim3((TM * (TN + 4) + 255) / 256, (unsigned)wt.n), 256, 0, s>>>(wt, (int)slices, ws, slab);
+    const unsigned fold_gx = (TM * (TN + 4) + 255) / 256;
+    ColExtra ex{};
+    unsigned extra_rows = 0;
+    if (extra) { ex = *extra; extra_rows = ((unsigned)(ex.col_gx * ex.col_ny) + fold_gx - 1) / fold_gx; }
+    wgrad2_fold_kernel<<<dim3(fold_gx, (unsigned)wt.n + extra_rows), 256, 0, s>>>(wt, (int)slices, ws, slab, ex);
     return true;
 }
 

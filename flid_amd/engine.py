@@ -562,8 +562,9 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_
                 if l >= 2:
                     ops.scatter_add_rows(d_raw, fr.ids_all[:R], d_table)
                 else:
-                    d_own += d_raw
+                    # (two scatters, not `d_own += d_raw` and one: that torch add cost the host 300 us per step -- tools/line_prof.py)
                     ops.scatter_add_rows(d_own, fr.ids_all[:R], d_table)
+                    ops.scatter_add_rows(d_raw, fr.ids_all[:R], d_table)
             if grad_ready is not None and l >= 2:
                 # layer l's own parameter gradients are final once its backward is queued (the time encoder's block keeps
                 # accumulating until layer 1): a data-parallel caller can start reducing this segment under the lower layers' backward
