@@ -40,7 +40,7 @@ class LayerBwdDesc(C.Structure):
     _fields_ = [("grads", LayerParams), ("dout", c_void)] + \
                [(n, c_void) for n in ("df1", "dy", "dsum", "dres", "dctx", "dagg", "du", "dq", "part", "vec", "d_cosb", "d_tew", "d_teb")] + \
                [("dfeat", c_void), ("dfeat_ld", c_i64), ("pad_row", c_i64), ("d_own", c_void), ("d_own_ld", c_i64),
-                ("d_own_accumulate", C.c_int), ("d_raw", c_void), ("defer_join", C.c_int)]
+                ("d_own_accumulate", C.c_int), ("d_raw", c_void), ("defer_join", C.c_int), ("finish_time_bias", C.c_int)]
 
 
 class PackJob(C.Structure):

@@ -1109,6 +1109,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             TG_TRY(tail(1, false));
             if (Bw->d_own) TG_TRY(tg_gemm_f32(0, 1, R, dn, hk, 1.f, Bw->du, hk, wt.PT, hk, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
             drain_guard.on = false;
+            if (Bw->finish_time_bias && T > 0) TG_TRY(tg_time_bias_finish(Bw->d_teb, a.d_te_b, Bw->d_cosb, T, stream));
             return TG_OK;
         }
         TG_TRY(flush_wgrad());
@@ -1159,11 +1160,12 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
         }
     }
-    if (overlap && !defer) {
+    if (overlap && (!defer || Bw->finish_time_bias)) {
         drain_guard.on = false;
         TG_TRY(side_join(s));
     }
     drain_guard.on = false;                   // deferred join: the closures own copies of the descriptors (Lc, Bc)
+    if (Bw->finish_time_bias && T > 0) TG_TRY(tg_time_bias_finish(Bw->d_teb, a.d_te_b, Bw->d_cosb, T, stream));
     return TG_OK;
 }
 

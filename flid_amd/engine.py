@@ -433,7 +433,7 @@ class _NativeLayer:
         return lay, off
 
     def backward(self, dout, params, gblock, vec, d_cosb, d_tew, d_teb, dfeat, pad_row, d_own, d_own_accumulate, want_d_raw,
-                 slot=0, defer_join=False):
+                 slot=0, defer_join=False, finish_time_bias=False):
         """gblock: this layer's zero-filled gradient block (layout = grad_layout(params)); vec: dq zero floats of scratch"""
         import ctypes as C
         from ._lib import LayerBwdDesc, LayerParams, check, lib
@@ -466,6 +466,7 @@ class _NativeLayer:
         b.d_own, b.d_own_ld, b.d_own_accumulate = ops._p(d_own), (0 if d_own is None else ops._rowmajor_ld(d_own, "d_own")), int(d_own_accumulate)
         b.d_raw = ops._p(d_raw)
         b.defer_join = int(defer_join)
+        b.finish_time_bias = int(finish_time_bias)
         with ops._timed("layer_bwd", self.R):
             check(lib().tg_tgat_layer_bwd(C.byref(self.desc), C.byref(b), ops._stream()), "tg_tgat_layer_bwd")
         return d_raw
@@ -556,7 +557,7 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_
                 d_own, acc = (torch.empty((R, Dn), device=dev), False) if table_grad else (None, False)
             v0 = npar + xt + _r4(T) + (l - 1) * vlen
             d_raw = lay.backward(dH[:R], params, zeroed[offs[2 + (l - 1) * 11]:], zeroed[v0:v0 + vlen], d_cosb, d_tew, d_teb,
-                                 dfeat, pad_row, d_own, acc, table_grad, slot=l, defer_join=True)
+                                 dfeat, pad_row, d_own, acc, table_grad, slot=l, defer_join=l > 1, finish_time_bias=l == 1)
             alive += [dH_prev, d_own, d_raw]
             if table_grad:
                 if l >= 2:
@@ -575,8 +576,7 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_
     finally:
         check(lib().tg_side_join(ops._stream()), "tg_side_join")
     del alive
-    # d cos(b) -> d b (zero interval: no weight gradient): d_teb -= sin(b) * d_cosb
-    check(lib().tg_time_bias_finish(ops._p(d_teb), ops._p(te_b), ops._p(d_cosb), T, ops._stream()), "tg_time_bias_finish")
+    # (d cos(b) -> d b, d_teb -= sin(b) * d_cosb, rode at the end of layer 1's call: finish_time_bias)
     return d_table, zeroed, offs, npar
 
 

@@ -197,6 +197,8 @@ typedef struct tg_layer_bwd_desc {
     float* d_raw;
     int defer_join;   /* 1: do not wait for the side streams before returning; the caller calls tg_side_join() after its last
                        * layer and must keep every buffer named here untouched (and alive) until then */
+    int finish_time_bias;  /* 1 (the caller's LAST layer): d_teb -= sin(b) * d_cosb at the end of this call (= tg_time_bias_finish: the
+                            * gradient that reached cos(b) of models/TGAT.py:84-85 handed on to b), after joining the side streams */
 } tg_layer_bwd_desc;
 int tg_tgat_layer_fwd(const tg_layer_desc* layer, void* stream);
 int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk);

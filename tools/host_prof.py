@@ -36,7 +36,23 @@ class Proxy:
 def main():
     h = _lib.lib()
     _lib._lib = Proxy(h)
+    import torch
     import bench
+    # host blocking points of the prefetch pipeline: Event.synchronize (the distinct-row count of a prepared batch), Stream.synchronize
+    for cls, name in ((torch.cuda.Event, "synchronize"), (torch.cuda.Stream, "synchronize"), (torch.cuda.Stream, "wait_event"),
+                      (torch.cuda.Stream, "wait_stream"), (torch.cuda.Event, "record")):
+        orig = getattr(cls, name)
+        rec = acc[f"torch {cls.__name__}.{name}"]
+
+        def make(orig=orig, rec=rec):
+            def w(*a, **k):
+                t = time.perf_counter()
+                r = orig(*a, **k)
+                rec[1] += time.perf_counter() - t
+                rec[0] += 1
+                return r
+            return w
+        setattr(cls, name, make())
     sys.argv = ["bench.py"] + (sys.argv[1:] or ["--no-cpu-baseline", "--no-breakdown"])
     t0 = time.perf_counter()
     bench.main()
