@@ -688,3 +688,54 @@ def test_tgat_on_device_random_draws_matches_oracle_given_the_same_draws():
     want = orc.embed(bs, bt, 2, 6)
     assert not queue
     np.testing.assert_allclose(emb.cpu().numpy(), want.numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("R,N,K", [(1000, 172, 444), (77, 272, 288), (13622, 444, 172), (5, 16, 32)])
+def test_packed_rows_product_vs_fp64(R, N, K):
+    """tg_pack_weights + tg_gemm_rows_nt (the row-block product the chain kernels are built from): out = a W^T with bias, ReLU,
+    accumulation and the ReLU-backward mask, both operand orientations, against float64 at the three-term split-bf16 error model"""
+    from flid_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(R + N)
+    a, w, b = torch.randn(R, K, device=dev), torch.randn(N, K, device=dev), torch.randn(N, device=dev)
+    packed, packed_t = ops.pack_weights([(w, False), (w.t().contiguous(), True)])
+    ref = a.double() @ w.double().t()
+    bound = 3.0 * 2.0 ** -16 * float((a.double().abs() @ w.double().abs().t()).max())      # dropped lo * lo term + bf16 rounding of lo
+    for pk in (packed, packed_t):
+        out = ops.gemm_rows(a, pk, torch.empty(R, N, device=dev))
+        assert float((out.double() - ref).abs().max()) <= bound
+    out = ops.gemm_rows(a, packed, torch.empty(R, N, device=dev), bias=b, relu=True)
+    assert float((out.double() - (ref + b.double()).clamp_min(0)).abs().max()) <= bound
+    acc0 = torch.randn(R, N, device=dev)
+    out = ops.gemm_rows(a, packed, acc0.clone(), accumulate=True)
+    assert float((out.double() - (ref + acc0.double())).abs().max()) <= bound
+    mask = torch.randn(R, N, device=dev)
+    out = ops.gemm_rows(a, packed, torch.empty(R, N, device=dev), mask=mask)
+    assert float((out.double() - ref * (mask > 0)).abs().max()) <= bound
+    with pytest.raises(Exception):
+        ops.gemm_rows(a[:, :K - 1].contiguous(), packed, torch.empty(R, N, device=dev))       # K does not match the packed operand
+
+
+def test_weight_gradient_forms_agree():
+    """tg_set_wgrad_form: the first form (64 x 64 tiles, float-atomic fold) and the second (192 x 256 tiles, slabs folded in fixed
+    order) compute the same sums; the second is bitwise reproducible from launch to launch"""
+    from flid_amd import ops
+    from flid_amd._lib import lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    rows = 5000
+    A, B = torch.randn(rows, 272, device=dev), torch.randn(rows, 444, device=dev)
+    res = {}
+    try:
+        for form in (2, 1, 2):
+            lib().tg_set_wgrad_form(form)
+            C_, cs = torch.zeros(272, 444, device=dev), torch.zeros(272, device=dev)
+            ops.wgrad_group([(A, B, C_, cs)])
+            res.setdefault(form, []).append((C_.clone(), cs.clone()))
+    finally:
+        lib().tg_set_wgrad_form(2)
+    assert torch.equal(res[2][0][0], res[2][1][0]) and torch.equal(res[2][0][1], res[2][1][1])
+    ref = A.double().t() @ B.double()
+    for form in (1, 2):
+        assert float((res[form][0][0].double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+        assert float((res[form][0][1].double() - A.double().sum(0)).abs().max()) <= 3e-5 * float(A.double().sum(0).abs().max()) + 1e-3

@@ -607,3 +607,32 @@ def test_link_prediction_warmup_three_steps_match_reference_golden():
         upd_ref, upd_mine = g["h:" + n_] - hp[n_].numpy(), prm.detach().cpu().numpy() - hp[n_].numpy()
         big = np.abs(upd_ref) >= 2.5 * lr                       # entries the reference moved three times the same way
         assert not big.any() or (np.abs(upd_mine - upd_ref)[big] > 0.25 * lr).mean() <= 0.05, n_
+
+
+def test_src_only_roots_and_chain_switch():
+    """roots="src" (single-way datasets: the M-step reads only the source embeddings, PTCL/M_step.py:285) embeds exactly the source
+    rows of the two-sided call; tg_set_layer_chain(0) (launch-per-product layer) and the default row-block chains agree to the
+    split-bf16 budget in values and gradients"""
+    from flid_amd._lib import lib
+    g = load_golden("tgat_L2_K20")
+    m, p, k = _model(g)
+    m.eval()
+    with torch.no_grad():
+        s2, d2 = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+        s1, d1 = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k, roots="src")
+    assert d1 is None and s1.shape == s2.shape
+    assert float((s1 - s2).abs().max()) <= 1e-6                  # (row sharing differs between the two frontiers: not bitwise)
+    res = []
+    try:
+        for chain in (1, 0):
+            lib().tg_set_layer_chain(chain)
+            m2, _, _ = _model(g)
+            m2.train()
+            s, d = m2.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"], k)
+            (s.sum() + 0.5 * d.sum()).backward()
+            res.append((torch.cat([s, d]).detach().clone(), [q.grad.clone() for q in m2.parameters() if q.grad is not None]))
+    finally:
+        lib().tg_set_layer_chain(1)
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5
+    for ga, gb in zip(res[0][1], res[1][1]):
+        assert float((ga - gb).abs().max()) <= 1e-4 * max(1e-6, float(gb.abs().max()))

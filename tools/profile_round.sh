@@ -10,6 +10,8 @@ KERNELS="chain_fwd chain_bwd wgrad2_kernel attn_bwd_fast attn_fwd_fast" bash too
 python3 bench.py --gemm-mode 0 --no-cpu-baseline > $O/r03_headline_bench_exact_f32.json 2> $O/exact.err
 python3 bench.py --roofline-kernel gemm --no-cpu-baseline > $O/r03_headline_bench_mfma.json 2> $O/mfma.err
 python3 bench.py --model tgn > $O/r03_tgn_bench.json 2> $O/tgn.err
+rocprofv3 --kernel-trace -d $O/kt_tgn -o tgn -- python3 bench.py --model tgn --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2> $O/kt_tgn.err
+python3 tools/rocpd_stats.py $O/kt_tgn/tgn_results.db --csv $O/r03_tgn_kernel_stats.csv --timeline > $O/r03_tgn_timeline.txt 2>&1
 python3 bench.py --model dygformer > $O/r03_dygformer_bench.json 2> $O/dyg.err
 python3 bench.py --mode sweep > $O/r03_sweep_bench.json 2> $O/sweep.err
 python3 bench.py --mode fwd > $O/r03_fwd_bench.json 2> $O/fwd.err
