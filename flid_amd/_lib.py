@@ -64,6 +64,7 @@ SIGNATURES = {
     "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),
     "tg_time_bias_finish": (C.c_int, [c_void, c_void, c_void, C.c_int, c_void]),
     "tg_bce_logits": (C.c_int, [c_void, c_i64, c_i64, c_void, c_void, c_void]),
+    "tg_weighted_ce": (C.c_int, [c_void, c_i64, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_i64, c_void]),
     "tg_weighted_sum": (C.c_int, [c_void, c_void, c_i64, c_f32, c_void, c_void]),
     "tg_hash_features": (C.c_int, [c_void, c_i64, c_i64, c_i64, C.c_int, C.c_uint64, c_void]),
     "tg_graph_create": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, C.POINTER(c_void)]),

@@ -345,6 +345,39 @@ extern "C" int tg_bce_logits(const float* d_z, int64_t n_pos, int64_t n, float* 
     return tg::launch_status("bce_logits_kernel");
 }
 
+// loss[0] = sum_i w_i CE(z_i, y_i) = sum_i w_i (logsumexp(z_i) - z_i[y_i]) over the rows with y_i >= 0, dz_i = w_i (softmax(z_i) - onehot(y_i))
+// (0 for ignored rows): nn.CrossEntropyLoss(reduction='none') of the M-step with its ground-truth / pseudo-label masks and per-sample
+// weights folded into w (PTCL/M_step.py:296-312).  One workgroup, a thread per row (C is the number of classes: a handful).
+__global__ void __launch_bounds__(256) weighted_ce_kernel(const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ y,
+                                                          const float* __restrict__ w, int64_t n, int C, float* __restrict__ loss,
+                                                          float* __restrict__ dz, int64_t lddz) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float* zi = z + i * ldz;
+        float* di = dz + i * lddz;
+        const int yi = y[i];
+        const float wi = (yi >= 0 && yi < C) ? w[i] : 0.f;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, zi[c]);
+        float den = 0.f;
+        for (int c = 0; c < C; ++c) den += expf(zi[c] - mx);
+        const float lse = mx + logf(den), inv = 1.f / den;
+        if (wi != 0.f) s += wi * (lse - zi[yi]);
+        for (int c = 0; c < C; ++c) di[c] = wi * (expf(zi[c] - mx) * inv - (c == yi ? 1.f : 0.f));
+    }
+    s = tg::wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+extern "C" int tg_weighted_ce(const float* d_z, int64_t ldz, const int32_t* d_labels, const float* d_weights, int64_t n, int classes,
+                              float* d_loss, float* d_dz, int64_t lddz, void* stream) {
+    TG_REQUIRE(d_z && d_labels && d_weights && d_loss && d_dz && n > 0 && classes > 0 && ldz >= classes && lddz >= classes, "tg_weighted_ce: arguments");
+    weighted_ce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(d_z, ldz, d_labels, d_weights, n, classes, d_loss, d_dz, lddz);
+    return tg::launch_status("weighted_ce_kernel");
+}
+
 extern "C" int tg_rowop_parts(int64_t n) { return (int)row_grid(n); }
 
 extern "C" int tg_gather_rows(const float* d_table, int64_t table_ld, const int32_t* d_idx, int64_t n, int cols, float* d_out,

@@ -2,8 +2,9 @@
 TGAT.train_step / MemoryModel.train_step, so that a whole trainer step -- backbone forward, head, loss, head backward, backbone
 backward -- runs without an autograd graph.
 
-replaces: PTCL/EM_warmup.py:212-231 (MergeLayer link predictor -> sigmoid -> nn.BCELoss -> backward) and, through
-`AutogradHeadLoss`, PTCL/M_step.py:285-318 (MLPClassifier -> masked / weighted cross entropy) and NPL/NPL.py:280-307."""
+replaces: PTCL/EM_warmup.py:212-231 (MergeLayer link predictor -> sigmoid -> nn.BCELoss -> backward: LinkPredictionLoss),
+PTCL/M_step.py:285-318 (MLPClassifier -> masked / weighted cross entropy: ClassifierLoss) and, through `AutogradHeadLoss`, any other
+head written with torch ops (MLPClassifier_BN, NPL/NPL.py:280-307)."""
 import torch
 
 from . import ops
@@ -58,6 +59,71 @@ class LinkPredictionLoss:
         _acc_grad(fc1.weight, dW1)
         _acc_grad(fc1.bias, ops.colsum(dh))
         d_emb = torch.cat([dX[:B, :D] + dX[B:, :D], dX[:B, D:], dX[B:, D:]], 0)
+        return self.loss_out, d_emb
+
+
+class ClassifierLoss:
+    """The M-step's head and loss on the rows `rows` (a slice; default: the first len(labels) rows = the source embeddings,
+    PTCL/M_step.py:285) of an embedding block:
+        z = MLPClassifier(x) = fc3(drop(relu(fc2(drop(relu(fc1(x)))))))                                  (models/modules.py:72-97)
+        loss = sum_i w_i CE(z_i, y_i)  over rows with y_i >= 0
+    where the caller folds the trainer's masks and weights into w (PTCL/M_step.py:296-312: ground-truth rows 1 / n_gt, pseudo-labelled
+    rows (1 - gt_weight) * exp(-alpha (patience_i - iter)) / n_ps, filtered rows 0 or y_i = -1).  Explicit forward / backward on
+    the library's kernels; dropout masks are a hash of (seed, element) recomputed in the backward.  The head's parameter gradients
+    are ADDED to their .grad; returns (loss, d loss / d emb) with zero rows outside `rows`.  `logits` holds z of the last call
+    (the trainers collect predictions for their metrics)."""
+
+    def __init__(self, head, labels: torch.Tensor, weights: torch.Tensor, rows=None, dropout=None):
+        self.head, self.labels, self.weights, self.rows = head, labels.to(torch.int32).contiguous(), weights.to(torch.float32).contiguous(), rows
+        self.p = float(head.dropout.p if dropout is None else dropout)
+        self.loss_out, self.logits = None, None
+
+    def __call__(self, emb: torch.Tensor):
+        from . import engine
+        fc1, fc2, fc3 = self.head.fc1, self.head.fc2, self.head.fc3
+        n = self.labels.numel()
+        rows = self.rows if self.rows is not None else slice(0, n)
+        X = emb[rows]
+        assert X.shape[0] == n and X.is_contiguous() and fc1.weight.shape[1] == X.shape[1]
+        dev, C_ = emb.device, fc3.weight.shape[0]
+        p = self.p if self.head.training else 0.0
+        s1, s2 = engine._next_seeds(2) if p > 0 else (0, 0)
+        h1 = torch.empty((n, fc1.weight.shape[0]), device=dev)
+        ops.gemm(X, fc1.weight.detach(), h1, tb=True, bias=fc1.bias.detach(), relu=True)
+        h1d = ops.dropout(h1, p, s1) if p > 0 else h1
+        h2 = torch.empty((n, fc2.weight.shape[0]), device=dev)
+        ops.gemm(h1d, fc2.weight.detach(), h2, tb=True, bias=fc2.bias.detach(), relu=True)
+        h2d = ops.dropout(h2, p, s2) if p > 0 else h2
+        z = torch.empty((n, C_), device=dev)
+        ops.gemm(h2d, fc3.weight.detach(), z, tb=True, bias=fc3.bias.detach())
+        if self.loss_out is None or self.loss_out.device != dev:
+            self.loss_out = torch.zeros(1, device=dev)
+        dz = torch.empty((n, C_), device=dev)
+        check(lib().tg_weighted_ce(ops._p(z), C_, ops._p(self.labels), ops._p(self.weights), n, C_, ops._p(self.loss_out), ops._p(dz), C_,
+                                   ops._stream()), "tg_weighted_ce")
+        self.logits = z
+        # backward
+        dW3 = torch.empty_like(fc3.weight)
+        ops.gemm(dz, h2d, dW3, ta=True)
+        dh2 = torch.empty_like(h2)
+        ops.gemm(dz, fc3.weight.detach(), dh2)
+        if p > 0:
+            dh2 = ops.dropout(dh2, p, s2)
+        ops.relu_bwd_(dh2, h2)
+        dW2 = torch.empty_like(fc2.weight)
+        ops.gemm(dh2, h1d, dW2, ta=True)
+        dh1 = torch.empty_like(h1)
+        ops.gemm(dh2, fc2.weight.detach(), dh1)
+        if p > 0:
+            dh1 = ops.dropout(dh1, p, s1)
+        ops.relu_bwd_(dh1, h1)
+        dW1 = torch.empty_like(fc1.weight)
+        ops.gemm(dh1, X, dW1, ta=True)
+        d_emb = torch.zeros_like(emb)
+        ops.gemm(dh1, fc1.weight.detach(), d_emb[rows])
+        for lin, dW, dy in ((fc3, dW3, dz), (fc2, dW2, dh2), (fc1, dW1, dh1)):
+            _acc_grad(lin.weight, dW)
+            _acc_grad(lin.bias, ops.colsum(dy))
         return self.loss_out, d_emb
 
 

@@ -238,6 +238,11 @@ int tg_weighted_sum(const float* d_a, const float* d_w, int64_t n, float scale, 
 /* d_loss[0] = mean_i BCE(sigmoid(z_i), y_i), y_i = 1 for i < n_pos else 0; d_dz[i] = (sigmoid(z_i) - y_i) / n.
  * replaces `.sigmoid()` + nn.BCELoss + its backward in the link-prediction warm-up (PTCL/EM_warmup.py:212-222). */
 int tg_bce_logits(const float* d_z, int64_t n_pos, int64_t n, float* d_loss, float* d_dz, void* stream);
+/* replaces: nn.CrossEntropyLoss(reduction='none') + the ground-truth / pseudo-label masks and per-sample weights of the M-step
+ * (PTCL/M_step.py:296-312), as ONE weighted sum: loss = sum_i w_i CE(z_i, y_i) over rows with 0 <= y_i < classes,
+ * dz_i = w_i (softmax(z_i) - onehot(y_i)), 0 for ignored rows. */
+int tg_weighted_ce(const float* d_z, int64_t ldz, const int32_t* d_labels, const float* d_weights, int64_t n, int classes,
+                   float* d_loss, float* d_dz, int64_t lddz, void* stream);
 
 /* C[M,N] = (Y > 0) ? A[M,K] B[N,K]^T : 0   -- the input gradient of `relu(x W^T)` with the ReLU mask applied in the product's
  * epilogue (Y = the forward output; models/modules.py:68 `self.act(self.fc1(...))` differentiated).  Operands 16-byte aligned,

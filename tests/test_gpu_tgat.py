@@ -636,3 +636,49 @@ def test_src_only_roots_and_chain_switch():
     assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5
     for ga, gb in zip(res[0][1], res[1][1]):
         assert float((ga - gb).abs().max()) <= 1e-4 * max(1e-6, float(gb.abs().max()))
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+def test_classifier_head_loss_matches_autograd(p_drop):
+    """flid_amd.heads.ClassifierLoss (MLPClassifier + weighted / masked cross entropy of the M-step, PTCL/M_step.py:285-312, explicit
+    forward / backward on the HIP kernels) against torch autograd on the same weights, labels (some ignored), per-sample weights and --
+    with dropout -- the same masks (recovered from the library's dropout kernel on ones)"""
+    from flid_amd import engine, ops
+    from flid_amd.heads import ClassifierLoss
+    from flid_amd.models.modules import MLPClassifier
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, D, C_ = 300, 172, 4
+    head = MLPClassifier(D, dropout=p_drop, num_classes=C_).to(dev)
+    head.train()
+    emb = torch.randn(2 * B, D, device=dev)
+    labels = torch.randint(-1, C_, (B,), device=dev)
+    w = torch.rand(B, device=dev) * (torch.rand(B, device=dev) > 0.2)
+    state = torch.random.get_rng_state()
+    loss_fn = ClassifierLoss(head, labels, w)
+    loss, d_emb = loss_fn(emb)
+    got = {n: q.grad.clone() for n, q in head.named_parameters()}
+    # reference: the same forward in torch (the masks of this call: same seeds -> same hash masks)
+    for q in head.parameters():
+        q.grad = None
+    torch.random.set_rng_state(state)
+    s1, s2 = engine._next_seeds(2) if p_drop > 0 else (0, 0)
+    x = emb[:B].detach().double().requires_grad_(True)
+    P = {n: q.detach().double().requires_grad_(True) for n, q in head.named_parameters()}
+    h1 = torch.relu(x @ P["fc1.weight"].t() + P["fc1.bias"])
+    if p_drop > 0:
+        h1 = h1 * ops.dropout(torch.ones(B, 80, device=dev), p_drop, s1).double()
+    h2 = torch.relu(h1 @ P["fc2.weight"].t() + P["fc2.bias"])
+    if p_drop > 0:
+        h2 = h2 * ops.dropout(torch.ones(B, 10, device=dev), p_drop, s2).double()
+    z = h2 @ P["fc3.weight"].t() + P["fc3.bias"]
+    keep = labels >= 0
+    ce = torch.nn.functional.cross_entropy(z[keep], labels[keep].long(), reduction="none")
+    ref = (ce * w[keep].double()).sum()
+    ref.backward()
+    assert abs(float(loss) - float(ref.detach())) <= 2e-5 * max(1.0, abs(float(ref.detach())))
+    assert float((loss_fn.logits.double() - z.detach()).abs().max()) <= 2e-5 * float(z.detach().abs().max())
+    assert float(d_emb[B:].abs().max()) == 0.0
+    assert float((d_emb[:B].double() - x.grad).abs().max()) <= 1e-4 * float(x.grad.abs().max())
+    for n in got:
+        assert float((got[n].double() - P[n].grad).abs().max()) <= 1e-4 * max(1e-6, float(P[n].grad.abs().max())), n
