@@ -26,6 +26,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK = 8.0e12            # B/s, MI355X_MICROARCH.md chip table
 DTYPE = "f32 (products as split-bf16x3 MFMA: hi*hi + hi*lo + lo*hi, fp32 accumulate; everything else fp32)"
 MFMA_F32_PEAK = 157.3e12     # FLOP/s dense f32-input MFMA
+BF16_PEAK = 2.5e15           # FLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
 BATCH, K, L, H, DN, DE, DT = 600, 20, 2, 2, 172, 172, 100
 
 
@@ -466,7 +467,10 @@ def main():
         out["roofline_mfma"] = {"bound": "mfma", "kernel": "tg_gemm_f32* (all product launches of a step)",
                                 "achieved": round(g_fl / (g_ms * 1e-3) / 1e12, 2), "peak": round(MFMA_F32_PEAK / 1e12, 1),
                                 "unit": "TFLOP/s", "frac": round(g_fl / (g_ms * 1e-3) / MFMA_F32_PEAK, 4), "launches": g_cnt,
-                                "gflop_per_step": round(g_fl / args.steps / 1e9, 2)}
+                                "gflop_per_step": round(g_fl / args.steps / 1e9, 2),
+                                # what the split-bf16 kernels actually issue: 3 (chains: 4) bf16 MFMAs per fp32 product term
+                                "peak_bf16x3_equivalent": round(BF16_PEAK / 3 / 1e12, 1),
+                                "frac_bf16x3_equivalent": round(g_fl / (g_ms * 1e-3) / (BF16_PEAK / 3), 4)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:        # reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(data, n_train, model, batch_slice(args.warmup), args.cpu_sample_edges)
