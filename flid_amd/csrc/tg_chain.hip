@@ -79,6 +79,7 @@ struct Wave {
     bf16x8 b0h[2][NTW], b0l[2][NTW], b1h[2][NTW], b1l[2][NTW];
     const uint4* bptr[NTW];
     int S, t0, tcnt;          // current product: steps, first tile of this wave (inside its operand), tiles it owns
+    bool pre = false;         // the first weight group of the product about to begin() is already on its way into b0 (prefetch())
 #if FLID_CHAIN_STAMPS == 2
     unsigned long long* fine = nullptr;     // diagnostic: stamps inside run_panel (one product only)
     int fine_i = 0;
@@ -110,6 +111,28 @@ struct Wave {
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // The NEXT product's first weight group, issued while the current product's epilogue runs (its b0 set is dead by then): a product
+    // otherwise starts with one exposed round trip to L2 (~3 k cycles; five products per chain, one wave per SIMD).  Same arguments as the
+    // begin() that follows; the current product's t0 / tcnt / S stay valid for its epilogue.
+    template <int NT>
+    __device__ __forceinline__ void prefetch(const void* packed, int nt, int steps, int w0 = 0, int nw = NW) {
+        const int cpw = (nt + nw - 1) / nw;
+        const int pt0 = (wave - w0) * cpw;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int sc = sl < steps ? sl : steps - 1;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                int t = pt0 + j;
+                if (t > nt - 1) t = nt - 1;
+                if (t < 0) t = 0;
+                const uint4* q = reinterpret_cast<const uint4*>(packed) + (int64_t)t * steps * 128 + lane + sc * 128;
+                b0h[sl][j] = __builtin_bit_cast(bf16x8, q[0]);
+                b0l[sl][j] = __builtin_bit_cast(bf16x8, q[64]);
+            }
+        }
+        pre = true;
     }
     // NT = tiles a wave owns in the current product (<= NTW): the loops below run over NT, not over the register arrays' NTW
     template <int NT>
@@ -193,7 +216,8 @@ struct Wave {
         const int ngroups = (S + 1) >> 1;
         const char* base = lds + chunk0 * G::CHUNK;
         fstamp();
-        loadB<NT>(b0h, b0l, 0);
+        if (!pre) loadB<NT>(b0h, b0l, 0);                      // (uniform: set by prefetch() at compile-time-known call sites)
+        pre = false;
         fstamp();
         for (int g = 0; g < ngroups; g += 2) {
             loadB<NT>(b1h, b1l, g + 1);
@@ -392,6 +416,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
         w.begin(reinterpret_cast<const float*>(a.pWv) + mine * wv_stride, ht, (dk + 31) >> 5, HH == 2 ? (NW / 2) * mine : 0, NW / HH);
         w.template run_stream<NTW, HH>(a.agg, (int64_t)HH * dk, dk, dk, mine);
         STAMP();
+        w.template prefetch<NTW>(a.pWr, (dq + 15) >> 4, (HH * a.hp + 31) >> 5);
 #pragma unroll
         for (int i = 0; i < RAWN; ++i) {
             const int f = tid + NTH * i, r = f / 48, c = f % 48;
@@ -450,6 +475,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
         w.fine = nullptr;
 #endif
         STAMP();
+        w.template prefetch<NTF>(a.pW1, (a.dn + 15) >> 4, ychunks + rchunks);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             if (j >= w.tcnt) break;
@@ -549,6 +575,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
     w.begin(a.pW1, (a.dn + 15) >> 4, ychunks + rchunks);
     w.template run_panel<NTF>(0);
     STAMP();
+    w.template prefetch<NTF>(a.pW2, (a.dn + 15) >> 4, rchunks);
     __syncthreads();                                           // every wave is done with [y | raw]: f1 takes its place
 #pragma unroll
     for (int j = 0; j < NTF; ++j) {
