@@ -306,10 +306,10 @@ def main():
     ops.profile_enable(False)
     barrier()
     marks = []
-    every = max(1, args.event_every)
+    ev_every = max(1, args.event_every)
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
-        if every == 1 or (s - args.warmup) % every == 0:
+        if ev_every == 1 or (s - args.warmup) % ev_every == 0:
             ops.profile_enable(args.roofline_kernel)
             step(s)
             ops.profile_enable(False)
@@ -411,7 +411,7 @@ def main():
     # roofline of the selected kernel family: HIP events on its launch stream over the timed region
     ms, units, cnt = fam[args.roofline_kernel]
     secs = max(ms * 1e-3, 1e-12)
-    sampled_steps = len(range(0, args.steps, every))
+    sampled_steps = len(range(0, args.steps, ev_every))
     if args.roofline_kernel == "gemm":
         roof = {"bound": "mfma", "kernel": "gemm_tile_kernel (tg_gemm_f32*, all shapes of a step)",
                 "achieved": round(units / secs / 1e12, 3), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
@@ -453,7 +453,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "path_roofline": {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4),
                           "edges_per_s_at_100pct": round(HBM_PEAK / bpe, 1)},
-        "roofline": dict(roof, timed_steps=f"{sampled_steps} of {args.steps} (every {every}th step of the timed region carries the HIP events)"),
+        "roofline": dict(roof, timed_steps=f"{sampled_steps} of {args.steps} (every {ev_every}th step of the timed region carries the HIP events)"),
         "breakdown_ms": breakdown,
     }
     if dedupe_off is not None:
@@ -656,7 +656,7 @@ def bench_memory_or_sequence_model(args):
         per_rank = [float(t.item()) for t in every]
         elapsed = max(per_rank)
         # the collective alone: the flat gradient (one bucket) reduced 20 times back to back
-        gbuf = torch.zeros(sum(p.numel() for p in train_params), device=dev)
+        gbuf = torch.zeros(sum(p.numel() for p in params), device=dev)
         for _ in range(3):
             torch.distributed.all_reduce(gbuf)
         torch.cuda.synchronize()
@@ -667,7 +667,7 @@ def bench_memory_or_sequence_model(args):
         dist_info = {"rccl_ranks": world, "backend": torch.distributed.get_backend(),
                      "per_rank_ms_per_step": [round(e / args.steps * 1e3, 4) for e in per_rank],
                      "allreduce_ms": round((time.perf_counter() - t_ar) / 20 * 1e3, 4), "allreduce_floats": int(gbuf.numel()),
-                     "overlap": "root-layer block reduced under the layer-1 backward (GradAllReducer.segment_ready)" if fused else "none"}
+                     "overlap": "none (one flat-bucket all-reduce between backward and optimizer)"}
     value = args.steps * BATCH * world / elapsed
     secs = max(ms * 1e-3, 1e-12)
     if args.model == "tgn":
@@ -698,6 +698,8 @@ def bench_memory_or_sequence_model(args):
                                   f"dropout {args.dropout:.2f}, host numpy ids per call, fwd+bwd+Adam ({'fused step' if fused else 'autograd'})",
                       "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}"},
            "path_roofline": path, "roofline": roof, "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 4)}
+    if dist_info is not None:
+        out["distributed"] = dist_info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_model(args.model, data, n_train, model, batch(args.warmup), args.dropout)
     if rank == 0:
