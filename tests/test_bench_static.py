@@ -60,7 +60,8 @@ def test_bench_has_no_undefined_names():
                 if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in scope:
                     bad.append((fn, func.name, n.id, n.lineno))
                 elif isinstance(n, ast.Lambda):                   # a lambda's body: its parameters + the enclosing scope
-                    inner = scope | {a.arg for a in n.args.args + n.args.kwonlyargs}
+                    inner = scope | {a.arg for a in n.args.args + n.args.kwonlyargs} | \
+                        {m.id for m in ast.walk(n.body) if isinstance(m, ast.Name) and isinstance(m.ctx, ast.Store)}
                     for m in ast.walk(n.body):
                         if isinstance(m, ast.Name) and isinstance(m.ctx, ast.Load) and m.id not in inner:
                             bad.append((fn, func.name, m.id, m.lineno))
