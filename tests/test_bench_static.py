@@ -10,14 +10,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _walk_scope(node):
     """the nodes of one scope: does not descend into nested function / class bodies (their names are theirs)"""
-    todo = list(ast.iter_child_nodes(node))
+    todo = list(node.body) if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef)) else list(ast.iter_child_nodes(node))
     while todo:
         n = todo.pop()
         yield n
         if not isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef, ast.Lambda)):
             todo.extend(ast.iter_child_nodes(n))
-        elif isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef)):
-            todo.extend(n.decorator_list)
 
 
 def _bound_names(node):
