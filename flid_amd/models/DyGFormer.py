@@ -39,8 +39,14 @@ class TransformerEncoder(nn.Module):
         self.linear_layers = nn.ModuleList([nn.Linear(attention_dim, 4 * attention_dim), nn.Linear(4 * attention_dim, attention_dim)])
         self.norm_layers = nn.ModuleList([nn.LayerNorm(attention_dim), nn.LayerNorm(attention_dim)])
 
+    FUSED = True      # one autograd node per block (seqops.encoder_block); False: the op-by-op form below (A/B, tests)
+
     def forward(self, inputs: torch.Tensor):
         mha, tr, p = self.multi_head_attention, self.training, self.p
+        if self.FUSED and inputs.dim() == 3:
+            return seqops.encoder_block(inputs, self.norm_layers[0], mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+                                        mha.out_proj.bias, self.norm_layers[1], self.linear_layers[0], self.linear_layers[1],
+                                        self.num_heads, p, tr)
         y = seqops.layer_norm(inputs, self.norm_layers[0].weight, self.norm_layers[0].bias)
         qkv = linear(y, mha.in_proj_weight, mha.in_proj_bias)
         att = seqops.self_attention(qkv, self.num_heads, p, tr)

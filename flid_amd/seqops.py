@@ -77,24 +77,48 @@ def segment_mean(x, lo, hi):
     return _SegmentMeanFn.apply(x, lo, hi)
 
 
+def _self_attn_fwd(qkv, heads, p_drop, seed):
+    """softmax(Q K^T / sqrt(hd)) V per (sequence, head) on the packed (B, S, 3d) in-projection; returns (out, prob, dropped prob)"""
+    B, S, d3 = qkv.shape
+    d = d3 // 3
+    hd = d // heads
+    q00, k00, v00 = qkv[0, :, 0:hd], qkv[0, :, d:d + hd], qkv[0, :, 2 * d:2 * d + hd]
+    sq = (S * d3, hd)
+    scores = torch.empty((B, heads, S, S), device=qkv.device)
+    ops.gemm_batched2(q00, k00, scores[0, 0], B, heads, sq, sq, (heads * S * S, S * S), tb=True, alpha=hd ** -0.5)
+    prob = ops.softmax_fwd(scores)
+    pd = ops.dropout(prob, p_drop, seed) if p_drop > 0 else prob
+    out = torch.empty((B, S, d), device=qkv.device)
+    ops.gemm_batched2(pd[0, 0], v00, out[0, :, 0:hd], B, heads, (heads * S * S, S * S), sq, (S * d, hd))
+    return out, prob, pd
+
+
+def _self_attn_bwd(qkv, prob, pd, dout, heads, p_drop, seed):
+    B, S, d3 = qkv.shape
+    d = d3 // 3
+    hd = d // heads
+    sq, sp, so = (S * d3, hd), (heads * S * S, S * S), (S * d, hd)
+    q00, k00, v00 = qkv[0, :, 0:hd], qkv[0, :, d:d + hd], qkv[0, :, 2 * d:2 * d + hd]
+    dqkv = torch.empty_like(qkv)
+    dpd = torch.empty_like(prob)
+    ops.gemm_batched2(dout[0, :, 0:hd], v00, dpd[0, 0], B, heads, so, sq, sp, tb=True)                  # dP = dO V^T
+    ops.gemm_batched2(pd[0, 0], dout[0, :, 0:hd], dqkv[0, :, 2 * d:2 * d + hd], B, heads, sp, so, sq, ta=True)   # dV = P^T dO
+    dp = ops.dropout(dpd, p_drop, seed) if p_drop > 0 else dpd
+    ds = ops.softmax_bwd(prob, dp)
+    scale = hd ** -0.5
+    ops.gemm_batched2(ds[0, 0], k00, dqkv[0, :, 0:hd], B, heads, sp, sq, sq, alpha=scale)               # dQ = dS K
+    ops.gemm_batched2(ds[0, 0], q00, dqkv[0, :, d:d + hd], B, heads, sp, sq, sq, ta=True, alpha=scale)  # dK = dS^T Q
+    return dqkv
+
+
 class _SelfAttentionFn(torch.autograd.Function):
     """softmax(Q K^T / sqrt(hd)) V per (sequence, head) on the packed (B, S, 3d) in-projection, as nn.MultiheadAttention does
     (models/DyGFormer.py:454; no masks).  All five products run on the two-level batched MFMA GEMM."""
 
     @staticmethod
     def forward(ctx, qkv, heads, p_drop, seed):
-        B, S, d3 = qkv.shape
-        d = d3 // 3
-        hd = d // heads
         qkv = qkv.contiguous()
-        q00, k00, v00 = qkv[0, :, 0:hd], qkv[0, :, d:d + hd], qkv[0, :, 2 * d:2 * d + hd]
-        sq = (S * d3, hd)
-        scores = torch.empty((B, heads, S, S), device=qkv.device)
-        ops.gemm_batched2(q00, k00, scores[0, 0], B, heads, sq, sq, (heads * S * S, S * S), tb=True, alpha=hd ** -0.5)
-        prob = ops.softmax_fwd(scores)
-        pd = ops.dropout(prob, p_drop, seed) if p_drop > 0 else prob
-        out = torch.empty((B, S, d), device=qkv.device)
-        ops.gemm_batched2(pd[0, 0], v00, out[0, :, 0:hd], B, heads, (heads * S * S, S * S), sq, (S * d, hd))
+        out, prob, pd = _self_attn_fwd(qkv, heads, p_drop, seed)
         ctx.save_for_backward(qkv, prob, pd)
         ctx.cfg = (heads, p_drop, seed)
         return out
@@ -103,22 +127,7 @@ class _SelfAttentionFn(torch.autograd.Function):
     def backward(ctx, dout):
         qkv, prob, pd = ctx.saved_tensors
         heads, p_drop, seed = ctx.cfg
-        B, S, d3 = qkv.shape
-        d = d3 // 3
-        hd = d // heads
-        dout = dout.contiguous()
-        sq, sp, so = (S * d3, hd), (heads * S * S, S * S), (S * d, hd)
-        q00, k00, v00 = qkv[0, :, 0:hd], qkv[0, :, d:d + hd], qkv[0, :, 2 * d:2 * d + hd]
-        dqkv = torch.empty_like(qkv)
-        dpd = torch.empty_like(prob)
-        ops.gemm_batched2(dout[0, :, 0:hd], v00, dpd[0, 0], B, heads, so, sq, sp, tb=True)                  # dP = dO V^T
-        ops.gemm_batched2(pd[0, 0], dout[0, :, 0:hd], dqkv[0, :, 2 * d:2 * d + hd], B, heads, sp, so, sq, ta=True)   # dV = P^T dO
-        dp = ops.dropout(dpd, p_drop, seed) if p_drop > 0 else dpd
-        ds = ops.softmax_bwd(prob, dp)
-        scale = hd ** -0.5
-        ops.gemm_batched2(ds[0, 0], k00, dqkv[0, :, 0:hd], B, heads, sp, sq, sq, alpha=scale)               # dQ = dS K
-        ops.gemm_batched2(ds[0, 0], q00, dqkv[0, :, d:d + hd], B, heads, sp, sq, sq, ta=True, alpha=scale)  # dK = dS^T Q
-        return dqkv, None, None, None
+        return _self_attn_bwd(qkv, prob, pd, dout.contiguous(), heads, p_drop, seed), None, None, None
 
 
 def self_attention(qkv, heads, p_drop, training):
@@ -191,3 +200,92 @@ class _MaskedTimeEncodeFn(torch.autograd.Function):
 
 def masked_time_encode(dt, mask_ids, w, b):
     return _MaskedTimeEncodeFn.apply(dt, mask_ids, w, b)
+
+
+class _EncoderBlockFn(torch.autograd.Function):
+    """One pre-LN transformer block of DyGFormer (models/DyGFormer.py:418-461) as ONE autograd node with a hand-written backward:
+        y1 = LN1(x); a = out_proj(self_attention(in_proj(y1))); o1 = x + drop(a); y2 = LN2(o1); out = o1 + drop(W2 drop(gelu(W1 y2)))
+    The op-by-op form was ~17 autograd nodes per block (each with its Python and its zero fills / gradient-accumulation adds) and took
+    the four weight gradients and four bias sums of a block as eight launches; here they are one grouped launch (tg_wgrad_group)
+    into one zero fill."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, Wqkv, bqkv, Wo, bo, g2, b2, W1, bf1, W2, bf2, heads, p, seeds):
+        B, S, d = x.shape
+        n = B * S
+        x2 = x.reshape(n, d).contiguous()
+        dev = x.device
+        y1, m1, r1 = ops.add_layernorm_fwd(x2, None, g1, b1)
+        qkv = torch.empty((n, 3 * d), device=dev)
+        ops.gemm(y1, Wqkv, qkv, tb=True, bias=bqkv)
+        qkv3 = qkv.view(B, S, 3 * d)
+        att, prob, pd = _self_attn_fwd(qkv3, heads, p, seeds[0])
+        att2 = att.view(n, d)
+        ao = torch.empty((n, d), device=dev)
+        ops.gemm(att2, Wo, ao, tb=True, bias=bo)
+        o1 = x2 + (ops.dropout(ao, p, seeds[1]) if p > 0 else ao)
+        y2, m2, r2 = ops.add_layernorm_fwd(o1, None, g2, b2)
+        h = torch.empty((n, W1.shape[0]), device=dev)
+        ops.gemm(y2, W1, h, tb=True, bias=bf1)
+        hg = ops.gelu_fwd(h)
+        hgd = ops.dropout(hg, p, seeds[2]) if p > 0 else hg
+        f = torch.empty((n, d), device=dev)
+        ops.gemm(hgd, W2, f, tb=True, bias=bf2)
+        out = o1 + (ops.dropout(f, p, seeds[3]) if p > 0 else f)
+        ctx.save_for_backward(x2, g1, m1, r1, y1, qkv, prob, pd, att2, Wqkv, Wo, o1, g2, m2, r2, y2, h, hgd, W1, W2)
+        ctx.cfg = (B, S, d, heads, p, seeds)
+        return out.view(B, S, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from ._lib import TgShapeNotCovered
+        x2, g1, m1, r1, y1, qkv, prob, pd, att2, Wqkv, Wo, o1, g2, m2, r2, y2, h, hgd, W1, W2 = ctx.saved_tensors
+        B, S, d, heads, p, seeds = ctx.cfg
+        n = B * S
+        dev = dout.device
+        do = dout.reshape(n, d).contiguous()
+        d_f = ops.dropout(do, p, seeds[3]) if p > 0 else do
+        d_hgd = torch.empty_like(h)
+        ops.gemm(d_f, W2, d_hgd)
+        d_hg = ops.dropout(d_hgd, p, seeds[2]) if p > 0 else d_hgd
+        d_h = ops.gelu_bwd(h, d_hg)
+        d_y2 = torch.empty((n, d), device=dev)
+        ops.gemm(d_h, W1, d_y2)
+        d_o1b, dg2, db2 = ops.add_layernorm_bwd(o1, None, d_y2, g2, m2, r2)
+        d_o1 = do + d_o1b
+        d_ao = ops.dropout(d_o1, p, seeds[1]) if p > 0 else d_o1
+        d_att = torch.empty((n, d), device=dev)
+        ops.gemm(d_ao, Wo, d_att)
+        dqkv = _self_attn_bwd(qkv.view(B, S, 3 * d), prob, pd, d_att.view(B, S, d), heads, p, seeds[0]).view(n, 3 * d)
+        d_y1 = torch.empty((n, d), device=dev)
+        ops.gemm(dqkv, Wqkv, d_y1)
+        d_xb, dg1, db1 = ops.add_layernorm_bwd(x2, None, d_y1, g1, m1, r1)
+        dx = d_o1 + d_xb
+        # the four weight gradients and bias sums: one zero fill, one grouped launch (shapes it does not cover: a product + a column sum each)
+        jobs = [(d_f, hgd, W2), (d_h, y2, W1), (d_ao, att2, Wo), (dqkv, y1, Wqkv)]
+        sizes = [w.numel() + w.shape[0] for _, _, w in jobs]
+        zb = torch.zeros(sum(sizes), device=dev)
+        grads, off = [], 0
+        for (_, _, w), sz in zip(jobs, sizes):
+            grads.append((zb[off:off + w.numel()].view(w.shape), zb[off + w.numel():off + sz]))
+            off += sz
+        ok = all(w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0 for _, _, w in jobs) and n >= 256
+        if ok:
+            try:
+                ops.wgrad_group([(a, b_, gw, gb) for (a, b_, _), (gw, gb) in zip(jobs, grads)])
+            except TgShapeNotCovered:
+                ok = False
+                zb.zero_()
+        if not ok:
+            for (a, b_, _), (gw, gb) in zip(jobs, grads):
+                ops.gemm(a, b_, gw, ta=True)
+                ops.colsum(a, out=gb)
+        (dW2, dbf2), (dW1, dbf1), (dWo, dbo), (dWqkv, dbqkv) = grads
+        return (dx.view(B, S, d), dg1, db1, dWqkv, dbqkv, dWo, dbo, dg2, db2, dW1, dbf1, dW2, dbf2, None, None, None)
+
+
+def encoder_block(x, ln1, in_w, in_b, out_w, out_b, ln2, fc1, fc2, heads, p, training):
+    p = p if training else 0.0
+    seeds = tuple(int(v) for v in torch.randint(0, 2 ** 62, (4,)).tolist()) if p > 0 else (0, 0, 0, 0)
+    return _EncoderBlockFn.apply(x, ln1.weight, ln1.bias, in_w, in_b, out_w, out_b, ln2.weight, ln2.bias, fc1.weight, fc1.bias,
+                                 fc2.weight, fc2.bias, heads, p, seeds)

@@ -110,3 +110,41 @@ def test_sequence_ops_vs_torch():
     out.backward(go)
     ref.backward(go.double())
     np.testing.assert_allclose(qkv.grad.cpu().numpy(), qd.grad.cpu().numpy(), atol=1e-4)
+
+
+def test_fused_encoder_block_equals_op_by_op():
+    """TransformerEncoder as one autograd node with a hand-written backward (seqops.encoder_block: grouped weight gradients, one zero
+    fill) against the op-by-op autograd form, values and every gradient; with dropout: finite and reproducible under one torch seed"""
+    from flid_amd.models.DyGFormer import TransformerEncoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    blk = TransformerEncoder(200, 2, dropout=0.0).to(dev).train()
+    x0 = torch.randn(300, 12, 200, device=dev)
+    r = torch.randn(300, 12, 200, device=dev)
+    res = []
+    try:
+        for fused in (True, False):
+            TransformerEncoder.FUSED = fused
+            for q in blk.parameters():
+                q.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = blk(x)
+            (y * r).sum().backward()
+            res.append((y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in blk.named_parameters()}))
+    finally:
+        TransformerEncoder.FUSED = True
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5 * float(res[1][0].abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-4 * float(res[1][1].abs().max())
+    for n in res[1][2]:
+        a, b = res[0][2][n], res[1][2][n]
+        assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max())), n
+    blk.p = 0.2
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(9)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        (y * r).sum().backward()
+        outs.append((y.detach().clone(), x.grad.clone()))
+    assert torch.isfinite(outs[0][0]).all() and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][0] - res[0][0]).abs().max()) > 1e-3          # the masks are on
