@@ -126,6 +126,9 @@ SIGNATURES = {
     "tg_recent_window_mean": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
     "tg_softmax_bwd": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void]),
     "tg_dropout": (C.c_int, [c_void, c_i64, c_f32, C.c_uint64, c_void, c_void]),
+    "tg_gelu_dropout_fwd": (C.c_int, [c_void, c_i64, c_f32, C.c_uint64, c_void, c_void]),
+    "tg_gelu_dropout_bwd": (C.c_int, [c_void, c_void, c_i64, c_f32, C.c_uint64, c_void, c_void]),
+    "tg_dropout_add": (C.c_int, [c_void, c_void, c_i64, c_f32, C.c_uint64, c_void, c_void]),
     "tg_segment_mean_fwd": (C.c_int, [c_void, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "tg_segment_mean_bwd": (C.c_int, [c_void, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "tg_gather_rows": (C.c_int, [c_void, c_i64, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),

@@ -102,6 +102,37 @@ __global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ 
     }
 }
 
+// Fused element-wise passes of a transformer block (models/DyGFormer.py:448-461): each replaces two launches over the same elements.
+//   gelu_dropout_fwd:  y = dropout(gelu(x))          gelu_dropout_bwd:  dx = gelu'(x) * dropout(dy)       (same mask: hash of seed, index)
+//   dropout_add:       y = res + dropout(x)
+__device__ __forceinline__ float drop_scale(uint64_t seed, int64_t i, float p, float scale) {
+    const float u = (float)(tg::mix32(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    return u >= p ? scale : 0.f;
+}
+__global__ void __launch_bounds__(256) gelu_dropout_fwd_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed, float* __restrict__ y) {
+    const float scale = 1.f / (1.f - p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f)) * drop_scale(seed, i, p, scale);
+    }
+}
+__global__ void __launch_bounds__(256) gelu_dropout_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n, float p,
+                                                               uint64_t seed, float* __restrict__ dx) {
+    const float scale = 1.f / (1.f - p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+        dx[i] = dy[i] * drop_scale(seed, i, p, scale) * (cdf + v * pdf);
+    }
+}
+__global__ void __launch_bounds__(256) dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, int64_t n, float p,
+                                                          uint64_t seed, float* __restrict__ y) {
+    const float scale = 1.f / (1.f - p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = res[i] + x[i] * drop_scale(seed, i, p, scale);
+}
+
 // x: (n, s, d); out[i, :] = mean_{j in [lo, hi)} x[i, j, :]
 __global__ void __launch_bounds__(256) segment_mean_fwd_kernel(const float* __restrict__ x, int64_t n, int s, int d, int lo, int hi,
                                                                float* __restrict__ out) {
@@ -191,6 +222,25 @@ extern "C" int tg_dropout(const float* d_x, int64_t n, float p, uint64_t seed, f
     if (n == 0) return TG_OK;
     dropout_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, n, p, seed, d_y);
     return tg::launch_status("dropout_kernel");
+}
+
+extern "C" int tg_gelu_dropout_fwd(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream) {
+    TG_REQUIRE(d_x && d_y && n >= 0 && p >= 0.f && p < 1.f, "tg_gelu_dropout_fwd: arguments");
+    if (n == 0) return TG_OK;
+    gelu_dropout_fwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, n, p, seed, d_y);
+    return tg::launch_status("gelu_dropout_fwd_kernel");
+}
+extern "C" int tg_gelu_dropout_bwd(const float* d_x, const float* d_dy, int64_t n, float p, uint64_t seed, float* d_dx, void* stream) {
+    TG_REQUIRE(d_x && d_dy && d_dx && n >= 0 && p >= 0.f && p < 1.f, "tg_gelu_dropout_bwd: arguments");
+    if (n == 0) return TG_OK;
+    gelu_dropout_bwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, d_dy, n, p, seed, d_dx);
+    return tg::launch_status("gelu_dropout_bwd_kernel");
+}
+extern "C" int tg_dropout_add(const float* d_x, const float* d_res, int64_t n, float p, uint64_t seed, float* d_y, void* stream) {
+    TG_REQUIRE(d_x && d_res && d_y && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_add: arguments");
+    if (n == 0) return TG_OK;
+    dropout_add_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, d_res, n, p, seed, d_y);
+    return tg::launch_status("dropout_add_kernel");
 }
 
 extern "C" int tg_segment_mean_fwd(const float* d_x, int64_t n, int s, int d, int lo, int hi, float* d_out, void* stream) {

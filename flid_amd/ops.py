@@ -367,6 +367,25 @@ def dropout(x, p, seed):
     return y
 
 
+def gelu_dropout_fwd(x, p, seed):
+    y = torch.empty_like(x)
+    check(lib().tg_gelu_dropout_fwd(_p(x), x.numel(), float(p), int(seed), _p(y), _stream()), "tg_gelu_dropout_fwd")
+    return y
+
+
+def gelu_dropout_bwd(x, dy, p, seed):
+    dx = torch.empty_like(x)
+    check(lib().tg_gelu_dropout_bwd(_p(x), _p(dy), x.numel(), float(p), int(seed), _p(dx), _stream()), "tg_gelu_dropout_bwd")
+    return dx
+
+
+def dropout_add(x, res, p, seed):
+    """res + dropout(x) in one pass"""
+    y = torch.empty_like(x)
+    check(lib().tg_dropout_add(_p(x), _p(res), x.numel(), float(p), int(seed), _p(y), _stream()), "tg_dropout_add")
+    return y
+
+
 def segment_mean_fwd(x, lo, hi):
     n, s, d = x.shape
     out = torch.empty((n, d), device=x.device)

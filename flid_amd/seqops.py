@@ -223,15 +223,14 @@ class _EncoderBlockFn(torch.autograd.Function):
         att2 = att.view(n, d)
         ao = torch.empty((n, d), device=dev)
         ops.gemm(att2, Wo, ao, tb=True, bias=bo)
-        o1 = x2 + (ops.dropout(ao, p, seeds[1]) if p > 0 else ao)
+        o1 = ops.dropout_add(ao, x2, p, seeds[1]) if p > 0 else x2 + ao
         y2, m2, r2 = ops.add_layernorm_fwd(o1, None, g2, b2)
         h = torch.empty((n, W1.shape[0]), device=dev)
         ops.gemm(y2, W1, h, tb=True, bias=bf1)
-        hg = ops.gelu_fwd(h)
-        hgd = ops.dropout(hg, p, seeds[2]) if p > 0 else hg
+        hgd = ops.gelu_dropout_fwd(h, p, seeds[2]) if p > 0 else ops.gelu_fwd(h)
         f = torch.empty((n, d), device=dev)
         ops.gemm(hgd, W2, f, tb=True, bias=bf2)
-        out = o1 + (ops.dropout(f, p, seeds[3]) if p > 0 else f)
+        out = ops.dropout_add(f, o1, p, seeds[3]) if p > 0 else o1 + f
         ctx.save_for_backward(x2, g1, m1, r1, y1, qkv, prob, pd, att2, Wqkv, Wo, o1, g2, m2, r2, y2, h, hgd, W1, W2)
         ctx.cfg = (B, S, d, heads, p, seeds)
         return out.view(B, S, d)
@@ -247,8 +246,7 @@ class _EncoderBlockFn(torch.autograd.Function):
         d_f = ops.dropout(do, p, seeds[3]) if p > 0 else do
         d_hgd = torch.empty_like(h)
         ops.gemm(d_f, W2, d_hgd)
-        d_hg = ops.dropout(d_hgd, p, seeds[2]) if p > 0 else d_hgd
-        d_h = ops.gelu_bwd(h, d_hg)
+        d_h = ops.gelu_dropout_bwd(h, d_hgd, p, seeds[2]) if p > 0 else ops.gelu_bwd(h, d_hgd)
         d_y2 = torch.empty((n, d), device=dev)
         ops.gemm(d_h, W1, d_y2)
         d_o1b, dg2, db2 = ops.add_layernorm_bwd(o1, None, d_y2, g2, m2, r2)

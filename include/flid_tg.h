@@ -423,6 +423,11 @@ int tg_softmax_bwd(const float* d_y, const float* d_dy, int64_t n, int cols, flo
 int tg_softmax_keymask_fwd(const float* d_x, int64_t n, int cols, const int32_t* d_key_ids, int64_t rows_per_batch, float* d_y, void* stream);
 /* y[i] = x[i] / (1-p) if hash(seed, i) >= p else 0.  Applying it to dy with the same seed is the backward. */
 int tg_dropout(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream);
+/* fused element-wise passes of the pre-LN transformer block (models/DyGFormer.py:448-461), masks as tg_dropout(seed, index):
+ * y = dropout(gelu(x)); dx = gelu'(x) * dropout(dy); y = res + dropout(x) */
+int tg_gelu_dropout_fwd(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream);
+int tg_gelu_dropout_bwd(const float* d_x, const float* d_dy, int64_t n, float p, uint64_t seed, float* d_dx, void* stream);
+int tg_dropout_add(const float* d_x, const float* d_res, int64_t n, float p, uint64_t seed, float* d_y, void* stream);
 /* out[i, :] = mean over positions [lo, hi) of x (n, s, d); backward writes dout/(hi-lo) into those positions of dx */
 int tg_segment_mean_fwd(const float* d_x, int64_t n, int s, int d, int lo, int hi, float* d_out, void* stream);
 int tg_segment_mean_bwd(const float* d_dout, int64_t n, int s, int d, int lo, int hi, float* d_dx, void* stream);

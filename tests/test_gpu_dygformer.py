@@ -148,3 +148,21 @@ def test_fused_encoder_block_equals_op_by_op():
         outs.append((y.detach().clone(), x.grad.clone()))
     assert torch.isfinite(outs[0][0]).all() and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert float((outs[0][0] - res[0][0]).abs().max()) > 1e-3          # the masks are on
+
+
+def test_fused_elementwise_passes_equal_their_compositions():
+    """tg_gelu_dropout_fwd / _bwd and tg_dropout_add against gelu, dropout and add as separate launches (same hash masks)"""
+    from flid_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    x, dy, res = (torch.randn(1000, 333, device=dev) for _ in range(3))
+    p, seed = 0.25, 123456789
+    a = ops.gelu_dropout_fwd(x, p, seed)
+    b = ops.dropout(ops.gelu_fwd(x), p, seed)
+    assert float((a - b).abs().max()) <= 1e-6 and 0.2 < float((a == 0).float().mean()) < 0.3
+    a = ops.gelu_dropout_bwd(x, dy, p, seed)
+    b = ops.gelu_bwd(x, ops.dropout(dy, p, seed))
+    assert float((a - b).abs().max()) <= 1e-6
+    a = ops.dropout_add(x, res, p, seed)
+    b = res + ops.dropout(x, p, seed)
+    assert float((a - b).abs().max()) <= 1e-6
