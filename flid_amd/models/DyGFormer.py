@@ -59,6 +59,7 @@ class TransformerEncoder(nn.Module):
 
 
 class DyGFormer(nn.Module):
+    FUSED_PROJECTION = True       # patch size 1: the four channel projections as one block-diagonal product (False: per channel and side)
 
     def __init__(self, node_raw_features: np.ndarray, edge_raw_features: np.ndarray, neighbor_sampler: NeighborSampler,
                  time_feat_dim: int, channel_embedding_dim: int, patch_size: int = 1, num_layers: int = 2, num_heads: int = 2,
@@ -116,6 +117,35 @@ class DyGFormer(nn.Module):
         counts = ops.cooccurrence(seqs[0][0], seqs[1][0])                                 # DyGFormer.py:104-106
         num_edges_rows = self.edge_raw_features.shape[0]
         enc = self.time_encoder
+        if self.FUSED_PROJECTION and P == 1 and B > 0:
+            # both sides' positions in the order the transformer reads them ([source positions | destination positions] per edge), all
+            # four channels from ONE product against the block-diagonal projection weight (seqops.patch_projection)
+            nbr = torch.cat([seqs[0][0], seqs[1][0]], dim=1).contiguous()
+            eid = torch.cat([seqs[0][1], seqs[1][1]], dim=1)
+            tt = torch.cat([seqs[0][2], seqs[1][2]], dim=1)
+            cnt = torch.cat([counts[0], counts[1]], dim=1)
+            S_tot = nbr.shape[1]
+            n_pos = B * S_tot
+            dn, de, T = self.node_feat_dim, self.edge_feat_dim, self.time_feat_dim
+            Kx = dn + de + T + self.neighbor_co_occurrence_feat_dim
+            Kp = (Kx + 3) // 4 * 4
+            X = torch.empty((n_pos, Kp), device=dev)
+            if Kp > Kx:
+                X[:, Kx:] = 0.0
+            ops.gather_rows(self.node_raw_features, nbr.reshape(-1), out=X[:, 0:dn])                       # :259
+            eidx = torch.remainder(eid.reshape(-1) - 1, num_edges_rows).to(torch.int32)                     # :261 (edge_ids - 1 wraps)
+            ops.gather_rows(self.edge_raw_features, eidx, out=X[:, dn:dn + de])
+            dt = (t_dev.unsqueeze(1) - tt.double()).float()
+            tf = seqops.masked_time_encode(dt, nbr, enc.w.weight, enc.w.bias)
+            cf = self.neighbor_co_occurrence_encoder.encode(cnt)
+            x = seqops.patch_projection(X, tf, cf, self.projection_layer).view(B, S_tot, -1)
+            ns = widths[0]
+            for block in self.transformers:
+                x = block(x)
+            nt = x.shape[1]
+            s_out, d_out = seqops.segment_mean(x, 0, ns), seqops.segment_mean(x, ns, nt)
+            return (linear(s_out, self.output_layer.weight, self.output_layer.bias),
+                    linear(d_out, self.output_layer.weight, self.output_layer.bias))
         chans_per_side = []
         for (nbr, eid, tt), cnt, w in zip(seqs, counts, widths):
             flat = nbr.reshape(-1)

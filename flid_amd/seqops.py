@@ -287,3 +287,66 @@ def encoder_block(x, ln1, in_w, in_b, out_w, out_b, ln2, fc1, fc2, heads, p, tra
     seeds = tuple(int(v) for v in torch.randint(0, 2 ** 62, (4,)).tolist()) if p > 0 else (0, 0, 0, 0)
     return _EncoderBlockFn.apply(x, ln1.weight, ln1.bias, in_w, in_b, out_w, out_b, ln2.weight, ln2.bias, fc1.weight, fc1.bias,
                                  fc2.weight, fc2.bias, heads, p, seeds)
+
+
+class _PatchProjFn(torch.autograd.Function):
+    """The four channel projections of DyGFormer at patch size 1 (models/DyGFormer.py:148-157: node / edge / time / co-occurrence
+    features of every sequence position -> 4 x C channels) as ONE product against the block-diagonal weight: X = [node row | edge row |
+    time encoding | co-occurrence encoding | pad] (n, Kp) is assembled once (the gathers write straight into it), Y = X Wbd^T + b lands
+    in the (B, S, 4 C) layout the transformer reads -- no torch.stack copy -- and the backward is one grouped weight-gradient launch
+    (the diagonal blocks are the four gradients) + the two input gradients that exist (time encoder, co-occurrence encoder).  Eight
+    products with 50-column outputs (half of every 128 x 96 tile idle), eight weight / bias gradient launches and two stack copies
+    before."""
+
+    @staticmethod
+    def forward(ctx, X, tf, cf, Wn, bn, We, be, Wt, bt, Wc, bc):
+        n, Kp = X.shape
+        dn, de, T, Cc = Wn.shape[1], We.shape[1], Wt.shape[1], Wc.shape[1]
+        C = Wn.shape[0]
+        o_e, o_t, o_c = dn, dn + de, dn + de + T
+        X[:, o_t:o_t + T] = tf.reshape(n, T)
+        X[:, o_c:o_c + Cc] = cf.reshape(n, Cc)
+        Wbd = torch.zeros((4 * C, Kp), device=X.device)
+        Wbd[0:C, 0:dn] = Wn
+        Wbd[C:2 * C, o_e:o_e + de] = We
+        Wbd[2 * C:3 * C, o_t:o_t + T] = Wt
+        Wbd[3 * C:, o_c:o_c + Cc] = Wc
+        bias = torch.cat([bn, be, bt, bc])
+        Y = torch.empty((n, 4 * C), device=X.device)
+        ops.gemm(X, Wbd, Y, tb=True, bias=bias)
+        ctx.save_for_backward(X, Wt, Wc)
+        ctx.dims = (dn, de, T, Cc, C, tf.shape, cf.shape)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        from ._lib import TgShapeNotCovered
+        X, Wt, Wc = ctx.saved_tensors
+        dn, de, T, Cc, C, tf_shape, cf_shape = ctx.dims
+        n, Kp = X.shape
+        o_e, o_t, o_c = dn, dn + de, dn + de + T
+        dY = dY.contiguous()
+        zb = torch.zeros(4 * C * Kp + 4 * C, device=X.device)
+        dW, db = zb[:4 * C * Kp].view(4 * C, Kp), zb[4 * C * Kp:]
+        done = False
+        if n >= 256 and (4 * C) % 4 == 0 and Kp % 4 == 0:
+            try:
+                ops.wgrad_group([(dY, X, dW, db)])
+                done = True
+            except TgShapeNotCovered:
+                zb.zero_()
+        if not done:
+            ops.gemm(dY, X, dW, ta=True)
+            ops.colsum(dY, out=db)
+        d_tf = torch.empty((n, T), device=X.device)
+        ops.gemm(dY[:, 2 * C:3 * C], Wt, d_tf)
+        d_cf = torch.empty((n, Cc), device=X.device)
+        ops.gemm(dY[:, 3 * C:], Wc, d_cf)
+        return (None, d_tf.view(tf_shape), d_cf.view(cf_shape),
+                dW[0:C, 0:dn].contiguous(), db[0:C].clone(), dW[C:2 * C, o_e:o_e + de].contiguous(), db[C:2 * C].clone(),
+                dW[2 * C:3 * C, o_t:o_t + T].contiguous(), db[2 * C:3 * C].clone(), dW[3 * C:, o_c:o_c + Cc].contiguous(), db[3 * C:].clone())
+
+
+def patch_projection(X, tf, cf, proj):
+    n, e, t, c = proj['node'], proj['edge'], proj['time'], proj['neighbor_co_occurrence']
+    return _PatchProjFn.apply(X, tf, cf, n.weight, n.bias, e.weight, e.bias, t.weight, t.bias, c.weight, c.bias)

@@ -166,3 +166,25 @@ def test_fused_elementwise_passes_equal_their_compositions():
     a = ops.dropout_add(x, res, p, seed)
     b = res + ops.dropout(x, p, seed)
     assert float((a - b).abs().max()) <= 1e-6
+
+
+def test_block_diagonal_patch_projection_equals_per_channel_products():
+    """DyGFormer.FUSED_PROJECTION (patch size 1: node / edge / time / co-occurrence projections of both sides as one product against
+    the block-diagonal weight, seqops.patch_projection) against the per-channel, per-side products: embeddings and every gradient"""
+    from flid_amd.models.DyGFormer import DyGFormer
+    g = load_golden("dyg_p1")
+    r = torch.from_numpy(g["r"]).cuda()
+    res = []
+    try:
+        for fused in (True, False):
+            DyGFormer.FUSED_PROJECTION = fused
+            m = _model(g).train()
+            s, d = m.compute_src_dst_node_temporal_embeddings(g["bs"], g["bd"], g["bt"])
+            ((s * r[0]).sum() + (d * r[1]).sum()).backward()
+            res.append((torch.cat([s, d]).detach().clone(), {k_: v.grad.clone() for k_, v in m.named_parameters()}))
+    finally:
+        DyGFormer.FUSED_PROJECTION = True
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5
+    for k_ in res[1][1]:
+        a, b = res[0][1][k_], res[1][1][k_]
+        assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max())), k_
