@@ -204,6 +204,7 @@ def main():
         return ops.weighted_sum(emb, rw_flat, 1.0 / (BATCH * DN), out=loss_out), rw_grad
 
     prepared, jobs = {}, {}
+    lp_fused = False
     if args.mode == "lp":
         from flid_amd import engine
         from flid_amd.models.modules import MergeLayer
@@ -220,6 +221,11 @@ def main():
         labels = torch.cat([torch.ones(BATCH, device=dev), torch.zeros(BATCH, device=dev)])
         bce = torch.nn.BCELoss()
         args.no_cpu_baseline = True
+
+        lp_fused = not args.autograd and not args.no_flat
+        if lp_fused:
+            from flid_amd.heads import LinkPredictionLoss
+            lp_loss = LinkPredictionLoss(head)
 
         def begin_lp(s_):
             src, dst, t = dev_batches[s_]
@@ -251,6 +257,16 @@ def main():
         prefetch(s)
         opt.zero_grad(set_to_none=True)
         head_opt.zero_grad(set_to_none=True)
+        if lp_fused:
+            # head + sigmoid + BCE with explicit forward / backward on the HIP kernels (flid_amd.heads.LinkPredictionLoss), the backbone
+            # through train_step: no autograd graph anywhere in the step
+            model.train_step(prepared.pop(s), lp_loss, K, grad_ready=reducer.segment_ready if reducer is not None else None)
+            if reducer is not None:
+                reducer.finish()
+                head_reducer.reduce()
+            opt.step()
+            head_opt.step()
+            return
         emb = model.compute_node_temporal_embeddings(prepared.pop(s), None, L, K)    # (3 B, Dn): src | dst | negative dst
         se, de_, ne = emb[:BATCH], emb[BATCH:2 * BATCH], emb[2 * BATCH:]
         prob = torch.cat([head(se, de_), head(se, ne)]).squeeze(1).sigmoid()         # EM_warmup.py:178-186
@@ -448,7 +464,7 @@ def main():
         "dtype": DTYPE if gemm_mode_now != 0 else "f32 (exact f32-input MFMA products)", "data": "synthetic",
         "config": {"workload": workload + " + TGAT L=2 H=2 T=100, batch 600 edges/GPU, 20 recent neighbors, dropout %.2f, %s"
                                % (args.dropout, {"train": "fwd+bwd+Adam (%s)" % ("fused step" if fused else "autograd"), "fwd": "fwd (eval)",
-                                                 "lp": "link-prediction step"}[args.mode]),
+                                                 "lp": "link-prediction step (%s)" % ("fused head + loss, no autograd graph" if args.mode == "lp" and lp_fused else "autograd")}[args.mode]),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world, "num_neighbors": K, "num_layers": L,
                    "parallelism": f"dp{world}"},
         "path_roofline": {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4),
