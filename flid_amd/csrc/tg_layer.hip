@@ -333,7 +333,6 @@ struct MergeJob {            // C[m, n] (+)= sum_k A(m, k) B(k, n); optionally a
     const float *A, *B;
     float *C, *CT;
     int M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, tiles_n, tile0, accumulate;
-    const float *r1_m, *r1_n;     // optional rank-1 term of the epilogue: C[m, n] += r1_m[m] r1_n[n]
 };
 struct MergeJobs { MergeJob j[4]; int n, total_tiles; };
 
@@ -409,9 +408,7 @@ __device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx
         Cs[ty + 8 * q][tx] = acc[q];
         if (m < J.M && n < J.N) {
             float* c = J.C + (int64_t)m * J.ldc + n;
-            float v = acc[q];
-            if (J.r1_m) v = fmaf(J.r1_m[m], J.r1_n[n], v);
-            *c = J.accumulate ? *c + v : v;
+            *c = J.accumulate ? *c + acc[q] : acc[q];
         }
     }
     if (!J.CT) return;                                                   // (uniform per workgroup)
@@ -427,7 +424,7 @@ __device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx
 inline void add_job(MergeJobs& mj, const float* A, const float* B, float* C, float* CT, int M, int N, int K, int sAm, int sAk, int sBk,
                     int sBn, int ldc, int ldct, int accumulate) {
     MergeJob& J = mj.j[mj.n++];
-    J = MergeJob{A, B, C, CT, M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, (N + 31) / 32, mj.total_tiles, accumulate, nullptr, nullptr};
+    J = MergeJob{A, B, C, CT, M, N, K, sAm, sAk, sBk, sBn, ldc, ldct, (N + 31) / 32, mj.total_tiles, accumulate};
     mj.total_tiles += ((M + 31) / 32) * J.tiles_n;
 }
 
