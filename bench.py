@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--autograd", action="store_true",
                     help="train mode: loss and backward through torch autograd (loss.backward()) instead of the fused step "
                          "TGAT.train_step (same kernels, no autograd graph, loss scalar from one HIP reduction)")
+    ap.add_argument("--python-step", action="store_true",
+                    help="fused step issued by the Python engine (flid_amd/engine.py) instead of the native stepper (csrc/tg_step.hip): A/B")
     ap.add_argument("--master-port", type=int, default=29533)
     ap.add_argument("--no-merged", action="store_true", help="tg_set_layer_merged(0): the reference's four separate projections per layer")
     ap.add_argument("--no-grouped", action="store_true", help="tg_set_wgrad_grouped(0): one exact product + one column sum per weight gradient")
@@ -236,12 +238,30 @@ def main():
         args.no_cpu_baseline = True
         args.roofline_kernel = "attn_fwd"
 
+    fused = args.mode == "train" and not args.autograd and not args.no_flat
+    native = (fused or lp_fused) and not args.python_step
+    if native:
+        # every launch of a step issued by the library (one C call per half of the preparation, one for the forward, one for backward + Adam)
+        model.enable_native_step((3 if args.mode == "lp" else 2) * BATCH, K)
+        if args.mode == "lp":
+            neg_host = [b.cpu().numpy().astype(np.int64) for b in neg_batches]
+
+            def begin_lp(s_):
+                src, dst, t = host_batches[s_]
+                return model.prepare_roots_begin([src, dst, neg_host[s_]], t, K)
+
+    def drop_prepared():
+        prepared.clear()
+        jobs.clear()
+        if native:
+            model._stepper.reset()
+
     def begin(s_):
         return begin_lp(s_) if args.mode == "lp" else model.prepare_batch_begin(*host_batches[s_], K)
 
     def finish(job):
         from flid_amd import engine as _e
-        return _e.prepare_finish(job) if args.mode == "lp" else model.prepare_batch_finish(job)
+        return _e.prepare_finish(job) if (args.mode == "lp" and not native) else model.prepare_batch_finish(job)
 
     def prefetch(s):
         """sampler work of FUTURE batches on the side stream (graph only, weight-independent -- the data-loader style prefetch):
@@ -260,6 +280,10 @@ def main():
         if lp_fused:
             # head + sigmoid + BCE with explicit forward / backward on the HIP kernels (flid_amd.heads.LinkPredictionLoss), the backbone
             # through train_step: no autograd graph anywhere in the step
+            if native and reducer is None:
+                model.train_step(prepared.pop(s), lp_loss, K, optimizer=opt)             # Adam on the backbone inside the backward's call
+                head_opt.step()
+                return
             model.train_step(prepared.pop(s), lp_loss, K, grad_ready=reducer.segment_ready if reducer is not None else None)
             if reducer is not None:
                 reducer.finish()
@@ -278,8 +302,6 @@ def main():
         opt.step()
         head_opt.step()
 
-    fused = args.mode == "train" and not args.autograd and not args.no_flat
-
     def step(s):
         if args.mode == "lp":
             return step_lp(s)
@@ -292,6 +314,9 @@ def main():
         if fused:
             # forward, loss, backward: no autograd graph; N > 1: the root layer's gradient block starts its all-reduce as soon as that
             # layer's backward is queued, under the lower layer's backward
+            if native and reducer is None:
+                model.train_step(prepared.pop(s), mean_loss, K, optimizer=opt)           # Adam inside the backward's call
+                return
             model.train_step(prepared.pop(s), mean_loss, K, grad_ready=reducer.segment_ready if reducer is not None else None)
             if reducer is not None:
                 reducer.finish()
@@ -347,17 +372,17 @@ def main():
     if args.host_profile and fused and rank == 0:
         # what the HOST spends issuing one step when nothing is queued ahead of it (the GPU can only be as fast as this)
         acc = {"prefetch": 0.0, "train_step": 0.0, "adam": 0.0}
-        prepared.clear()
-        jobs.clear()
+        drop_prepared()
         for s in range(args.warmup, total_steps):
             torch.cuda.synchronize()
             a = time.perf_counter()
             prefetch(s)
             b = time.perf_counter()
             opt.zero_grad(set_to_none=True)
-            model.train_step(prepared.pop(s), mean_loss, K)
+            model.train_step(prepared.pop(s), mean_loss, K, optimizer=opt if native else None)
             c = time.perf_counter()
-            opt.step()
+            if not native:
+                opt.step()
             d = time.perf_counter()
             if s > args.warmup:
                 acc["prefetch"] += b - a; acc["train_step"] += c - b; acc["adam"] += d - c
@@ -366,8 +391,7 @@ def main():
     others = [t for t in ("attn_fwd", "attn_bwd", "gemm") if t != args.roofline_kernel]
     if not args.no_breakdown:
         ops.profile_enable(others)
-        prepared.clear()
-        jobs.clear()
+        drop_prepared()
         for s in range(args.warmup, total_steps):          # same batches again (weights have moved on; shapes are identical)
             step(s)
         fam.update({tag: ops.profile_collect(tag) for tag in others})
@@ -406,11 +430,14 @@ def main():
         from flid_amd import engine as _eng
         _eng.DEDUPE = False
         try:
-            prepared.clear(); jobs.clear()
+            drop_prepared()
+            if native:
+                model.enable_native_step(2 * BATCH, K)      # (row sharing is a property of the stepper, read at its creation)
             n_off = min(20, args.steps)
             for s in range(args.warmup, args.warmup + 3):
                 step(s)
             torch.cuda.synchronize()
+            drop_prepared()
             t1 = time.perf_counter()
             for s in range(args.warmup, args.warmup + n_off):
                 step(s)
@@ -420,7 +447,9 @@ def main():
                           "note": "engine.DEDUPE = False: 24 000 layer-1 instances per step instead of the ~13 k distinct ones"}
         finally:
             _eng.DEDUPE = True
-            prepared.clear(); jobs.clear()
+            drop_prepared()
+            if native:
+                model.enable_native_step(2 * BATCH, K)
     # fwd = half of fwd+bwd; the link-prediction step embeds 3 roots per edge instead of 2
     bpe = {"train": tgat_bytes_per_edge(), "fwd": tgat_bytes_per_edge() // 2, "lp": tgat_bytes_per_edge() * 3 // 2}[args.mode]
 
@@ -463,7 +492,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE if gemm_mode_now != 0 else "f32 (exact f32-input MFMA products)", "data": "synthetic",
         "config": {"workload": workload + " + TGAT L=2 H=2 T=100, batch 600 edges/GPU, 20 recent neighbors, dropout %.2f, %s"
-                               % (args.dropout, {"train": "fwd+bwd+Adam (%s)" % ("fused step" if fused else "autograd"), "fwd": "fwd (eval)",
+                               % (args.dropout, {"train": "fwd+bwd+Adam (%s)" % (("fused step, native stepper" if native else "fused step") if fused else "autograd"), "fwd": "fwd (eval)",
                                                  "lp": "link-prediction step (%s)" % ("fused head + loss, no autograd graph" if args.mode == "lp" and lp_fused else "autograd")}[args.mode]),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world, "num_neighbors": K, "num_layers": L,
                    "parallelism": f"dp{world}"},

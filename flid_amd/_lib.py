@@ -55,12 +55,39 @@ class WgradJob(C.Structure):
                 ("colsum_A", c_void)]
 
 
+class StepperCfg(C.Structure):
+    """struct tg_stepper_cfg"""
+    _fields_ = [("graph", c_void), ("d_node", c_void), ("node_ld", c_i64), ("d_edge", c_void), ("edge_ld", c_i64),
+                ("dn", C.c_int), ("de", C.c_int), ("dt_dim", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("k", C.c_int),
+                ("max_roots", c_i64), ("slots", C.c_int), ("d_param", c_void), ("param_floats", c_i64), ("dropout_p", c_f32),
+                ("dedupe", C.c_int), ("extra_grad_floats", c_i64)]
+
+
+class AdamArgs(C.Structure):
+    """struct tg_adam_args"""
+    _fields_ = [("d_exp_avg", c_void), ("d_exp_avg_sq", c_void), ("n", c_i64), ("lr", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("step", c_i64)]
+
+
+GRAD_READY_FN = C.CFUNCTYPE(None, c_void, c_void, c_i64)          # tg_grad_ready_fn
+
 # name -> (restype, argtypes); every symbol declared in include/flid_tg.h
 SIGNATURES = {
     "tg_last_error": (C.c_char_p, []),
     "tg_version": (C.c_int, []),
     "tg_profile_enable": (None, [C.c_int]),
     "tg_profile_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.c_int]),
+    "tg_stepper_param_floats": (c_i64, [C.POINTER(StepperCfg)]),
+    "tg_stepper_arena_floats": (c_i64, [C.POINTER(StepperCfg)]),
+    "tg_stepper_create": (C.c_int, [C.POINTER(StepperCfg), c_void, c_i64, C.POINTER(c_void)]),
+    "tg_stepper_destroy": (None, [c_void]),
+    "tg_stepper_regions": (C.c_int, [c_void, c_void, C.POINTER(c_i64)]),
+    "tg_stepper_prepare_begin": (C.c_int, [c_void, C.c_int, c_void, c_void, c_i64]),
+    "tg_stepper_prepare_finish": (C.c_int, [c_void, C.c_int, C.POINTER(c_i64)]),
+    "tg_stepper_release": (C.c_int, [c_void, C.c_int]),
+    "tg_stepper_slot_view": (C.c_int, [c_void, C.c_int, C.POINTER(c_void), C.POINTER(c_i64)]),
+    "tg_stepper_forward": (C.c_int, [c_void, C.c_int, C.c_int, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void)]),
+    "tg_stepper_backward": (C.c_int, [c_void, C.c_int, c_void, c_void, GRAD_READY_FN, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
     "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),
     "tg_time_bias_finish": (C.c_int, [c_void, c_void, c_void, C.c_int, c_void]),
     "tg_bce_logits": (C.c_int, [c_void, c_i64, c_i64, c_void, c_void, c_void]),

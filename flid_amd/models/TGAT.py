@@ -67,6 +67,16 @@ class TGAT(nn.Module):
         self._flat_pack = [flat_param, views]          # a list: nn.Module must not register it (state_dict stays the reference's)
         return flat_param
 
+    def enable_native_step(self, max_batch_roots: int, num_neighbors: int = 20, slots: int = 4):
+        """Opt-in (not in the reference; needs flatten_parameters()): prepare_batch_begin / prepare_roots_begin / prepare_batch_finish /
+        train_step go through ONE native object (flid_amd.stepper.Stepper, csrc/tg_step.hip) -- a C call each, every launch of a step
+        issued by the library out of a pre-sized arena.  max_batch_roots: roots of a prepared batch at most (2 B; 3 B for the
+        link-prediction warm-up's [src | dst | negative dst]).  Host numpy batches only; a prepared batch of this mode is consumed by
+        train_step (the autograd-facing calls keep the Python engine)."""
+        from ..stepper import Stepper
+        self._stepper = Stepper(self, max_batch_roots, num_neighbors, slots)
+        return self._stepper
+
     def compute_src_dst_node_temporal_embeddings(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray,
                                                  node_interact_times: np.ndarray, num_neighbors: int = 20, roots: str = "both"):
         # both sides share one device pass: rows are independent (reference computes them one after the other, :61-65)
@@ -102,6 +112,10 @@ class TGAT(nn.Module):
         # roots = "src": embed the source nodes only -- single-way datasets' M-step classifies `batch_src_node_embeddings` alone
         # (PTCL/M_step.py:285: the destination rows the reference computes there are never read), half the roots of a step
         assert roots in ("both", "src")
+        st = getattr(self, "_stepper", None)
+        if st is not None and not torch.is_tensor(src_node_ids) and num_neighbors == st.k:
+            return st.begin([np.asarray(src_node_ids)] if roots == "src" else [np.asarray(src_node_ids), np.asarray(dst_node_ids)],
+                            node_interact_times)
         if not torch.is_tensor(src_node_ids):
             # host numpy int64 ids / float64 times, as the reference's trainers hand them over (PTCL/EM_warmup.py:128-130): one pinned
             # staging block, one asynchronous copy ON THE SIDE STREAM (the main stream is a step behind and must not be waited for)
@@ -128,6 +142,9 @@ class TGAT(nn.Module):
         [src, dst, negative dst] (PTCL/EM_warmup.py:128-153; the reference embeds the sources twice, once per pair).  Host numpy
         int64 / float64 in; the embedding block of the prepared batch is the lists' rows one after the other."""
         from .. import ops
+        st = getattr(self, "_stepper", None)
+        if st is not None and num_neighbors == st.k:
+            return st.begin([np.asarray(a) for a in id_lists], node_interact_times)
         graph = self.neighbor_sampler.graph
         arrs = [np.asarray(a) for a in id_lists]
         for a in arrs:
@@ -141,14 +158,26 @@ class TGAT(nn.Module):
         return job
 
     def prepare_batch_finish(self, job):
+        from ..stepper import StepJob
+        if isinstance(job, StepJob):
+            return job.stepper.finish(job)
         pf = engine.prepare_finish(job)
         pf.nsrc = job.nsrc
         return pf
 
-    def train_step(self, prepared, loss_fn, num_neighbors: int = 20, grad_ready=None):
+    def train_step(self, prepared, loss_fn, num_neighbors: int = 20, grad_ready=None, optimizer=None):
         """Fused-trainer step (not in the reference): forward of the prepared batch, `loss_fn(emb) -> (loss, d_emb)` on
         the detached (2 B, Dn) embedding block [src rows | dst rows], backward -- without an autograd graph.  Needs
-        flatten_parameters(); the gradient lands in the flat parameter's .grad exactly as loss.backward() would leave it."""
+        flatten_parameters(); the gradient lands in the flat parameter's .grad exactly as loss.backward() would leave it.
+        optimizer (a FlatAdam over the flat parameter; native step only, not together with grad_ready): its update is issued in the
+        same native call as the backward -- the caller then does not call optimizer.step()."""
+        from ..stepper import StepJob
+        if isinstance(prepared, StepJob):
+            assert prepared.finished and prepared.k == num_neighbors and prepared.stepper is getattr(self, "_stepper", None), \
+                "prepared by another stepper / not finished"
+            return prepared.stepper.step(prepared, loss_fn, grad_ready=grad_ready, optimizer=optimizer)
+        if optimizer is not None:
+            raise NotImplementedError("train_step(optimizer=...) is the native step's (enable_native_step())")
         flat = getattr(self, "_flat_pack", None)
         if flat is None:
             raise RuntimeError("TGAT.train_step needs the flat-parameter mode: call flatten_parameters() first")

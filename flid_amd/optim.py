@@ -38,6 +38,23 @@ class FlatAdam(torch.optim.Optimizer):
                                         int(st["step"]), ops._stream()), "tg_adam_f32")
         return loss
 
+    def native_args(self, p):
+        """the update of parameter `p` as a tg_adam_args struct for a native step (flid_amd.stepper: the library issues the kernel behind
+        its backward); counts the step as step() does"""
+        from ._lib import AdamArgs
+        for group in self.param_groups:
+            if any(q is p for q in group["params"]):
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                b1, b2 = group["betas"]
+                return AdamArgs(st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]), float(b1), float(b2),
+                                float(group["eps"]), float(group["weight_decay"]), int(st["step"]))
+        raise RuntimeError("FlatAdam.native_args: not a parameter of this optimizer")
+
     def zero_grad(self, set_to_none: bool = True):
         """as torch.optim.Optimizer.zero_grad, without its profiler context (~10 us of host time per step)"""
         for group in self.param_groups:

@@ -1,0 +1,154 @@
+"""The trainer's step through ONE native object (tg_stepper, csrc/tg_step.hip): a batch is prepared on the object's own side stream
+(one C call per half), the forward of every layer is one C call, the backward of every layer + the optimizer's update another.
+
+replaces the host side of models/TGAT.py:50-144 and of the loss.backward() / optimizer.step() sequence around it
+(PTCL/EM_warmup.py:126-238, PTCL/M_step.py:209-325) for the fused trainers; flid_amd/engine.py's Python form of the same work stays as
+the autograd-facing path (and as the test oracle of this one: same kernels, same seeds, same numbers).
+
+PyTorch supplies the arena (one allocation, sized by the library) and the views a caller sees (embeddings, gradient); every launch of
+a step is issued by the library."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import engine, ops
+from ._lib import AdamArgs, GRAD_READY_FN, StepperCfg, check, lib
+
+
+class StepJob:
+    """a batch in preparation / prepared (a slot of the native object)"""
+    __slots__ = ("stepper", "slot", "n", "nsrc", "finished", "rows", "k", "num_layers")
+
+    def __init__(self, stepper, slot, n, nsrc):
+        self.stepper, self.slot, self.n, self.nsrc, self.finished, self.rows = stepper, slot, n, nsrc, False, None
+        self.k, self.num_layers = stepper.k, stepper.num_layers
+
+
+class Stepper:
+    """model: a TGAT in flat-parameter mode (flatten_parameters()).  max_roots: roots of one prepared batch at most."""
+
+    def __init__(self, model, max_roots: int, num_neighbors: int = 20, slots: int = 4, dedupe=None):
+        flat = getattr(model, "_flat_pack", None)
+        if flat is None:
+            raise RuntimeError("Stepper needs the flat-parameter mode: call flatten_parameters() first")
+        if model.neighbor_sampler.sample_neighbor_strategy != "recent":
+            raise NotImplementedError("the native step samples on the device ('recent')")
+        self.model, self.flat = model, flat[0]
+        self.k, self.num_layers = int(num_neighbors), int(model.num_layers)
+        self.graph = model.neighbor_sampler.graph
+        node, edge = model.node_raw_features, model.edge_raw_features
+        dev = node.device
+        cfg = StepperCfg()
+        cfg.graph = self.graph.handle
+        cfg.d_node, cfg.node_ld = node.data_ptr(), node.stride(0)
+        cfg.d_edge, cfg.edge_ld = edge.data_ptr(), edge.stride(0)
+        cfg.dn, cfg.de, cfg.dt_dim = node.shape[1], edge.shape[1], model.time_feat_dim
+        cfg.heads, cfg.layers, cfg.k = model.num_heads, model.num_layers, self.k
+        cfg.max_roots, cfg.slots = int(max_roots), int(slots)
+        cfg.d_param, cfg.param_floats = self.flat.data_ptr(), self.flat.numel()
+        cfg.dropout_p = float(model.dropout)
+        cfg.dedupe = int(engine.DEDUPE if dedupe is None else dedupe)
+        cfg.extra_grad_floats = 0
+        need = int(lib().tg_stepper_param_floats(C.byref(cfg)))
+        if need != self.flat.numel():
+            raise RuntimeError(f"flat parameter holds {self.flat.numel()} floats, the native layout {need}")
+        total = int(lib().tg_stepper_arena_floats(C.byref(cfg)))
+        if total <= 0:
+            check(-1, "tg_stepper_arena_floats")
+        self.arena = torch.empty(total + 64, dtype=torch.float32, device=dev)
+        base = self.arena.data_ptr()
+        shift = (-base // 4) % 64                                   # 256-byte aligned start
+        self.arena = self.arena[shift:shift + total]
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(lib().tg_stepper_create(C.byref(cfg), self.arena.data_ptr(), total, C.byref(h)), "tg_stepper_create")
+        self._h = h
+        off = (C.c_int64 * 4)()
+        check(lib().tg_stepper_regions(h, self.arena.data_ptr(), off), "tg_stepper_regions")
+        self.grad = self.arena[off[0]:off[0] + self.flat.numel()]        # parameter gradients, laid out like the flat parameter
+        self._emb_off, self.dn, self.max_roots, self.nslots = int(off[2]), int(cfg.dn), int(max_roots), int(slots)
+        self._next = 0
+        self._seeds = (C.c_uint64 * (2 * self.num_layers))()
+        self._rows = (C.c_int64 * 2)()
+        self._emb_views = {}
+        self.keep = (node, edge, self.flat)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().tg_stepper_destroy(h)
+            except Exception:
+                pass
+
+    # ---- preparation (side stream of the native object) ---------------------------------------------------------------------------
+    def begin(self, id_lists, node_interact_times) -> StepJob:
+        """id_lists: host int64 arrays that share `node_interact_times` ([src, dst], [src], [src, dst, negative dst]); the embedding block
+        of the step holds their rows one after the other"""
+        ids = np.ascontiguousarray(np.concatenate(id_lists) if len(id_lists) > 1 else id_lists[0], dtype=np.int64)
+        t = np.ascontiguousarray(node_interact_times, dtype=np.float64)
+        times = np.ascontiguousarray(np.tile(t, len(id_lists))) if len(id_lists) > 1 else t
+        slot = self._next
+        self._next = (self._next + 1) % self.nslots
+        check(lib().tg_stepper_prepare_begin(self._h, slot, ids.ctypes.data, times.ctypes.data, len(ids)), "tg_stepper_prepare_begin")
+        return StepJob(self, slot, len(ids), len(id_lists[0]))
+
+    def finish(self, job: StepJob) -> StepJob:
+        check(lib().tg_stepper_prepare_finish(self._h, job.slot, self._rows), "tg_stepper_prepare_finish")
+        job.finished, job.rows = True, (int(self._rows[0]), int(self._rows[1]))
+        return job
+
+    def reset(self):
+        """drop every batch in preparation (a trainer that restarts its prefetch pipeline)"""
+        for slot in range(self.nslots):
+            check(lib().tg_stepper_release(self._h, slot), "tg_stepper_release")
+        self._next = 0
+
+    def release(self, job: StepJob):
+        check(lib().tg_stepper_release(self._h, job.slot), "tg_stepper_release")
+
+    # ---- the step -----------------------------------------------------------------------------------------------------------------
+    def forward(self, job: StepJob) -> torch.Tensor:
+        training = bool(self.model.training)
+        if training and self.cfg.dropout_p > 0:
+            for i, v in enumerate(engine._next_seeds(2 * self.num_layers)):
+                self._seeds[i] = v
+        check(lib().tg_stepper_forward(self._h, job.slot, int(training), self._seeds, ops._stream(), None), "tg_stepper_forward")
+        emb = self._emb_views.get(job.n)
+        if emb is None:
+            emb = self._emb_views[job.n] = self.arena[self._emb_off:self._emb_off + job.n * self.dn].view(job.n, self.dn)
+        return emb
+
+    def backward(self, job: StepJob, d_emb: torch.Tensor, grad_ready=None, optimizer=None):
+        """leaves the step's gradient in `self.grad` (and in the flat parameter's .grad); optimizer (a FlatAdam over the flat parameter):
+        its update is issued right behind the last layer's backward, in the same call"""
+        assert d_emb.is_contiguous() and d_emb.dtype == torch.float32 and d_emb.numel() == job.n * self.dn
+        cb, adam = None, None
+        if grad_ready is not None:
+            g, base = self.grad, self.grad.data_ptr()
+
+            def _cb(_user, seg_ptr, floats):
+                o = (seg_ptr - base) // 4
+                grad_ready(g[o:o + floats])
+            cb = GRAD_READY_FN(_cb)
+        prev = self.flat.grad
+        if prev is not None and prev.data_ptr() == self.grad.data_ptr():
+            prev = None
+        if prev is not None and (optimizer is not None or cb is not None):
+            raise RuntimeError("Stepper.backward: zero_grad(set_to_none=True) first (the update / the reduction runs on this step's gradient block)")
+        if optimizer is not None:
+            adam = optimizer.native_args(self.flat)
+        check(lib().tg_stepper_backward(self._h, job.slot, d_emb.data_ptr(), ops._stream(), cb if cb is not None else GRAD_READY_FN(),
+                                        None, None if adam is None else C.byref(adam), None), "tg_stepper_backward")
+        if prev is None:
+            self.flat.grad = self.grad
+        else:
+            prev.add_(self.grad)                                    # as autograd accumulates
+
+    def step(self, job: StepJob, loss_fn, grad_ready=None, optimizer=None):
+        """forward, `loss_fn(emb) -> (loss, d loss / d emb)`, backward (+ update): (embeddings, loss)"""
+        emb = self.forward(job)
+        loss, d_emb = loss_fn(emb)
+        self.backward(job, d_emb, grad_ready=grad_ready, optimizer=optimizer)
+        return emb, loss

@@ -221,6 +221,51 @@ void tg_set_layer_chain(int on);
 /* `stream` waits for everything tg_tgat_layer_bwd(defer_join = 1) put on the side streams (drains the helper thread first) */
 int tg_side_join(void* stream);
 
+/* ---- the trainers' step from one native object ---------------------------------------------------------
+ * replaces the HOST side of models/TGAT.py:50-144 (the recursion, its sampler calls utils/utils.py:149-214 and its index bookkeeping)
+ * together with the loss.backward() / optimizer.step() sequence the trainers run around it (PTCL/EM_warmup.py:126-238,
+ * PTCL/M_step.py:209-325): a batch is PREPARED (ids to the device, neighbor lookups, row sharing: graph-only work on the object's own
+ * side stream, one or two batches ahead), then one call runs the forward of every layer and one call the backward of every layer and
+ * the Adam update -- launches issued back to back out of a caller-allocated arena, no device allocation, nothing between them.
+ * The flat parameter is [time_encoder.w.weight | .bias | per layer: Wq Wk Wv ln_g ln_b Wr br W1 b1 W2 b2], every tensor starting on a
+ * 16-byte boundary (tg_stepper_param_floats gives the length); the gradient block has the same layout. */
+typedef struct tg_stepper tg_stepper;
+typedef struct tg_stepper_cfg {
+    const tg_graph* graph;
+    const float* d_node; int64_t node_ld;        /* node table (row 0 = padding node), models/TGAT.py:26 */
+    const float* d_edge; int64_t edge_ld;        /* edge table, models/TGAT.py:27 */
+    int dn, de, dt_dim, heads, layers, k;        /* layers 1 or 2, heads 1 or 2 */
+    int64_t max_roots;                           /* roots of one prepared batch at most (2 B, or 3 B for [src | dst | negative dst]) */
+    int slots;                                   /* batches in preparation / in use at a time (a two-stage prefetch needs 3) */
+    float* d_param; int64_t param_floats;
+    float dropout_p;                             /* train-mode dropout of the attention weights and of the residual path */
+    int dedupe;                                  /* 1: repeated (node, time) rows inside a batch are computed once (flid_amd/engine.py row sharing) */
+    int64_t extra_grad_floats;                   /* room behind the parameter gradients for the caller's own (zero-filled with them) */
+} tg_stepper_cfg;
+typedef void (*tg_grad_ready_fn)(void* user, float* d_segment, int64_t floats);
+typedef struct tg_adam_args {                    /* torch.optim.Adam's update (utils/utils.py:40-60 create_optimizer), as tg_adam_f32 */
+    float *d_exp_avg, *d_exp_avg_sq; int64_t n;  /* n = 0: the whole flat parameter */
+    double lr, beta1, beta2, eps, weight_decay; int64_t step;
+} tg_adam_args;
+int64_t tg_stepper_param_floats(const tg_stepper_cfg* cfg);
+int64_t tg_stepper_arena_floats(const tg_stepper_cfg* cfg);
+int tg_stepper_create(const tg_stepper_cfg* cfg, float* d_arena, int64_t arena_floats, tg_stepper** out);
+void tg_stepper_destroy(tg_stepper* st);
+/* offsets (floats from d_arena): [0] gradient block, [1] its length up to the end of the extra floats, [2] embeddings h^L, [3] d cos(b) */
+int tg_stepper_regions(const tg_stepper* st, const float* d_arena, int64_t* off4);
+/* HOST ids (int64) / times (float64), n_roots of each (several root lists of one batch concatenated, their times repeated).
+ * TG_ERANGE for an id outside the graph.  Nothing waits for the GPU. */
+int tg_stepper_prepare_begin(tg_stepper* st, int slot, const int64_t* h_ids, const double* h_times, int64_t n_roots);
+/* a step later: reads the distinct-row count (pinned word) and issues the level-1 lookups; rows2 (optional) = {roots, distinct level-1 rows} */
+int tg_stepper_prepare_finish(tg_stepper* st, int slot, int64_t* rows2);
+int tg_stepper_release(tg_stepper* st, int slot);
+/* device pointers of a prepared slot: {ids_all, S_nbr, S_eid, S_t, S_dt, child}; *pad_row = frontier row of the padding pair or -1 */
+int tg_stepper_slot_view(const tg_stepper* st, int slot, void** p6, int64_t* pad_row);
+/* seeds: 2 per layer (attention dropout, residual dropout), layer 1 first; may be NULL in eval mode.  *d_emb: (roots, dn) */
+int tg_stepper_forward(tg_stepper* st, int slot, int training, const uint64_t* seeds, void* stream, float** d_emb);
+int tg_stepper_backward(tg_stepper* st, int slot, const float* d_demb, void* stream, tg_grad_ready_fn grad_ready, void* user,
+                        const tg_adam_args* adam, float** d_grad);
+
 /* ---- optimizer step for the flat-parameter mode (the trainers' torch.optim.Adam, utils/utils.py:40-60 create_optimizer) ----
  * one element-wise pass over a flat fp32 parameter: exp_avg / exp_avg_sq updated in place, bias-corrected step `step` (>= 1),
  * L2 weight decay folded into the gradient.  No amsgrad. */

@@ -682,3 +682,104 @@ def test_classifier_head_loss_matches_autograd(p_drop):
     assert float((d_emb[:B].double() - x.grad).abs().max()) <= 1e-4 * float(x.grad.abs().max())
     for n in got:
         assert float((got[n].double() - P[n].grad).abs().max()) <= 1e-4 * max(1e-6, float(P[n].grad.abs().max())), n
+
+
+def _native_vs_python_steps(g, layers, dropout, id_lists_fn, steps=3, dedupe=True):
+    """`steps` fused steps with Adam on the same batches through (a) the Python engine's train_step + FlatAdam.step and (b) the native
+    stepper with the update issued inside its backward call; same dropout seeds -> same numbers"""
+    from flid_amd import engine, ops
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.optim import FlatAdam
+    from flid_amd.utils.utils import get_neighbor_sampler
+    dev = torch.device("cuda:0")
+    dn, de, dt, _, k = [int(v) for v in g["dims"]]
+    lists = id_lists_fn(g)
+    n = sum(len(a) for a in lists)
+    w = torch.from_numpy(np.random.RandomState(4).standard_normal((n, g["node_feat"].shape[1])).astype(np.float32)).to(dev)
+    loss_fn = lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w)
+    out = []
+    old = engine.DEDUPE
+    engine.DEDUPE = dedupe
+    try:
+        for native in (False, True):
+            smp = get_neighbor_sampler(_Data(g), "recent", seed=0)
+            torch.manual_seed(3)
+            m = TGAT(g["node_feat"], g["edge_feat"], smp, dt, layers, 2, dropout, "cuda:0").to(dev).train()
+            flat = m.flatten_parameters()
+            opt = FlatAdam([flat], lr=1e-2)
+            engine.seed_dropout(1234)
+            if native:
+                m.enable_native_step(n, k)
+            rec = []
+            for s in range(steps):
+                opt.zero_grad(set_to_none=True)
+                if native:
+                    job = m.prepare_batch_finish(m.prepare_roots_begin(lists, g["bt"], k))
+                    assert job.rows[0] == n
+                    emb, loss = m.train_step(job, loss_fn, k, optimizer=opt)
+                else:
+                    pf = m.prepare_batch_finish(m.prepare_roots_begin(lists, g["bt"], k))
+                    emb, loss = m.train_step(pf, loss_fn, k)
+                    opt.step()
+                rec.append((emb.clone(), float(loss), flat.grad.clone(), flat.detach().clone()))
+            out.append(rec)
+    finally:
+        engine.DEDUPE = old
+        engine._SEED_GEN = None
+    for i, (a, b) in enumerate(zip(*out)):
+        # step 0 runs the same kernels on the same numbers; later steps start from parameters whose update saw gradients that differ
+        # in the last bits (float-atomic column sums)
+        assert torch.equal(a[0], b[0]) if i == 0 else float((a[0] - b[0]).abs().max()) <= 2e-5, float((a[0] - b[0]).abs().max())
+        assert abs(a[1] - b[1]) <= 1e-5 * max(1.0, abs(a[1]))
+        scale = float(a[2].abs().max())
+        assert float((a[2] - b[2]).abs().max()) <= 2e-6 * scale               # column sums fold with float atomics
+        assert float((a[3] - b[3]).abs().max()) <= 1e-4 * float(a[3].abs().max())     # parameters after the update (lr 1e-2)
+
+
+@pytest.mark.parametrize("layers,dropout,dedupe", [(2, 0.0, True), (2, 0.2, True), (2, 0.0, False), (1, 0.1, True)])
+def test_native_step_equals_python_fused_step(layers, dropout, dedupe):
+    g = load_golden("tgat_L2_K20")
+    _native_vs_python_steps(g, layers, dropout, lambda g: [g["bs"], g["bd"]], dedupe=dedupe)
+
+
+def test_native_step_three_root_lists_and_src_only():
+    g = load_golden("tgat_L2_K20")
+    rs = np.random.RandomState(0)
+    neg = rs.randint(1, int(g["node_feat"].shape[0]), len(g["bs"])).astype(np.int64)
+    _native_vs_python_steps(g, 2, 0.0, lambda g: [g["bs"], g["bd"], neg])
+    _native_vs_python_steps(g, 2, 0.0, lambda g: [g["bs"]])
+
+
+def test_native_step_slots_errors_and_prefetch_order():
+    """every slot in preparation at a time (a two-stage prefetch holds three), slot reuse across steps, an id beyond the graph raises the
+    reference's IndexError, a fourth begin without a free slot is refused"""
+    from flid_amd import ops
+    from flid_amd._lib import TgError
+    from flid_amd.optim import FlatAdam
+    g = load_golden("tgat_L2_K20")
+    dev = torch.device("cuda:0")
+    m, p, k = _model(g)
+    flat = m.flatten_parameters()
+    m.train()
+    n = 2 * len(g["bs"])
+    st = m.enable_native_step(n, k)
+    w = torch.ones((n, g["node_feat"].shape[1]), device=dev)
+    loss_fn = lambda e: (ops.weighted_sum(e, w, 1.0), w)
+    with pytest.raises(IndexError):
+        m.prepare_batch_begin(g["bs"] + 10 ** 6, g["bd"], g["bt"], k)
+    jobs = [m.prepare_batch_begin(g["bs"], g["bd"], g["bt"], k) for _ in range(st.nslots)]
+    with pytest.raises(TgError):
+        m.prepare_batch_begin(g["bs"], g["bd"], g["bt"], k)
+    ref = None
+    for i in range(7):                                     # every slot is reused at least twice
+        job = m.prepare_batch_finish(jobs.pop(0))
+        flat.grad = None
+        emb, _ = m.train_step(job, loss_fn, k)
+        jobs.append(m.prepare_batch_begin(g["bs"], g["bd"], g["bt"], k))
+        if ref is None:
+            ref = (emb.clone(), flat.grad.clone())
+        else:
+            assert torch.equal(emb, ref[0])
+            assert float((flat.grad - ref[1]).abs().max()) <= 2e-6 * float(ref[1].abs().max())
+    for j in jobs:
+        st.release(j)
