@@ -30,6 +30,16 @@ BF16_PEAK = 2.5e15           # FLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
 BATCH, K, L, H, DN, DE, DT = 600, 20, 2, 2, 172, 172, 100
 
 
+def kernel_src_sha(files=("tg_attn_fast.hip", "tg_attn.hip", "tg_common.h")):
+    """identity of the attention kernels' SOURCE: the PMC traffic figures under profiles/ are valid for the build they were taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(REPO, "flid_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def tgat_bytes_per_edge(k=K, layers=L, dn=DN, de=DE):
     """SURVEY.md 8(d): de-duplicated minimum bytes per root, forward: node rows + edge rows + sampler + output row;
     an edge has 2 roots; backward re-reads the gathered inputs once."""
@@ -91,6 +101,9 @@ def main():
                          "TGAT.train_step (same kernels, no autograd graph, loss scalar from one HIP reduction)")
     ap.add_argument("--python-step", action="store_true",
                     help="fused step issued by the Python engine (flid_amd/engine.py) instead of the native stepper (csrc/tg_step.hip): A/B")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="--model tgn on ONE GPU: one rank's step of an N-GPU job (global batch N x 600, this rank embeds its 600-edge shard and "
+                         "advances the replicated state with the whole batch; no collective): what the replicated advance costs as N grows")
     ap.add_argument("--master-port", type=int, default=29533)
     ap.add_argument("--no-merged", action="store_true", help="tg_set_layer_merged(0): the reference's four separate projections per layer")
     ap.add_argument("--no-grouped", action="store_true", help="tg_set_wgrad_grouped(0): one exact product + one column sum per weight gradient")
@@ -450,6 +463,39 @@ def main():
             drop_prepared()
             if native:
                 model.enable_native_step(2 * BATCH, K)
+    # the same step with the reference's plain fp32 products (models/modules.py:190-245 are fp32 mm: tg_set_gemm_mode(0), exact f32-input
+    # MFMA everywhere -- chains, packed weights and the second weight-gradient form are bypassed), and with BOTH relaxations off
+    # (exact products + the reference's row-for-row recursion): short extra runs beside the headline
+    exact_f32 = strict = None
+    if args.mode == "train" and world == 1 and not args.no_breakdown and gemm_mode_now != 0 and fused:
+        from flid_amd import engine as _eng
+
+        def short_leg(n_leg=min(20, args.steps)):
+            drop_prepared()
+            if native:
+                model.enable_native_step(2 * BATCH, K)
+            for s in range(args.warmup, args.warmup + 3):
+                step(s)
+            torch.cuda.synchronize()
+            drop_prepared()
+            t1 = time.perf_counter()
+            for s in range(args.warmup, args.warmup + n_leg):
+                step(s)
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t1
+            return {"value": round(n_leg * BATCH / dt_, 1), "ms_per_step": round(dt_ / n_leg * 1e3, 4), "steps": n_leg}
+        _lib_().tg_set_gemm_mode(0)
+        try:
+            exact_f32 = dict(short_leg(), note="tg_set_gemm_mode(0): every product exact fp32 (f32-input MFMA), as the reference's mm")
+            _eng.DEDUPE = False
+            strict = dict(short_leg(), note="exact fp32 products AND engine.DEDUPE = False (24 000 layer-1 instances, per-root dropout "
+                                            "masks): the reference's arithmetic and recursion, row for row")
+        finally:
+            _eng.DEDUPE = True
+            _lib_().tg_set_gemm_mode(gemm_mode_now)
+            drop_prepared()
+            if native:
+                model.enable_native_step(2 * BATCH, K)
     # fwd = half of fwd+bwd; the link-prediction step embeds 3 roots per edge instead of 2
     bpe = {"train": tgat_bytes_per_edge(), "fwd": tgat_bytes_per_edge() // 2, "lp": tgat_bytes_per_edge() * 3 // 2}[args.mode]
 
@@ -476,10 +522,18 @@ def main():
                 "bytes_per_launch_avg": round(inst * alg / max(1, cnt), 1),
                 "activation_bytes_per_instance": act, "achieved_incl_activations": round(units / secs / 1e9, 1),
                 "instances_per_launch_avg": round(inst / max(1, cnt), 1)}
-        tr = os.path.join(REPO, "profiles", "traffic_r03.json")     # PMC passes of the same command (tools/traffic_from_pmc.py)
+        # PMC passes of the same command (tools/traffic_from_pmc.py, separate rocprofv3 --pmc runs): reported only when they were
+        # taken on THIS source of the attention kernels; a file from another build is named, not quoted
+        tr = os.path.join(REPO, "profiles", "traffic_r04.json")
         if os.path.exists(tr) and args.workload == "wikipedia" and args.mode == "train":
             try:
-                roof["traffic"] = json.load(open(tr)).get(args.roofline_kernel)
+                tj = json.load(open(tr))
+                if tj.get("_kernel_src_sha") == kernel_src_sha():
+                    roof["traffic"] = tj.get(args.roofline_kernel)
+                else:
+                    roof["traffic_stale"] = {"file": "profiles/traffic_r04.json", "kernel_src_sha": tj.get("_kernel_src_sha"),
+                                             "current_kernel_src_sha": kernel_src_sha(),
+                                             "note": "PMC passes taken on another build of the attention kernels: not quoted"}
             except Exception:
                 pass
 
@@ -503,6 +557,10 @@ def main():
     }
     if dedupe_off is not None:
         out["row_sharing_off"] = dedupe_off
+    if exact_f32 is not None:
+        out["exact_f32"] = exact_f32
+    if strict is not None:
+        out["strict"] = strict
     if dist_info is not None:
         out["distributed"] = dist_info
     if "gemm" in fam and args.roofline_kernel != "gemm" and fam["gemm"][2] > 0:
@@ -516,6 +574,15 @@ def main():
                                 # what the split-bf16 kernels actually issue: 3 (chains: 4) bf16 MFMAs per fp32 product term
                                 "peak_bf16x3_equivalent": round(BF16_PEAK / 3 / 1e12, 1),
                                 "frac_bf16x3_equivalent": round(g_fl / (g_ms * 1e-3) / (BF16_PEAK / 3), 4)}
+        # the dense side (row-block chains, products, weight gradients) is the largest share of the step, not the named HBM-bound
+        # attention kernel: its time, work and rate against what the split-bf16 kernels could issue
+        out["dominant_family"] = {"family": "dense side: chain_fwd/bwd + product + weight-gradient launches (HIP events, untimed second pass)",
+                                  "us_per_step": round(g_ms / args.steps * 1e3, 1),
+                                  "share_of_step": round(g_ms / args.steps / (elapsed / args.steps * 1e3), 3),
+                                  "gflop_per_step": round(g_fl / args.steps / 1e9, 2),
+                                  "tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 2),
+                                  "frac_of_bf16x3_peak": round(g_fl / (g_ms * 1e-3) / (BF16_PEAK / 3), 4),
+                                  "frac_of_f32_mfma_peak": round(g_fl / (g_ms * 1e-3) / MFMA_F32_PEAK, 4)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:        # reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(data, n_train, model, batch_slice(args.warmup), args.cpu_sample_edges)
@@ -611,6 +678,10 @@ def bench_memory_or_sequence_model(args):
         params = [p for p in model.parameters() if p.requires_grad]
         opt = torch.optim.Adam(params, lr=1e-4, fused=True)
     reducer = fdist.GradAllReducer(params) if world > 1 else None
+    native = fused and not args.python_step
+    wsim = args.simulate_world if (args.simulate_world > 1 and args.model == "tgn" and world == 1) else world
+    if native:
+        model.enable_native_step(BATCH * wsim, K)            # (the state advance covers the whole global batch on every rank)
     total_steps = args.warmup + args.steps
     n_batches = n_train // BATCH
     first = n_batches // 2
@@ -628,8 +699,8 @@ def bench_memory_or_sequence_model(args):
         # the global batch of world x 600 edges and advances the replicated state with the whole batch); DyGFormer: rank r takes
         # batch step * world + r
         if args.model == "tgn":
-            b = first + step % max(1, span // world)
-            return slice(b * BATCH * world, (b + 1) * BATCH * world)
+            b = first + step % max(1, span // wsim)
+            return slice(b * BATCH * wsim, (b + 1) * BATCH * wsim)
         b = first + (step * world + rank) % span
         return slice(b * BATCH, (b + 1) * BATCH)
 
@@ -638,7 +709,7 @@ def bench_memory_or_sequence_model(args):
     def tgn_begin(s_):
         sl_ = batch(s_)
         return model.prepare_batch_begin(data.src_node_ids[sl_], data.dst_node_ids[sl_], data.node_interact_times[sl_], K,
-                                         None if world == 1 else (rank * BATCH, (rank + 1) * BATCH), edge_ids=data.edge_ids[sl_])
+                                         None if wsim == 1 else (rank * BATCH, (rank + 1) * BATCH), edge_ids=data.edge_ids[sl_])
 
     def step(s):
         sl = batch(s)
@@ -653,6 +724,9 @@ def bench_memory_or_sequence_model(args):
             if s + 2 not in jobs:
                 jobs[s + 2] = tgn_begin(s + 2)
             pf = prepared.pop(s)
+            if native and reducer is None:                   # ... and Adam, every launch issued by the library
+                model.train_step(pf, data.edge_ids[sl], mean_loss, K, optimizer=opt)
+                return
             if fused:                                        # forward, loss, backward, state advance: no autograd graph
                 model.train_step(pf, data.edge_ids[sl], mean_loss, K)
                 if reducer is not None:
@@ -741,10 +815,15 @@ def bench_memory_or_sequence_model(args):
            "dtype": DTYPE, "data": "synthetic",
            "config": {"workload": f"Reddit-shape synthetic (10984 nodes, 672447 edges, 172-d edge feats) + {desc}, batch 600 edges/GPU, "
                                   f"dropout {args.dropout:.2f}, host numpy ids per call, fwd+bwd+Adam ({'fused step' if fused else 'autograd'})",
-                      "batch_per_gpu": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+                      "batch_per_gpu": BATCH, "global_batch": BATCH * wsim, "parallelism": f"dp{world}"},
            "path_roofline": path, "roofline": roof, "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 4)}
     if dist_info is not None:
         out["distributed"] = dist_info
+    if wsim != world:
+        out["simulated_world"] = {"ranks": wsim, "note": "ONE rank's step of a %d-GPU data-parallel TGN job on one GPU: its 600-edge shard embedded, "
+                                  "the replicated memory / message state advanced with the whole %d-edge global batch, no collective; `value` "
+                                  "counts this rank's 600 edges per step" % (wsim, BATCH * wsim)}
+        args.no_cpu_baseline = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_model(args.model, data, n_train, model, batch(args.warmup), args.dropout)
     if rank == 0:

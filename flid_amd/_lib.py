@@ -60,7 +60,14 @@ class StepperCfg(C.Structure):
     _fields_ = [("graph", c_void), ("d_node", c_void), ("node_ld", c_i64), ("d_edge", c_void), ("edge_ld", c_i64),
                 ("dn", C.c_int), ("de", C.c_int), ("dt_dim", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("k", C.c_int),
                 ("max_roots", c_i64), ("slots", C.c_int), ("d_param", c_void), ("param_floats", c_i64), ("dropout_p", c_f32),
-                ("dedupe", C.c_int), ("extra_grad_floats", c_i64)]
+                ("dedupe", C.c_int), ("extra_grad_floats", c_i64), ("tgn", C.c_int)]
+
+
+class TgnBank(C.Structure):
+    """struct tg_tgn_bank"""
+    _fields_ = [("d_mem", c_void), ("mem_ld", c_i64), ("d_last_update", c_void), ("d_msg", c_void), ("msg_ld", c_i64), ("d_has", c_void),
+                ("d_msg_time", c_void), ("d_last_idx_ws", c_void), ("h_has", c_void), ("h_msg_time", c_void), ("h_last", c_void),
+                ("num_nodes", c_i64), ("past_violation", C.c_int)]
 
 
 class AdamArgs(C.Structure):
@@ -88,6 +95,9 @@ SIGNATURES = {
     "tg_stepper_slot_view": (C.c_int, [c_void, C.c_int, C.POINTER(c_void), C.POINTER(c_i64)]),
     "tg_stepper_forward": (C.c_int, [c_void, C.c_int, C.c_int, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void)]),
     "tg_stepper_backward": (C.c_int, [c_void, C.c_int, c_void, c_void, GRAD_READY_FN, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
+    "tg_stepper_tgn_prepare_begin": (C.c_int, [c_void, C.c_int, c_void, c_void, c_void, c_void, c_i64, c_i64, c_i64]),
+    "tg_stepper_tgn_forward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), C.c_int, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void)]),
+    "tg_stepper_tgn_backward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), c_void, C.c_int, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
     "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),
     "tg_time_bias_finish": (C.c_int, [c_void, c_void, c_void, C.c_int, c_void]),
     "tg_bce_logits": (C.c_int, [c_void, c_i64, c_i64, c_void, c_void, c_void]),

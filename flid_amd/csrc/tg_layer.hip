@@ -881,7 +881,8 @@ extern "C" int64_t tg_tgat_layer_vec_floats(int dn, int dq, int dk, int heads) {
 
 extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int dt_dim) {
     const int64_t a = ((rows + 15) / 16) * dn;                       // ReLU-mask slabs
-    const int64_t b = row_grid(rows) * 4 * dq;                       // LayerNorm slabs
+    const int64_t b = std::max<int64_t>(row_grid(rows), tg::chain_blocks(rows)) * 4 * dq;   // LayerNorm slabs (one per workgroup of the chain
+                                                                                             // kernel when it runs: uncapped, rows / 64 from 8 192 rows)
     const int64_t c = (int64_t)tg_attn_bwd_parts(rows) * 2 * dt_dim; // time-encoder slabs
     return 16 + a + b + c;                                            // disjoint regions: they are consumed concurrently
     // (with merged projections the caller appends dq * heads * dk + heads * dk * dn + 32 floats: dV and dP)

@@ -217,11 +217,18 @@ extern "C" int tg_hash_features(float* d_out, int64_t ld, int64_t row0, int64_t 
 // Adam update of ONE flat fp32 parameter (TGAT.flatten_parameters): the arithmetic of torch.optim.Adam (no amsgrad, L2 weight
 // decay folded into the gradient, bias-corrected step) in a single element-wise pass -- torch's multi-tensor kernel spends 46 us
 // on a single 1 M-element tensor (16 workgroups), this one ~5 us.
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// tb_n > 0: elements [tb_off, tb_off + tb_n) are the time encoder's bias b, whose gradient still lacks what reached cos(b) (the
+// encoding of a zero interval, models/TGAT.py:84-85): g -= sin(b) * d_cosb first, written back to the gradient block (= tg_time_bias_finish
+// riding in this launch)
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float step_size, float omb1, float b2, float omb2,
-                                                   float eps, float wd, float bc2_sqrt) {
+                                                   float eps, float wd, float bc2_sqrt, int64_t tb_off, int tb_n, const float* __restrict__ d_cosb) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gi = g[i];
+        if (i >= tb_off && i < tb_off + tb_n) {
+            gi -= sinf(p[i]) * d_cosb[i - tb_off];
+            g[i] = gi;
+        }
         const float pi = p[i];
         if (wd != 0.f) gi = fmaf(wd, pi, gi);
         const float mi = m[i] + omb1 * (gi - m[i]);                     // lerp, as torch's fused kernel
@@ -233,8 +240,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
-extern "C" int tg_adam_f32(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1,
-                double beta2, double eps, double weight_decay, int64_t step, void* stream) {
+int tg::adam_time_bias(float* d_param, float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, int64_t step, int64_t tb_off, int tb_n, const float* d_cosb, void* stream) {
     TG_REQUIRE(d_param && d_grad && d_exp_avg && d_exp_avg_sq && n >= 0 && step >= 1, "tg_adam_f32: arguments");
     if (n == 0) return TG_OK;
     // scalars in double, as torch's host side computes them
@@ -243,8 +250,12 @@ extern "C" int tg_adam_f32(float* d_param, const float* d_grad, float* d_exp_avg
     const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
     const int64_t blocks = std::min<int64_t>((n + 255) / 256, tg::kMaxGridBlocks);
     adam_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(d_param, d_grad, d_exp_avg, d_exp_avg_sq, n, step_size, omb1, (float)beta2, omb2,
-                                                                    (float)eps, (float)weight_decay, bc2_sqrt);
+                                                                    (float)eps, (float)weight_decay, bc2_sqrt, tb_off, tb_n, d_cosb);
     return tg::launch_status("adam_kernel");
+}
+extern "C" int tg_adam_f32(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1,
+                double beta2, double eps, double weight_decay, int64_t step, void* stream) {
+    return tg::adam_time_bias(d_param, const_cast<float*>(d_grad), d_exp_avg, d_exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, 0, 0, nullptr, stream);
 }
 
 // d_teb[j] -= sin(b[j]) * d_cosb[j]: the gradient that reached cos(b) (the time encoding of a zero interval, models/TGAT.py:84-85)

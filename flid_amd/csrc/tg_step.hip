@@ -44,6 +44,18 @@ struct Slot {
     int32_t* h_ids = nullptr; double* h_times = nullptr; int32_t* h_count_pad = nullptr;
     hipEvent_t copied = nullptr, counted = nullptr, ready = nullptr, consumed = nullptr;
     bool consumed_pending = false;
+    // TGN (tg_stepper_cfg.tgn): the blob of tg_tgn_prepare_batch and what hangs off it
+    int64_t nb = 0, lo = 0, hi = 0, uniq_count = 0;      // batch edges, embedded shard [lo, hi), distinct touched nodes
+    int64_t off[8] = {};
+    int32_t *blob = nullptr, *uniq = nullptr, *rowmap = nullptr;      // (uniq_t above: the distinct nodes' all-zero times)
+    void* h_stage = nullptr;              // pinned: the staged blob + the (count, pad) words
+    std::vector<int64_t> h_u; std::vector<double> h_newt; int64_t h_nu = 0;     // host mirror of the state advance
+    bool has_eid = false;
+};
+
+struct TgnBuf {                           // arena regions of the memory stage (floats); U = touched nodes at most
+    float *h_rows, *msg_rows, *gi, *gh, *rows, *base, *d_own, *d_raw, *dgi, *dgh, *msgs, *zero_t;
+    int64_t max_u;
 };
 
 struct LayerBuf {                         // arena regions of one layer (floats)
@@ -61,7 +73,8 @@ struct tg_stepper {
     std::vector<Slot> slots;
     std::vector<LayerBuf> lay;
     std::vector<tg_layer_desc> desc;      // of the forward in flight (read by its backward)
-    std::vector<int64_t> poff;            // offsets of [te_w, te_b, 11 per layer] in the flat parameter, then the total
+    std::vector<int64_t> poff;            // offsets of [te_w, te_b, 11 per layer] in the flat parameter, then where they end
+    int64_t ptotal = 0;                   // floats of the flat parameter (TGN: the GRU's four tensors behind the layers')
     float* cosb = nullptr;
     float* gblock = nullptr;              // [parameter gradients (flat layout) | extra | d cos b | vec per layer | lower layers' gradient rows]
     int64_t g_extra = 0, g_cosb = 0, g_vec = 0, vlen = 0, g_rows = 0, g_floats = 0;
@@ -71,6 +84,10 @@ struct tg_stepper {
     void* pinned = nullptr;
     int fwd_slot = -1;
     int64_t fwd_rows[8];
+    TgnBuf tb{};
+    int md = 0;                           // TGN message width 2 dn + dt_dim + de
+    int64_t gru_off[4] = {};              // w_ih, w_hh, b_ih, b_hh inside the flat parameter
+    bool fwd_pending = false;
 };
 
 namespace {
@@ -93,6 +110,30 @@ int layout(tg_stepper* st, float* base, int64_t* total) {
     Arena A(base);
     st->cap = L == 1 ? c.max_roots : c.max_roots * (1 + (int64_t)k);
     st->slots.resize((size_t)c.slots);
+    if (c.tgn) {
+        // a TGN batch: max_roots = 2 x (edges of a batch); every edge may be embedded (m = n).  The blob of tg_tgn_prepare_batch, the
+        // slot lists behind it and the distinct-node lists, per slot
+        const int64_t n = c.max_roots / 2;
+        int64_t off[8];
+        TG_TRY(tg_tgn_prepare_layout(n, n, k, off));
+        const int64_t total = off[7] - off[4], mk = 2 * n * k;
+        for (Slot& s : st->slots) {
+            s.blob = reinterpret_cast<int32_t*>(A.take(off[7]));
+            s.S_eid = reinterpret_cast<int32_t*>(A.take(mk)); s.S_t = A.take(mk); s.S_dt = A.take(mk);
+            s.uniq = reinterpret_cast<int32_t*>(A.take(total)); s.uniq_t = A.take(total); s.rowmap = reinterpret_cast<int32_t*>(A.take(total));
+            s.count_pad = reinterpret_cast<int32_t*>(A.take(4));
+        }
+        st->ded_cap = tg_dedupe_capacity(total);
+        st->ded_keys = A.take(2 * st->ded_cap);
+        st->ded_vals = reinterpret_cast<int32_t*>(A.take(st->ded_cap));
+        st->ded_pos = reinterpret_cast<int32_t*>(A.take(total));
+        TgnBuf& t = st->tb;
+        const int64_t U = total, D = dn, MD = st->md;
+        t.max_u = U;
+        t.h_rows = A.take(U * D); t.msg_rows = A.take(U * MD); t.gi = A.take(U * 3 * D); t.gh = A.take(U * 3 * D); t.rows = A.take(U * D);
+        t.base = A.take(U * D); t.d_own = A.take(c.max_roots * D); t.d_raw = A.take(c.max_roots * D); t.dgi = A.take(U * 3 * D);
+        t.dgh = A.take(U * 3 * D); t.msgs = A.take(c.max_roots * MD); t.zero_t = A.take(U);
+    } else
     for (Slot& s : st->slots) {
         s.ids_all = reinterpret_cast<int32_t*>(A.take(st->cap));
         s.S_nbr = reinterpret_cast<int32_t*>(A.take(st->cap * k));
@@ -104,10 +145,12 @@ int layout(tg_stepper* st, float* base, int64_t* total) {
         s.child = reinterpret_cast<int32_t*>(A.take(c.max_roots * k));
         s.count_pad = reinterpret_cast<int32_t*>(A.take(4));
     }
-    st->ded_cap = tg_dedupe_capacity(c.max_roots * k);
-    st->ded_keys = A.take(2 * st->ded_cap);
-    st->ded_vals = reinterpret_cast<int32_t*>(A.take(st->ded_cap));
-    st->ded_pos = reinterpret_cast<int32_t*>(A.take(c.max_roots * k));
+    if (!c.tgn) {
+        st->ded_cap = tg_dedupe_capacity(c.max_roots * k);
+        st->ded_keys = A.take(2 * st->ded_cap);
+        st->ded_vals = reinterpret_cast<int32_t*>(A.take(st->ded_cap));
+        st->ded_pos = reinterpret_cast<int32_t*>(A.take(c.max_roots * k));
+    }
     st->cosb = A.take(T);
     st->lay.resize((size_t)L);
     const int64_t wt = tg_tgat_layer_wt_floats(dn, dq, dk);
@@ -125,13 +168,14 @@ int layout(tg_stepper* st, float* base, int64_t* total) {
     }
     // gradient block, zero-filled once per backward
     st->vlen = r4(tg_tgat_layer_vec_floats(dn, dq, dk, H));
-    const int64_t npar = st->poff.back();
+    const int64_t npar = st->ptotal;
     st->g_extra = npar;
     st->g_cosb = st->g_extra + r4(c.extra_grad_floats);
     st->g_vec = st->g_cosb + r4(T);
     st->g_rows = st->g_vec + L * st->vlen;
     int64_t tot = st->g_rows;
     for (int l = L; l > 1; --l) tot += r4(st->lay[(size_t)l - 2].max_rows * dn);      // gradient rows of layer l - 1's output
+    if (c.tgn) tot += r4(st->tb.max_u * dn);                                          // gradient of the compact layer-0 table (memory' + raw)
     st->g_floats = tot;
     st->gblock = A.take(tot);
     *total = A.off;
@@ -146,6 +190,7 @@ int check_cfg(const tg_stepper_cfg* c) {
     TG_REQUIRE((c->dn + c->dt_dim) % c->heads == 0, "The sum of node_feat_dim and time_feat_dim should be divided by num_heads!");
     TG_REQUIRE(c->max_roots > 0 && c->slots >= 1 && c->slots <= 16, "tg_stepper: max_roots / slots");
     TG_REQUIRE(c->dn > 0 && c->de >= 0 && c->dt_dim > 0 && c->extra_grad_floats >= 0, "tg_stepper: dimensions");
+    TG_REQUIRE(!c->tgn || (c->layers == 1 && c->max_roots % 2 == 0), "tg_stepper: the memory stage sits under ONE attention layer (the reference's TGN)");
     return TG_OK;
 }
 
@@ -161,7 +206,13 @@ void param_offsets(tg_stepper* st) {
     st->poff.clear();
     int64_t o = 0;
     for (int64_t s : sz) { st->poff.push_back(o); o += r4(s); }
-    st->poff.push_back(o);
+    st->poff.push_back(o);                                      // = where the layer parameters end
+    st->md = 2 * dn + T + c.de;
+    if (c.tgn) {                                                // nn.GRUCell(message_dim, memory_dim): weight_ih, weight_hh, bias_ih, bias_hh
+        const int64_t gz[4] = {3 * (int64_t)dn * st->md, 3 * (int64_t)dn * dn, 3 * dn, 3 * dn};
+        for (int i = 0; i < 4; ++i) { st->gru_off[i] = o; o += r4(gz[i]); }
+    }
+    st->ptotal = o;
 }
 
 tg_layer_params params_at(float* base, const std::vector<int64_t>& poff, int l /* 0-based */) {
@@ -178,7 +229,7 @@ extern "C" int64_t tg_stepper_param_floats(const tg_stepper_cfg* cfg) {
     st.c = *cfg;
     st.dq = cfg->dn + cfg->dt_dim; st.dk = cfg->dn + cfg->de + cfg->dt_dim; st.hd = st.dq / cfg->heads;
     param_offsets(&st);
-    return st.poff.back();
+    return st.ptotal;
 }
 
 extern "C" int64_t tg_stepper_arena_floats(const tg_stepper_cfg* cfg) {
@@ -213,25 +264,37 @@ extern "C" int tg_stepper_create(const tg_stepper_cfg* cfg, float* d_arena, int6
     int64_t total = 0;
     int rc = layout(st, d_arena, &total);
     if (rc == TG_OK && total > arena_floats) { tg::set_error("invalid argument: tg_stepper_create: arena smaller than tg_stepper_arena_floats()"); rc = TG_EINVAL; }
-    if (rc == TG_OK && cfg->param_floats != st->poff.back()) { tg::set_error("invalid argument: tg_stepper_create: param_floats != tg_stepper_param_floats()"); rc = TG_EINVAL; }
+    if (rc == TG_OK && cfg->param_floats != st->ptotal) { tg::set_error("invalid argument: tg_stepper_create: param_floats != tg_stepper_param_floats()"); rc = TG_EINVAL; }
     if (rc != TG_OK) { delete st; return rc; }
     auto fail = [&](const char* what, hipError_t e) { tg::set_error(std::string(what) + ": " + hipGetErrorString(e)); tg_stepper_destroy(st); return TG_EHIP; };
     hipError_t e = hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking);
     if (e != hipSuccess) return fail("hipStreamCreateWithFlags", e);
-    // pinned staging per slot: ids (int32) | times (f64) | (count, pad)
-    const int64_t per = r4(cfg->max_roots) * 4 + cfg->max_roots * 8 + 64;
+    // pinned staging per slot: ids (int32) | times (f64) | (count, pad); TGN: the staged blob of tg_tgn_prepare_batch | (count, pad)
+    int64_t toff[8] = {};
+    if (cfg->tgn) (void)tg_tgn_prepare_layout(cfg->max_roots / 2, cfg->max_roots / 2, cfg->k, toff);
+    const int64_t per = cfg->tgn ? r64(toff[6]) * 4 + 64 : r4(cfg->max_roots) * 4 + cfg->max_roots * 8 + 64;
     e = hipHostMalloc(&st->pinned, (size_t)(per * cfg->slots), hipHostMallocDefault);
     if (e != hipSuccess) return fail("hipHostMalloc", e);
     char* hp = reinterpret_cast<char*>(st->pinned);
     for (Slot& s : st->slots) {
-        s.h_times = reinterpret_cast<double*>(hp);
-        s.h_ids = reinterpret_cast<int32_t*>(hp + cfg->max_roots * 8);
-        s.h_count_pad = reinterpret_cast<int32_t*>(hp + cfg->max_roots * 8 + r4(cfg->max_roots) * 4);
+        if (cfg->tgn) {
+            s.h_stage = hp;
+            s.h_count_pad = reinterpret_cast<int32_t*>(hp + r64(toff[6]) * 4);
+            s.h_u.resize((size_t)cfg->max_roots); s.h_newt.resize((size_t)cfg->max_roots);
+        } else {
+            s.h_times = reinterpret_cast<double*>(hp);
+            s.h_ids = reinterpret_cast<int32_t*>(hp + cfg->max_roots * 8);
+            s.h_count_pad = reinterpret_cast<int32_t*>(hp + cfg->max_roots * 8 + r4(cfg->max_roots) * 4);
+        }
         hp += per;
         for (hipEvent_t* ev : {&s.copied, &s.counted, &s.ready, &s.consumed}) {
             e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
             if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
         }
+    }
+    if (cfg->tgn) {                       // the touched-node set's times: all zero, never written
+        e = hipMemset(st->tb.zero_t, 0, sizeof(float) * (size_t)st->tb.max_u);
+        if (e != hipSuccess) return fail("hipMemset", e);
     }
     *out = st;
     return TG_OK;
@@ -253,6 +316,7 @@ extern "C" int tg_stepper_regions(const tg_stepper* st, const float* d_arena, in
 // of one batch -- [src | dst], [src | dst | negative dst] -- are passed concatenated, their times repeated).
 extern "C" int tg_stepper_prepare_begin(tg_stepper* st, int slot, const int64_t* h_ids, const double* h_times, int64_t n_roots) {
     TG_REQUIRE(st && h_ids && h_times, "tg_stepper_prepare_begin: null pointer");
+    TG_REQUIRE(!st->c.tgn, "tg_stepper_prepare_begin: a TGN stepper prepares with tg_stepper_tgn_prepare_begin");
     TG_REQUIRE(slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_prepare_begin: slot");
     TG_REQUIRE(n_roots > 0 && n_roots <= st->c.max_roots, "tg_stepper_prepare_begin: more roots than the stepper was sized for");
     Slot& s = st->slots[(size_t)slot];
@@ -302,7 +366,13 @@ extern "C" int tg_stepper_prepare_finish(tg_stepper* st, int slot, int64_t* rows
     TG_REQUIRE(s.state == Slot::BEGUN, "tg_stepper_prepare_finish: prepare_begin first");
     hipStream_t sd = st->side;
     const int k = st->c.k;
-    if (st->c.layers == 2) {
+    if (st->c.tgn) {
+        TG_HIP_CHECK(hipEventSynchronize(s.counted));
+        s.uniq_count = s.h_count_pad[0];
+        s.pad = s.h_count_pad[1];
+        TG_REQUIRE(s.uniq_count >= 0 && s.uniq_count <= st->tb.max_u, "tg_stepper_prepare_finish: distinct-node count out of range");
+        s.count1 = s.uniq_count;
+    } else if (st->c.layers == 2) {
         if (st->c.dedupe) {
             TG_HIP_CHECK(hipEventSynchronize(s.counted));
             s.count1 = s.h_count_pad[0];
@@ -342,14 +412,25 @@ extern "C" int tg_stepper_slot_view(const tg_stepper* st, int slot, void** p6, i
 // ---- forward of every layer ------------------------------------------------------------------------------------------------------------
 // seeds: 2 per layer (attention dropout, residual dropout), layer 1 first -- the order flid_amd/engine.py draws them in.
 // *d_emb: (roots, dn) embeddings h^L inside the arena, valid until the next forward.
+namespace {
+// what the lowest layer reads: the node table by node id (TGAT), or a compact per-batch table through row maps (TGN)
+struct Base { const float* table; int64_t ld; const int32_t* feat_idx0; const int32_t* gather_idx; };
+int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int training, const uint64_t* seeds, void* stream, float** d_emb);
+}  // namespace
+
 extern "C" int tg_stepper_forward(tg_stepper* st, int slot, int training, const uint64_t* seeds, void* stream, float** d_emb) {
     TG_REQUIRE(st && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_forward: slot");
+    TG_REQUIRE(!st->c.tgn, "tg_stepper_forward: a TGN stepper runs tg_stepper_tgn_forward");
     Slot& s = st->slots[(size_t)slot];
     TG_REQUIRE(s.state == Slot::READY, "tg_stepper_forward: the slot holds no finished preparation");
+    TG_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, s.ready, 0));
+    return run_forward(st, s, slot, Base{st->c.d_node, st->c.node_ld, s.S_nbr, s.ids_all}, training, seeds, stream, d_emb);
+}
+
+namespace {
+int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int training, const uint64_t* seeds, void* stream, float** d_emb) {
     const tg_stepper_cfg& c = st->c;
     const int L = c.layers, H = c.heads, dn = c.dn, T = c.dt_dim, dq = st->dq, k = c.k;
-    hipStream_t ms = (hipStream_t)stream;
-    TG_HIP_CHECK(hipStreamWaitEvent(ms, s.ready, 0));
     const float p_eff = training ? c.dropout_p : 0.f;
     TG_REQUIRE(p_eff == 0.f || seeds, "tg_stepper_forward: dropout needs seeds");
     float* te_w = c.d_param + st->poff[0];
@@ -363,12 +444,13 @@ extern "C" int tg_stepper_forward(tg_stepper* st, int slot, int training, const 
         st->fwd_rows[l - 1] = R;
         tg_layer_desc& d = st->desc[(size_t)l - 1];
         tg_attn_desc& a = d.attn;
-        if (l == 1) { a.d_feat = c.d_node; a.feat_ld = c.node_ld; a.d_feat_idx = s.S_nbr; }
+        if (l == 1) { a.d_feat = base.table; a.feat_ld = base.ld; a.d_feat_idx = base.feat_idx0; }
         else { a.d_feat = H_prev; a.feat_ld = dn; a.d_feat_idx = s.child; }
         a.d_edge = c.d_edge; a.edge_ld = c.edge_ld; a.d_edge_idx = s.S_eid;
         a.d_nbr = s.S_nbr; a.d_dt = s.S_dt; a.d_te_w = te_w; a.d_te_b = te_b;
         a.m = R; a.k = k; a.heads = H; a.dn = dn; a.de = c.de; a.dt_dim = T;
-        a.scale = (float)pow((double)st->hd, -0.5);        // float(head_dim ** -0.5), as the Python engine passes it a.dropout_p = p_eff; a.seed = p_eff > 0.f ? seeds[2 * (l - 1)] : 0; a.row0 = 0;
+        a.scale = (float)pow((double)st->hd, -0.5);        // float(head_dim ** -0.5), as the Python engine passes it
+        a.dropout_p = p_eff; a.seed = p_eff > 0.f ? seeds[2 * (l - 1)] : 0; a.row0 = 0;
         d.params = params_at(c.d_param, st->poff, l - 1);
         d.raw = b.y + dq; d.raw_ld = dq + dn;
         if (l == 1) { d.own = d.raw; d.own_ld = d.raw_ld; } else { d.own = H_prev; d.own_ld = dn; }
@@ -378,15 +460,16 @@ extern "C" int tg_stepper_forward(tg_stepper* st, int slot, int training, const 
         d.mean = b.mean; d.rstd = b.rstd; d.f1 = b.f1; d.out = b.out; d.wT = b.wT;
         d.y_ld = dq + dn;
         d.compute_cosb = l == 1;
-        d.gather_table = c.d_node; d.gather_ld = c.node_ld; d.gather_idx = s.ids_all;
-        TG_TRY(tg_tgat_layer_fwd(&d, stream));
+        d.gather_table = base.table; d.gather_ld = base.ld; d.gather_idx = base.gather_idx;
         H_prev = b.out;
     }
+    for (int l = 1; l <= L; ++l) TG_TRY(tg_tgat_layer_fwd(&st->desc[(size_t)l - 1], stream));
     s.state = Slot::FORWARDED;
     st->fwd_slot = slot;
     if (d_emb) *d_emb = st->lay.back().out;
     return TG_OK;
 }
+}  // namespace
 
 // ---- backward of every layer (+ the optimizer's update) -------------------------------------------------------------------------------
 // d_demb: (roots, dn) gradient of the loss w.r.t. the embeddings.  The gradient block [te_w | te_b | layer parameters ...], laid out like
@@ -395,25 +478,25 @@ extern "C" int tg_stepper_forward(tg_stepper* st, int slot, int training, const 
 // caller starts reducing it under the lower layers' backward); everything on side streams is joined first.
 // adam (optional): the update of torch.optim.Adam on the flat parameter right behind the last layer's backward -- not with grad_ready
 // (the caller reduces first and applies the update itself).
-extern "C" int tg_stepper_backward(tg_stepper* st, int slot, const float* d_demb, void* stream, tg_grad_ready_fn grad_ready, void* user,
-                                   const tg_adam_args* adam, float** d_grad) {
-    TG_REQUIRE(st && d_demb && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_backward: arguments");
-    Slot& s = st->slots[(size_t)slot];
-    TG_REQUIRE(s.state == Slot::FORWARDED && st->fwd_slot == slot, "tg_stepper_backward: the last forward ran another slot");
-    TG_REQUIRE(!(adam && grad_ready), "tg_stepper_backward: reduce first, then apply the update");
+namespace {
+// gradient w.r.t. the lowest layer's table (TGN: the compact `memory' + raw` table) -- null for TGAT, whose node table carries none
+struct BaseGrad { float* d_table; int64_t pad_row; float* d_own; float* d_raw; };
+
+// the layers' backward calls; `fill_extra` floats behind the lower layers' gradient rows are zeroed with the gradient block
+int run_backward(tg_stepper* st, Slot& s, const float* d_demb, void* stream, tg_grad_ready_fn grad_ready, void* user, bool fuse_tb,
+                 const BaseGrad& bg, int64_t fill_extra) {
     const tg_stepper_cfg& c = st->c;
     const int L = c.layers, dn = c.dn;
     hipStream_t ms = (hipStream_t)stream;
     // ONE zero fill: parameter gradients + scratch + the gradient rows of the lower layers' outputs that this batch has
     int64_t fill = st->g_rows;
     for (int l = L; l > 1; --l) fill += r4(st->fwd_rows[l - 2] * dn);
-    TG_HIP_CHECK(hipMemsetAsync(st->gblock, 0, sizeof(float) * (size_t)fill, ms));
+    TG_HIP_CHECK(hipMemsetAsync(st->gblock, 0, sizeof(float) * (size_t)(fill + fill_extra), ms));
     float* g = st->gblock;
     const float* dH = d_demb;
     int64_t rows_off = st->g_rows;
     int rc = TG_OK;
     for (int l = L; l >= 1 && rc == TG_OK; --l) {
-        const int64_t R = st->fwd_rows[l - 1];
         LayerBuf& b = st->lay[(size_t)l - 1];
         tg_layer_bwd_desc bw{};
         const tg_layer_params gp = params_at(g, st->poff, l - 1);
@@ -421,7 +504,7 @@ extern "C" int tg_stepper_backward(tg_stepper* st, int slot, const float* d_demb
                                   const_cast<float*>(gp.ln_b), const_cast<float*>(gp.Wr), const_cast<float*>(gp.br), const_cast<float*>(gp.W1),
                                   const_cast<float*>(gp.b1), const_cast<float*>(gp.W2), const_cast<float*>(gp.b2)};
         bw.dout = dH;
-        bw.df1 = b.df1; bw.dy = b.dy; bw.dsum = b.dsum; bw.dres = c.dropout_p > 0.f && st->desc[(size_t)l - 1].res_dropout_p > 0.f ? b.dres : nullptr;
+        bw.df1 = b.df1; bw.dy = b.dy; bw.dsum = b.dsum; bw.dres = st->desc[(size_t)l - 1].res_dropout_p > 0.f ? b.dres : nullptr;
         bw.dctx = b.dctx; bw.dagg = b.dagg; bw.du = b.du; bw.dq = b.dq; bw.part = b.part;
         bw.vec = g + st->g_vec + (l - 1) * st->vlen;
         bw.d_cosb = g + st->g_cosb; bw.d_tew = g + st->poff[0]; bw.d_teb = g + st->poff[1];
@@ -432,12 +515,13 @@ extern "C" int tg_stepper_backward(tg_stepper* st, int slot, const float* d_demb
             bw.dfeat = dH_prev; bw.dfeat_ld = dn; bw.pad_row = s.pad;
             bw.d_own = dH_prev; bw.d_own_ld = dn; bw.d_own_accumulate = 1;
         } else {
-            bw.dfeat = nullptr; bw.dfeat_ld = 0; bw.pad_row = 0;                    // the node table carries no gradient (models/TGAT.py:26-29)
-            bw.d_own = nullptr; bw.d_own_ld = 0; bw.d_own_accumulate = 0;
+            // TGAT: the node table carries no gradient (models/TGAT.py:26-29); TGN: the compact table does (the GRU's output)
+            bw.dfeat = bg.d_table; bw.dfeat_ld = bg.d_table ? dn : 0; bw.pad_row = bg.d_table ? bg.pad_row : 0;
+            bw.d_own = bg.d_own; bw.d_own_ld = bg.d_own ? dn : 0; bw.d_own_accumulate = 0;
+            bw.d_raw = bg.d_raw;
         }
-        bw.d_raw = nullptr;
         bw.defer_join = (l > 1 && !grad_ready) ? 1 : 0;
-        bw.finish_time_bias = l == 1;
+        bw.finish_time_bias = (l == 1 && !fuse_tb) ? 1 : 0;
         rc = tg_tgat_layer_bwd(&st->desc[(size_t)l - 1], &bw, stream);
         if (rc == TG_OK && grad_ready && l >= 2) {
             const int64_t lo = st->poff[2 + (size_t)(l - 1) * 11], hi = l < L ? st->poff[2 + (size_t)l * 11] : st->poff.back();
@@ -446,14 +530,147 @@ extern "C" int tg_stepper_backward(tg_stepper* st, int slot, const float* d_demb
         dH = dH_prev;
     }
     const int rj = tg_side_join(stream);          // queued side-stream products must not outlive this call's operands
-    if (rc == TG_OK) rc = rj;
-    if (rc == TG_OK && adam)
-        rc = tg_adam_f32(c.d_param, g, adam->d_exp_avg, adam->d_exp_avg_sq, adam->n > 0 ? adam->n : st->poff.back(), adam->lr, adam->beta1, adam->beta2,
-                         adam->eps, adam->weight_decay, adam->step, stream);
+    return rc != TG_OK ? rc : rj;
+}
+
+int finish_backward(tg_stepper* st, Slot& s, int rc, void* stream, const tg_adam_args* adam, float** d_grad) {
+    const tg_stepper_cfg& c = st->c;
+    float* g = st->gblock;
+    if (rc == TG_OK && adam)       // d b -= sin(b) d cos(b) rides in the update's launch
+        rc = tg::adam_time_bias(c.d_param, g, adam->d_exp_avg, adam->d_exp_avg_sq, adam->n > 0 ? adam->n : st->ptotal, adam->lr, adam->beta1,
+                                adam->beta2, adam->eps, adam->weight_decay, adam->step, st->poff[1], c.dt_dim, g + st->g_cosb, stream);
     // the slot's lists have been read for the last time once everything above has run
-    if (hipEventRecord(s.consumed, ms) == hipSuccess) s.consumed_pending = true;
+    if (hipEventRecord(s.consumed, (hipStream_t)stream) == hipSuccess) s.consumed_pending = true;
     s.state = Slot::FREE;
     st->fwd_slot = -1;
     if (d_grad) *d_grad = g;
     return rc;
+}
+}  // namespace
+
+extern "C" int tg_stepper_backward(tg_stepper* st, int slot, const float* d_demb, void* stream, tg_grad_ready_fn grad_ready, void* user,
+                                   const tg_adam_args* adam, float** d_grad) {
+    TG_REQUIRE(st && d_demb && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_backward: arguments");
+    TG_REQUIRE(!st->c.tgn, "tg_stepper_backward: a TGN stepper runs tg_stepper_tgn_backward");
+    Slot& s = st->slots[(size_t)slot];
+    TG_REQUIRE(s.state == Slot::FORWARDED && st->fwd_slot == slot, "tg_stepper_backward: the last forward ran another slot");
+    TG_REQUIRE(!(adam && grad_ready), "tg_stepper_backward: reduce first, then apply the update");
+    const int rc = run_backward(st, s, d_demb, stream, grad_ready, user, adam != nullptr, BaseGrad{nullptr, 0, nullptr, nullptr}, 0);
+    return finish_backward(st, s, rc, stream, adam, d_grad);
+}
+
+// ==== TGN: the memory stage around ONE attention layer ===================================================================================
+// replaces the host side of models/MemoryModel.py:96-189 (compute_src_dst_node_temporal_embeddings: get_updated_memories over the
+// touched nodes, the embedding, update_memories / store_node_raw_messages of a positive batch) for the fused trainers, as
+// flid_amd/models/MemoryModel.py::train_step did from Python.  The flat parameter carries the GRU cell's four tensors behind the layer's.
+
+// graph-only part of a batch on the side stream: tg_tgn_prepare_batch on the slot's buffers.  n edges; the embedded shard is [lo, hi).
+extern "C" int tg_stepper_tgn_prepare_begin(tg_stepper* st, int slot, const int64_t* h_src, const int64_t* h_dst, const double* h_t,
+                                            const int64_t* h_eid, int64_t n, int64_t lo, int64_t hi) {
+    TG_REQUIRE(st && st->c.tgn && h_src && h_dst && h_t, "tg_stepper_tgn_prepare_begin: arguments");
+    TG_REQUIRE(slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_tgn_prepare_begin: slot");
+    TG_REQUIRE(n > 0 && 2 * n <= st->c.max_roots && 0 <= lo && lo < hi && hi <= n, "tg_stepper_tgn_prepare_begin: more edges than the stepper was sized for");
+    Slot& s = st->slots[(size_t)slot];
+    TG_REQUIRE(s.state == Slot::FREE, "tg_stepper_tgn_prepare_begin: the slot still holds a batch (finish its step or release it)");
+    const int k = st->c.k;
+    hipStream_t sd = st->side;
+    if (s.consumed_pending) { TG_HIP_CHECK(hipStreamWaitEvent(sd, s.consumed, 0)); s.consumed_pending = false; }
+    if (s.nb > 0) TG_HIP_CHECK(hipEventSynchronize(s.copied));
+    TG_TRY(tg_tgn_prepare_layout(n, hi - lo, k, s.off));
+    const int64_t total = s.off[7] - s.off[4];
+    int64_t nu = 0;
+    // (the times of the touched-node set are all zero: st->tb.zero_t is zero-filled at creation and never written)
+    TG_TRY(tg_tgn_prepare_batch(st->c.graph, h_src, h_dst, h_t, h_eid, n, lo, hi, k, tg_graph_num_rows(st->c.graph), s.h_stage, s.blob, s.S_eid, s.S_t,
+                                s.S_dt, st->tb.zero_t, tg_dedupe_capacity(total), st->ded_keys, st->ded_vals, st->ded_pos, s.uniq, s.uniq_t, s.rowmap,
+                                s.count_pad, s.h_count_pad, s.h_u.data(), s.h_newt.data(), &nu, sd));
+    TG_HIP_CHECK(hipEventRecord(s.copied, sd));
+    TG_HIP_CHECK(hipEventRecord(s.counted, sd));
+    s.h_nu = nu; s.nb = n; s.lo = lo; s.hi = hi; s.n = 2 * (hi - lo); s.has_eid = h_eid != nullptr;
+    s.S_nbr = s.blob + s.off[6];
+    s.ids_all = s.rowmap;                 // the roots' rows of the compact table
+    s.state = Slot::BEGUN;
+    return TG_OK;
+}
+
+namespace {
+inline bool any_pending(const tg_tgn_bank* b) {
+    for (int64_t i = 0; i < b->num_nodes; ++i) if (b->h_has[i]) return true;
+    return false;
+}
+int check_bank(const tg_tgn_bank* b, const tg_stepper* st) {
+    TG_REQUIRE(b && b->d_mem && b->d_last_update && b->d_msg && b->d_has && b->d_msg_time && b->d_last_idx_ws && b->h_has && b->h_msg_time && b->h_last,
+               "tg_stepper_tgn: null pointer in the memory bank");
+    TG_REQUIRE(b->num_nodes == tg_graph_num_rows(st->c.graph) || b->num_nodes > 0, "tg_stepper_tgn: num_nodes");
+    return TG_OK;
+}
+}  // namespace
+
+// updated memory rows of the touched nodes (GRU on their pending messages, not persisted), `memory' + raw` as the layer's table, the layer
+extern "C" int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_bank* bank, int training, const uint64_t* seeds, void* stream,
+                                      float** d_emb) {
+    TG_REQUIRE(st && st->c.tgn && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_tgn_forward: arguments");
+    TG_TRY(check_bank(bank, st));
+    Slot& s = st->slots[(size_t)slot];
+    TG_REQUIRE(s.state == Slot::READY, "tg_stepper_tgn_forward: the slot holds no finished preparation");
+    TG_REQUIRE(!bank->past_violation, "Trying to update memory to time in the past!");          // models/MemoryModel.py:515-516
+    const tg_stepper_cfg& c = st->c;
+    const int D = c.dn;
+    TG_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, s.ready, 0));
+    const bool pending = any_pending(bank);
+    st->fwd_pending = pending;
+    TgnBuf& t = st->tb;
+    float* P = c.d_param;
+    TG_TRY(tg_tgn_rows_fwd(bank->d_mem, bank->mem_ld, bank->d_msg, bank->msg_ld, c.d_node, c.node_ld, s.uniq, s.uniq_count, bank->d_has, D, st->md,
+                           P + st->gru_off[0], P + st->gru_off[1], P + st->gru_off[2], P + st->gru_off[3], pending ? 1 : 0, t.h_rows,
+                           pending ? t.msg_rows : nullptr, pending ? t.gi : nullptr, pending ? t.gh : nullptr, t.rows, t.base, stream));
+    const int64_t roots = s.n, nb2 = 2 * s.nb;
+    return run_forward(st, s, slot, Base{t.base, D, s.rowmap + roots + nb2, s.rowmap}, training, seeds, stream, d_emb);
+}
+
+// backward of the layer and of the GRU; positive != 0: the state advance of models/MemoryModel.py:155-180 (persist the batch nodes' GRU rows,
+// build the new raw messages from the post-update state, file them last-message-wins; the host mirrors first: TG_EINVAL "Trying to update
+// memory to time in the past!" leaves everything unchanged) BEFORE the update of the parameters, as the trainers order it.
+extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* bank, const float* d_demb, int positive, void* stream,
+                                       const tg_adam_args* adam, float** d_grad) {
+    TG_REQUIRE(st && st->c.tgn && d_demb && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_tgn_backward: arguments");
+    TG_TRY(check_bank(bank, st));
+    Slot& s = st->slots[(size_t)slot];
+    TG_REQUIRE(s.state == Slot::FORWARDED && st->fwd_slot == slot, "tg_stepper_tgn_backward: the last forward ran another slot");
+    TG_REQUIRE(!positive || s.has_eid, "tg_stepper_tgn_backward: a positive batch needs its edge ids (prepare_begin)");
+    const tg_stepper_cfg& c = st->c;
+    const int D = c.dn, MD = st->md;
+    const bool pending = st->fwd_pending;
+    TgnBuf& t = st->tb;
+    float* g = st->gblock;
+    float* d_table = g + st->g_rows;                       // behind the (absent) lower layers' rows: zeroed with the block
+    const int64_t U = s.uniq_count, roots = s.n, nb2 = 2 * s.nb;
+    int rc = run_backward(st, s, d_demb, stream, nullptr, nullptr, adam != nullptr,
+                          pending ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw} : BaseGrad{nullptr, 0, nullptr, nullptr}, pending ? r4(U * D) : 0);
+    if (rc == TG_OK && pending) {
+        // the merge layer's and the query's share of the gradient w.r.t. the roots' own rows, then the GRU
+        rc = tg_scatter_add_rows(t.d_own, D, s.rowmap, roots, D, d_table, D, stream);
+        if (rc == TG_OK) rc = tg_scatter_add_rows(t.d_raw, D, s.rowmap, roots, D, d_table, D, stream);
+        if (rc == TG_OK) rc = tg_gru_gates_bwd_masked(t.gi, t.gh, t.h_rows, d_table, s.uniq, bank->d_has, U, D, t.dgi, t.dgh, stream);
+        if (rc == TG_OK) {
+            const tg_wgrad_job jobs[2] = {{t.dgi, 3 * (int64_t)D, 3 * D, t.msg_rows, MD, MD, g + st->gru_off[0], MD, g + st->gru_off[2]},
+                                          {t.dgh, 3 * (int64_t)D, 3 * D, t.h_rows, D, D, g + st->gru_off[1], D, g + st->gru_off[3]}};
+            rc = tg_wgrad_group(2, jobs, U, stream);
+        }
+    }
+    if (rc == TG_OK && positive) {
+        int viol = 0;
+        rc = tg_tgn_host_advance(s.h_u.data(), s.h_newt.data(), s.h_nu, bank->h_has, bank->h_msg_time, bank->h_last, bank->num_nodes, &viol);
+        if (rc == TG_OK) {
+            if (viol) bank->past_violation = 1;
+            const int32_t *batch_d = s.blob + s.off[5], *b_d = s.blob + s.off[1], *e_d = s.blob + s.off[2];
+            const float* t32_d = reinterpret_cast<const float*>(s.blob + s.off[3]);
+            rc = tg_tgn_persist(t.rows, D, s.rowmap + roots, batch_d, bank->d_has, bank->d_msg_time, bank->d_mem, bank->mem_ld, bank->d_last_update, nb2, D, stream);
+            if (rc == TG_OK)
+                rc = tg_build_messages(bank->d_mem, bank->mem_ld, bank->d_last_update, batch_d, b_d, t32_d, c.d_edge, c.edge_ld, e_d, c.d_param + st->poff[0],
+                                       c.d_param + st->poff[1], nb2, D, c.de, c.dt_dim, t.msgs, stream);
+            if (rc == TG_OK)
+                rc = tg_msg_scatter_last(batch_d, t.msgs, MD, t32_d, nb2, MD, bank->d_msg, bank->msg_ld, bank->d_has, bank->d_msg_time, bank->d_last_idx_ws, stream);
+        }
+    }
+    return finish_backward(st, s, rc, stream, adam, d_grad);
 }

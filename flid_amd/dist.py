@@ -131,15 +131,3 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
-
-
-def all_gather_rows(x: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
-    """concatenate per-rank row blocks of possibly different heights (used for the TGN raw-message exchange)"""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return x
-    mx = max(counts)
-    pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    pad[:x.shape[0]] = x
-    out = [torch.empty_like(pad) for _ in counts]
-    dist.all_gather(out, pad, group=group)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)

@@ -557,7 +557,8 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_
                 d_own, acc = (torch.empty((R, Dn), device=dev), False) if table_grad else (None, False)
             v0 = npar + xt + _r4(T) + (l - 1) * vlen
             d_raw = lay.backward(dH[:R], params, zeroed[offs[2 + (l - 1) * 11]:], zeroed[v0:v0 + vlen], d_cosb, d_tew, d_teb,
-                                 dfeat, pad_row, d_own, acc, table_grad, slot=l, defer_join=l > 1, finish_time_bias=l == 1)
+                                 dfeat, pad_row, d_own, acc, table_grad, slot=l, defer_join=l > 1 and grad_ready is None,
+                                 finish_time_bias=l == 1)
             alive += [dH_prev, d_own, d_raw]
             if table_grad:
                 if l >= 2:
@@ -569,6 +570,8 @@ def _native_backward(cfg, fr, table, te_w, te_b, layer_params, saved, dH, extra_
             if grad_ready is not None and l >= 2:
                 # layer l's own parameter gradients are final once its backward is queued (the time encoder's block keeps
                 # accumulating until layer 1): a data-parallel caller can start reducing this segment under the lower layers' backward
+                # (with grad_ready the layer joined its side streams before returning -- defer_join off above: the segment is complete
+                # in stream order, also under tg_set_overlap(1))
                 lo_ = offs[2 + (l - 1) * 11]
                 hi_ = offs[2 + l * 11] if l < L else npar
                 grad_ready(zeroed[lo_:hi_])

@@ -321,13 +321,30 @@ class MemoryModel(torch.nn.Module):
         self._flat_pack = [flat_param, views]
         return flat_param
 
-    def train_step(self, prepared, edge_ids, loss_fn, num_neighbors: int = 20):
+    def enable_native_step(self, max_batch_edges: int, num_neighbors: int = 20, slots: int = 4):
+        """Opt-in (not in the reference; needs flatten_parameters()): prepare_batch_begin(edge_ids=...) / prepare_batch_finish / train_step go
+        through ONE native object (flid_amd.stepper.Stepper, csrc/tg_step.hip) -- the graph-only preparation, the forward (GRU on the
+        touched rows + the layer) and the backward + state advance + Adam are a C call each, every launch issued by the library out of a
+        pre-sized arena.  A prepared batch of this mode is consumed by train_step."""
+        from ..stepper import Stepper
+        self._stepper = Stepper(self, 2 * int(max_batch_edges), num_neighbors, slots)
+        return self._stepper
+
+    def train_step(self, prepared, edge_ids, loss_fn, num_neighbors: int = 20, optimizer=None, edges_are_positive: bool = True):
         """Fused-trainer step on a prepared (prepare_batch_begin / _finish) POSITIVE batch: updated memory rows of the touched
         nodes, embeddings, `loss_fn(emb) -> (loss, d_emb)` on the detached (2 B, D) block [src rows | dst rows], backward into the
         flat parameter's .grad (added, as autograd accumulates), and the state advance (persist, new messages, last-message-wins
         scatter) -- no autograd graph, ~40 launches.  Same kernels and numbers as compute_src_dst_node_temporal_embeddings +
         loss.backward()."""
         from .._lib import check, lib
+        from ..stepper import StepJob
+        if isinstance(prepared, StepJob):
+            # (optimizer: a FlatAdam over the flat parameter -- its update is issued behind the state advance, in the backward's call)
+            assert prepared.finished and prepared.k == int(num_neighbors) and prepared.stepper is getattr(self, "_stepper", None), \
+                "prepared by another stepper / not finished"
+            return prepared.stepper.step_tgn(prepared, loss_fn, positive=edges_are_positive, optimizer=optimizer)
+        if optimizer is not None or not edges_are_positive:
+            raise NotImplementedError("train_step(optimizer=..., edges_are_positive=False) are the native step's (enable_native_step())")
         flat = getattr(self, "_flat_pack", None)
         if flat is None:
             raise RuntimeError("MemoryModel.train_step needs the flat-parameter mode: call flatten_parameters() first")
@@ -424,6 +441,10 @@ class MemoryModel(torch.nn.Module):
         `src_node_ids` of compute_src_dst_node_temporal_embeddings / compute_shard_embeddings_and_advance (dst / times then None)."""
         import ctypes as C
         from .._lib import check, lib
+        st = getattr(self, "_stepper", None)
+        if st is not None and int(num_neighbors) == st.k:
+            assert int(num_neighbors) > 0, 'Number of sampled neighbors for each node should be greater than 0!'
+            return st.begin_tgn(src_node_ids, dst_node_ids, node_interact_times, edge_ids, shard)
         dev = self.node_raw_features.device
         src = np.ascontiguousarray(src_node_ids, dtype=np.int64)
         dst = np.ascontiguousarray(dst_node_ids, dtype=np.int64)
@@ -482,6 +503,9 @@ class MemoryModel(torch.nn.Module):
                     keep=(stage, dev_all, src, dst, times, eid))
 
     def prepare_batch_finish(self, job):
+        from ..stepper import StepJob
+        if isinstance(job, StepJob):
+            return job.stepper.finish(job)
         job["ready"].synchronize()
         count, pad = job["count_host"].tolist()
         job["uniq"] = job["uniq"][:count]

@@ -26,17 +26,20 @@ class StepJob:
 
 
 class Stepper:
-    """model: a TGAT in flat-parameter mode (flatten_parameters()).  max_roots: roots of one prepared batch at most."""
+    """model: a TGAT or a MemoryModel (TGN, one layer) in flat-parameter mode (flatten_parameters()).  max_roots: roots of one prepared
+    batch at most (TGN: 2 x the edges of a batch)."""
 
     def __init__(self, model, max_roots: int, num_neighbors: int = 20, slots: int = 4, dedupe=None):
         flat = getattr(model, "_flat_pack", None)
         if flat is None:
             raise RuntimeError("Stepper needs the flat-parameter mode: call flatten_parameters() first")
-        if model.neighbor_sampler.sample_neighbor_strategy != "recent":
+        self.tgn = hasattr(model, "memory_bank")
+        sampler = model.embedding_module.neighbor_sampler if self.tgn else model.neighbor_sampler
+        if sampler.sample_neighbor_strategy != "recent":
             raise NotImplementedError("the native step samples on the device ('recent')")
         self.model, self.flat = model, flat[0]
         self.k, self.num_layers = int(num_neighbors), int(model.num_layers)
-        self.graph = model.neighbor_sampler.graph
+        self.graph = sampler.graph
         node, edge = model.node_raw_features, model.edge_raw_features
         dev = node.device
         cfg = StepperCfg()
@@ -50,6 +53,7 @@ class Stepper:
         cfg.dropout_p = float(model.dropout)
         cfg.dedupe = int(engine.DEDUPE if dedupe is None else dedupe)
         cfg.extra_grad_floats = 0
+        cfg.tgn = int(self.tgn)
         need = int(lib().tg_stepper_param_floats(C.byref(cfg)))
         if need != self.flat.numel():
             raise RuntimeError(f"flat parameter holds {self.flat.numel()} floats, the native layout {need}")
@@ -90,8 +94,8 @@ class Stepper:
         t = np.ascontiguousarray(node_interact_times, dtype=np.float64)
         times = np.ascontiguousarray(np.tile(t, len(id_lists))) if len(id_lists) > 1 else t
         slot = self._next
-        self._next = (self._next + 1) % self.nslots
         check(lib().tg_stepper_prepare_begin(self._h, slot, ids.ctypes.data, times.ctypes.data, len(ids)), "tg_stepper_prepare_begin")
+        self._next = (slot + 1) % self.nslots
         return StepJob(self, slot, len(ids), len(id_lists[0]))
 
     def finish(self, job: StepJob) -> StepJob:
@@ -145,6 +149,67 @@ class Stepper:
             self.flat.grad = self.grad
         else:
             prev.add_(self.grad)                                    # as autograd accumulates
+
+    # ---- TGN: the memory stage around the layer (tg_stepper_tgn_*) -------------------------------------------------------------------
+    def begin_tgn(self, src, dst, t, edge_ids=None, shard=None) -> StepJob:
+        src, dst = np.ascontiguousarray(src, dtype=np.int64), np.ascontiguousarray(dst, dtype=np.int64)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        eid = None if edge_ids is None else np.ascontiguousarray(edge_ids, dtype=np.int64)
+        n = len(src)
+        lo, hi = (0, n) if shard is None else shard
+        slot = self._next
+        check(lib().tg_stepper_tgn_prepare_begin(self._h, slot, src.ctypes.data, dst.ctypes.data, t.ctypes.data,
+                                                 None if eid is None else eid.ctypes.data, n, lo, hi), "tg_stepper_tgn_prepare_begin")
+        self._next = (slot + 1) % self.nslots
+        return StepJob(self, slot, 2 * (hi - lo), hi - lo)
+
+    def _bank(self):
+        from ._lib import TgnBank
+        b = self.model.memory_bank
+        mem = b.node_memories.data
+        if b._has.dtype != np.bool_ or b._msg_time.dtype != np.float64 or b._h_last.dtype != np.float32:
+            raise RuntimeError("memory bank host mirrors changed type")
+        return TgnBank(mem.data_ptr(), mem.stride(0), b.node_last_updated_times.data.data_ptr(), b._msg.data_ptr(), b._msg.stride(0),
+                       b._has_dev.data_ptr(), b._msg_time_dev.data_ptr(), b._last_idx_ws.data_ptr(), b._has.ctypes.data, b._msg_time.ctypes.data,
+                       b._h_last.ctypes.data, len(b._has), int(bool(b._past_violation)))
+
+    def forward_tgn(self, job: StepJob) -> torch.Tensor:
+        training = bool(self.model.training)
+        if training and self.cfg.dropout_p > 0:
+            for i, v in enumerate(engine._next_seeds(2 * self.num_layers)):
+                self._seeds[i] = v
+        bank = self._bank()
+        check(lib().tg_stepper_tgn_forward(self._h, job.slot, C.byref(bank), int(training), self._seeds, ops._stream(), None), "tg_stepper_tgn_forward")
+        emb = self._emb_views.get(job.n)
+        if emb is None:
+            emb = self._emb_views[job.n] = self.arena[self._emb_off:self._emb_off + job.n * self.dn].view(job.n, self.dn)
+        return emb
+
+    def backward_tgn(self, job: StepJob, d_emb: torch.Tensor, positive: bool = True, optimizer=None):
+        assert d_emb.is_contiguous() and d_emb.dtype == torch.float32 and d_emb.numel() == job.n * self.dn
+        prev = self.flat.grad
+        if prev is not None and prev.data_ptr() == self.grad.data_ptr():
+            prev = None
+        if prev is not None and optimizer is not None:
+            raise RuntimeError("Stepper.backward_tgn: zero_grad(set_to_none=True) first (the update runs on this step's gradient block)")
+        adam = None if optimizer is None else optimizer.native_args(self.flat)
+        bank = self._bank()
+        try:
+            check(lib().tg_stepper_tgn_backward(self._h, job.slot, C.byref(bank), d_emb.data_ptr(), int(bool(positive)), ops._stream(),
+                                                None if adam is None else C.byref(adam), None), "tg_stepper_tgn_backward")
+        finally:
+            if bank.past_violation:
+                self.model.memory_bank._past_violation = True
+        if prev is None:
+            self.flat.grad = self.grad
+        else:
+            prev.add_(self.grad)
+
+    def step_tgn(self, job: StepJob, loss_fn, positive: bool = True, optimizer=None):
+        emb = self.forward_tgn(job)
+        loss, d_emb = loss_fn(emb)
+        self.backward_tgn(job, d_emb, positive=positive, optimizer=optimizer)
+        return emb, loss
 
     def step(self, job: StepJob, loss_fn, grad_ready=None, optimizer=None):
         """forward, `loss_fn(emb) -> (loss, d loss / d emb)`, backward (+ update): (embeddings, loss)"""

@@ -241,7 +241,20 @@ typedef struct tg_stepper_cfg {
     float dropout_p;                             /* train-mode dropout of the attention weights and of the residual path */
     int dedupe;                                  /* 1: repeated (node, time) rows inside a batch are computed once (flid_amd/engine.py row sharing) */
     int64_t extra_grad_floats;                   /* room behind the parameter gradients for the caller's own (zero-filled with them) */
+    int tgn;                                     /* 1: the memory stage of models/MemoryModel.py under ONE layer (tg_stepper_tgn_*): the flat parameter
+                                                  * continues with nn.GRUCell's weight_ih (3 dn, 2 dn + dt_dim + de), weight_hh (3 dn, dn), bias_ih,
+                                                  * bias_hh; d_node = the raw node features; max_roots = 2 x the edges of a batch */
 } tg_stepper_cfg;
+/* TGN state (models/MemoryModel.py:334-459 MemoryBank as flid_amd keeps it): memory (N, dn), last-update times (N), the pending-message
+ * table (N, 2 dn + dt_dim + de: only a node's LAST message is ever read, :312-320) with its device flags / times, the all -1 workspace of
+ * tg_msg_scatter_last, and the HOST mirrors of the scalars the reference's assertion needs (:485-486).  Passed per call: the trainers
+ * re-create the bank's arrays (epoch reset, backup / reload). */
+typedef struct tg_tgn_bank {
+    float* d_mem; int64_t mem_ld; float* d_last_update;
+    float* d_msg; int64_t msg_ld; int32_t* d_has; float* d_msg_time; int32_t* d_last_idx_ws;
+    uint8_t* h_has; double* h_msg_time; float* h_last; int64_t num_nodes;
+    int past_violation;                          /* in: the reference's next get_updated_memories would raise; out: set by a state advance */
+} tg_tgn_bank;
 typedef void (*tg_grad_ready_fn)(void* user, float* d_segment, int64_t floats);
 typedef struct tg_adam_args {                    /* torch.optim.Adam's update (utils/utils.py:40-60 create_optimizer), as tg_adam_f32 */
     float *d_exp_avg, *d_exp_avg_sq; int64_t n;  /* n = 0: the whole flat parameter */
@@ -265,6 +278,14 @@ int tg_stepper_slot_view(const tg_stepper* st, int slot, void** p6, int64_t* pad
 int tg_stepper_forward(tg_stepper* st, int slot, int training, const uint64_t* seeds, void* stream, float** d_emb);
 int tg_stepper_backward(tg_stepper* st, int slot, const float* d_demb, void* stream, tg_grad_ready_fn grad_ready, void* user,
                         const tg_adam_args* adam, float** d_grad);
+/* TGN (cfg.tgn): HOST arrays of one batch (n edges; h_eid may be NULL for a negative batch); the embedded shard is edges [lo, hi) (both
+ * roles: 2 (hi - lo) roots), the state advance always covers the whole batch.  Then tg_stepper_prepare_finish, and: */
+int tg_stepper_tgn_prepare_begin(tg_stepper* st, int slot, const int64_t* h_src, const int64_t* h_dst, const double* h_t, const int64_t* h_eid,
+                                 int64_t n, int64_t lo, int64_t hi);
+int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_bank* bank, int training, const uint64_t* seeds, void* stream, float** d_emb);
+/* positive != 0: the state advance of models/MemoryModel.py:155-180 runs behind the backward, before the update */
+int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* bank, const float* d_demb, int positive, void* stream,
+                            const tg_adam_args* adam, float** d_grad);
 
 /* ---- optimizer step for the flat-parameter mode (the trainers' torch.optim.Adam, utils/utils.py:40-60 create_optimizer) ----
  * one element-wise pass over a flat fp32 parameter: exp_avg / exp_avg_sq updated in place, bias-corrected step `step` (>= 1),

@@ -33,10 +33,8 @@ def _worker(rank, world, port, q, single=False):
     loss.backward()
     red = fdist.GradAllReducer(model.parameters())
     red.reduce(weight=(hi - lo) / len(x))              # mean loss over the GLOBAL batch
-    rows = fdist.all_gather_rows(x[lo:hi], [fdist.shard_bounds(len(x), i, world)[1] - fdist.shard_bounds(len(x), i, world)[0] for i in range(world)])
     # numpy, not tensors: a tensor travels through the queue as a shared-memory handle that dies with this process
-    q.put((rank, [p_.grad.numpy().copy() for p_ in model.parameters()], [p_.data.numpy().copy() for p_ in model.parameters()],
-           rows.numpy().copy()))
+    q.put((rank, [p_.grad.numpy().copy() for p_ in model.parameters()], [p_.data.numpy().copy() for p_ in model.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,11 +63,10 @@ def test_grad_allreduce_equals_single_process_full_batch(single):
     x = torch.from_numpy(np.random.RandomState(1).standard_normal((11, 6)).astype(np.float32))
     y = torch.from_numpy(np.random.RandomState(2).standard_normal((11, 3)).astype(np.float32))
     ((model(x) - y) ** 2).mean().backward()
-    for rank, grads, weights, rows in out:
+    for rank, grads, weights in out:
         for g_, w_, p_ in zip(grads, weights, model.parameters()):
             assert np.allclose(w_, p_.data.numpy()), "broadcast_parameters did not install rank 0's weights"
             assert np.allclose(g_, p_.grad.numpy(), atol=1e-6), "weighted all-reduce != full-batch gradient"
-        assert np.array_equal(rows, x.numpy())
 
 
 def test_shard_bounds_partition():

@@ -53,6 +53,28 @@ def test_tgat_b600_matches_reference(name, flat):
     assert lib().tg_version() >= 1
 
 
+@pytest.mark.parametrize("name", ["tgat_B600_full", "tgat_B600_kinkfree"])
+def test_tgat_b600_native_step_matches_reference(name):
+    """the same fixtures through the native stepper (csrc/tg_step.hip: batch preparation, both layers forward, both layers backward as
+    one C call each -- the path bench.py times): embeddings and every parameter gradient against the reference's"""
+    from flid_amd import engine
+    g = load_golden(name)
+    data, p, (bs, bd, bt), r = fullsize.tgat_case(g)
+    m = _tgat(data, p)
+    flat_param = m.flatten_parameters()
+    m.enable_native_step(2 * len(bs), 20)
+    rr = torch.from_numpy(r).cuda().reshape(2 * len(bs), -1).contiguous()
+    job = m.prepare_batch_finish(m.prepare_batch_begin(bs, bd, bt, 20))
+    emb, _ = m.train_step(job, lambda e: (None, rr), 20)
+    np.testing.assert_allclose(emb[:len(bs)].cpu().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(emb[len(bs):].cpu().numpy(), g["d_emb"], atol=TOL)
+    named = [m.time_encoder.w.weight, m.time_encoder.w.bias] + m._layer_params()
+    offs, _ = engine.block_layout(named)
+    by_id = {id(q): flat_param.grad[o:o + q.numel()].view(q.shape) for o, q in zip(offs, named)}
+    grads = {k_: by_id[id(v)].cpu().numpy() for k_, v in m.named_parameters()}
+    assert_grads_match(g, grads, atol=1e-4, rtol=1e-3, kink_frac=0.03, strict=bool(g["kink_free"]))
+
+
 def test_tgn_b600_sequence_matches_reference():
     """30 warm-up batches + 3 recorded batches of 600 at the Reddit shape, train() with gradients, neg-then-pos order"""
     from flid_amd.models.MemoryModel import MemoryModel

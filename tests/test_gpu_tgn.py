@@ -253,6 +253,57 @@ def test_tgn_fused_train_step_equals_autograd_path():
         assert np.array_equal(a._has, c._has) and torch.allclose(a._msg, c._msg, atol=1e-6)
 
 
+def test_tgn_native_step_equals_python_fused_step():
+    """the native stepper's TGN step (csrc/tg_step.hip: preparation, GRU on the touched rows + layer, backward + state advance + Adam as
+    one C call each) against MemoryModel.train_step's Python form on two identically initialised models over 6 positive batches with a
+    two-stage prefetch: embeddings, loss, gradient, the advanced state and the parameters after the update"""
+    from flid_amd import ops
+    from flid_amd.optim import FlatAdam
+    g = load_golden("tgn_small")
+    res = []
+    bsz = 12
+    w = torch.from_numpy(np.random.RandomState(1).standard_normal((2 * bsz, g["node_feat"].shape[1])).astype(np.float32)).cuda()
+    loss_fn = lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w)
+    for native in (False, True):
+        m, p, k = _model(g)
+        flat = m.flatten_parameters()
+        # (a tiny learning rate: Adam turns rounding-level gradients into +-lr steps of either sign, which must not separate the two runs)
+        opt = FlatAdam([flat], lr=1e-7)
+        p0 = flat.detach().clone()
+        m.memory_bank.__init_memory_bank__()
+        if native:
+            m.enable_native_step(bsz, k)
+        batch = lambda b: (g["src"][b * bsz:(b + 1) * bsz], g["dst"][b * bsz:(b + 1) * bsz], g["t"][b * bsz:(b + 1) * bsz])
+        eids = lambda b: g["eid"][b * bsz:(b + 1) * bsz]
+        rec = []
+        jobs = {0: m.prepare_batch_begin(*batch(0), k, edge_ids=eids(0)), 1: m.prepare_batch_begin(*batch(1), k, edge_ids=eids(1))}
+        for b in range(6):
+            opt.zero_grad(set_to_none=True)
+            job = m.prepare_batch_finish(jobs.pop(b))
+            if b + 2 < 6:
+                jobs[b + 2] = m.prepare_batch_begin(*batch(b + 2), k, edge_ids=eids(b + 2))
+            if native:
+                emb, loss = m.train_step(job, eids(b), loss_fn, k, optimizer=opt)
+            else:
+                emb, loss = m.train_step(job, eids(b), loss_fn, k)
+                opt.step()
+            bank = m.memory_bank
+            rec.append((emb.clone(), float(loss), flat.grad.clone(), flat.detach().clone(), bank.node_memories.data.clone(),
+                        bank.node_last_updated_times.data.clone(), bank._msg.clone(), bank._has.copy(), bank._msg_time.copy(), bank._h_last.copy()))
+        res.append(rec)
+    for b, (x, y) in enumerate(zip(*res)):
+        assert float((x[0] - y[0]).abs().max()) <= 1e-5, (b, float((x[0] - y[0]).abs().max()))
+        assert abs(x[1] - y[1]) <= 1e-5 * max(1.0, abs(x[1]))
+        scale = max(1.0, float(x[2].abs().max()))
+        assert float((x[2] - y[2]).abs().max()) <= 2e-5 * scale, b
+        assert torch.allclose(x[4], y[4], atol=1e-5) and torch.equal(x[5], y[5]) and torch.allclose(x[6], y[6], atol=1e-5)
+        assert np.array_equal(x[7], y[7]) and np.array_equal(x[8], y[8]) and np.array_equal(x[9], y[9])
+    a, c = res[0][0], res[1][0]              # the first update, where the gradient is significant: the same +-lr step in both
+    sig = a[2].abs() > 1e-3 * float(a[2].abs().max())
+    assert int(sig.sum()) > 100
+    assert float((((a[3] - p0) - (c[3] - p0)).abs() * sig).max()) <= 0.05e-7 and float(((c[3] - p0).abs() * sig).max()) >= 0.9e-7
+
+
 def test_tgn_regeneration_sweep_equals_sequential_positive_calls():
     """TGN sweep (M_step.py:456-509 with the memory bank reset first): stores == the loop of positive calls; state advanced alike"""
     from flid_amd.sweep import regenerate_embeddings

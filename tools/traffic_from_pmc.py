@@ -72,6 +72,14 @@ def main():
                     "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); mean over every launch "
                             "of the family in the profiled steps",
                     "source": source}
+    # identity of the attention kernels' source at the time of the passes: bench.py quotes these figures only for the same source
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import bench
+        res["_kernel_src_sha"] = bench.kernel_src_sha()
+    except Exception as e:                      # noqa: BLE001
+        res["_kernel_src_sha"] = None
+        print("kernel_src_sha unavailable:", e, file=sys.stderr)
     json.dump(res, open(dst, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
