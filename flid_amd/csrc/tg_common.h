@@ -67,6 +67,8 @@ inline int64_t attn_grid_blocks(int64_t m) {
     const int64_t b = (m + 3) / 4;
     return b < 1 ? 1 : (b > kAttnMaxBlocks ? kAttnMaxBlocks : b);
 }
+// tg_layer.hip: the forward of a step's one or two layers with ONE prelude launch (optionally zero-filling a region in it)
+int layers_forward(int n, const tg_layer_desc* const* Ls, float* zero, int64_t zero_floats, void* stream);
 // tg_rowops.hip: tg_adam_f32 that first finishes the time-encoder bias gradient (elements [tb_off, tb_off + tb_n) of the flat parameter)
 int adam_time_bias(float* d_param, float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int64_t step, int64_t tb_off, int tb_n, const float* d_cosb, void* stream);

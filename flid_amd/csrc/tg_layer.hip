@@ -443,18 +443,16 @@ struct PreludeArgs {
     int H, hd, dk;
     float* ub;
 };
-__global__ void __launch_bounds__(256) layer_prelude_kernel(PreludeArgs a) {
-    __shared__ float sm[3][32][33];
-    __shared__ float qbs[1024];
+__device__ __forceinline__ void prelude_body(const PreludeArgs& a, int bid, float (*sm)[32][33], float* qbs) {
     // (the merge tiles are the longest dependent chains of the launch: they take the lowest workgroup numbers and start first)
-    int b = (int)blockIdx.x - a.nb_merge;
+    int b = bid - a.nb_merge;
     if (b >= 0) {
         if (b < a.nb_pack) { tgs::pack_body(a.pk, b, a.nb_pack); return; }
         b -= a.nb_pack;
         transpose_many_body(a.tr, b & 63, b >> 6, 64, sm[0]);
         return;
     }
-    b = (int)blockIdx.x;
+    b = bid;
     if (b >= a.mj.total_tiles) {
         // the query-bias rows of the head(s) this workgroup's 32 outputs belong to; 8 rows of a wave in flight at a time (one row at a
         // time was 68 exposed load round trips: the launch took 35 us longer than the three it replaced)
@@ -486,6 +484,23 @@ __global__ void __launch_bounds__(256) layer_prelude_kernel(PreludeArgs a) {
         __syncthreads();
     }
     merge_weights_body(a.mj, b, a.Wk, qbs, a.H, a.hd, a.dk, a.ub, sm[0], sm[1], sm[2]);
+}
+__global__ void __launch_bounds__(256) layer_prelude_kernel(PreludeArgs a) {
+    __shared__ float sm[3][32][33];
+    __shared__ float qbs[1024];
+    prelude_body(a, (int)blockIdx.x, sm, qbs);
+}
+// The preludes of TWO layers of a step in one launch (the upper layer's depends on the weights and the row ids only, like the lower one's:
+// as a launch of its own, 6-7 us of a 1 200-row layer's forward), plus -- workgroups behind them -- a zero fill (the step's gradient
+// block: one memset launch less).  Workgroups [0, nb_a): layer a, [nb_a, nb_a + nb_b): layer b, the rest: zero z4 float4s.
+__global__ void __launch_bounds__(256) layer_prelude2_kernel(PreludeArgs a, PreludeArgs b, int nb_a, int nb_b, float4* __restrict__ z, int64_t z4) {
+    __shared__ float sm[3][32][33];
+    __shared__ float qbs[1024];
+    const int bid = (int)blockIdx.x;
+    if (bid < nb_a) { prelude_body(a, bid, sm, qbs); return; }
+    if (bid < nb_a + nb_b) { prelude_body(b, bid - nb_a, sm, qbs); return; }
+    const int64_t nz = (int64_t)gridDim.x - nb_a - nb_b;
+    for (int64_t i = ((int64_t)bid - nb_a - nb_b) * 256 + threadIdx.x; i < z4; i += nz * 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), UBR query rows i = h hd + k per workgroup:
@@ -725,7 +740,9 @@ extern "C" int tg_side_join(void* stream) { return side_join((hipStream_t)stream
 // [y | raw] laid out as one (R, dq + dn) buffer by the caller (y_ld = raw_ld = dq + dn, raw = y + dq)
 static inline bool yr_joined(const tg_layer_desc* L, int dq) { return L->y_ld != 0 && L->raw == L->y + dq && L->raw_ld == L->y_ld; }
 
-extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
+// mode 0: the whole forward; 1: the forward behind its prelude launch (the caller issued it: tg::layers_prelude); 2: only FILL *out with
+// the prelude launch's arguments and workgroup count (nothing launched)
+static int layer_fwd_impl(const tg_layer_desc* L, void* stream, int mode, PreludeArgs* out_pa, int64_t* out_blocks) {
     TG_REQUIRE(L, "tg_tgat_layer_fwd: null descriptor");
     const tg_attn_desc& a = L->attn;
     const int64_t R = a.m;
@@ -754,6 +771,8 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         pa.tr_gy = n_tr + 1 + gather_y;
         pa.nb_merge = pa.mj.total_tiles + (with_ub ? (int)(((int64_t)H * dk + 31) / 32) : 0);
         const int64_t blocks = (int64_t)pa.nb_merge + pa.nb_pack + 64 * pa.tr_gy;
+        if (mode == 2) { *out_pa = pa; *out_blocks = blocks; return TG_OK; }
+        if (mode == 1) return TG_OK;
         layer_prelude_kernel<<<(unsigned)blocks, 256, 0, s>>>(pa);
         return tg::launch_status("layer_prelude_kernel");
     };
@@ -813,6 +832,7 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
             add_job(pa.mj, P.Wk + (int64_t)h * hd * dk, P.Wq + (int64_t)h * hd * dq, wt.P + (int64_t)h * dk * dn, wt.PT + (int64_t)h * dk,
                     dk, dn, hd, 1, dk, dq, 1, dn, H * dk, 0);
         TG_TRY(launch_prelude(n, gather_rows_y, true));
+        if (mode == 2) return TG_OK;
         // u = own P^T + ub   (all heads in one product, K = dn)
         TG_TRY(tg_gemm_f32(0, 1, R, H * dk, dn, 1.f, L->own, L->own_ld, wt.P, dn, L->u, (int64_t)H * dk, wt.ub, 0, 0, stream));
         TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
@@ -836,6 +856,7 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
         with_qbias(jobs);
         pa.tr = jobs;
         TG_TRY(launch_prelude(n, gather_rows_y, false));
+        if (mode == 2) return TG_OK;
         // q = [own | cos b] Wq^T : the constant half is a bias row
         TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
         // u_h = Wk_h^T q_h
@@ -863,6 +884,33 @@ extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) {
     TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, L->f1, dn, P.W2, dn, L->out, dn, P.b2, 0, 0, stream));
     return TG_OK;
 }
+
+extern "C" int tg_tgat_layer_fwd(const tg_layer_desc* L, void* stream) { return layer_fwd_impl(L, stream, 0, nullptr, nullptr); }
+
+namespace tg {
+// a step's forward with ONE prelude launch for its (one or two) layers, optionally zero-filling `zero_floats` floats at `zero` (16-byte
+// aligned, a multiple of 4) in the same launch; then every layer's forward behind it, in order
+int layers_forward(int n, const tg_layer_desc* const* Ls, float* zero, int64_t zero_floats, void* stream) {
+    TG_REQUIRE(n >= 1 && n <= 2 && Ls, "layers_forward: one or two layers");
+    TG_REQUIRE(!zero || ((reinterpret_cast<uintptr_t>(zero) & 15) == 0 && zero_floats % 4 == 0), "layers_forward: zero region alignment");
+    if (n == 1 && !zero) return layer_fwd_impl(Ls[0], stream, 0, nullptr, nullptr);
+    PreludeArgs pa[2];
+    int64_t nb[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        if (Ls[i]->attn.m == 0) continue;
+        TG_TRY(layer_fwd_impl(Ls[i], stream, 2, &pa[i], &nb[i]));
+    }
+    if (n == 1) { pa[1] = pa[0]; nb[1] = 0; }
+    const int64_t z4 = zero ? zero_floats / 4 : 0;
+    const int64_t nz = z4 > 0 ? std::min<int64_t>((z4 + 1023) / 1024, 1024) : 0;
+    if (nb[0] + nb[1] + nz > 0) {
+        layer_prelude2_kernel<<<(unsigned)(nb[0] + nb[1] + nz), 256, 0, (hipStream_t)stream>>>(pa[0], pa[1], (int)nb[0], (int)nb[1], reinterpret_cast<float4*>(zero), z4);
+        TG_TRY(tg::launch_status("layer_prelude2_kernel"));
+    }
+    for (int i = 0; i < n; ++i) TG_TRY(layer_fwd_impl(Ls[i], stream, 1, nullptr, nullptr));
+    return TG_OK;
+}
+}  // namespace tg
 
 extern "C" int64_t tg_tgat_layer_wt_floats(int dn, int dq, int dk) {
     // transposed copies + merged projections (the native layer path supports 1 or 2 heads: sized for 2), then the packed weights of

@@ -84,6 +84,7 @@ struct tg_stepper {
     void* pinned = nullptr;
     int fwd_slot = -1;
     int64_t fwd_rows[8];
+    int64_t zeroed_floats = 0;            // floats of the gradient block the forward's prelude launch has zero-filled (0: none)
     TgnBuf tb{};
     int md = 0;                           // TGN message width 2 dn + dt_dim + de
     int64_t gru_off[4] = {};              // w_ih, w_hh, b_ih, b_hh inside the flat parameter
@@ -415,7 +416,8 @@ extern "C" int tg_stepper_slot_view(const tg_stepper* st, int slot, void** p6, i
 namespace {
 // what the lowest layer reads: the node table by node id (TGAT), or a compact per-batch table through row maps (TGN)
 struct Base { const float* table; int64_t ld; const int32_t* feat_idx0; const int32_t* gather_idx; };
-int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int training, const uint64_t* seeds, void* stream, float** d_emb);
+int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int training, const uint64_t* seeds, void* stream, float** d_emb,
+                int64_t fill_extra = 0);
 }  // namespace
 
 extern "C" int tg_stepper_forward(tg_stepper* st, int slot, int training, const uint64_t* seeds, void* stream, float** d_emb) {
@@ -428,7 +430,8 @@ extern "C" int tg_stepper_forward(tg_stepper* st, int slot, int training, const 
 }
 
 namespace {
-int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int training, const uint64_t* seeds, void* stream, float** d_emb) {
+int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int training, const uint64_t* seeds, void* stream, float** d_emb,
+                int64_t fill_extra) {
     const tg_stepper_cfg& c = st->c;
     const int L = c.layers, H = c.heads, dn = c.dn, T = c.dt_dim, dq = st->dq, k = c.k;
     const float p_eff = training ? c.dropout_p : 0.f;
@@ -459,11 +462,20 @@ int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int trainin
         d.qbias = b.qbias; d.q = b.q; d.u = b.u; d.agg = b.agg; d.prob = b.prob; d.ctx = b.ctx; d.res = b.res; d.y = b.y;
         d.mean = b.mean; d.rstd = b.rstd; d.f1 = b.f1; d.out = b.out; d.wT = b.wT;
         d.y_ld = dq + dn;
-        d.compute_cosb = l == 1;
+        d.compute_cosb = 1;       // every layer's prelude takes cos b from b itself: they run in ONE launch (equal values, written twice)
         d.gather_table = base.table; d.gather_ld = base.ld; d.gather_idx = base.gather_idx;
         H_prev = b.out;
     }
-    for (int l = 1; l <= L; ++l) TG_TRY(tg_tgat_layer_fwd(&st->desc[(size_t)l - 1], stream));
+    // ONE prelude launch for the step's layers; in train mode it also zero-fills the gradient block the backward accumulates into
+    // (parameter gradients + scratch + the gradient rows of the lower layers' outputs + fill_extra floats behind them)
+    const tg_layer_desc* ls[2] = {&st->desc[0], L > 1 ? &st->desc[1] : nullptr};
+    int64_t fill = 0;
+    if (training) {
+        fill = st->g_rows + fill_extra;
+        for (int l = L; l > 1; --l) fill += r4(st->fwd_rows[l - 2] * dn);
+    }
+    TG_TRY(tg::layers_forward(L, ls, fill > 0 ? st->gblock : nullptr, fill, stream));
+    st->zeroed_floats = fill;
     s.state = Slot::FORWARDED;
     st->fwd_slot = slot;
     if (d_emb) *d_emb = st->lay.back().out;
@@ -491,7 +503,9 @@ int run_backward(tg_stepper* st, Slot& s, const float* d_demb, void* stream, tg_
     // ONE zero fill: parameter gradients + scratch + the gradient rows of the lower layers' outputs that this batch has
     int64_t fill = st->g_rows;
     for (int l = L; l > 1; --l) fill += r4(st->fwd_rows[l - 2] * dn);
-    TG_HIP_CHECK(hipMemsetAsync(st->gblock, 0, sizeof(float) * (size_t)(fill + fill_extra), ms));
+    if (st->zeroed_floats < fill + fill_extra)                 // (else: zero-filled by the forward's prelude launch)
+        TG_HIP_CHECK(hipMemsetAsync(st->gblock, 0, sizeof(float) * (size_t)(fill + fill_extra), ms));
+    st->zeroed_floats = 0;
     float* g = st->gblock;
     const float* dH = d_demb;
     int64_t rows_off = st->g_rows;
@@ -624,7 +638,8 @@ extern "C" int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_ban
                            P + st->gru_off[0], P + st->gru_off[1], P + st->gru_off[2], P + st->gru_off[3], pending ? 1 : 0, t.h_rows,
                            pending ? t.msg_rows : nullptr, pending ? t.gi : nullptr, pending ? t.gh : nullptr, t.rows, t.base, stream));
     const int64_t roots = s.n, nb2 = 2 * s.nb;
-    return run_forward(st, s, slot, Base{t.base, D, s.rowmap + roots + nb2, s.rowmap}, training, seeds, stream, d_emb);
+    return run_forward(st, s, slot, Base{t.base, D, s.rowmap + roots + nb2, s.rowmap}, training, seeds, stream, d_emb,
+                       pending ? r4(s.uniq_count * D) : 0);
 }
 
 // backward of the layer and of the GRU; positive != 0: the state advance of models/MemoryModel.py:155-180 (persist the batch nodes' GRU rows,

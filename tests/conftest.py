@@ -56,5 +56,10 @@ def assert_grads_match(gold, named, atol=1e-4, rtol=1e-4, kink_frac=0.005, stric
         assert float(err.max()) <= 0.02 * big, (k, float(err.max()), big)
         s = "gs:" + k[2:]
         scale = max(1.0, np.sqrt(gold[s][1]))
-        assert abs(mine[s][0] - gold[s][0]) <= 50 * atol * scale, (s, mine[s], gold[s])
-        assert abs(mine[s][1] - gold[s][1]) <= 1e-3 * max(1.0, gold[s][1]), (s, mine[s], gold[s])
+        loose = not (strict or kink_frac < 0.1)             # entries may have moved by up to 2 % of the largest (flipped ReLU units)
+        # (the plain sum of a tensor's entries: a flipped unit adds a rank-one term whose entries do not cancel in it -- checked only
+        # where every entry was held to atol)
+        assert loose or abs(mine[s][0] - gold[s][0]) <= 50 * atol * scale, (s, mine[s], gold[s])
+        # (sum of squares: 1e-3 when every entry was held to atol; where flipped ReLU units may move entries by up to 2 % of the largest,
+        # the squared norm follows by up to ~1 %)
+        assert abs(mine[s][1] - gold[s][1]) <= (1e-2 if loose else 1e-3) * max(1.0, gold[s][1]), (s, mine[s], gold[s])
