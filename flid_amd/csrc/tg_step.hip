@@ -462,19 +462,23 @@ int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int trainin
         d.qbias = b.qbias; d.q = b.q; d.u = b.u; d.agg = b.agg; d.prob = b.prob; d.ctx = b.ctx; d.res = b.res; d.y = b.y;
         d.mean = b.mean; d.rstd = b.rstd; d.f1 = b.f1; d.out = b.out; d.wT = b.wT;
         d.y_ld = dq + dn;
-        d.compute_cosb = 1;       // every layer's prelude takes cos b from b itself: they run in ONE launch (equal values, written twice)
+        d.compute_cosb = l == 1;
         d.gather_table = base.table; d.gather_ld = base.ld; d.gather_idx = base.gather_idx;
         H_prev = b.out;
     }
-    // ONE prelude launch for the step's layers; in train mode it also zero-fills the gradient block the backward accumulates into
-    // (parameter gradients + scratch + the gradient rows of the lower layers' outputs + fill_extra floats behind them)
-    const tg_layer_desc* ls[2] = {&st->desc[0], L > 1 ? &st->desc[1] : nullptr};
+    // In train mode the lowest layer's prelude launch also zero-fills the gradient block the backward accumulates into (parameter
+    // gradients + scratch + the gradient rows of the lower layers' outputs + fill_extra floats behind them): one memset launch less.
+    // (The upper layer keeps its own prelude launch right in front of its forward: folded into the first launch as well it ran 7 us
+    // faster by itself, but the packed weights it writes were no longer L2-resident when the 1 200-row chains stream them 200-400 us
+    // later -- chain_fwd / chain_bwd of the root layer 27 -> 32 and 31 -> 40 us, the step 7 us slower on the same box.)
+    const tg_layer_desc* l0 = &st->desc[0];
     int64_t fill = 0;
     if (training) {
         fill = st->g_rows + fill_extra;
         for (int l = L; l > 1; --l) fill += r4(st->fwd_rows[l - 2] * dn);
     }
-    TG_TRY(tg::layers_forward(L, ls, fill > 0 ? st->gblock : nullptr, fill, stream));
+    TG_TRY(tg::layers_forward(1, &l0, fill > 0 ? st->gblock : nullptr, fill, stream));
+    for (int l = 2; l <= L; ++l) TG_TRY(tg_tgat_layer_fwd(&st->desc[(size_t)l - 1], stream));
     st->zeroed_floats = fill;
     s.state = Slot::FORWARDED;
     st->fwd_slot = slot;
