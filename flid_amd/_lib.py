@@ -138,7 +138,6 @@ SIGNATURES = {
     "tg_gemm_f32_nt_masked": (C.c_int, [c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void]),
     "tg_packed_floats": (c_i64, [C.c_int, C.c_int]),
     "tg_pack_weights": (C.c_int, [C.c_int, C.POINTER(PackJob), c_void]),
-    "tg_gemm_rows_nt": (C.c_int, [c_i64, C.c_int, C.c_int, c_void, c_i64, c_void, c_void, c_i64, c_void, C.c_int, C.c_int, c_void, c_i64, c_void]),
     "tg_wgrad_group": (C.c_int, [C.c_int, C.POINTER(WgradJob), c_i64, c_void]),
     "tg_set_wgrad_form": (None, [C.c_int]),
     "tg_set_gemm_mode": (None, [C.c_int]),

@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_fwd_kernel(tg_att
 // ------------------------------------------------------------------------------------------------ backward
 // d score_{h,n} = a'_{h,n} (dagg_h . z_n) - a_{h,n} (dagg_h . agg_h)      a' = dropped/scaled prob, a = softmax prob
 // masked slots get no score gradient (masked_fill), but still pass d z through a'.
-template <int VEC, int CPL, int H, bool SPLIT = false, int RBB = 4>
+template <int VEC, int CPL, int H, int RBB = 4>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_attn_desc a, const float* __restrict__ u,
         const float* __restrict__ agg, const float* __restrict__ prob, const float* __restrict__ dagg,
         float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld, float* __restrict__ dte_part, int64_t pad_row,
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
     const int wave = threadIdx.x / kWave;
     const int dk = a.dn + a.de + a.dt_dim;
     const int k = a.k;
-    extern __shared__ float red[];   // WAVES_PER_BLOCK * (2 * dt_dim + dn)  [+ WAVES_PER_BLOCK * H * CPL * VEC * 64 when SPLIT]
+    extern __shared__ float red[];   // WAVES_PER_BLOCK * (2 * dt_dim + dn)
     // every padded slot gathers the SAME row (pad_row): its gradient is summed in registers and leaves the workgroup as one
     // row of atomics instead of thousands of adds onto one address (14x slower per the float-atomic contention rule)
     float dpad[CPL][VEC];
@@ -299,8 +299,8 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
         }
     }
 
-    const int64_t row_first = SPLIT ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
-    const int64_t row_step = SPLIT ? (int64_t)gridDim.x : (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t row_first = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int64_t row_step = (int64_t)gridDim.x * WAVES_PER_BLOCK;
     for (int64_t row = row_first; row < a.m; row += row_step) {
         float uh[H][CPL][VEC], dg[H][CPL][VEC], dacc[H][CPL][VEC];
         float cterm[H];
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
 #pragma unroll
             for (int h = 0; h < H; ++h) my_p[h] = sl < k ? prob[(row * H + h) * k + sl] : 0.f;
             const int cnt = (k - s0) < kWave ? (k - s0) : kWave;
-            for (int sb = SPLIT ? wave * RBB : 0; sb < cnt; sb += SPLIT ? WAVES_PER_BLOCK * RBB : RBB) {
+            for (int sb = 0; sb < cnt; sb += RBB) {
                 float z[RBB][CPL][VEC];
                 int nb[RBB];
                 int64_t fis[RBB], eis[RBB];
@@ -415,41 +415,11 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK* kWave) attn_bwd_kernel(tg_att
                 }
             }
         }
-        if constexpr (SPLIT) {
-            // the four waves hold the du contributions of their own rows: fold through LDS, wave 0 stores
-            float* racc = red + WAVES_PER_BLOCK * (2 * a.dt_dim + a.dn);
 #pragma unroll
-            for (int h = 0; h < H; ++h)
+        for (int h = 0; h < H; ++h)
 #pragma unroll
-                for (int i = 0; i < CPL; ++i)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) racc[(wave * H * CPL * VEC + (h * CPL + i) * VEC + e) * kWave + lane] = dacc[h][i][e];
-            __syncthreads();
-            if (wave == 0) {
-#pragma unroll
-                for (int h = 0; h < H; ++h)
-#pragma unroll
-                    for (int i = 0; i < CPL; ++i) {
-                        if (seg[i].kind == 3) continue;
-                        float o[VEC];
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            float t = 0.f;
-#pragma unroll
-                            for (int w = 0; w < WAVES_PER_BLOCK; ++w) t += racc[(w * H * CPL * VEC + (h * CPL + i) * VEC + e) * kWave + lane];
-                            o[e] = t;
-                        }
-                        store_chunk<VEC>(du + (row * H + h) * dk + (lane + kWave * i) * VEC, o);
-                    }
-            }
-            __syncthreads();
-        } else {
-#pragma unroll
-            for (int h = 0; h < H; ++h)
-#pragma unroll
-                for (int i = 0; i < CPL; ++i)
-                    if (seg[i].kind != 3) store_chunk<VEC>(du + (row * H + h) * dk + (lane + kWave * i) * VEC, dacc[h][i]);
-        }
+            for (int i = 0; i < CPL; ++i)
+                if (seg[i].kind != 3) store_chunk<VEC>(du + (row * H + h) * dk + (lane + kWave * i) * VEC, dacc[h][i]);
     }
 
     // block partial of (dw | db): waves -> LDS -> one slab row per workgroup (no atomics, deterministic)
@@ -516,8 +486,8 @@ int launch_bwd(const tg_attn_desc& a, const float* u, const float* agg, const fl
                float* dfeat, int64_t dfeat_ld, float* dte, int64_t pad_row, float* dedge, int64_t dedge_ld, hipStream_t s) {
     const dim3 grid((unsigned)attn_grid(a.m)), block(WAVES_PER_BLOCK * kWave);
     const size_t lds = sizeof(float) * WAVES_PER_BLOCK * (2 * a.dt_dim + a.dn);
-    // (the SPLIT form of the backward kernel is not launched: 68 -> 65 us on the root layer, whose time is the 4 M float atomics of
-    // the neighbor-feature gradient, not row latency)
+    // (a one-instance-per-workgroup form of the backward was measured and dropped: 68 -> 65 us on the root layer, whose time is the 4 M
+    // float atomics of the neighbor-feature gradient, not row latency)
     switch (a.heads) {
         case 1: attn_bwd_kernel<VEC, CPL, 1><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row, dedge, dedge_ld); break;
         case 2: attn_bwd_kernel<VEC, CPL, 2><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, dte, pad_row, dedge, dedge_ld); break;

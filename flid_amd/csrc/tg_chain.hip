@@ -9,7 +9,7 @@
 // Every intermediate the backward / the weight gradients need is still written to HBM once (ctx, res, y, f1; df1, dres, dctx,
 // dagg) -- what disappears is reading them back, and above all the launch + first-load + drain latency of five dependent launches:
 // at 13.6 k rows a product is 213 workgroups that each wait ~2 us for their first rows, compute for 1-3 us and drain
-// (tools/rows_prof.sh: 11-17 us per launch whatever is ablated), so a layer's ten products + two LayerNorm passes cost ~200 us for
+// (round-3 ablation builds: 11-17 us per launch whatever is ablated), so a layer's ten products + two LayerNorm passes cost ~200 us for
 // ~25 us of MFMA work.
 //
 // Machine.  4 waves; wave w owns a block of 16-column tiles of the current product's output, all 64 rows (four 16-row blocks):
@@ -173,7 +173,7 @@ struct Wave {
         // weight fragment as operand A: acc[rb][j][r] = C[row 16 rb + (lane & 15)][column 16 (t0 + j) + 4 (lane >> 4) + r]
         // The chain keeps the lo * lo term too (4 MFMAs per fragment pair): its launches are bound by the weight stream and by latency,
         // not by the matrix pipe (PMC: 23 % busy), and with three terms the realistic full-size fixture showed hundreds of gradient
-        // entries off by 1e-3 of the tensor's largest (ReLU units of the merge layer flipping; tools/kink_probe.py) where four show none.
+        // entries off by 1e-3 of the tensor's largest (ReLU units of the merge layer flipping; see tools/fullsize_err.py) where four show none.
         if (RB == 1 || FLID_CHAIN_X4) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)

@@ -72,12 +72,9 @@ int layers_forward(int n, const tg_layer_desc* const* Ls, float* zero, int64_t z
 // tg_rowops.hip: tg_adam_f32 that first finishes the time-encoder bias gradient (elements [tb_off, tb_off + tb_n) of the flat parameter)
 int adam_time_bias(float* d_param, float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int64_t step, int64_t tb_off, int tb_n, const float* d_cosb, void* stream);
-// tg_gemm_rows.hip: products on packed weights (false = shape / alignment not covered, nothing launched)
+// tg_pack.hip: packed (split-bf16, MFMA fragment order) weights of the chain kernels
 int64_t packed_floats(int N, int K);
 int pack_weights(int njobs, const tg_pack_job* jobs, hipStream_t s);
-bool gemm_rows_nt(int64_t R, int N, int K, const float* A, int64_t lda, int64_t strideA, const void* packed, int64_t packed_stride_floats,
-                  float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate, const float* mask,
-                  int64_t ldm, hipStream_t s);
 // tg_chain.hip: everything behind the attention of a layer's forward as one launch
 bool chain_shape_ok(int H, int dn, int T, int de);
 int chain_hp(int H, int dn, int T);

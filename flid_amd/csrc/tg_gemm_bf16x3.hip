@@ -668,7 +668,7 @@ namespace tg {
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s) {
     if (njobs < 1 || njobs > 8 || rows < 1) return false;
     // One column-tile width (64 or 96) and one K-slice count (a multiple of 8: XCD pinning) for the launch.  Swept on MI355X
-    // (tools/wgrad_sweep.py, 13.6 k rows): the best point of every launch of a layer has 500-700 workgroups (768 are resident at
+    // (a slice-count sweep at 13.6 k rows, round 2): the best point of every launch of a layer has 500-700 workgroups (768 are resident at
     // once: 3 per CU at 46 KB of LDS) and the 64-wide tile unless it pads the outputs > 10 % more than the 96-wide one:
     //   dW2 + dW1a + dW1b: 33 tiles x 16 slices 52.6 us (x8 71.8, x24 58.6, x32 71.6);  dP: 42 x 16 51.6 us (x8 67.6, x24 54.9);
     //   dV: 70 x 8 83.5 us (x16 87.9).  More slices only multiply the atomic fold's traffic, fewer leave the chip half empty.
@@ -733,7 +733,11 @@ bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     if (M < 1 || N < 1 || K < 8 || nbatch > 65535) return false;
     // column block 96 or 64: the smaller padded N wins (272 -> 288, 172 -> 192, 444 -> 480, 136 -> 192 either way), ties to 96
     const int64_t pad3 = (N + 95) / 96 * 96, pad2 = (N + 63) / 64 * 64;
-    const int tnw = pad3 <= pad2 ? 3 : 2;
+    // (96-column blocks also where they pad up to 8 % more than 64-column ones: every block of columns re-stages and re-splits the whole
+    // row panel, and fewer, wider blocks won 4-10 % at N = 600 / 800 / 888 -- tools/nt_tile_sweep.sh; 128-column blocks lost)
+    int tnw = pad3 * 100 <= pad2 * 108 ? 3 : 2;
+    static const int force_tnw = (getenv("FLID_GEMM_TUNE") && getenv("FLID_NT_TNW")) ? atoi(getenv("FLID_NT_TNW")) : 0;
+    if (force_tnw == 2 || force_tnw == 3) tnw = force_tnw;
     const int64_t gx = (N + 32 * tnw - 1) / (32 * tnw), gy = (M + BM - 1) / BM;
     if (gx * gy >= ((int64_t)1 << 30)) return false;
     const float* zeros = zero_block();      // the kernel's out-of-range loads are pointed at it

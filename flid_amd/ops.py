@@ -115,7 +115,7 @@ def gemm_batched(a0: torch.Tensor, b0: torch.Tensor, out0: torch.Tensor, batch: 
 
 def pack_weights(jobs):
     """jobs: [(weight (N, K) fp32 row-major, or (K, N) with trans=True), trans]; returns one packed operand per job (tg_pack_weights:
-    bf16 hi / lo in MFMA fragment order, what gemm_rows multiplies with).  One launch for all of them."""
+    bf16 hi / lo in MFMA fragment order, what the chain kernels multiply with).  One launch for all of them."""
     import ctypes as C
     from ._lib import PackJob
     arr = (PackJob * len(jobs))()
@@ -128,19 +128,6 @@ def pack_weights(jobs):
         outs.append((dst, N, K))
     check(lib().tg_pack_weights(len(jobs), arr, _stream()), "tg_pack_weights")
     return outs
-
-
-def gemm_rows(a: torch.Tensor, packed, out: torch.Tensor, bias=None, relu=False, accumulate=False, mask=None):
-    """out[R, N] = a[R, K] @ W^T (+ bias) (+ out) (relu) (keep where mask > 0) with W packed by pack_weights"""
-    dst, N, K = packed
-    _chk(a, torch.float32, "a"); _chk(out, torch.float32, "out")
-    if a.shape[1] != K or out.shape != (a.shape[0], N):
-        raise ValueError(f"gemm_rows: shape mismatch a={tuple(a.shape)} W=({N},{K}) out={tuple(out.shape)}")
-    with _timed("gemm", (a.shape[0], N, K)):
-        check(lib().tg_gemm_rows_nt(a.shape[0], N, K, _p(a), _rowmajor_ld(a, "a"), _p(dst), _p(out), _rowmajor_ld(out, "out"), _p(bias),
-                                    int(relu), int(accumulate), _p(mask), 0 if mask is None else _rowmajor_ld(mask, "mask"), _stream()),
-              "tg_gemm_rows_nt")
-    return out
 
 
 def gather_rows(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None):

@@ -316,14 +316,12 @@ int tg_weighted_ce(const float* d_z, int64_t ldz, const int32_t* d_labels, const
 int tg_gemm_f32_nt_masked(int64_t M, int64_t N, int64_t K, const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C, int64_t ldc,
                           const float* d_Y, int64_t ldy, void* stream);
 
-/* ---- row-block products on PACKED weights (split-bf16 MFMA, tg_gemm_rows.hip) -----------------------------
- * replaces the aten::mm / addmm calls behind the nn.Linear layers of models/modules.py:54-69,152-163,199-235 (and their input
- * gradients) for the tall-times-small products of a layer: C[R,N] = A[R,K] W^T (+ bias[N]) (+ C) (ReLU) (keep where mask > 0).
- * W is given PACKED: tg_pack_weights splits an (N x K) fp32 weight into bf16 hi / lo and stores it in MFMA fragment order,
- * tg_packed_floats(N, K) floats per weight, once per optimizer step (weights change only there).
- *   trans = 0: W[n][k] = src[n * ld + k];  trans = 1: W[n][k] = src[k * ld + n] (the transposed weight of an input gradient).
- * Constraints of tg_gemm_rows_nt: N, K, lda, ldc multiples of 4, 16-byte aligned operands (else TG_EINVAL: use
- * tg_gemm_f32 on the unpacked weight). */
+/* ---- PACKED weights of the row-block chain kernels (split-bf16 MFMA, tg_chain.hip / tg_pack.hip) -----------------
+ * The chains that replace the aten::mm / addmm calls behind the nn.Linear layers of models/modules.py:54-69,152-163,199-235 (and their
+ * input gradients) multiply 64-row blocks by weights given PACKED: tg_pack_weights splits an (N x K) fp32 weight into bf16 hi / lo and
+ * stores it in MFMA fragment order, tg_packed_floats(N, K) floats per weight, once per optimizer step (tg_tgat_layer_fwd does it in its
+ * prelude launch; this is the stand-alone entry point).
+ *   trans = 0: W[n][k] = src[n * ld + k];  trans = 1: W[n][k] = src[k * ld + n] (the transposed weight of an input gradient). */
 typedef struct tg_pack_job {
     const float* src; int64_t ld; int N, K, trans; void* dst;
     /* optional index maps (0 = identity): packed row n' -> source row (n' / n_pad) * n_len + n' % n_pad, zero where n' % n_pad >= n_len or
@@ -333,8 +331,6 @@ typedef struct tg_pack_job {
 } tg_pack_job;
 int64_t tg_packed_floats(int N, int K);
 int tg_pack_weights(int njobs, const tg_pack_job* jobs, void* stream);
-int tg_gemm_rows_nt(int64_t R, int N, int K, const float* d_A, int64_t lda, const void* d_packed, float* d_C, int64_t ldc,
-                    const float* d_bias, int relu, int accumulate, const float* d_mask, int64_t ldm, void* stream);
 
 /* ---- grouped weight gradients (split-bf16 MFMA) ------------------------------------------------------
  * replaces the autograd weight / bias gradients of the nn.Linear layers in models/modules.py:54-69,152-163,235 for one layer:

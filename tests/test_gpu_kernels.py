@@ -690,30 +690,29 @@ def test_tgat_on_device_random_draws_matches_oracle_given_the_same_draws():
     np.testing.assert_allclose(emb.cpu().numpy(), want.numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize("R,N,K", [(1000, 172, 444), (77, 272, 288), (13622, 444, 172), (5, 16, 32)])
-def test_packed_rows_product_vs_fp64(R, N, K):
-    """tg_pack_weights + tg_gemm_rows_nt (the row-block product the chain kernels are built from): out = a W^T with bias, ReLU,
-    accumulation and the ReLU-backward mask, both operand orientations, against float64 at the three-term split-bf16 error model"""
+@pytest.mark.parametrize("N,K", [(172, 444), (272, 288), (16, 32), (20, 36)])
+def test_pack_weights_layout(N, K):
+    """tg_pack_weights (the operand layout of the chain kernels, tg_pack.h): [tile n / 16][step k / 32][plane hi, lo][lane][8 bf16], lane l
+    of (tile, step) = W[16 t + (l & 15)][32 s + 8 (l >> 4) + 0..7], zero beyond N or K; hi = bf16(w), lo = bf16(w - hi); both orientations
+    of the source"""
     from flid_amd import ops
     dev = torch.device("cuda:0")
-    torch.manual_seed(R + N)
-    a, w, b = torch.randn(R, K, device=dev), torch.randn(N, K, device=dev), torch.randn(N, device=dev)
-    packed, packed_t = ops.pack_weights([(w, False), (w.t().contiguous(), True)])
-    ref = a.double() @ w.double().t()
-    bound = 3.0 * 2.0 ** -16 * float((a.double().abs() @ w.double().abs().t()).max())      # dropped lo * lo term + bf16 rounding of lo
-    for pk in (packed, packed_t):
-        out = ops.gemm_rows(a, pk, torch.empty(R, N, device=dev))
-        assert float((out.double() - ref).abs().max()) <= bound
-    out = ops.gemm_rows(a, packed, torch.empty(R, N, device=dev), bias=b, relu=True)
-    assert float((out.double() - (ref + b.double()).clamp_min(0)).abs().max()) <= bound
-    acc0 = torch.randn(R, N, device=dev)
-    out = ops.gemm_rows(a, packed, acc0.clone(), accumulate=True)
-    assert float((out.double() - (ref + acc0.double())).abs().max()) <= bound
-    mask = torch.randn(R, N, device=dev)
-    out = ops.gemm_rows(a, packed, torch.empty(R, N, device=dev), mask=mask)
-    assert float((out.double() - ref * (mask > 0)).abs().max()) <= bound
-    with pytest.raises(Exception):
-        ops.gemm_rows(a[:, :K - 1].contiguous(), packed, torch.empty(R, N, device=dev))       # K does not match the packed operand
+    torch.manual_seed(N + K)
+    w = torch.randn(N, K, device=dev)
+    (p0, _, _), (p1, _, _) = ops.pack_weights([(w, False), (w.t().contiguous(), True)])
+    assert torch.equal(p0, p1)
+    nt, ns = (N + 15) // 16, (K + 31) // 32
+    wp = torch.zeros(nt * 16, ns * 32, device=dev)
+    wp[:N, :K] = w
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.float()).to(torch.bfloat16)
+    # (tile, step, plane, lane, 8): lane -> row 16 t + (l & 15), columns 32 s + 8 (l >> 4) + q
+    def plane(x):
+        x = x.view(nt, 16, ns, 4, 8)                     # [t][l & 15][s][l >> 4][q]
+        return x.permute(0, 2, 3, 1, 4).reshape(nt, ns, 64, 8)    # [t][s][(l >> 4) * 16 + (l & 15)][q]
+    want = torch.stack([plane(hi), plane(lo)], dim=2).contiguous()       # [t][s][plane][lane][8]
+    got = p0.view(torch.bfloat16).view(nt, ns, 2, 64, 8)
+    assert torch.equal(got, want)
 
 
 def test_weight_gradient_forms_agree():
