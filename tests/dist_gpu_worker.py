@@ -62,6 +62,12 @@ def main():
         g_one = flat_grad(model, flat, data, slice(2000, 2600), 10, 1.0)
         err = float((g_dp - g_one).abs().max()) / max(1e-12, float(g_one.abs().max()))
         assert err <= tol, f"rank {rank} mode {mode}: reduced gradient differs from the full-batch gradient by {err:.2e} of its largest entry"
+        # the same through the native stepper (csrc/tg_step.hip): its backward hands the root layer's block to the reducer through the
+        # C callback (tg_grad_ready_fn) while the lower layer's backward is still being issued
+        model.enable_native_step(1200, 10)
+        g_dp_n = flat_grad(model, flat, data, slice(2000 + lo, 2000 + hi), 10, (hi - lo) / 600.0, reducer)
+        err = float((g_dp_n - g_one).abs().max()) / max(1e-12, float(g_one.abs().max()))
+        assert err <= tol, f"rank {rank} mode {mode}: native stepper, reduced gradient differs from the full-batch gradient by {err:.2e}"
     lib().tg_set_gemm_mode(1)
 
     # ---- (ii) TGN: replicas stay bit-identical over 5 sharded steps
@@ -88,6 +94,36 @@ def main():
     s_dp, d_dp = regenerate_embeddings(m2, data, 200, 10, chunk_edges=512, rank=rank, world=world)
     s_1, d_1 = regenerate_embeddings(m2, data, 200, 10, chunk_edges=512, rank=0, world=1)
     assert float((s_dp - s_1).abs().max()) < 2e-5 and float((d_dp - d_1).abs().max()) < 2e-5, "sharded sweep != single-rank stores"
+
+    # ---- (iv) DyGFormer: data parallelism runs WHOLE batches per rank (the reference pads every batch to its own longest sequence,
+    # models/DyGFormer.py:196-245, and the unmasked transformer sees the padding: splitting one batch over ranks would change the result).
+    # The weighted all-reduce of the ranks' gradients == the mean of the two batches' gradients computed by one process.
+    from flid_amd.models.DyGFormer import DyGFormer
+    torch.manual_seed(0)
+    dyg = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, 100, 50, 1, 2, 2, 0.0, 32, dev).to(dev).train()
+    fdist.broadcast_parameters(dyg)
+    params = [p_ for p_ in dyg.parameters() if p_.requires_grad]
+    rs = np.random.RandomState(9)
+    r_all = torch.from_numpy(rs.standard_normal((world, 2, 200, data.node_raw_features.shape[1])).astype(np.float32)).cuda()
+
+    def dyg_grads(b):
+        sl = slice(3000 + 200 * b, 3200 + 200 * b)
+        for p_ in params:
+            p_.grad = None
+        se, de = dyg.compute_src_dst_node_temporal_embeddings(data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl])
+        ((se * r_all[b, 0]).sum() + (de * r_all[b, 1]).sum()).div(200.0).backward()
+        return [p_.grad.clone() for p_ in params]
+    mine = dyg_grads(rank)
+    for p_, g_ in zip(params, mine):
+        p_.grad = g_
+    red = fdist.GradAllReducer(params)
+    red.reduce(weight=1.0 / world)
+    g_dp = [p_.grad.clone() for p_ in params]
+    every = [dyg_grads(b) for b in range(world)]
+    for i, g_ in enumerate(g_dp):
+        want = sum(e[i] for e in every) / world
+        err = float((g_ - want).abs().max()) / max(1e-12, float(want.abs().max()))
+        assert err <= 2e-4, f"rank {rank}: DyGFormer reduced gradient of parameter {i} off by {err:.2e}"
 
     dist.barrier()
     if rank == 0:
