@@ -705,6 +705,40 @@ def bench_memory_or_sequence_model(args):
         return slice(b * BATCH, (b + 1) * BATCH)
 
     jobs, prepared = {}, {}
+    tgn_lp = args.model == "tgn" and args.mode == "lp"
+    if tgn_lp:
+        # the warm-up's link-prediction step on the memory model (PTCL/EM_warmup.py:126-238): negatives first (no state advance), then
+        # positives, one BCE over both through the MergeLayer head, Adam on backbone + head
+        assert native and world == 1, "--model tgn --mode lp runs the native stepper on one GPU"
+        from flid_amd.heads import PairLinkLoss
+        from flid_amd.models.modules import MergeLayer
+        torch.manual_seed(1)
+        head = MergeLayer(DN, DN, DN, 1).to(dev)
+        head_opt = torch.optim.Adam(head.parameters(), lr=1e-4, fused=True)
+        loss_neg, loss_pos = PairLinkLoss(head, False), PairLinkLoss(head, True)
+        first_item, n_items = int(data.dst_node_ids.min()), int(data.dst_node_ids.max() - data.dst_node_ids.min() + 1)
+        rs_neg = np.random.RandomState(7)
+        neg_ids = [rs_neg.randint(first_item, first_item + n_items, BATCH).astype(np.int64) for _ in range(total_steps + 3)]
+        args.no_cpu_baseline = True
+
+        def lp_begin(s_):
+            sl_ = batch(s_)
+            t_ = data.node_interact_times[sl_]
+            return (model.prepare_batch_begin(data.src_node_ids[sl_], neg_ids[s_], t_, K),
+                    model.prepare_batch_begin(data.src_node_ids[sl_], data.dst_node_ids[sl_], t_, K, edge_ids=data.edge_ids[sl_]))
+
+        def lp_step(s):
+            # two batches are in preparation per step (4 slots): this step's pair was begun a step ago
+            if s not in jobs:
+                jobs[s] = lp_begin(s)
+            jn, jp = (model.prepare_batch_finish(j_) for j_ in jobs.pop(s))
+            opt.zero_grad(set_to_none=True)
+            head_opt.zero_grad(set_to_none=True)
+            model.train_step(jn, None, loss_neg, K, edges_are_positive=False, more=True)
+            model.train_step(jp, data.edge_ids[batch(s)], loss_pos, K, optimizer=opt, accumulate=True)
+            head_opt.step()
+            if s + 1 < total_steps + 3:
+                jobs[s + 1] = lp_begin(s + 1)
 
     def tgn_begin(s_):
         sl_ = batch(s_)
@@ -712,6 +746,8 @@ def bench_memory_or_sequence_model(args):
                                          None if wsim == 1 else (rank * BATCH, (rank + 1) * BATCH), edge_ids=data.edge_ids[sl_])
 
     def step(s):
+        if tgn_lp:
+            return lp_step(s)
         sl = batch(s)
         a = (data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl])
         opt.zero_grad(set_to_none=True)
@@ -800,7 +836,8 @@ def bench_memory_or_sequence_model(args):
                 "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / max(1, cnt), 4),
                 "bytes_per_instance": attn_bytes_per_instance(backward=True)}
         path = {"bytes_per_edge_fwd_bwd": bpe, "hbm_frac": round(value / world * bpe / HBM_PEAK, 4), "edges_per_s_at_100pct": round(HBM_PEAK / bpe, 1)}
-        metric = "edges/sec (temporal-embedding fwd+bwd, memory update + message scatter), TGN Reddit, 1/2/4/8 MI355X"
+        metric = ("edges/sec (link-prediction warm-up step: negatives then positives, MergeLayer head + BCE, memory update + message scatter), TGN Reddit"
+                  if tgn_lp else "edges/sec (temporal-embedding fwd+bwd, memory update + message scatter), TGN Reddit, 1/2/4/8 MI355X")
     else:
         roof = {"bound": "mfma", "kernel": "tg_gemm_f32* (all product launches of a step: projections, feed-forward, attention products)",
                 "achieved": round(units / secs / 1e12, 2), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
@@ -814,7 +851,7 @@ def bench_memory_or_sequence_model(args):
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": DTYPE, "data": "synthetic",
            "config": {"workload": f"Reddit-shape synthetic (10984 nodes, 672447 edges, 172-d edge feats) + {desc}, batch 600 edges/GPU, "
-                                  f"dropout {args.dropout:.2f}, host numpy ids per call, fwd+bwd+Adam ({'fused step' if fused else 'autograd'})",
+                                  f"dropout {args.dropout:.2f}, host numpy ids per call, fwd+bwd+Adam ({('fused step, native stepper' if native else 'fused step') if fused else 'autograd'}{', neg-then-pos warm-up step' if tgn_lp else ''})",
                       "batch_per_gpu": BATCH, "global_batch": BATCH * wsim, "parallelism": f"dp{world}"},
            "path_roofline": path, "roofline": roof, "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 4)}
     if dist_info is not None:

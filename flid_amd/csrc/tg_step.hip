@@ -434,7 +434,7 @@ int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int trainin
                 int64_t fill_extra) {
     const tg_stepper_cfg& c = st->c;
     const int L = c.layers, H = c.heads, dn = c.dn, T = c.dt_dim, dq = st->dq, k = c.k;
-    const float p_eff = training ? c.dropout_p : 0.f;
+    const float p_eff = training ? c.dropout_p : 0.f;              // (training == 2: train mode, the gradient block is left alone)
     TG_REQUIRE(p_eff == 0.f || seeds, "tg_stepper_forward: dropout needs seeds");
     float* te_w = c.d_param + st->poff[0];
     float* te_b = c.d_param + st->poff[1];
@@ -473,7 +473,7 @@ int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int trainin
     // later -- chain_fwd / chain_bwd of the root layer 27 -> 32 and 31 -> 40 us, the step 7 us slower on the same box.)
     const tg_layer_desc* l0 = &st->desc[0];
     int64_t fill = 0;
-    if (training) {
+    if (training == 1) {
         fill = st->g_rows + fill_extra;
         for (int l = L; l > 1; --l) fill += r4(st->fwd_rows[l - 2] * dn);
     }
@@ -500,15 +500,19 @@ struct BaseGrad { float* d_table; int64_t pad_row; float* d_own; float* d_raw; }
 
 // the layers' backward calls; `fill_extra` floats behind the lower layers' gradient rows are zeroed with the gradient block
 int run_backward(tg_stepper* st, Slot& s, const float* d_demb, void* stream, tg_grad_ready_fn grad_ready, void* user, bool fuse_tb,
-                 const BaseGrad& bg, int64_t fill_extra) {
+                 const BaseGrad& bg, int64_t fill_extra, bool accumulate = false) {
     const tg_stepper_cfg& c = st->c;
     const int L = c.layers, dn = c.dn;
     hipStream_t ms = (hipStream_t)stream;
     // ONE zero fill: parameter gradients + scratch + the gradient rows of the lower layers' outputs that this batch has
     int64_t fill = st->g_rows;
     for (int l = L; l > 1; --l) fill += r4(st->fwd_rows[l - 2] * dn);
-    if (st->zeroed_floats < fill + fill_extra)                 // (else: zero-filled by the forward's prelude launch)
+    if (accumulate) {
+        // the parameter gradients (and d cos b) of an earlier backward stay; the per-call scratch behind them starts from zero again
+        TG_HIP_CHECK(hipMemsetAsync(st->gblock + st->g_vec, 0, sizeof(float) * (size_t)(fill + fill_extra - st->g_vec), ms));
+    } else if (st->zeroed_floats < fill + fill_extra) {       // (else: zero-filled by the forward's prelude launch)
         TG_HIP_CHECK(hipMemsetAsync(st->gblock, 0, sizeof(float) * (size_t)(fill + fill_extra), ms));
+    }
     st->zeroed_floats = 0;
     float* g = st->gblock;
     const float* dH = d_demb;
@@ -625,7 +629,7 @@ int check_bank(const tg_tgn_bank* b, const tg_stepper* st) {
 
 // updated memory rows of the touched nodes (GRU on their pending messages, not persisted), `memory' + raw` as the layer's table, the layer
 extern "C" int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_bank* bank, int training, const uint64_t* seeds, void* stream,
-                                      float** d_emb) {
+                                      float** d_emb, int keep_grad) {
     TG_REQUIRE(st && st->c.tgn && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_tgn_forward: arguments");
     TG_TRY(check_bank(bank, st));
     Slot& s = st->slots[(size_t)slot];
@@ -642,15 +646,19 @@ extern "C" int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_ban
                            P + st->gru_off[0], P + st->gru_off[1], P + st->gru_off[2], P + st->gru_off[3], pending ? 1 : 0, t.h_rows,
                            pending ? t.msg_rows : nullptr, pending ? t.gi : nullptr, pending ? t.gh : nullptr, t.rows, t.base, stream));
     const int64_t roots = s.n, nb2 = 2 * s.nb;
-    return run_forward(st, s, slot, Base{t.base, D, s.rowmap + roots + nb2, s.rowmap}, training, seeds, stream, d_emb,
+    // keep_grad: an earlier backward's gradients wait in the block for this batch's to be added (the warm-up's negative-then-positive
+    // pair, PTCL/EM_warmup.py:159-175): no zero fill here
+    return run_forward(st, s, slot, Base{t.base, D, s.rowmap + roots + nb2, s.rowmap}, keep_grad ? 2 : training, seeds, stream, d_emb,
                        pending ? r4(s.uniq_count * D) : 0);
 }
 
 // backward of the layer and of the GRU; positive != 0: the state advance of models/MemoryModel.py:155-180 (persist the batch nodes' GRU rows,
 // build the new raw messages from the post-update state, file them last-message-wins; the host mirrors first: TG_EINVAL "Trying to update
 // memory to time in the past!" leaves everything unchanged) BEFORE the update of the parameters, as the trainers order it.
-extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* bank, const float* d_demb, int positive, void* stream,
+extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* bank, const float* d_demb, int flags, void* stream,
                                        const tg_adam_args* adam, float** d_grad) {
+    const int positive = flags & 1;
+    const bool accumulate = (flags & 2) != 0, more = (flags & 4) != 0;
     TG_REQUIRE(st && st->c.tgn && d_demb && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_tgn_backward: arguments");
     TG_TRY(check_bank(bank, st));
     Slot& s = st->slots[(size_t)slot];
@@ -663,8 +671,11 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
     float* g = st->gblock;
     float* d_table = g + st->g_rows;                       // behind the (absent) lower layers' rows: zeroed with the block
     const int64_t U = s.uniq_count, roots = s.n, nb2 = 2 * s.nb;
-    int rc = run_backward(st, s, d_demb, stream, nullptr, nullptr, adam != nullptr,
-                          pending ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw} : BaseGrad{nullptr, 0, nullptr, nullptr}, pending ? r4(U * D) : 0);
+    TG_REQUIRE(!(more && adam), "tg_stepper_tgn_backward: the update belongs to the LAST backward of a step");
+    // (fuse_tb argument: true also when more backward calls follow -- d b is finished once, on the summed d cos b, by the last call)
+    int rc = run_backward(st, s, d_demb, stream, nullptr, nullptr, adam != nullptr || more,
+                          pending ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw} : BaseGrad{nullptr, 0, nullptr, nullptr}, pending ? r4(U * D) : 0,
+                          accumulate);
     if (rc == TG_OK && pending) {
         // the merge layer's and the query's share of the gradient w.r.t. the roots' own rows, then the GRU
         rc = tg_scatter_add_rows(t.d_own, D, s.rowmap, roots, D, d_table, D, stream);

@@ -62,6 +62,51 @@ class LinkPredictionLoss:
         return self.loss_out, d_emb
 
 
+class PairLinkLoss:
+    """One half of the link-prediction warm-up's loss on an embedding block [src | dst] (2 B rows) of ONE backbone call -- the form a
+    memory model needs, whose negative and positive pairs come from two calls (PTCL/EM_warmup.py:159-175):
+        p = sigmoid(head(src, dst)),  this call's share of BCELoss over the 2 B samples of the step = sum_i BCE(p_i, label) / (2 B)
+    (`share` = B / (2 B) = 0.5 rescales the mean over this call's B samples).  Explicit forward / backward on the library's kernels;
+    the head's parameter gradients are ADDED to their .grad; returns (loss share, d loss / d emb)."""
+
+    def __init__(self, head, positive: bool, share: float = 0.5):
+        self.head, self.positive, self.share = head, bool(positive), float(share)
+        self.loss_out = None
+
+    def __call__(self, emb: torch.Tensor):
+        fc1, fc2 = self.head.fc1, self.head.fc2
+        n2, D = emb.shape
+        B = n2 // 2
+        assert n2 == 2 * B and fc1.weight.shape[1] == 2 * D and fc2.weight.shape[0] == 1
+        H = fc1.weight.shape[0]
+        dev = emb.device
+        X = torch.cat([emb[:B], emb[B:]], 1)                                                     # (B, 2 D)
+        h = torch.empty((B, H), device=dev)
+        ops.gemm(X, fc1.weight.detach(), h, tb=True, bias=fc1.bias.detach(), relu=True)
+        z = torch.empty((B, 1), device=dev)
+        ops.gemm(h, fc2.weight.detach(), z, tb=True, bias=fc2.bias.detach())
+        if self.loss_out is None or self.loss_out.device != dev:
+            self.loss_out = torch.zeros(1, device=dev)
+        dz = torch.empty((B, 1), device=dev)
+        check(lib().tg_bce_logits(ops._p(z), B if self.positive else 0, B, ops._p(self.loss_out), ops._p(dz), ops._stream()), "tg_bce_logits")
+        if self.share != 1.0:
+            dz.mul_(self.share)
+        dW2 = torch.empty_like(fc2.weight)
+        ops.gemm(dz, h, dW2, ta=True)
+        dh = torch.empty((B, H), device=dev)
+        ops.gemm(dz, fc2.weight.detach(), dh)
+        ops.relu_bwd_(dh, h)
+        dW1 = torch.empty_like(fc1.weight)
+        ops.gemm(dh, X, dW1, ta=True)
+        dX = torch.empty((B, 2 * D), device=dev)
+        ops.gemm(dh, fc1.weight.detach(), dX)
+        _acc_grad(fc2.weight, dW2)
+        _acc_grad(fc2.bias, ops.colsum(dz))
+        _acc_grad(fc1.weight, dW1)
+        _acc_grad(fc1.bias, ops.colsum(dh))
+        return self.loss_out * self.share, torch.cat([dX[:, :D], dX[:, D:]], 0).contiguous()
+
+
 class ClassifierLoss:
     """The M-step's head and loss on the rows `rows` (a slice; default: the first len(labels) rows = the source embeddings,
     PTCL/M_step.py:285) of an embedding block:

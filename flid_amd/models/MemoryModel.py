@@ -330,7 +330,8 @@ class MemoryModel(torch.nn.Module):
         self._stepper = Stepper(self, 2 * int(max_batch_edges), num_neighbors, slots)
         return self._stepper
 
-    def train_step(self, prepared, edge_ids, loss_fn, num_neighbors: int = 20, optimizer=None, edges_are_positive: bool = True):
+    def train_step(self, prepared, edge_ids, loss_fn, num_neighbors: int = 20, optimizer=None, edges_are_positive: bool = True,
+                   accumulate: bool = False, more: bool = False):
         """Fused-trainer step on a prepared (prepare_batch_begin / _finish) POSITIVE batch: updated memory rows of the touched
         nodes, embeddings, `loss_fn(emb) -> (loss, d_emb)` on the detached (2 B, D) block [src rows | dst rows], backward into the
         flat parameter's .grad (added, as autograd accumulates), and the state advance (persist, new messages, last-message-wins
@@ -342,9 +343,13 @@ class MemoryModel(torch.nn.Module):
             # (optimizer: a FlatAdam over the flat parameter -- its update is issued behind the state advance, in the backward's call)
             assert prepared.finished and prepared.k == int(num_neighbors) and prepared.stepper is getattr(self, "_stepper", None), \
                 "prepared by another stepper / not finished"
-            return prepared.stepper.step_tgn(prepared, loss_fn, positive=edges_are_positive, optimizer=optimizer)
-        if optimizer is not None or not edges_are_positive:
-            raise NotImplementedError("train_step(optimizer=..., edges_are_positive=False) are the native step's (enable_native_step())")
+            # The warm-up's link-prediction step (PTCL/EM_warmup.py:159-175, :212-231) embeds the negative pairs first (edge_ids None,
+            # edges_are_positive False: no state advance), then the positive ones, and backpropagates ONE loss over both: two calls here,
+            # train_step(neg, ..., edges_are_positive=False, more=True) then train_step(pos, ..., accumulate=True, optimizer=opt) -- the
+            # loss is a mean over independent samples, so each call backpropagates its own samples' share into the same gradient block
+            return prepared.stepper.step_tgn(prepared, loss_fn, positive=edges_are_positive, optimizer=optimizer, accumulate=accumulate, more=more)
+        if optimizer is not None or not edges_are_positive or accumulate or more:
+            raise NotImplementedError("train_step(optimizer / edges_are_positive=False / accumulate / more) are the native step's (enable_native_step())")
         flat = getattr(self, "_flat_pack", None)
         if flat is None:
             raise RuntimeError("MemoryModel.train_step needs the flat-parameter mode: call flatten_parameters() first")

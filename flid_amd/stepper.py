@@ -173,19 +173,21 @@ class Stepper:
                        b._has_dev.data_ptr(), b._msg_time_dev.data_ptr(), b._last_idx_ws.data_ptr(), b._has.ctypes.data, b._msg_time.ctypes.data,
                        b._h_last.ctypes.data, len(b._has), int(bool(b._past_violation)))
 
-    def forward_tgn(self, job: StepJob) -> torch.Tensor:
+    def forward_tgn(self, job: StepJob, keep_grad: bool = False) -> torch.Tensor:
         training = bool(self.model.training)
         if training and self.cfg.dropout_p > 0:
             for i, v in enumerate(engine._next_seeds(2 * self.num_layers)):
                 self._seeds[i] = v
         bank = self._bank()
-        check(lib().tg_stepper_tgn_forward(self._h, job.slot, C.byref(bank), int(training), self._seeds, ops._stream(), None), "tg_stepper_tgn_forward")
+        check(lib().tg_stepper_tgn_forward(self._h, job.slot, C.byref(bank), int(training), self._seeds, ops._stream(), None, int(keep_grad)),
+              "tg_stepper_tgn_forward")
         emb = self._emb_views.get(job.n)
         if emb is None:
             emb = self._emb_views[job.n] = self.arena[self._emb_off:self._emb_off + job.n * self.dn].view(job.n, self.dn)
         return emb
 
-    def backward_tgn(self, job: StepJob, d_emb: torch.Tensor, positive: bool = True, optimizer=None):
+    def backward_tgn(self, job: StepJob, d_emb: torch.Tensor, positive: bool = True, optimizer=None, accumulate: bool = False, more: bool = False):
+        """accumulate: add to the gradients an earlier backward of this step left in the block; more: another backward follows"""
         assert d_emb.is_contiguous() and d_emb.dtype == torch.float32 and d_emb.numel() == job.n * self.dn
         prev = self.flat.grad
         if prev is not None and prev.data_ptr() == self.grad.data_ptr():
@@ -195,7 +197,8 @@ class Stepper:
         adam = None if optimizer is None else optimizer.native_args(self.flat)
         bank = self._bank()
         try:
-            check(lib().tg_stepper_tgn_backward(self._h, job.slot, C.byref(bank), d_emb.data_ptr(), int(bool(positive)), ops._stream(),
+            check(lib().tg_stepper_tgn_backward(self._h, job.slot, C.byref(bank), d_emb.data_ptr(),
+                                                int(bool(positive)) | (2 if accumulate else 0) | (4 if more else 0), ops._stream(),
                                                 None if adam is None else C.byref(adam), None), "tg_stepper_tgn_backward")
         finally:
             if bank.past_violation:
@@ -205,10 +208,10 @@ class Stepper:
         else:
             prev.add_(self.grad)
 
-    def step_tgn(self, job: StepJob, loss_fn, positive: bool = True, optimizer=None):
-        emb = self.forward_tgn(job)
+    def step_tgn(self, job: StepJob, loss_fn, positive: bool = True, optimizer=None, accumulate: bool = False, more: bool = False):
+        emb = self.forward_tgn(job, keep_grad=accumulate)
         loss, d_emb = loss_fn(emb)
-        self.backward_tgn(job, d_emb, positive=positive, optimizer=optimizer)
+        self.backward_tgn(job, d_emb, positive=positive, optimizer=optimizer, accumulate=accumulate, more=more)
         return emb, loss
 
     def step(self, job: StepJob, loss_fn, grad_ready=None, optimizer=None):

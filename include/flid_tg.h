@@ -282,9 +282,14 @@ int tg_stepper_backward(tg_stepper* st, int slot, const float* d_demb, void* str
  * roles: 2 (hi - lo) roots), the state advance always covers the whole batch.  Then tg_stepper_prepare_finish, and: */
 int tg_stepper_tgn_prepare_begin(tg_stepper* st, int slot, const int64_t* h_src, const int64_t* h_dst, const double* h_t, const int64_t* h_eid,
                                  int64_t n, int64_t lo, int64_t hi);
-int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_bank* bank, int training, const uint64_t* seeds, void* stream, float** d_emb);
-/* positive != 0: the state advance of models/MemoryModel.py:155-180 runs behind the backward, before the update */
-int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* bank, const float* d_demb, int positive, void* stream,
+/* keep_grad != 0: the gradient block holds an earlier backward's gradients that this batch's will be added to (flags bit 1 below) */
+int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_bank* bank, int training, const uint64_t* seeds, void* stream, float** d_emb,
+                           int keep_grad);
+/* flags: bit 0 = positive batch: the state advance of models/MemoryModel.py:155-180 runs behind the backward, before the update;
+ * bit 1 = ADD this batch's gradients to what the block holds (the warm-up embeds the negative pairs first, then the positive ones, and
+ * backpropagates one loss over both: PTCL/EM_warmup.py:159-175, :212-231); bit 2 = another backward of the same step follows (the
+ * time-encoder bias gradient is finished by the last one; no update here) */
+int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* bank, const float* d_demb, int flags, void* stream,
                             const tg_adam_args* adam, float** d_grad);
 
 /* ---- optimizer step for the flat-parameter mode (the trainers' torch.optim.Adam, utils/utils.py:40-60 create_optimizer) ----

@@ -304,6 +304,74 @@ def test_tgn_native_step_equals_python_fused_step():
     assert float((((a[3] - p0) - (c[3] - p0)).abs() * sig).max()) <= 0.05e-7 and float(((c[3] - p0).abs() * sig).max()) >= 0.9e-7
 
 
+def test_tgn_native_warmup_step_negative_then_positive_equals_autograd():
+    """the warm-up's link-prediction step on a memory model (PTCL/EM_warmup.py:159-231): negatives first (edge_ids None, no state
+    advance), then positives, ONE BCE over both through the MergeLayer head, backward, Adam.  Native stepper: two calls that add into one
+    gradient block (PairLinkLoss halves) + the update inside the second.  Against the autograd path with torch's head, BCELoss and the
+    same FlatAdam: embeddings, loss, backbone + head gradients, advanced state, over 4 batches."""
+    from flid_amd import engine
+    from flid_amd.heads import PairLinkLoss
+    from flid_amd.models.modules import MergeLayer
+    from flid_amd.optim import FlatAdam
+    g = load_golden("tgn_small")
+    bsz = 12
+    rs = np.random.RandomState(3)
+    n_nodes = g["node_feat"].shape[0]
+    negs = [rs.randint(1, n_nodes, bsz).astype(np.int64) for _ in range(4)]
+    out = []
+    for native in (False, True):
+        m, p, k = _model(g)
+        D = g["node_feat"].shape[1]
+        torch.manual_seed(5)
+        head = MergeLayer(D, D, D, 1).cuda()
+        m.memory_bank.__init_memory_bank__()
+        if native:
+            # (the update's learning rate is negligible: the autograd twin below takes no update)
+            flat = m.flatten_parameters()
+            opt = FlatAdam([flat], lr=1e-9)
+            m.enable_native_step(bsz, k)
+            offs, _ = engine.block_layout(m._trainable())
+        rec = []
+        for b in range(4):
+            sl = slice(b * bsz, (b + 1) * bsz)
+            src, dst, t, eid = g["src"][sl], g["dst"][sl], g["t"][sl], g["eid"][sl]
+            m.zero_grad(set_to_none=True)
+            head.zero_grad(set_to_none=True)
+            if native:
+                opt.zero_grad(set_to_none=True)
+                jn = m.prepare_batch_finish(m.prepare_batch_begin(src, negs[b], t, k))
+                jp = m.prepare_batch_finish(m.prepare_batch_begin(src, dst, t, k, edge_ids=eid))
+                en, ln = m.train_step(jn, None, PairLinkLoss(head, False), k, edges_are_positive=False, more=True)
+                en = en.clone()
+                ep, lp = m.train_step(jp, eid, PairLinkLoss(head, True), k, optimizer=opt, accumulate=True)
+                loss = float(ln) + float(lp)
+                gflat = torch.cat([flat.grad[o:o + q.numel()] for o, q in zip(offs, m._trainable())])
+            else:
+                ns_, nd_ = m.compute_src_dst_node_temporal_embeddings(src, negs[b], t, None, False, k)
+                ps_, pd_ = m.compute_src_dst_node_temporal_embeddings(src, dst, t, eid, True, k)
+                prob = torch.cat([head(ps_, pd_), head(ns_, nd_)]).squeeze(1).sigmoid()
+                lab = torch.cat([torch.ones(bsz), torch.zeros(bsz)]).cuda()
+                l_ = torch.nn.BCELoss()(prob, lab)
+                l_.backward()
+                loss = float(l_)
+                gflat = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in m._trainable()])
+                m.memory_bank.detach_memory_bank()
+                en, ep = torch.cat([ns_, nd_]).detach(), torch.cat([ps_, pd_]).detach()
+            bank = m.memory_bank
+            rec.append((en.clone(), ep.clone(), loss, gflat, [q.grad.clone() for q in head.parameters()], bank.node_memories.data.clone(),
+                        bank._msg.clone(), bank._has.copy()))
+        out.append(rec)
+    for b, (x, y) in enumerate(zip(*out)):
+        assert float((x[0] - y[0]).abs().max()) <= 1e-5 and float((x[1] - y[1]).abs().max()) <= 1e-5, b
+        assert abs(x[2] - y[2]) <= 1e-5 * max(1.0, abs(x[2])), (b, x[2], y[2])
+        scale = max(1e-3, float(x[3].abs().max()))
+        # (2e-4 of the block's largest entry: the time encoder's weight gradient -- sums of (time interval x d phase) over all slots of both calls -- is the largest and the worst conditioned)
+        assert float((x[3] - y[3]).abs().max()) <= 2e-4 * scale, (b, float((x[3] - y[3]).abs().max()), scale)
+        for ga, gb in zip(x[4], y[4]):
+            assert float((ga - gb).abs().max()) <= 5e-5 * max(1e-3, float(ga.abs().max()))
+        assert torch.allclose(x[5], y[5], atol=1e-5) and torch.allclose(x[6], y[6], atol=1e-5) and np.array_equal(x[7], y[7])
+
+
 def test_tgn_regeneration_sweep_equals_sequential_positive_calls():
     """TGN sweep (M_step.py:456-509 with the memory bank reset first): stores == the loop of positive calls; state advanced alike"""
     from flid_amd.sweep import regenerate_embeddings
