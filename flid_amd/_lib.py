@@ -160,6 +160,8 @@ SIGNATURES = {
     "tg_tgn_prepare_layout": (C.c_int, [c_i64, c_i64, C.c_int, c_void]),
     "tg_tgn_prepare_batch": (C.c_int, [c_void] * 5 + [c_i64, c_i64, c_i64, C.c_int, c_i64] + [c_void] * 6 + [c_i64] + [c_void] * 11 + [c_void]),
     "tg_recent_window_mean": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_i64, C.c_int, c_void, c_i64, c_void]),
+    "tg_seq_attn_fwd": (C.c_int, [c_void, c_i64, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint64, c_void, c_void, c_void]),
+    "tg_seq_attn_bwd": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, C.c_int, C.c_int, c_f32, C.c_uint64, c_void, c_void]),
     "tg_softmax_bwd": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void]),
     "tg_dropout": (C.c_int, [c_void, c_i64, c_f32, C.c_uint64, c_void, c_void]),
     "tg_gelu_dropout_fwd": (C.c_int, [c_void, c_i64, c_f32, C.c_uint64, c_void, c_void]),

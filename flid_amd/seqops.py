@@ -77,11 +77,27 @@ def segment_mean(x, lo, hi):
     return _SegmentMeanFn.apply(x, lo, hi)
 
 
+FUSED_ATTENTION = True     # the attention core of a (sequence, head) as one launch per direction (tg_seq_attn_fwd / _bwd) where it fits
+
+
+def _fused_attn_ok(S, d, heads):
+    hd = d // heads
+    return FUSED_ATTENTION and S <= 64 and d % heads == 0 and hd % 4 == 0 and hd <= 100 and d % 4 == 0
+
+
 def _self_attn_fwd(qkv, heads, p_drop, seed):
-    """softmax(Q K^T / sqrt(hd)) V per (sequence, head) on the packed (B, S, 3d) in-projection; returns (out, prob, dropped prob)"""
+    """softmax(Q K^T / sqrt(hd)) V per (sequence, head) on the packed (B, S, 3d) in-projection; returns (out, prob, dropped prob);
+    the fused launch keeps no dropped probabilities (third item = prob: its backward regenerates the mask)"""
+    from ._lib import check, lib
     B, S, d3 = qkv.shape
     d = d3 // 3
     hd = d // heads
+    if _fused_attn_ok(S, d, heads):
+        out = torch.empty((B, S, d), device=qkv.device)
+        prob = torch.empty((B, heads, S, S), device=qkv.device)
+        check(lib().tg_seq_attn_fwd(ops._p(qkv), B, S, d, heads, float(p_drop), int(seed), ops._p(out), ops._p(prob), ops._stream()),
+              "tg_seq_attn_fwd")
+        return out, prob, prob
     q00, k00, v00 = qkv[0, :, 0:hd], qkv[0, :, d:d + hd], qkv[0, :, 2 * d:2 * d + hd]
     sq = (S * d3, hd)
     scores = torch.empty((B, heads, S, S), device=qkv.device)
@@ -94,9 +110,15 @@ def _self_attn_fwd(qkv, heads, p_drop, seed):
 
 
 def _self_attn_bwd(qkv, prob, pd, dout, heads, p_drop, seed):
+    from ._lib import check, lib
     B, S, d3 = qkv.shape
     d = d3 // 3
     hd = d // heads
+    if _fused_attn_ok(S, d, heads) and pd.data_ptr() == prob.data_ptr():
+        dqkv = torch.empty_like(qkv)
+        check(lib().tg_seq_attn_bwd(ops._p(qkv), ops._p(prob), ops._p(dout), B, S, d, heads, float(p_drop), int(seed), ops._p(dqkv),
+                                    ops._stream()), "tg_seq_attn_bwd")
+        return dqkv
     sq, sp, so = (S * d3, hd), (heads * S * S, S * S), (S * d, hd)
     q00, k00, v00 = qkv[0, :, 0:hd], qkv[0, :, d:d + hd], qkv[0, :, 2 * d:2 * d + hd]
     dqkv = torch.empty_like(qkv)

@@ -488,6 +488,14 @@ int tg_softmax_bwd(const float* d_y, const float* d_dy, int64_t n, int cols, flo
  * the rows_per_batch rows of batch b counts as -inf where d_key_ids[b * cols + c] == 0 (backward: tg_softmax_bwd, masked
  * probabilities are exactly 0).  Rows with every key masked are NaN, as in the reference. */
 int tg_softmax_keymask_fwd(const float* d_x, int64_t n, int cols, const int32_t* d_key_ids, int64_t rows_per_batch, float* d_y, void* stream);
+/* the attention core of nn.MultiheadAttention on the packed in-projection d_qkv (B, S, 3 d) = [Q | K | V], no masks
+ * (models/DyGFormer.py:442-461): per (sequence, head) P = softmax(Q K^T / sqrt(d / heads)), O = dropout(P) V, as ONE launch -- and its
+ * backward (dQ | dK | dV into d_dqkv) as one launch.  d_prob (B, heads, S, S) keeps P for the backward; the dropout mask is tg_dropout's
+ * on that tensor's flat index.  Exact fp32 (f32-input MFMA).  TG_ESHAPE for S > 64 or d / heads > 100 (nothing launched). */
+int tg_seq_attn_fwd(const float* d_qkv, int64_t B, int S, int d, int heads, float dropout_p, uint64_t seed, float* d_out, float* d_prob,
+                    void* stream);
+int tg_seq_attn_bwd(const float* d_qkv, const float* d_prob, const float* d_dout, int64_t B, int S, int d, int heads, float dropout_p,
+                    uint64_t seed, float* d_dqkv, void* stream);
 /* y[i] = x[i] / (1-p) if hash(seed, i) >= p else 0.  Applying it to dy with the same seed is the backward. */
 int tg_dropout(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream);
 /* fused element-wise passes of the pre-LN transformer block (models/DyGFormer.py:448-461), masks as tg_dropout(seed, index):

@@ -188,3 +188,35 @@ def test_block_diagonal_patch_projection_equals_per_channel_products():
     for k_ in res[1][1]:
         a, b = res[0][1][k_], res[1][1][k_]
         assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max())), k_
+
+
+@pytest.mark.parametrize("B,S,d,heads,p", [(7, 64, 200, 2, 0.0), (5, 37, 200, 2, 0.3), (3, 5, 16, 2, 0.0), (4, 64, 100, 1, 0.2), (9, 33, 48, 4, 0.1)])
+def test_fused_self_attention_equals_batched_products(B, S, d, heads, p):
+    """tg_seq_attn_fwd / _bwd (the attention core of a (sequence, head) as one launch per direction, tg_seqattn.hip) against the batched
+    exact-fp32 products + softmax + dropout passes they replace (same seed, same mask), and against float64"""
+    from flid_amd import seqops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * S + d)
+    qkv = torch.randn(B, S, 3 * d, device=dev)
+    dout = torch.randn(B, S, d, device=dev)
+    seed = 123456789
+    res = []
+    for fused in (True, False):
+        seqops.FUSED_ATTENTION = fused
+        try:
+            out, prob, pd = seqops._self_attn_fwd(qkv, heads, p, seed)
+            dqkv = seqops._self_attn_bwd(qkv, prob, pd, dout, heads, p, seed)
+        finally:
+            seqops.FUSED_ATTENTION = True
+        res.append((out, prob, dqkv))
+    for a, b_ in zip(*res):
+        assert float((a - b_).abs().max()) <= 2e-5 * max(1.0, float(b_.abs().max())), float((a - b_).abs().max())
+    if p == 0.0:
+        hd = d // heads
+        q, k, v = (qkv[..., i * d:(i + 1) * d].double().view(B, S, heads, hd).transpose(1, 2).requires_grad_(True) for i in range(3))
+        pr = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1)
+        o = (pr @ v).transpose(1, 2).reshape(B, S, d)
+        o.backward(dout.double())
+        assert float((res[0][0].double() - o).abs().max()) <= 1e-5 and float((res[0][1].double() - pr).abs().max()) <= 1e-6
+        want = torch.cat([g_.grad.transpose(1, 2).reshape(B, S, d) for g_ in (q, k, v)], dim=-1)
+        assert float((res[0][2].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
