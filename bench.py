@@ -763,6 +763,11 @@ def bench_memory_or_sequence_model(args):
             if native and reducer is None:                   # ... and Adam, every launch issued by the library
                 model.train_step(pf, data.edge_ids[sl], mean_loss, K, optimizer=opt)
                 return
+            if native:                                       # N > 1: the layer's block starts its all-reduce under the GRU's backward + the state advance
+                model.train_step(pf, data.edge_ids[sl], mean_loss, K, grad_ready=reducer.segment_ready)
+                reducer.finish()
+                opt.step()
+                return
             if fused:                                        # forward, loss, backward, state advance: no autograd graph
                 model.train_step(pf, data.edge_ids[sl], mean_loss, K)
                 if reducer is not None:
@@ -822,7 +827,8 @@ def bench_memory_or_sequence_model(args):
         dist_info = {"rccl_ranks": world, "backend": torch.distributed.get_backend(),
                      "per_rank_ms_per_step": [round(e / args.steps * 1e3, 4) for e in per_rank],
                      "allreduce_ms": round((time.perf_counter() - t_ar) / 20 * 1e3, 4), "allreduce_floats": int(gbuf.numel()),
-                     "overlap": "none (one flat-bucket all-reduce between backward and optimizer)"}
+                     "overlap": ("attention + merge layer block reduced under the GRU backward and the state advance (GradAllReducer.segment_ready)"
+                                 if (args.model == "tgn" and native) else "none (one flat-bucket all-reduce between backward and optimizer)")}
     value = args.steps * BATCH * world / elapsed
     secs = max(ms * 1e-3, 1e-12)
     if args.model == "tgn":

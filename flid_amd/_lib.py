@@ -97,7 +97,8 @@ SIGNATURES = {
     "tg_stepper_backward": (C.c_int, [c_void, C.c_int, c_void, c_void, GRAD_READY_FN, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
     "tg_stepper_tgn_prepare_begin": (C.c_int, [c_void, C.c_int, c_void, c_void, c_void, c_void, c_i64, c_i64, c_i64]),
     "tg_stepper_tgn_forward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), C.c_int, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void), C.c_int]),
-    "tg_stepper_tgn_backward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), c_void, C.c_int, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
+    "tg_stepper_tgn_backward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), c_void, C.c_int, c_void, C.POINTER(AdamArgs), C.POINTER(c_void),
+                                          GRAD_READY_FN, c_void]),
     "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),
     "tg_time_bias_finish": (C.c_int, [c_void, c_void, c_void, C.c_int, c_void]),
     "tg_bce_logits": (C.c_int, [c_void, c_i64, c_i64, c_void, c_void, c_void]),

@@ -656,7 +656,7 @@ extern "C" int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_ban
 // build the new raw messages from the post-update state, file them last-message-wins; the host mirrors first: TG_EINVAL "Trying to update
 // memory to time in the past!" leaves everything unchanged) BEFORE the update of the parameters, as the trainers order it.
 extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* bank, const float* d_demb, int flags, void* stream,
-                                       const tg_adam_args* adam, float** d_grad) {
+                                       const tg_adam_args* adam, float** d_grad, tg_grad_ready_fn grad_ready, void* user) {
     const int positive = flags & 1;
     const bool accumulate = (flags & 2) != 0, more = (flags & 4) != 0;
     TG_REQUIRE(st && st->c.tgn && d_demb && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_tgn_backward: arguments");
@@ -672,10 +672,14 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
     float* d_table = g + st->g_rows;                       // behind the (absent) lower layers' rows: zeroed with the block
     const int64_t U = s.uniq_count, roots = s.n, nb2 = 2 * s.nb;
     TG_REQUIRE(!(more && adam), "tg_stepper_tgn_backward: the update belongs to the LAST backward of a step");
+    TG_REQUIRE(!(grad_ready && (adam || more)), "tg_stepper_tgn_backward: grad_ready is for the last backward of a step, before a reduction (no update here)");
     // (fuse_tb argument: true also when more backward calls follow -- d b is finished once, on the summed d cos b, by the last call)
     int rc = run_backward(st, s, d_demb, stream, nullptr, nullptr, adam != nullptr || more,
                           pending ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw} : BaseGrad{nullptr, 0, nullptr, nullptr}, pending ? r4(U * D) : 0,
                           accumulate);
+    // the attention + merge layer's block is final (the time encoder's two tensors in front of it are not: d b is finished below / by the
+    // caller's update): a data-parallel caller starts reducing it under the GRU's backward and the state advance
+    if (rc == TG_OK && grad_ready) grad_ready(user, g + st->poff[2], st->poff.back() - st->poff[2]);
     if (rc == TG_OK && pending) {
         // the merge layer's and the query's share of the gradient w.r.t. the roots' own rows, then the GRU
         rc = tg_scatter_add_rows(t.d_own, D, s.rowmap, roots, D, d_table, D, stream);

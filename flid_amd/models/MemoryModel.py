@@ -331,7 +331,7 @@ class MemoryModel(torch.nn.Module):
         return self._stepper
 
     def train_step(self, prepared, edge_ids, loss_fn, num_neighbors: int = 20, optimizer=None, edges_are_positive: bool = True,
-                   accumulate: bool = False, more: bool = False):
+                   accumulate: bool = False, more: bool = False, grad_ready=None):
         """Fused-trainer step on a prepared (prepare_batch_begin / _finish) POSITIVE batch: updated memory rows of the touched
         nodes, embeddings, `loss_fn(emb) -> (loss, d_emb)` on the detached (2 B, D) block [src rows | dst rows], backward into the
         flat parameter's .grad (added, as autograd accumulates), and the state advance (persist, new messages, last-message-wins
@@ -347,8 +347,11 @@ class MemoryModel(torch.nn.Module):
             # edges_are_positive False: no state advance), then the positive ones, and backpropagates ONE loss over both: two calls here,
             # train_step(neg, ..., edges_are_positive=False, more=True) then train_step(pos, ..., accumulate=True, optimizer=opt) -- the
             # loss is a mean over independent samples, so each call backpropagates its own samples' share into the same gradient block
-            return prepared.stepper.step_tgn(prepared, loss_fn, positive=edges_are_positive, optimizer=optimizer, accumulate=accumulate, more=more)
-        if optimizer is not None or not edges_are_positive or accumulate or more:
+            # grad_ready(segment): the layer's gradient block, handed over while the GRU's backward and the state advance are being issued
+            # (flid_amd.dist.GradAllReducer.segment_ready starts its all-reduce there; reducer.finish() reduces the rest)
+            return prepared.stepper.step_tgn(prepared, loss_fn, positive=edges_are_positive, optimizer=optimizer, accumulate=accumulate, more=more,
+                                             grad_ready=grad_ready)
+        if optimizer is not None or not edges_are_positive or accumulate or more or grad_ready is not None:
             raise NotImplementedError("train_step(optimizer / edges_are_positive=False / accumulate / more) are the native step's (enable_native_step())")
         flat = getattr(self, "_flat_pack", None)
         if flat is None:

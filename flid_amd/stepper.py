@@ -186,9 +186,20 @@ class Stepper:
             emb = self._emb_views[job.n] = self.arena[self._emb_off:self._emb_off + job.n * self.dn].view(job.n, self.dn)
         return emb
 
-    def backward_tgn(self, job: StepJob, d_emb: torch.Tensor, positive: bool = True, optimizer=None, accumulate: bool = False, more: bool = False):
-        """accumulate: add to the gradients an earlier backward of this step left in the block; more: another backward follows"""
+    def backward_tgn(self, job: StepJob, d_emb: torch.Tensor, positive: bool = True, optimizer=None, accumulate: bool = False, more: bool = False,
+                     grad_ready=None):
+        """accumulate: add to the gradients an earlier backward of this step left in the block; more: another backward follows;
+        grad_ready(segment): called with the layer's finished gradient block while the GRU's backward and the state advance are still
+        being issued (a data-parallel caller starts its reduction there)"""
         assert d_emb.is_contiguous() and d_emb.dtype == torch.float32 and d_emb.numel() == job.n * self.dn
+        cb = GRAD_READY_FN()
+        if grad_ready is not None:
+            g_, base_ = self.grad, self.grad.data_ptr()
+
+            def _cb(_user, seg_ptr, floats):
+                o = (seg_ptr - base_) // 4
+                grad_ready(g_[o:o + floats])
+            cb = GRAD_READY_FN(_cb)
         prev = self.flat.grad
         if prev is not None and prev.data_ptr() == self.grad.data_ptr():
             prev = None
@@ -199,7 +210,7 @@ class Stepper:
         try:
             check(lib().tg_stepper_tgn_backward(self._h, job.slot, C.byref(bank), d_emb.data_ptr(),
                                                 int(bool(positive)) | (2 if accumulate else 0) | (4 if more else 0), ops._stream(),
-                                                None if adam is None else C.byref(adam), None), "tg_stepper_tgn_backward")
+                                                None if adam is None else C.byref(adam), None, cb, None), "tg_stepper_tgn_backward")
         finally:
             if bank.past_violation:
                 self.model.memory_bank._past_violation = True
@@ -208,10 +219,11 @@ class Stepper:
         else:
             prev.add_(self.grad)
 
-    def step_tgn(self, job: StepJob, loss_fn, positive: bool = True, optimizer=None, accumulate: bool = False, more: bool = False):
+    def step_tgn(self, job: StepJob, loss_fn, positive: bool = True, optimizer=None, accumulate: bool = False, more: bool = False,
+                 grad_ready=None):
         emb = self.forward_tgn(job, keep_grad=accumulate)
         loss, d_emb = loss_fn(emb)
-        self.backward_tgn(job, d_emb, positive=positive, optimizer=optimizer, accumulate=accumulate, more=more)
+        self.backward_tgn(job, d_emb, positive=positive, optimizer=optimizer, accumulate=accumulate, more=more, grad_ready=grad_ready)
         return emb, loss
 
     def step(self, job: StepJob, loss_fn, grad_ready=None, optimizer=None):

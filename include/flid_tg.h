@@ -290,7 +290,9 @@ int tg_stepper_tgn_forward(tg_stepper* st, int slot, const tg_tgn_bank* bank, in
  * backpropagates one loss over both: PTCL/EM_warmup.py:159-175, :212-231); bit 2 = another backward of the same step follows (the
  * time-encoder bias gradient is finished by the last one; no update here) */
 int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* bank, const float* d_demb, int flags, void* stream,
-                            const tg_adam_args* adam, float** d_grad);
+                            const tg_adam_args* adam, float** d_grad, tg_grad_ready_fn grad_ready, void* user);
+/* (grad_ready, optional: called with the attention + merge layer's finished gradient block as soon as the layer's backward is queued --
+ * the GRU's backward and the state advance follow -- so that a data-parallel caller overlaps its reduction with them) */
 
 /* ---- optimizer step for the flat-parameter mode (the trainers' torch.optim.Adam, utils/utils.py:40-60 create_optimizer) ----
  * one element-wise pass over a flat fp32 parameter: exp_avg / exp_avg_sq updated in place, bias-corrected step `step` (>= 1),

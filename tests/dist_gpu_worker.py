@@ -86,6 +86,44 @@ def main():
     dist.all_gather(both, state)
     assert all(torch.equal(both[0], b_) for b_ in both[1:]), "TGN replicas diverged"
 
+    # ---- (ii-b) TGN fused step through the native stepper under data parallelism: every rank embeds its shard of the 200-edge batch with
+    # the layer's gradient block handed to the reducer from C (grad_ready) and advances the replicated state with the whole batch; the
+    # reduced gradient == the single-process gradient of the whole batch, the replicas' states stay identical
+    torch.manual_seed(0)
+    tn = MemoryModel(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, model_name="TGN", num_layers=1,
+                     num_heads=2, dropout=0.0, device=dev).to(dev).train()
+    fdist.broadcast_parameters(tn)
+    t1 = MemoryModel(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, model_name="TGN", num_layers=1,
+                     num_heads=2, dropout=0.0, device=dev).to(dev).train()
+    t1.load_state_dict(tn.state_dict())
+    fl_n, fl_1 = tn.flatten_parameters(), t1.flatten_parameters()
+    red_n = fdist.GradAllReducer([fl_n])
+    tn.enable_native_step(200, 10)
+    t1.enable_native_step(200, 10)
+    tn.memory_bank.__init_memory_bank__()
+    t1.memory_bank.__init_memory_bank__()
+    rs = np.random.RandomState(11)
+    for b in range(4):
+        sl = slice(b * 200, (b + 1) * 200)
+        args_ = (data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl])
+        lo, hi = fdist.shard_bounds(200, rank, world)
+        r_full = torch.from_numpy(rs.standard_normal((2, 200, data.node_raw_features.shape[1])).astype(np.float32)).cuda()
+        r_loc = torch.cat([r_full[0, lo:hi], r_full[1, lo:hi]]).contiguous()
+        r_all = torch.cat([r_full[0], r_full[1]]).contiguous()
+        w_ = (hi - lo) / 200.0
+        fl_n.grad = None
+        job = tn.prepare_batch_finish(tn.prepare_batch_begin(*args_, 10, (lo, hi), edge_ids=data.edge_ids[sl]))
+        tn.train_step(job, data.edge_ids[sl], lambda e: ((e * r_loc).sum() / (hi - lo), r_loc / (hi - lo)), 10,
+                      grad_ready=lambda seg: red_n.segment_ready(seg, w_))
+        red_n.finish(w_)
+        fl_1.grad = None
+        job = t1.prepare_batch_finish(t1.prepare_batch_begin(*args_, 10, edge_ids=data.edge_ids[sl]))
+        t1.train_step(job, data.edge_ids[sl], lambda e: ((e * r_all).sum() / 200.0, r_all / 200.0), 10)
+        torch.cuda.synchronize()
+        err = float((fl_n.grad - fl_1.grad).abs().max()) / max(1e-12, float(fl_1.grad.abs().max()))
+        assert err <= 1e-4, f"rank {rank} batch {b}: TGN reduced gradient differs from the whole-batch gradient by {err:.2e}"
+        assert torch.allclose(tn.memory_bank.node_memories.data, t1.memory_bank.node_memories.data, atol=1e-6), "TGN shard step: state differs"
+
     # ---- (iii) regeneration sweep: rank-interleaved chunks + all-gather == one rank
     torch.manual_seed(0)
     m2 = TGAT(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, num_layers=2, num_heads=2, dropout=0.1,
