@@ -699,7 +699,8 @@ def bench_memory_or_sequence_model(args):
         # the global batch of world x 600 edges and advances the replicated state with the whole batch); DyGFormer: rank r takes
         # batch step * world + r
         if args.model == "tgn":
-            b = first + step % max(1, span // wsim)
+            n_gb = n_train // (BATCH * wsim)                 # global batches in the train stream; the second half is walked, cyclically
+            b = n_gb // 2 + step % max(1, n_gb - n_gb // 2)
             return slice(b * BATCH * wsim, (b + 1) * BATCH * wsim)
         b = first + (step * world + rank) % span
         return slice(b * BATCH, (b + 1) * BATCH)
@@ -746,6 +747,12 @@ def bench_memory_or_sequence_model(args):
                                          None if wsim == 1 else (rank * BATCH, (rank + 1) * BATCH), edge_ids=data.edge_ids[sl_])
 
     def step(s):
+        if args.model == "tgn":
+            n_gb_ = n_train // (BATCH * wsim)
+            if s > 0 and s % max(1, n_gb_ - n_gb_ // 2) == 0:
+                # the walk over the stream's second half starts over: the memory must not see time run backwards (the reference resets it
+                # at every epoch start, PTCL/EM_warmup.py:121)
+                model.memory_bank.__init_memory_bank__()
         if tgn_lp:
             return lp_step(s)
         sl = batch(s)
