@@ -72,6 +72,10 @@ int layers_forward(int n, const tg_layer_desc* const* Ls, float* zero, int64_t z
 // tg_rowops.hip: tg_adam_f32 that first finishes the time-encoder bias gradient (elements [tb_off, tb_off + tb_n) of the flat parameter)
 int adam_time_bias(float* d_param, float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int64_t step, int64_t tb_off, int tb_n, const float* d_cosb, void* stream);
+// tg_gemm_direct.hip: the weight-space end of a merged-projection layer's backward (two small products + the constant part's gradient)
+// as one launch; false = not covered, nothing launched
+bool wspace_tail(const float* Wq, const float* Wk, const float* dP, const float* qb, const float* dub, const float* cosb, float* dWk, float* dWq,
+                 float* d_cosb, int H, int hd, int dn, int dq, int dk, int T, hipStream_t s);
 // tg_pack.hip: packed (split-bf16, MFMA fragment order) weights of the chain kernels
 int64_t packed_floats(int N, int K);
 int pack_weights(int njobs, const tg_pack_job* jobs, hipStream_t s);

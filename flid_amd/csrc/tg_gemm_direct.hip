@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "tg_common.h"
+#include "tg_tail.h"
 
 namespace tg {
 namespace {
@@ -21,20 +22,21 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int U = 8;   // chunks (of 8 k) in flight per wave and operand: 16 float4 = 64 VGPRs
 
+// (bx, by) = tile number and batch index of the workgroup; r1a / r1b (optional, vec_c form only): C += r1a[row] * r1b[col], a rank-one
+// term riding in the epilogue (both indexed inside the batch: + by * M / + by * N)
 template <bool BT, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_direct_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
-                                                             int64_t lda, int64_t sA, const float* __restrict__ B, int64_t ldb,
-                                                             int64_t sB, float* __restrict__ C, int64_t ldc, int64_t sC,
-                                                             const float* __restrict__ bias, int relu, int accumulate, int gx, int vec_c,
-                                                             const float* __restrict__ mask, int64_t ldm) {
-    __shared__ float red[NW][32][36];               // stride 36 floats: 16-byte aligned rows for the fold's float4 reads
+__device__ __forceinline__ void direct_tile(int bx, int by, float (*red)[32][36], int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
+                                            int64_t lda, int64_t sA, const float* __restrict__ B, int64_t ldb, int64_t sB,
+                                            float* __restrict__ C, int64_t ldc, int64_t sC, const float* __restrict__ bias, int relu,
+                                            int accumulate, int gx, int vec_c, const float* __restrict__ mask, int64_t ldm,
+                                            const float* __restrict__ r1a = nullptr, const float* __restrict__ r1b = nullptr) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t tn = blockIdx.x % gx, tm = blockIdx.x / gx;
-    A += blockIdx.y * sA;
-    B += blockIdx.y * sB;
-    C += blockIdx.y * sC;
-    if (bias) bias += blockIdx.y * N;
+    const int64_t tn = bx % gx, tm = bx / gx;
+    A += by * sA;
+    B += by * sB;
+    C += by * sC;
+    if (bias) bias += by * N;
     int64_t row = tm * 32 + i, col = tn * 32 + i;
     row = row < M ? row : M - 1;                    // clamped rows are loaded but never stored
     col = col < N ? col : N - 1;
@@ -91,6 +93,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_direct_nt_kernel(int64_t M, int6
     if (vec_c) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
         if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + ocol); o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w; }
+        if (r1a) {
+            const float ra = r1a[by * M + orow];
+            const float4 rb = *reinterpret_cast<const float4*>(r1b + by * N + ocol);
+            o.x = fmaf(ra, rb.x, o.x); o.y = fmaf(ra, rb.y, o.y); o.z = fmaf(ra, rb.z, o.z); o.w = fmaf(ra, rb.w, o.w);
+        }
         if (accumulate) { const float4 c = *reinterpret_cast<const float4*>(p); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         if (mask) {                                   // ReLU backward fused: keep the entries whose forward output was positive
@@ -111,8 +118,62 @@ __global__ __launch_bounds__(64 * NW) void gemm_direct_nt_kernel(int64_t M, int6
     }
 }
 
+template <bool BT, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_direct_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
+                                                             int64_t lda, int64_t sA, const float* __restrict__ B, int64_t ldb,
+                                                             int64_t sB, float* __restrict__ C, int64_t ldc, int64_t sC,
+                                                             const float* __restrict__ bias, int relu, int accumulate, int gx, int vec_c,
+                                                             const float* __restrict__ mask, int64_t ldm) {
+    __shared__ float red[NW][32][36];               // stride 36 floats: 16-byte aligned rows for the fold's float4 reads
+    direct_tile<BT, NW>((int)blockIdx.x, (int)blockIdx.y, red, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, bias, relu, accumulate, gx, vec_c, mask, ldm);
+}
+
+// The weight-space end of a merged-projection layer's backward in ONE launch (three launches before: 7 + 9 + 10 us, each a single
+// latency chain on a few dozen workgroups).  With dP_h = du_h^T own (dk x dn, from the weight-gradient launch) and dub = sum_rows du:
+//   workgroups [0, nA):        dWk_h (hd x dk) += Wq_h[:, :dn] dP_h^T  +  qb_h (x) dub_h      (the rank-one term = the dWk part of ub_bwd)
+//   workgroups [nA, nA + nB):  dWq_h[:, :dn] (hd x dn) += Wk_h dP_h
+//   the rest:                  ub_bwd without its dWk update: dWq[:, dn:] += dqb (x) cos b, d cos b += Wq[:, dn:]^T dqb
+struct WspaceTail {
+    const float *Wq, *Wk, *dP, *qb, *dub, *cosb;
+    float *dWk, *dWq, *d_cosb;
+    int H, hd, dn, dq, dk, T;
+    int gxA, nA, gxB, nB;
+};
+__global__ __launch_bounds__(512) void wspace_tail_kernel(WspaceTail t) {
+    __shared__ float red[8][32][36];
+    const int bid = (int)blockIdx.x;
+    if (bid < t.nA) {
+        const int per = t.nA / t.H;
+        direct_tile<true, 8>(bid % per, bid / per, red, t.hd, t.dk, t.dn, t.Wq, t.dq, (int64_t)t.hd * t.dq, t.dP, t.dn, (int64_t)t.dk * t.dn,
+                             t.dWk, t.dk, (int64_t)t.hd * t.dk, nullptr, 0, 1, t.gxA, 1, nullptr, 0, t.qb, t.dub);
+    } else if (bid < t.nA + t.nB) {
+        const int b = bid - t.nA, per = t.nB / t.H;
+        direct_tile<false, 8>(b % per, b / per, red, t.hd, t.dn, t.dk, t.Wk, t.dk, (int64_t)t.hd * t.dk, t.dP, t.dn, (int64_t)t.dk * t.dn,
+                              t.dWq, t.dq, (int64_t)t.hd * t.dq, nullptr, 0, 1, t.gxB, 1, nullptr, 0);
+    } else {
+        ub_bwd_body(bid - t.nA - t.nB, t.dub, t.qb, t.Wk, t.Wq, t.cosb, t.hd, t.dn, t.dq, t.dk, t.T, nullptr, t.dWq, t.d_cosb, &red[0][0][0]);
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+}  // namespace
+
+// false = shapes / alignment not covered (nothing launched: the caller issues the two products and the tail launch)
+bool wspace_tail(const float* Wq, const float* Wk, const float* dP, const float* qb, const float* dub, const float* cosb, float* dWk, float* dWq,
+                 float* d_cosb, int H, int hd, int dn, int dq, int dk, int T, hipStream_t s) {
+    if (dn % 4 || dk % 4 || dq % 4 || dn < 8 || dk < 8 || dn > 8 * 64 || dk > 8 * 64) return false;       // one batch of <= 8 chunks per wave
+    if (!(al16(Wq) && al16(Wk) && al16(dP) && al16(dWk) && al16(dWq) && al16(dub))) return false;
+    WspaceTail t{Wq, Wk, dP, qb, dub, cosb, dWk, dWq, d_cosb, H, hd, dn, dq, dk, T, 0, 0, 0, 0};
+    t.gxA = (dk + 31) / 32; t.nA = t.gxA * ((hd + 31) / 32) * H;
+    t.gxB = (dn + 31) / 32; t.nB = t.gxB * ((hd + 31) / 32) * H;
+    const int nC = (dq + UBR - 1) / UBR;
+    ProfScope prof("gemm", 4.0 * H * hd * dk * dn, s);
+    wspace_tail_kernel<<<(unsigned)(t.nA + t.nB + nC), 512, 0, s>>>(t);
+    return true;
+}
+
+namespace {
 }  // namespace
 
 // true = launched (or nothing to do); false = shape not handled here, the caller falls through to the tiled kernels

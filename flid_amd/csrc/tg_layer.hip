@@ -17,6 +17,7 @@
 #include "tg_common.h"
 #include "tg_pack.h"
 #include "tg_colsum.h"
+#include "tg_tail.h"
 
 namespace {
 
@@ -503,46 +504,8 @@ __global__ void __launch_bounds__(256) layer_prelude2_kernel(PreludeArgs a, Prel
     for (int64_t i = ((int64_t)bid - nb_a - nb_b) * 256 + threadIdx.x; i < z4; i += nz * 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), UBR query rows i = h hd + k per workgroup:
-//   dqb_i = Wk[i, :] . dub_h ;  dWk[i, :] += qb_i dub_h ;  dWq[i, dn:] += dqb_i cos b ;  d cos b += Wq[i, dn:] dqb_i
-// (one workgroup per row was 272 workgroups adding into the same T addresses of d cos b: 17 us of serialised float atomics; here the
-// rows of a workgroup are summed first and the launch makes dq / UBR adds per address)
-constexpr int UBR = 8;
-__device__ __forceinline__ void ub_bwd_body(int blk, const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
-        const float* __restrict__ Wq, const float* __restrict__ cosb, int hd, int dn, int dq, int dk, int T, float* __restrict__ dWk,
-        float* __restrict__ dWq, float* __restrict__ d_cosb, float* red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = blk * UBR;
-    for (int r = wave; r < UBR; r += 4) {                     // a wave per row: dqb_i, and the rank-1 update of dWk's row
-        const int i = i0 + r;
-        if (i >= dq) break;                                    // (wave-uniform)
-        const float* du = dub + (int64_t)(i / hd) * dk;
-        const float qbi = qb[i];
-        float part = 0.f;
-        for (int j = lane; j < dk; j += 64) {
-            const float d = du[j];
-            part = fmaf(Wk[(int64_t)i * dk + j], d, part);
-            dWk[(int64_t)i * dk + j] += qbi * d;
-        }
-        part = tg::wave_sum(part);
-        if (lane == 0) red[r] = part;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const float cb = cosb[t];
-        float acc = 0.f;
-#pragma unroll
-        for (int r = 0; r < UBR; ++r) {
-            const int i = i0 + r;
-            if (i < dq) {
-                const float dqb = red[r];
-                dWq[(int64_t)i * dq + dn + t] += dqb * cb;
-                acc = fmaf(Wq[(int64_t)i * dq + dn + t], dqb, acc);
-            }
-        }
-        atomicAdd(d_cosb + t, acc);
-    }
-}
+using tg::UBR;
+using tg::ub_bwd_body;
 
 // The layer's backward TAIL in one launch: three independent finishing steps that used to be a launch each (4.5-12 us apiece for
 // a few hundred KB of work).  Workgroups [0, n_head): the constant-part gradients of the query -- ub_bwd (merged projection,
@@ -1150,9 +1113,14 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             // P_h = Wk_h^T Wq_h[:, :dn] :  dWk_h += Wq_h[:, :dn] dP_h^T ;  dWq_h[:, :dn] += Wk_h dP_h ;  then the constant part (ub_bwd, which
             // also adds into dWk).  (One launch of 32 x 32 fp32 tiles for both products and ub_bwd was measured: 42 us against 7 + 9 + 5 --
             // its K = 444 product is 14 dependent chunk round trips per tile.)
-            TG_TRY(tg_gemm_f32_batched(0, 1, hd, dk, dn, 1.f, P.Wq, dq, (int64_t)hd * dq, dPm, dn, (int64_t)dk * dn, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, stream));
-            TG_TRY(tg_gemm_f32_batched(0, 0, hd, dn, dk, 1.f, P.Wk, dk, (int64_t)hd * dk, dPm, dn, (int64_t)dk * dn, G.Wq, dq, (int64_t)hd * dq, H, nullptr, 0, 1, stream));
-            TG_TRY(tail(1, false));
+            static const bool no_wtail = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_WSPACE_TAIL") && atoi(getenv("FLID_NO_WSPACE_TAIL")) != 0;   // A/B timing
+            if (!no_wtail && tg_get_gemm_mode() != 0 && tg::wspace_tail(P.Wq, P.Wk, dPm, Lc.qbias, dub, Lc.cosb, G.Wk, G.Wq, Bc.d_cosb, H, hd, dn, dq, dk, T, s)) {
+                TG_TRY(tg::launch_status("wspace_tail_kernel"));       // both products and ub_bwd in one launch (exact fp32, as before)
+            } else {
+                TG_TRY(tg_gemm_f32_batched(0, 1, hd, dk, dn, 1.f, P.Wq, dq, (int64_t)hd * dq, dPm, dn, (int64_t)dk * dn, G.Wk, dk, (int64_t)hd * dk, H, nullptr, 0, 1, stream));
+                TG_TRY(tg_gemm_f32_batched(0, 0, hd, dn, dk, 1.f, P.Wk, dk, (int64_t)hd * dk, dPm, dn, (int64_t)dk * dn, G.Wq, dq, (int64_t)hd * dq, H, nullptr, 0, 1, stream));
+                TG_TRY(tail(1, false));
+            }
             if (Bw->d_own) TG_TRY(tg_gemm_f32(0, 1, R, dn, hk, 1.f, Bw->du, hk, wt.PT, hk, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
             drain_guard.on = false;
             if (Bw->finish_time_bias && T > 0) TG_TRY(tg_time_bias_finish(Bw->d_teb, a.d_te_b, Bw->d_cosb, T, stream));

@@ -1,0 +1,51 @@
+// The constant part of the merged query projection's gradient as a device-side body (layer_tail_kernel of tg_layer.hip, the fused
+// weight-space launch of tg_gemm_direct.hip).
+#pragma once
+#include "tg_common.h"
+
+namespace tg {
+
+// Gradient of the constant part of u (ub_h = Wk_h^T qb_h, qb = Wq[:, dn:] cos b), UBR query rows i = h hd + k per workgroup:
+//   dqb_i = Wk[i, :] . dub_h ;  dWk[i, :] += qb_i dub_h ;  dWq[i, dn:] += dqb_i cos b ;  d cos b += Wq[i, dn:] dqb_i
+// (one workgroup per row was 272 workgroups adding into the same T addresses of d cos b: 17 us of serialised float atomics; here the
+// rows of a workgroup are summed first and the launch makes dq / UBR adds per address)
+constexpr int UBR = 8;
+__device__ __forceinline__ void ub_bwd_body(int blk, const float* __restrict__ dub, const float* __restrict__ qb, const float* __restrict__ Wk,
+        const float* __restrict__ Wq, const float* __restrict__ cosb, int hd, int dn, int dq, int dk, int T, float* __restrict__ dWk,
+        float* __restrict__ dWq, float* __restrict__ d_cosb, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blk * UBR;
+    const int nwaves = (int)blockDim.x >> 6;
+    for (int r = wave; r < UBR; r += nwaves) {                // a wave per row: dqb_i, and the rank-1 update of dWk's row
+        const int i = i0 + r;
+        if (i >= dq) break;                                    // (wave-uniform)
+        const float* du = dub + (int64_t)(i / hd) * dk;
+        const float qbi = qb[i];
+        float part = 0.f;
+        for (int j = lane; j < dk; j += 64) {
+            const float d = du[j];
+            part = fmaf(Wk[(int64_t)i * dk + j], d, part);
+            if (dWk) dWk[(int64_t)i * dk + j] += qbi * d;
+        }
+        part = tg::wave_sum(part);
+        if (lane == 0) red[r] = part;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float cb = cosb[t];
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < UBR; ++r) {
+            const int i = i0 + r;
+            if (i < dq) {
+                const float dqb = red[r];
+                dWq[(int64_t)i * dq + dn + t] += dqb * cb;
+                acc = fmaf(Wq[(int64_t)i * dq + dn + t], dqb, acc);
+            }
+        }
+        atomicAdd(d_cosb + t, acc);
+    }
+}
+
+
+}  // namespace tg
