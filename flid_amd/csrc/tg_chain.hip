@@ -893,6 +893,134 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
     STAMP();
 }
 
+
+// ---- the query side of a SHORT layer (the 1 200-row root layer, TGN's layer; the long layers take the merged projection) -------------
+// forward:   q = own Wq[:, :dn]^T + qb   ->   u_h = q_h Wk_h            (models/modules.py:199-210 reassociated)
+// backward:  dq_h = du_h Wk_h^T          ->   d_own (+)= dq Wq[:, :dn]
+// Two products each, a launch apiece before (9 + 11 us forward, 20 + 8 us backward at 1 200 rows: single latency chains); here a 16-row
+// block runs both, q / dq handed over through the LDS panel, against packed weights (the layer's prelude launch packs them).
+struct QuFwdArgs {
+    int64_t R;
+    int H, dn, T, de, hpb;            // hpb: per-head block of q inside the panel (hd rounded up to 32)
+    const float* own; int64_t own_ld;
+    const void *pWq, *pWkT;           // packed Wq[:, :dn] (N = dq, K = dn); per head Wk_h^T (N = dk, K = hpb), heads back to back
+    const float* qbias;
+    float *q, *u;                     // (R, dq), (R, H dk)
+};
+template <int HH, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) qu_fwd_kernel(QuFwdArgs a) {
+    using G = Geo<1, NW>;
+    constexpr int NTH = G::NTH, NTD = 7, NTQ = 5;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    Wave<1, NW, NTD> w;
+    w.lds = lds; w.lane = threadIdx.x & 63; w.wave = threadIdx.x >> 6;
+    w.row0 = (int64_t)blockIdx.x * 16; w.R = a.R;
+    const int tid = threadIdx.x;
+    const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
+    const int r = w.out_row(0);
+    const bool rok = w.row0 + r < a.R;
+    const int64_t rg = rok ? w.row0 + r : a.R - 1;
+    // q = own Wq[:, :dn]^T + qb: rows streamed from memory, all dq columns (NTQ tiles per wave)
+    w.begin(a.pWq, (dq + 15) >> 4, (a.dn + 31) >> 5);
+    w.template run_stream<NTQ, 1>(a.own, a.own_ld, 0, a.dn, 0);
+#pragma unroll
+    for (int j = 0; j < NTQ; ++j) {
+        if (j >= w.tcnt) break;
+        const int col = w.out_col(j);
+        if (col >= dq) continue;
+        const float4 v = rok ? add4(f4(w.acc[0][j]), ld4(a.qbias + col)) : zero4();
+        if (rok) st4(a.q + rg * dq + col, v);
+        const int h = col / hd, ch = col - h * hd;               // (hd % 4 == 0: a float4 never straddles two heads)
+        w.panel_store(0, r, h * a.hpb + ch, v);
+    }
+    // the tails of the heads' blocks ([hd, hpb)) multiply zero rows of the packed weights but must be finite
+    {
+        const int per = (a.hpb - hd) >> 2;
+        for (int f = tid; f < 16 * HH * per; f += NTH) {
+            const int rr = f / (HH * per), x = f % (HH * per), h = x / per;
+            w.panel_store(0, rr, h * a.hpb + hd + 4 * (x % per), zero4());
+        }
+    }
+    __syncthreads();
+    // u_h = q_h Wk_h: dk columns per head, NTD tiles per wave and pass
+    {
+        const int ht = (dk + 15) >> 4, hs = a.hpb >> 5;
+        const int64_t stride = (int64_t)ht * hs * 512;
+        const int npass = (ht + NTD * NW - 1) / (NTD * NW);
+        const int tpp = (ht + npass - 1) / npass;
+        for (int h = 0; h < HH; ++h)
+            for (int tb = 0; tb < ht; tb += tpp) {
+                const int nt = ht - tb < tpp ? ht - tb : tpp;
+                w.begin(reinterpret_cast<const float*>(a.pWkT) + h * stride + (int64_t)tb * hs * 512, nt, hs);
+                w.template run_panel<NTD>(h * hs);
+#pragma unroll
+                for (int j = 0; j < NTD; ++j) {
+                    if (j >= w.tcnt) break;
+                    const int col = 16 * tb + w.out_col(j);
+                    if (col < dk && rok) st4(a.u + rg * ((int64_t)HH * dk) + h * dk + col, f4(w.acc[0][j]));
+                }
+            }
+    }
+}
+
+struct DqBwdArgs {
+    int64_t R;
+    int H, dn, T, de, hp;             // hp: per-head block of dq inside the panel (hd rounded up to 16)
+    const float* du;                  // (R, H dk)
+    const void *pWk, *pWqT;           // packed per head Wk_h (N = hd, K = dk), heads back to back; Wq[:, :dn]^T (N = dn, K = H hp)
+    float* dq;                        // (R, dq)
+    float* d_own; int64_t d_own_ld; int d_own_acc;     // optional
+};
+template <int HH, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) dq_bwd_kernel(DqBwdArgs a) {
+    using G = Geo<1, NW>;
+    constexpr int NTH = G::NTH, NTW = G::NTW, NTF = 3;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    Wave<1, NW> w;
+    w.lds = lds; w.lane = threadIdx.x & 63; w.wave = threadIdx.x >> 6;
+    w.row0 = (int64_t)blockIdx.x * 16; w.R = a.R;
+    const int tid = threadIdx.x;
+    const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
+    const int r = w.out_row(0);
+    const bool rok = w.row0 + r < a.R;
+    const int64_t rg = rok ? w.row0 + r : a.R - 1;
+    // dq_h = du_h Wk_h^T: both heads at once (waves [0, NW / 2) on head 0, the rest on head 1), rows streamed from memory
+    {
+        const int ht = (hd + 15) >> 4;
+        const int64_t stride = (int64_t)ht * ((dk + 31) / 32) * 512;
+        const int mine = HH == 2 ? w.wave / (NW / 2) : 0;
+        w.begin(reinterpret_cast<const float*>(a.pWk) + mine * stride, ht, (dk + 31) >> 5, HH == 2 ? (NW / 2) * mine : 0, NW / HH);
+        w.template run_stream<NTW, HH>(a.du, (int64_t)HH * dk, dk, dk, mine);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            if (j >= w.tcnt) break;
+            const int col = w.out_col(j);                        // inside the head's block
+            const float4 v = rok ? f4(w.acc[0][j]) : zero4();
+            w.panel_store(0, r, mine * a.hp + col, v);           // columns >= hd of the block are zero (zero rows of the packed weight)
+            if (col < hd && rok) st4(a.dq + rg * dq + mine * hd + col, v);
+        }
+    }
+    if ((HH * a.hp) & 31) {                                      // tail of the panel's last chunk
+        const int c0 = HH * a.hp, per = (32 - (c0 & 31)) >> 2;
+        for (int f = tid; f < 16 * per; f += NTH) w.panel_store(0, f / per, c0 + 4 * (f % per), zero4());
+    }
+    __syncthreads();
+    if (!a.d_own) return;                                        // (uniform)
+    // d_own (+)= dq Wq[:, :dn]
+    w.begin(a.pWqT, (a.dn + 15) >> 4, (HH * a.hp + 31) >> 5);
+    w.template run_panel<NTF>(0);
+#pragma unroll
+    for (int j = 0; j < NTF; ++j) {
+        if (j >= w.tcnt) break;
+        const int col = w.out_col(j);
+        if (col >= a.dn || !rok) continue;
+        float* p = a.d_own + rg * a.d_own_ld + col;
+        float4 v = f4(w.acc[0][j]);
+        if (a.d_own_acc) v = add4(v, ld4(p));
+        st4(p, v);
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 unsigned long long* g_chain_dbg = nullptr;
 unsigned long long* g_chain_dbg_bwd = nullptr;
@@ -967,6 +1095,48 @@ int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const vo
 }
 
 int chain_hpb(int H, int dn, int T) { const int hd = (dn + T) / H; return (hd + 31) / 32 * 32; }
+
+// the query side of a short layer (see qu_fwd_kernel / dq_bwd_kernel); shapes: chain_shape_ok plus dk <= 16 * 7 * 4 columns per head
+bool qu_shape_ok(int H, int dn, int T, int de) {
+    if (!chain_shape_ok(H, dn, T, de)) return false;
+    const int dq = dn + T, dk = dn + de + T, hd = dq / H;
+    return hd % 4 == 0 && (dq + 15) / 16 <= 5 * 4 && (dk + 15) / 16 <= 2 * 7 * 4 && H * chain_hpb(H, dn, T) <= 32 * NCH && (dn + 15) / 16 <= 3 * 4;
+}
+int qu_fwd(const tg_layer_desc* L, const void* pWq, const void* pWkT, hipStream_t s) {
+    const tg_attn_desc& at = L->attn;
+    QuFwdArgs a{at.m, at.heads, at.dn, at.dt_dim, at.de, chain_hpb(at.heads, at.dn, at.dt_dim), L->own, L->own_ld, pWq, pWkT, L->qbias, L->q, L->u};
+    const int dq = at.dn + at.dt_dim, dk = at.dn + at.de + at.dt_dim;
+    ProfScope prof("gemm", 2.0 * at.m * ((double)dq * at.dn + (double)dq * dk), s);
+    using G = Geo<1, 4>;
+    const unsigned grid = (unsigned)((at.m + 15) / 16);
+    static bool attr[2] = {false, false};
+    if (at.heads == 2) {
+        if (!attr[1]) { TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qu_fwd_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)); attr[1] = true; }
+        qu_fwd_kernel<2, 4><<<grid, G::NTH, G::LDS_BYTES, s>>>(a);
+    } else {
+        if (!attr[0]) { TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qu_fwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)); attr[0] = true; }
+        qu_fwd_kernel<1, 4><<<grid, G::NTH, G::LDS_BYTES, s>>>(a);
+    }
+    return tg::launch_status("qu_fwd_kernel");
+}
+int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, hipStream_t s) {
+    const tg_attn_desc& at = L->attn;
+    DqBwdArgs a{at.m, at.heads, at.dn, at.dt_dim, at.de, chain_hp(at.heads, at.dn, at.dt_dim), Bw->du, pWk, pWqT, Bw->dq,
+                Bw->d_own, Bw->d_own_ld, 1};      // (the residual's share is already there: chain_bwd wrote or added it)
+    const int dq = at.dn + at.dt_dim, dk = at.dn + at.de + at.dt_dim;
+    ProfScope prof("gemm", 2.0 * at.m * ((double)dq * dk + (Bw->d_own ? (double)dq * at.dn : 0.0)), s);
+    using G = Geo<1, 4>;
+    const unsigned grid = (unsigned)((at.m + 15) / 16);
+    static bool attr[2] = {false, false};
+    if (at.heads == 2) {
+        if (!attr[1]) { TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dq_bwd_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)); attr[1] = true; }
+        dq_bwd_kernel<2, 4><<<grid, G::NTH, G::LDS_BYTES, s>>>(a);
+    } else {
+        if (!attr[0]) { TG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dq_bwd_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)); attr[0] = true; }
+        dq_bwd_kernel<1, 4><<<grid, G::NTH, G::LDS_BYTES, s>>>(a);
+    }
+    return tg::launch_status("dq_bwd_kernel");
+}
 // workgroups of a chain launch over `rows` rows (= slabs of column sums the backward chain leaves in `part`)
 int64_t chain_blocks(int64_t rows) { return rows >= 64 * 128 ? (rows + 63) / 64 : (rows + 15) / 16; }
 

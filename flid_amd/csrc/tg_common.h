@@ -84,6 +84,10 @@ bool chain_shape_ok(int H, int dn, int T, int de);
 int chain_hp(int H, int dn, int T);
 int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const void* pW1, const void* pW2, int64_t packed_bytes, hipStream_t s);
 int chain_hpb(int H, int dn, int T);
+// the query side of a short (not merged) layer as one launch per direction: q -> u, dq -> d_own (tg_chain.hip)
+bool qu_shape_ok(int H, int dn, int T, int de);
+int qu_fwd(const tg_layer_desc* L, const void* pWq, const void* pWkT, hipStream_t s);
+int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, hipStream_t s);
 int64_t chain_blocks(int64_t rows);
 int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, float* part, const void* pW2T, const void* pW1aT,
               const void* pWrT, const void* pWvT, hipStream_t s);

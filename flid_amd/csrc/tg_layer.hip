@@ -552,7 +552,7 @@ inline WT wt_layout(float* base, int H, int dn, int dq, int dk) {
 }
 
 // Packed weights of the chain kernels (tg_chain.hip), behind the transposed copies in the layer's wT block
-struct PK { float *Wv, *Wr, *W1, *W2, *W2T, *W1aT, *WrT, *WvT; int64_t total; };
+struct PK { float *Wv, *Wr, *W1, *W2, *W2T, *W1aT, *WrT, *WvT, *Wq, *WkT, *Wk, *WqT; int64_t total; };
 inline int64_t r4(int64_t n) { return (n + 3) / 4 * 4; }
 inline PK pk_layout(float* base, int H, int dn, int dq, int dk) {
     PK k;
@@ -568,6 +568,12 @@ inline PK pk_layout(float* base, int H, int dn, int dq, int dk) {
     k.W1aT = p; p += tg::packed_floats(dq, dn);
     k.WrT = p; p += tg::packed_floats(H * hpb, dq);
     k.WvT = p; p += H * tg::packed_floats(dk, hpb);
+    // query side of a short (not merged) layer (qu_fwd_kernel / dq_bwd_kernel): Wq[:, :dn]; per head Wk_h^T (K = hd padded to hpb) and
+    // Wk_h; Wq[:, :dn]^T with K in per-head blocks of hp
+    k.Wq = p; p += tg::packed_floats(dq, dn);
+    k.WkT = p; p += H * tg::packed_floats(dk, hpb);
+    k.Wk = p; p += H * tg::packed_floats(hd, dk);
+    k.WqT = p; p += tg::packed_floats(dn, H * hp);
     k.total = p - base;
     return k;
 }
@@ -739,9 +745,13 @@ static int layer_fwd_impl(const tg_layer_desc* L, void* stream, int mode, Prelud
         layer_prelude_kernel<<<(unsigned)blocks, 256, 0, s>>>(pa);
         return tg::launch_status("layer_prelude_kernel");
     };
+    // the query side of a layer that does not take the merged projection (short layers) as one launch: q -> u
+    const bool merged = g_merged && R >= kMergedMinRows;
+    static const bool no_qu = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_QU") && atoi(getenv("FLID_NO_QU")) != 0;       // A/B timing
+    const bool use_qu = !no_qu && use_chain && !merged && tg::qu_shape_ok(H, dn, T, a.de) && a16(L->q) && a16(L->u) && a16(L->qbias);
     if (use_chain) {
         const int hp = tg::chain_hp(H, dn, T), yc = (dq + 31) / 32, rc = (dn + 31) / 32;
-        tg_pack_job jobs[12];
+        tg_pack_job jobs[20];
         int n = 0;
         for (int h = 0; h < H; ++h)
             jobs[n++] = tg_pack_job{P.Wv + (int64_t)h * hd * dk, dk, hd, dk, 0, pk.Wv + h * tg::packed_floats(hd, dk), 0, 0, 0, 0, 0, 0};
@@ -755,6 +765,14 @@ static int layer_fwd_impl(const tg_layer_desc* L, void* stream, int mode, Prelud
         jobs[n++] = tg_pack_job{P.Wr, dq, H * hpb, dq, 1, pk.WrT, dq, 0, hd, hpb, 0, 0};                             // dctx = dres Wr, columns in head blocks
         for (int h = 0; h < H; ++h)                                                                                  // dagg_h = dctx_h Wv_h
             jobs[n++] = tg_pack_job{P.Wv + (int64_t)h * hd * dk, dk, dk, hd, 1, pk.WvT + h * tg::packed_floats(dk, hpb), 0, 0, 0, 0, 0, 0};
+        if (use_qu) {
+            jobs[n++] = tg_pack_job{P.Wq, dq, dq, dn, 0, pk.Wq, 0, 0, 0, 0, 0, 0};                                       // q = own Wq[:, :dn]^T
+            for (int h = 0; h < H; ++h)                                                                              // u_h = q_h Wk_h
+                jobs[n++] = tg_pack_job{P.Wk + (int64_t)h * hd * dk, dk, dk, hpb, 1, pk.WkT + h * tg::packed_floats(dk, hpb), 0, hd, 0, 0, 0, 0};
+            for (int h = 0; h < H; ++h)                                                                              // dq_h = du_h Wk_h^T
+                jobs[n++] = tg_pack_job{P.Wk + (int64_t)h * hd * dk, dk, hd, dk, 0, pk.Wk + h * tg::packed_floats(hd, dk), 0, 0, 0, 0, 0, 0};
+            jobs[n++] = tg_pack_job{P.Wq, dq, dn, H * hp, 1, pk.WqT, 0, dq, 0, 0, hd, hp};                                // d_own += dq Wq[:, :dn]
+        }
         const int frags = tgs::pack_jobs_fill(pa.pk, n, jobs);
         TG_REQUIRE(frags >= 0, "tg_tgat_layer_fwd: packed-weight job table");
         pa.nb_pack = (int)std::min<int64_t>((frags + 3) / 4, 2048);
@@ -771,7 +789,7 @@ static int layer_fwd_impl(const tg_layer_desc* L, void* stream, int mode, Prelud
         gather_rows_y = L->gather_table ? (int)std::min<int64_t>(32, (R + 255) / 256) : 0;      // 64 workgroups x 4 rows per grid row
         jobs.g_rows_y = gather_rows_y;
     };
-    if (g_merged && R >= kMergedMinRows) {
+    if (merged) {
         // merged QUERY side (u = own P^T + ub: the q intermediate and one product per direction leave the chain); the value side keeps
         // the reference's two products (ctx_h = Wv_h agg_h, res = Wr ctx + br): its merged form V_h = Wr[:, h] Wv_h cost as much on the
         // main chain but needed a (dq x H dk) gradient product over all rows (89 us) plus a weight-space chain behind it
@@ -804,7 +822,7 @@ static int layer_fwd_impl(const tg_layer_desc* L, void* stream, int mode, Prelud
         // backward): with them EVERY product of the main chain has two k-contiguous operands and runs on the split-bf16 kernel.
         TrJobs jobs;
         int n = 0;
-        for (int h = 0; h < H && n < 4; ++h) {
+        for (int h = 0; h < H && n < 4 && !use_qu; ++h) {
             jobs.j[n++] = TrJob{P.Wk + (int64_t)h * hd * dk, wt.Wk + (int64_t)h * dk * hd, hd, dk, dk, hd};
         }
         if (!use_chain) {
@@ -814,16 +832,20 @@ static int layer_fwd_impl(const tg_layer_desc* L, void* stream, int mode, Prelud
         }
         jobs.j[n++] = TrJob{P.W1 + dq, wt.W1b, dn, dn, (int64_t)dq + dn, dn};
         if (!use_chain) jobs.j[n++] = TrJob{P.Wr, wt.Wr, dq, dq, dq, dq};
-        jobs.j[n++] = TrJob{P.Wq, wt.WqL, dq, dn, dq, dq};
+        if (!use_qu) jobs.j[n++] = TrJob{P.Wq, wt.WqL, dq, dn, dq, dq};
         jobs.n = n;
         with_qbias(jobs);
         pa.tr = jobs;
         TG_TRY(launch_prelude(n, gather_rows_y, false));
         if (mode == 2) return TG_OK;
-        // q = [own | cos b] Wq^T : the constant half is a bias row
-        TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
-        // u_h = Wk_h^T q_h
-        TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, L->q, dq, hd, wt.Wk, hd, (int64_t)dk * hd, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
+        if (use_qu) {
+            TG_TRY(tg::qu_fwd(L, pk.Wq, pk.WkT, s));               // q = [own | cos b] Wq^T and u_h = Wk_h^T q_h in one launch
+        } else {
+            // q = [own | cos b] Wq^T : the constant half is a bias row
+            TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, L->own, L->own_ld, P.Wq, dq, L->q, dq, L->qbias, 0, 0, stream));
+            // u_h = Wk_h^T q_h
+            TG_TRY(tg_gemm_f32_batched(0, 1, R, dk, hd, 1.f, L->q, dq, hd, wt.Wk, hd, (int64_t)dk * hd, L->u, (int64_t)H * dk, dk, H, nullptr, 0, 0, stream));
+        }
         TG_TRY(tg_attn_fwd(&a, L->u, L->agg, L->prob, stream));
     }
     if (use_chain) return tg::chain_fwd(L, pk.Wv, pk.Wr, pk.W1, pk.W2, pk.total * 4, s);
@@ -926,6 +948,10 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     TG_REQUIRE(!use_chain || (a16(Bw->dout) && a16(Bw->df1) && a16(dres_c) && a16(Bw->dctx) && a16(Bw->dagg) && a16(Bw->part) &&
                               (!Bw->d_own || (a16(Bw->d_own) && Bw->d_own_ld % 4 == 0))),
                "tg_tgat_layer_bwd: backward buffers must be 16-byte aligned (the layer's forward ran the chain kernel)");
+    const bool merged = g_merged && R >= kMergedMinRows;
+    static const bool no_qu = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_QU") && atoi(getenv("FLID_NO_QU")) != 0;
+    const bool use_qu = !no_qu && use_chain && !merged && tg::qu_shape_ok(H, dn, T, a.de) && a16(L->q) && a16(L->u) && a16(L->qbias) && a16(Bw->du) &&
+                        a16(Bw->dq) && (!Bw->d_own || (a16(Bw->d_own) && Bw->d_own_ld % 4 == 0));          // = the forward's decision (+ this call's buffers)
     const bool overlap = g_overlap && g_side.init();
     // where everything that only feeds parameter gradients goes: re-pointed by every fork()
     void* wstream = stream;
@@ -1086,7 +1112,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             return tg::launch_status("layer_tail_kernel");
         });
     };
-    if (g_merged && R >= kMergedMinRows) {
+    if (merged) {
         // ---- output projection + value path (the reference's two products; weight gradients in one grouped launch) ------------------
         if (!use_chain) {
             TG_TRY(tg_gemm_f32(0, 1, R, dq, dq, 1.f, dres, dq, wt.Wr, dq, Bw->dctx, dq, nullptr, 0, 0, stream));
@@ -1148,7 +1174,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         // ---- fused attention backward -------------------------------------------------------------------------------------------------
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         // ---- key / query path --------------------------------------------------------------------------------------------------------
-        TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, hk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
+        if (use_qu) TG_TRY(tg::dq_bwd(L, Bw, pk.Wk, pk.WqT, s));          // dq_h = du_h Wk_h^T and d_own += dq Wq[:, :dn] in one launch
+        else TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, hk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
         TG_TRY(fork());                           // dres, dctx, du, dq are final: the attention block's five weight gradients in one launch
         {
             std::vector<WJ> jobs;
@@ -1169,7 +1196,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             TG_TRY(flush_wgrad());
             TG_TRY(tail(2));                      // wq_time + the slab sums
         }
-        if (Bw->d_own) {
+        if (Bw->d_own && !use_qu) {
             // (the residual's share is already there: ln_res_bwd_kernel)
             TG_TRY(tg_gemm_f32(0, 1, R, dn, dq, 1.f, Bw->dq, dq, wt.WqL, dq, Bw->d_own, Bw->d_own_ld, nullptr, 0, 1, stream));
         }
