@@ -87,7 +87,7 @@ int chain_hpb(int H, int dn, int T);
 // the query side of a short (not merged) layer as one launch per direction: q -> u, dq -> d_own (tg_chain.hip)
 bool qu_shape_ok(int H, int dn, int T, int de);
 int qu_fwd(const tg_layer_desc* L, const void* pWq, const void* pWkT, hipStream_t s);
-int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, hipStream_t s);
+int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, float* dq_sum, hipStream_t s);
 int64_t chain_blocks(int64_t rows);
 int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, float* part, const void* pW2T, const void* pW1aT,
               const void* pWrT, const void* pWvT, hipStream_t s);
@@ -97,7 +97,12 @@ struct SegDst { float* p[6]; int end[6]; int n; };
 struct ColJob { const float* x; int64_t ld, n; int cols; SegDst d; };
 // two slab matrices summed by extra workgroups of another launch: a (col_gx x col_ny) grid of 256-thread workgroups, the first groups_a
 // grid columns on `a`
-struct ColExtra { ColJob a, b; int groups_a, col_gx, col_ny; };
+// ... and, optionally (wq_n > 0 workgroups more), the time half of a query projection's weight gradient (tg_tail.h wq_time_body), which needs
+// nothing of the fold either
+struct ColExtra {
+    ColJob a, b; int groups_a, col_gx, col_ny;
+    int wq_n, wq_gx, wq_dq, wq_T; const float *wq_sq, *wq_cosb, *wq_W; float *wq_dW, *wq_dcosb; int64_t wq_ld;
+};
 // tg_wgrad.hip: big tiles + transposing LDS reads + slice fold; `extra` (optional): slab sums that ride in the fold launch
 bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s, const ColExtra* extra = nullptr);
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);   // tg_gemm_bf16x3.hip; false = shapes not covered

@@ -222,28 +222,8 @@ int colsum_seg2(const ColJob& a, const ColJob& b, hipStream_t s) {
     return tg::launch_status("colsum_seg2_kernel");
 }
 
-// The query projection sees [own | cos(b)]: with sq = sum_rows dq,
-//   dWq[:, dn:] += sq (x) cos(b)      and      d cos(b) += sq^T Wq[:, dn:].
-// Thread = one time column x 16 rows (independent loads), grid.y walks the rows.
-constexpr int WQT_ROWS = 16;
-__device__ __forceinline__ void wq_time_body(int bx, int by, const float* __restrict__ sq, int dq, const float* __restrict__ cosb, int T,
-                                             const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld, float* __restrict__ d_cosb) {
-    const int c = bx * 64 + (int)threadIdx.x;                    // the first 64 threads of the workgroup work
-    if (threadIdx.x >= 64 || c >= T) return;
-    const float cb = cosb[c];
-    const int r0 = by * WQT_ROWS;
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < WQT_ROWS; ++j) {
-        const int r = r0 + j;
-        if (r < dq) {
-            const float v = sq[r];
-            dWq_t[(int64_t)r * ld + c] += v * cb;
-            acc = fmaf(v, Wq_t[(int64_t)r * ld + c], acc);
-        }
-    }
-    atomicAdd(d_cosb + c, acc);
-}
+using tg::WQT_ROWS;
+using tg::wq_time_body;
 __global__ void __launch_bounds__(64) wq_time_kernel(const float* __restrict__ sq, int dq, const float* __restrict__ cosb, int T,
                                                      const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld,
                                                      float* __restrict__ d_cosb) {
@@ -1020,6 +1000,13 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             for (int i = 0; i < n; ++i) q[i] = tg_wgrad_job{jobs[i].A, jobs[i].lda, jobs[i].M, jobs[i].B, jobs[i].ldb, jobs[i].N, jobs[i].C, jobs[i].ldc, jobs[i].cs};
             if (g_wgrad_grouped && tg_get_gemm_mode() != 0 && tg::wgrad_group2(n, q, R, st, has_extra ? &ex : nullptr)) return tg::launch_status("wgrad kernel");
             if (has_extra) TG_TRY(colsum_seg2(ex.a, ex.b, st));
+            if (has_extra && ex.wq_n > 0) {            // the time half of dWq that would have ridden in the fold launch
+                TailArgs t{};
+                t.head_mode = 2; t.n_head = ex.wq_n; t.wq_gx = ex.wq_gx; t.v = ex.wq_sq; t.cosb = ex.wq_cosb; t.dq = ex.wq_dq; t.T = ex.wq_T;
+                t.Wq = ex.wq_W; t.dWq = ex.wq_dW; t.dn = 0; t.d_cosb = ex.wq_dcosb;
+                layer_tail_kernel<<<(unsigned)t.n_head, 256, 0, st>>>(t);
+                TG_TRY(tg::launch_status("layer_tail_kernel"));
+            }
             if (g_wgrad_grouped && tg::wgrad_group(n, q, R, st)) return tg::launch_status("wgrad kernel");
             for (int i = 0; i < n; ++i) {
                 TG_TRY(tg_gemm_f32(1, 0, q[i].M, q[i].N, R, 1.f, q[i].A, q[i].lda, q[i].B, q[i].ldb, q[i].C, q[i].ldc, nullptr, 0, 1, stv));
@@ -1174,7 +1161,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         // ---- fused attention backward -------------------------------------------------------------------------------------------------
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         // ---- key / query path --------------------------------------------------------------------------------------------------------
-        if (use_qu) TG_TRY(tg::dq_bwd(L, Bw, pk.Wk, pk.WqT, s));          // dq_h = du_h Wk_h^T and d_own += dq Wq[:, :dn] in one launch
+        // dq_h = du_h Wk_h^T and d_own += dq Wq[:, :dn] in one launch, which also leaves sum_rows dq in `vec` (the weight-gradient launch's
+        // ones column delivered it before: the time half of dWq then had to wait for the fold)
+        if (use_qu) TG_TRY(tg::dq_bwd(L, Bw, pk.Wk, pk.WqT, vec_dq, s));
         else TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, hk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
         TG_TRY(fork());                           // dres, dctx, du, dq are final: the attention block's five weight gradients in one launch
         {
@@ -1184,14 +1173,23 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
                 jobs.push_back(WJ{Bc.dctx + h * hd, dq, hd, Lc.agg + (int64_t)h * dk, hk, dk, G.Wv + (int64_t)h * hd * dk, dk, nullptr});
             for (int h = 0; h < H; ++h)                                                                                           // dWk_h = q_h^T du_h
                 jobs.push_back(WJ{Lc.q + h * hd, dq, hd, Bc.du + (int64_t)h * dk, hk, dk, G.Wk + (int64_t)h * hd * dk, dk, nullptr});
-            jobs.push_back(WJ{Bc.dq, dq, dq, Lc.own, Lc.own_ld, dn, G.Wq, dq, vec_dq});                                          // dWq[:, :dn], sum_rows dq
+            jobs.push_back(WJ{Bc.dq, dq, dq, Lc.own, Lc.own_ld, dn, G.Wq, dq, use_qu ? nullptr : vec_dq});                       // dWq[:, :dn] (, sum_rows dq)
             TG_TRY(wgrad(jobs));
         }
         if (!overlap && g_wgrad_grouped) {        // the slab sums ride in the weight gradients' fold launch
             tg::ColExtra ce{};
             slab_jobs(ce.a, ce.b, ce.groups_a, ce.col_gx, ce.col_ny);
-            TG_TRY(flush_wgrad(&ce));
-            TG_TRY(tail(2, false));               // wq_time (the time half of dWq, d cos b)
+            static const bool no_fold_wq = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_FOLD_WQ") && atoi(getenv("FLID_NO_FOLD_WQ")) != 0;
+            if (use_qu && T > 0 && !no_fold_wq) {
+                // ... and so does the time half of dWq (sum_rows dq came out of the dq launch): no tail launch
+                ce.wq_gx = (T + 63) / 64; ce.wq_n = ce.wq_gx * ((dq + WQT_ROWS - 1) / WQT_ROWS);
+                ce.wq_dq = dq; ce.wq_T = T; ce.wq_sq = vec_dq; ce.wq_cosb = Lc.cosb; ce.wq_W = P.Wq + dn; ce.wq_dW = G.Wq + dn;
+                ce.wq_dcosb = Bc.d_cosb; ce.wq_ld = dq;
+                TG_TRY(flush_wgrad(&ce));
+            } else {
+                TG_TRY(flush_wgrad(&ce));
+                TG_TRY(tail(2, false));           // wq_time (the time half of dWq, d cos b)
+            }
         } else {
             TG_TRY(flush_wgrad());
             TG_TRY(tail(2));                      // wq_time + the slab sums

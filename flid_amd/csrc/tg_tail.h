@@ -48,4 +48,27 @@ __device__ __forceinline__ void ub_bwd_body(int blk, const float* __restrict__ d
 }
 
 
+// The query projection sees [own | cos(b)]: with sq = sum_rows dq,
+//   dWq[:, dn:] += sq (x) cos(b)      and      d cos(b) += sq^T Wq[:, dn:].
+// Thread = one time column x 16 rows (independent loads), grid.y walks the rows.
+constexpr int WQT_ROWS = 16;
+__device__ __forceinline__ void wq_time_body(int bx, int by, const float* __restrict__ sq, int dq, const float* __restrict__ cosb, int T,
+                                             const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld, float* __restrict__ d_cosb) {
+    const int c = bx * 64 + (int)threadIdx.x;                    // the first 64 threads of the workgroup work
+    if (threadIdx.x >= 64 || c >= T) return;
+    const float cb = cosb[c];
+    const int r0 = by * WQT_ROWS;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < WQT_ROWS; ++j) {
+        const int r = r0 + j;
+        if (r < dq) {
+            const float v = sq[r];
+            dWq_t[(int64_t)r * ld + c] += v * cb;
+            acc = fmaf(v, Wq_t[(int64_t)r * ld + c], acc);
+        }
+    }
+    atomicAdd(d_cosb + c, acc);
+}
+
 }  // namespace tg

@@ -24,6 +24,7 @@
 
 #include "tg_common.h"
 #include "tg_colsum.h"
+#include "tg_tail.h"
 
 namespace {
 
@@ -295,7 +296,10 @@ __global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, int nsli
     if ((int)blockIdx.y >= tiles.n) {
         __shared__ float red[4][64];
         const int c = ((int)blockIdx.y - tiles.n) * (int)gridDim.x + (int)blockIdx.x;
-        if (c < ex.col_gx * ex.col_ny) tg::colsum_seg2_body(ex.a, ex.b, ex.groups_a, c % ex.col_gx, c / ex.col_gx, ex.col_ny, red);
+        const int ncol = ex.col_gx * ex.col_ny;
+        if (c < ncol) tg::colsum_seg2_body(ex.a, ex.b, ex.groups_a, c % ex.col_gx, c / ex.col_gx, ex.col_ny, red);
+        else if (c - ncol < ex.wq_n)
+            tg::wq_time_body((c - ncol) % ex.wq_gx, (c - ncol) / ex.wq_gx, ex.wq_sq, ex.wq_dq, ex.wq_cosb, ex.wq_T, ex.wq_W, ex.wq_dW, ex.wq_ld, ex.wq_dcosb);
         return;
     }
     const WTile T = tiles.t[blockIdx.y];
@@ -409,7 +413,7 @@ bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t
     const unsigned fold_gx = (TM * (TN + 4) + 255) / 256;
     ColExtra ex{};
     unsigned extra_rows = 0;
-    if (extra) { ex = *extra; extra_rows = ((unsigned)(ex.col_gx * ex.col_ny) + fold_gx - 1) / fold_gx; }
+    if (extra) { ex = *extra; extra_rows = ((unsigned)(ex.col_gx * ex.col_ny + ex.wq_n) + fold_gx - 1) / fold_gx; }
     wgrad2_fold_kernel<<<dim3(fold_gx, (unsigned)wt.n + extra_rows), 256, 0, s>>>(wt, (int)slices, ws, slab, ex);
     return true;
 }
