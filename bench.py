@@ -669,7 +669,8 @@ def bench_memory_or_sequence_model(args):
         desc = "DyGFormer L=2 H=2 C=50 patch 1, max sequence 32"
     model = model.to(dev).train()
     fdist.broadcast_parameters(model)
-    fused = args.model == "tgn" and not args.autograd and not args.no_flat
+    # TGN and DyGFormer: flat parameter + the native stepper (DyGFormer's --python-step is its autograd path)
+    fused = ((args.model == "tgn") or (args.model == "dygformer" and not args.python_step)) and not args.autograd and not args.no_flat
     if fused:
         from flid_amd.optim import FlatAdam
         params = [model.flatten_parameters()]
@@ -680,7 +681,9 @@ def bench_memory_or_sequence_model(args):
     reducer = fdist.GradAllReducer(params) if world > 1 else None
     native = fused and not args.python_step
     wsim = args.simulate_world if (args.simulate_world > 1 and args.model == "tgn" and world == 1) else world
-    if native:
+    if native and args.model == "dygformer":
+        model.enable_native_step(BATCH)
+    elif native:
         model.enable_native_step(BATCH * wsim, K)            # (the state advance covers the whole global batch on every rank)
     total_steps = args.warmup + args.steps
     n_batches = n_train // BATCH
@@ -785,6 +788,14 @@ def bench_memory_or_sequence_model(args):
                 se, de = model.compute_shard_embeddings_and_advance(pf, None, None, data.edge_ids[sl], (rank * BATCH, (rank + 1) * BATCH), True, K)
             else:
                 se, de = model.compute_src_dst_node_temporal_embeddings(pf, None, None, data.edge_ids[sl], True, K)
+        elif native:                                         # DyGFormer: forward + backward (+ Adam) as two library calls, no autograd graph
+            if reducer is None:
+                model.train_step(*a, mean_loss, optimizer=opt)
+            else:
+                model.train_step(*a, mean_loss)
+                reducer.reduce()
+                opt.step()
+            return
         else:
             se, de = model.compute_src_dst_node_temporal_embeddings(*a)
         loss = torch.addcmul(se * rw[0], de, rw[1]).mean()
@@ -804,8 +815,14 @@ def bench_memory_or_sequence_model(args):
         step(s)
     torch.cuda.synchronize()
     fam_name = "attn_bwd" if args.model == "tgn" else "gemm"
-    ops.profile_enable(fam_name)
-    ops.profile_collect(fam_name)  
+    # the roofline family's launches are timed with HIP events on their stream: one or two launches of a TGN step (inside the timed
+    # region), but 32 of a DyGFormer step -- two event creations each, ~1 ms of host time per step -- so the other models take the
+    # family's times from `prof_steps` extra steps behind the timed region
+    prof_inside = args.model == "tgn"
+    prof_steps = 0 if (prof_inside or args.no_breakdown) else min(10, args.steps)
+    if prof_inside:
+        ops.profile_enable(fam_name)
+        ops.profile_collect(fam_name)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
@@ -813,8 +830,15 @@ def bench_memory_or_sequence_model(args):
     host_issue = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    if not prof_inside:
+        ops.profile_enable(fam_name)
+        ops.profile_collect(fam_name)
+        for s in range(total_steps, total_steps + prof_steps):
+            step(s)
+        torch.cuda.synchronize()
     ms, units, cnt = ops.profile_collect(fam_name)
     ops.profile_enable(False)
+    unit_steps = max(1, args.steps if prof_inside else prof_steps)
     dist_info = None
     if world > 1:
         mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -855,8 +879,8 @@ def bench_memory_or_sequence_model(args):
         roof = {"bound": "mfma", "kernel": "tg_gemm_f32* (all product launches of a step: projections, feed-forward, attention products)",
                 "achieved": round(units / secs / 1e12, 2), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
                 "frac": round(units / secs / MFMA_F32_PEAK, 4), "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / max(1, cnt), 4),
-                "gflop_per_step": round(units / args.steps / 1e9, 2)}
-        flops_edge = units / (args.steps * BATCH)
+                "gflop_per_step": round(units / unit_steps / 1e9, 2), "measured_over": f"{prof_steps} steps behind the timed region"}
+        flops_edge = units / (unit_steps * BATCH)
         path = {"flops_per_edge_fwd_bwd": round(flops_edge, 1), "mfma_frac": round(value / world * flops_edge / MFMA_F32_PEAK, 4),
                 "edges_per_s_at_100pct": round(MFMA_F32_PEAK / max(flops_edge, 1.0), 1)}
         metric = "edges/sec (temporal-embedding fwd+bwd), %s Reddit, 1/2/4/8 MI355X" % {"dygformer": "DyGFormer", "tcl": "TCL", "graphmixer": "GraphMixer"}[args.model]

@@ -76,6 +76,13 @@ class AdamArgs(C.Structure):
                 ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("step", c_i64)]
 
 
+class DygCfg(C.Structure):
+    """struct tg_dyg_cfg"""
+    _fields_ = [("graph", c_void), ("d_node", c_void), ("node_ld", c_i64), ("d_edge", c_void), ("edge_ld", c_i64), ("num_edge_rows", c_i64),
+                ("d_param", c_void), ("param_floats", c_i64), ("poff", c_i64 * 64)] + \
+               [(n, C.c_int32) for n in ("dn", "de", "dt_dim", "channel", "layers", "heads", "max_len", "max_edges")]
+
+
 GRAD_READY_FN = C.CFUNCTYPE(None, c_void, c_void, c_i64)          # tg_grad_ready_fn
 
 # name -> (restype, argtypes); every symbol declared in include/flid_tg.h
@@ -99,6 +106,14 @@ SIGNATURES = {
     "tg_stepper_tgn_forward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), C.c_int, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void), C.c_int]),
     "tg_stepper_tgn_backward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), c_void, C.c_int, c_void, C.POINTER(AdamArgs), C.POINTER(c_void),
                                           GRAD_READY_FN, c_void]),
+    "tg_dyg_arena_floats": (c_i64, [C.POINTER(DygCfg)]),
+    "tg_dyg_create": (C.c_int, [C.POINTER(DygCfg), c_void, c_i64, C.POINTER(c_void)]),
+    "tg_dyg_destroy": (None, [c_void]),
+    "tg_dyg_regions": (C.c_int, [c_void, c_void, C.POINTER(c_i64)]),
+    "tg_dyg_forward": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_int, C.c_int, c_f32, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void)]),
+    "tg_dyg_backward": (C.c_int, [c_void, c_void, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
+    "tg_add_layernorm_bwd_res": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_f32,
+                                           C.c_uint64, c_void, c_void]),
     "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),
     "tg_time_bias_finish": (C.c_int, [c_void, c_void, c_void, C.c_int, c_void]),
     "tg_bce_logits": (C.c_int, [c_void, c_i64, c_i64, c_void, c_void, c_void]),

@@ -78,8 +78,12 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const float* __restrict
 template <int MAXC>
 __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
         const float* __restrict__ dy, int64_t n, int cols, const float* __restrict__ gamma, const float* __restrict__ mean,
-        const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ part) {
+        const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ part,
+        const float* __restrict__ dres = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0, float* __restrict__ dx_dropped = nullptr) {
+    // dres (optional): dx = dres + dLN(dy) (the residual branch's gradient joins here); dx_dropped (optional): dropout(dx) with the mask
+    // of (drop_seed, flat index) as tg_dropout draws it -- the gradient entering a dropout that sits in front of the residual sum
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float drop_scale = 1.f / (1.f - drop_p);
     extern __shared__ float red[];   // ROW_WAVES * 2 * cols
     float dgam[MAXC], dbet[MAXC], gm[MAXC];
 #pragma unroll
@@ -108,7 +112,16 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
-            if (c < cols) dx[r * cols + c] = rs * (g[i] - m1 - xh[i] * m2);
+            if (c < cols) {
+                const int64_t o = r * cols + c;
+                float v = rs * (g[i] - m1 - xh[i] * m2);
+                if (dres) v += dres[o];
+                dx[o] = v;
+                if (dx_dropped) {
+                    const float u = (float)(tg::mix32(drop_seed ^ ((uint64_t)o * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
+                    dx_dropped[o] = u >= drop_p ? v * drop_scale : 0.f;
+                }
+            }
         }
     }
 #pragma unroll
@@ -433,6 +446,20 @@ extern "C" int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const fl
     if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
     else if (cols <= 320) add_ln_bwd_kernel<5><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
     else add_ln_bwd_kernel<16><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
+    return tg::launch_status("add_ln_bwd_kernel");
+}
+
+extern "C" int tg_add_layernorm_bwd_res(const float* d_a, const float* d_b, const float* d_dy, int64_t n, int cols, const float* d_gamma,
+                                        const float* d_mean, const float* d_rstd, const float* d_dres, float* d_dx, float* d_dgb_part,
+                                        float drop_p, uint64_t drop_seed, float* d_dx_dropped, void* stream) {
+    TG_REQUIRE(d_a && d_dy && d_gamma && d_mean && d_rstd && d_dx && d_dgb_part, "tg_add_layernorm_bwd_res: null pointer");
+    TG_REQUIRE(cols > 0 && cols <= 1024 && drop_p >= 0.f && drop_p < 1.f, "tg_add_layernorm_bwd_res: cols must be in 1..1024, p in [0, 1)");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = (unsigned)row_grid(n);
+    const size_t lds = sizeof(float) * ROW_WAVES * 2 * cols;
+    if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped);
+    else if (cols <= 320) add_ln_bwd_kernel<5><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped);
+    else add_ln_bwd_kernel<16><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped);
     return tg::launch_status("add_ln_bwd_kernel");
 }
 

@@ -88,6 +88,59 @@ class DyGFormer(nn.Module):
         self.output_layer = nn.Linear(self.num_channels * self.channel_embedding_dim, self.node_feat_dim, bias=True)
 
     # ----------------------------------------------------------------------------------------------------------------------
+    def _native_param_order(self):
+        """the parameter tensors in the order of tg_dyg_cfg.poff (include/flid_tg.h)"""
+        co = self.neighbor_co_occurrence_encoder.neighbor_co_occurrence_encode_layer
+        out = [self.time_encoder.w.weight, self.time_encoder.w.bias, co[0].weight, co[0].bias, co[2].weight, co[2].bias]
+        for name in ("node", "edge", "time", "neighbor_co_occurrence"):
+            out += [self.projection_layer[name].weight, self.projection_layer[name].bias]
+        for blk in self.transformers:
+            mha = blk.multi_head_attention
+            out += [mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
+                    blk.norm_layers[0].weight, blk.norm_layers[0].bias, blk.norm_layers[1].weight, blk.norm_layers[1].bias,
+                    blk.linear_layers[0].weight, blk.linear_layers[0].bias, blk.linear_layers[1].weight, blk.linear_layers[1].bias]
+        return out + [self.output_layer.weight, self.output_layer.bias]
+
+    def flatten_parameters(self) -> nn.Parameter:
+        """Opt-in (not in the reference): re-home every parameter in ONE flat nn.Parameter and return it -- the named parameters stay
+        (same state_dict keys) as views of the flat buffer with requires_grad off; the trainer hands the returned parameter to its
+        optimizer (flid_amd.optim.FlatAdam).  As TGAT.flatten_parameters; needed by enable_native_step()."""
+        from .. import engine
+        params = self._native_param_order()
+        assert len(params) == len(list(self.parameters()))
+        offs, total = engine.block_layout(params)
+        flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        views = []
+        with torch.no_grad():
+            for o, p in zip(offs, params):
+                v = flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                p.requires_grad_(False)
+                views.append(v)
+        flat_param = nn.Parameter(flat)
+        self._flat_pack = [flat_param, views]          # a list: nn.Module must not register it (state_dict stays the reference's)
+        return flat_param
+
+    def enable_native_step(self, max_batch_edges: int):
+        """Opt-in (not in the reference; needs flatten_parameters()): train_step goes through ONE native object
+        (flid_amd.stepper.DygStepper, csrc/tg_dyg.hip) -- forward and backward (+ update) a C call each, every launch of a step issued by
+        the library out of a pre-sized arena.  Patch size 1, two sides of at most 32 positions; raises for other shapes (the autograd
+        path takes those)."""
+        from ..stepper import DygStepper
+        self._stepper = DygStepper(self, max_batch_edges)
+        return self._stepper
+
+    def train_step(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray, node_interact_times: np.ndarray, loss_fn, optimizer=None):
+        """One training step without an autograd graph: forward of compute_src_dst_node_temporal_embeddings, `loss_fn(emb)` ->
+        (loss, d loss / d emb) on the (2 B, dn) block [source rows | destination rows], backward into the flat parameter's .grad and, with
+        optimizer (a FlatAdam over the flat parameter), its update -- what the trainers' loss.backward(); optimizer.step() do
+        (PTCL/M_step.py:297-325).  Returns (embeddings, loss)."""
+        st = getattr(self, "_stepper", None)
+        if st is None:
+            raise RuntimeError("DyGFormer.train_step: call flatten_parameters() and enable_native_step() first")
+        return st.step(src_node_ids, dst_node_ids, node_interact_times, loss_fn, optimizer=optimizer)
+
     def _windows(self, ids_dev, t_dev):
         """device restatement of get_all_first_hop_neighbors + pad_sequences (utils/utils.py:254-273, DyGFormer.py:196-245)"""
         P, L = self.patch_size, self.max_input_sequence_length

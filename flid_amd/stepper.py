@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import engine, ops
-from ._lib import AdamArgs, GRAD_READY_FN, StepperCfg, check, lib
+from ._lib import AdamArgs, DygCfg, GRAD_READY_FN, StepperCfg, check, lib
 
 
 class StepJob:
@@ -231,4 +231,105 @@ class Stepper:
         emb = self.forward(job)
         loss, d_emb = loss_fn(emb)
         self.backward(job, d_emb, grad_ready=grad_ready, optimizer=optimizer)
+        return emb, loss
+
+
+class DygStepper:
+    """DyGFormer's step through ONE native object (tg_dyg, csrc/tg_dyg.hip): forward = one C call from the host id arrays to the
+    (2 B, dn) embeddings, backward (+ the optimizer's update) another; model: a flid_amd DyGFormer at patch size 1 in flat-parameter mode.
+
+    replaces the host side of models/DyGFormer.py:60-194 and the loss.backward() / optimizer.step() around it (PTCL/M_step.py:209-325);
+    the autograd form (DyGFormer.compute_src_dst_node_temporal_embeddings + seqops) stays as the reference-facing path and this one's
+    test oracle."""
+
+    def __init__(self, model, max_batch_edges: int):
+        flat = getattr(model, "_flat_pack", None)
+        if flat is None:
+            raise RuntimeError("DygStepper needs the flat-parameter mode: call flatten_parameters() first")
+        if model.patch_size != 1:
+            raise NotImplementedError("the native DyGFormer step covers patch_size 1 (the autograd path takes other patch sizes)")
+        self.model, self.flat = model, flat[0]
+        self.graph = model.neighbor_sampler.graph
+        node, edge = model.node_raw_features, model.edge_raw_features
+        cfg = DygCfg()
+        cfg.graph = self.graph.handle
+        cfg.d_node, cfg.node_ld = node.data_ptr(), node.stride(0)
+        cfg.d_edge, cfg.edge_ld, cfg.num_edge_rows = edge.data_ptr(), edge.stride(0), edge.shape[0]
+        cfg.d_param, cfg.param_floats = self.flat.data_ptr(), self.flat.numel()
+        base = self.flat.data_ptr()
+        tensors = model._native_param_order()
+        assert len(tensors) <= 64
+        for i, t in enumerate(tensors):
+            assert t.is_contiguous() and (t.data_ptr() - base) % 16 == 0
+            cfg.poff[i] = (t.data_ptr() - base) // 4
+        cfg.dn, cfg.de, cfg.dt_dim, cfg.channel = node.shape[1], edge.shape[1], model.time_feat_dim, model.channel_embedding_dim
+        cfg.layers, cfg.heads, cfg.max_len, cfg.max_edges = model.num_layers, model.num_heads, model.max_input_sequence_length, int(max_batch_edges)
+        total = int(lib().tg_dyg_arena_floats(C.byref(cfg)))
+        if total <= 0:
+            check(-5 if "native step covers" in (lib().tg_last_error() or b"").decode() else -1, "tg_dyg_arena_floats")
+        self.arena = torch.empty(total + 64, dtype=torch.float32, device=node.device)
+        shift = (-self.arena.data_ptr() // 4) % 64
+        self.arena = self.arena[shift:shift + total]
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(lib().tg_dyg_create(C.byref(cfg), self.arena.data_ptr(), total, C.byref(h)), "tg_dyg_create")
+        self._h = h
+        off = (C.c_int64 * 2)()
+        check(lib().tg_dyg_regions(h, self.arena.data_ptr(), off), "tg_dyg_regions")
+        self.grad = self.arena[off[0]:off[0] + self.flat.numel()]
+        self._emb_off, self.dn, self.max_edges = int(off[1]), int(cfg.dn), int(max_batch_edges)
+        self._seeds = (C.c_uint64 * (4 * model.num_layers))()
+        self._emb_views = {}
+        self.keep = (node, edge, self.flat)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().tg_dyg_destroy(h)
+            except Exception:
+                pass
+
+    def forward(self, src_node_ids, dst_node_ids, node_interact_times) -> torch.Tensor:
+        """(2 B, dn): source embeddings, then destination embeddings"""
+        m = self.model
+        src = np.ascontiguousarray(src_node_ids, dtype=np.int64)
+        dst = np.ascontiguousarray(dst_node_ids, dtype=np.int64)
+        t = np.ascontiguousarray(node_interact_times, dtype=np.float64)
+        B, L = len(src), m.max_input_sequence_length
+        # every side is as wide as ITS longest sequence of the batch (the node itself + its history, at most L): host binary searches
+        ws, wd = (int(np.minimum(self.graph.count_before_host(ids, t), L - 1).max()) + 1 for ids in (src, dst))
+        p = float(m.dropout) if m.training else 0.0
+        if p > 0:                                               # four per block, drawn block by block as seqops.encoder_block draws them
+            for l in range(m.num_layers):
+                for i, v in enumerate(engine._next_seeds(4)):
+                    self._seeds[4 * l + i] = v
+        check(lib().tg_dyg_forward(self._h, src.ctypes.data, dst.ctypes.data, t.ctypes.data, B, ws, wd, p, self._seeds, ops._stream(), None),
+              "tg_dyg_forward")
+        emb = self._emb_views.get(B)
+        if emb is None:
+            emb = self._emb_views[B] = self.arena[self._emb_off:self._emb_off + 2 * B * self.dn].view(2 * B, self.dn)
+        return emb
+
+    def backward(self, d_emb: torch.Tensor, optimizer=None):
+        """leaves the step's gradient in `self.grad` (= the flat parameter's .grad); optimizer (a FlatAdam over the flat parameter): its
+        update is issued right behind the backward, in the same call"""
+        assert d_emb.is_contiguous() and d_emb.dtype == torch.float32
+        prev = self.flat.grad
+        if prev is not None and prev.data_ptr() == self.grad.data_ptr():
+            prev = None
+        if prev is not None and optimizer is not None:
+            raise RuntimeError("DygStepper.backward: zero_grad(set_to_none=True) first (the update runs on this step's gradient block)")
+        adam = None if optimizer is None else optimizer.native_args(self.flat)
+        check(lib().tg_dyg_backward(self._h, d_emb.data_ptr(), ops._stream(), None if adam is None else C.byref(adam), None), "tg_dyg_backward")
+        if prev is None:
+            self.flat.grad = self.grad
+        else:
+            prev.add_(self.grad)
+
+    def step(self, src_node_ids, dst_node_ids, node_interact_times, loss_fn, optimizer=None):
+        """forward, `loss_fn(emb) -> (loss, d loss / d emb)`, backward (+ update): (embeddings, loss)"""
+        emb = self.forward(src_node_ids, dst_node_ids, node_interact_times)
+        loss, d_emb = loss_fn(emb)
+        self.backward(d_emb, optimizer=optimizer)
         return emb, loss

@@ -338,7 +338,6 @@ typedef struct tg_pack_job {
 } tg_pack_job;
 int64_t tg_packed_floats(int N, int K);
 int tg_pack_weights(int njobs, const tg_pack_job* jobs, void* stream);
-
 /* ---- grouped weight gradients (split-bf16 MFMA) ------------------------------------------------------
  * replaces the autograd weight / bias gradients of the nn.Linear layers in models/modules.py:54-69,152-163,235 for one layer:
  * up to 8 products C_j[M_j, N_j] += A_j^T B_j over the same `rows` (A_j: rows x M_j, B_j: rows x N_j, row-major) in ONE launch;
@@ -508,6 +507,43 @@ int tg_dropout_add(const float* d_x, const float* d_res, int64_t n, float p, uin
 /* out[i, :] = mean over positions [lo, hi) of x (n, s, d); backward writes dout/(hi-lo) into those positions of dx */
 int tg_segment_mean_fwd(const float* d_x, int64_t n, int s, int d, int lo, int hi, float* d_out, void* stream);
 int tg_segment_mean_bwd(const float* d_dout, int64_t n, int s, int d, int lo, int hi, float* d_dx, void* stream);
+/* tg_add_layernorm_bwd with the residual branch joined: d_dx = d_dres (optional) + dLN(d_dy); d_dx_dropped (optional) = dropout(d_dx)
+ * with tg_dropout's mask of (drop_seed, flat index) -- the gradient entering the dropout in front of a pre-LN block's residual sum */
+int tg_add_layernorm_bwd_res(const float* d_a, const float* d_b, const float* d_dy, int64_t n, int cols, const float* d_gamma,
+                             const float* d_mean, const float* d_rstd, const float* d_dres, float* d_dx, float* d_dgb_part,
+                             float drop_p, uint64_t drop_seed, float* d_dx_dropped, void* stream);
+
+/* ---- DyGFormer's training step as one native object (csrc/tg_dyg.hip) ----------------------------------------
+ * replaces the host side of models/DyGFormer.py:60-194 compute_src_dst_node_temporal_embeddings (patch size 1) and the
+ * loss.backward() / optimizer.step() of the trainers around it (PTCL/M_step.py:209-325): tg_dyg_forward issues every launch from the
+ * id copy to the (2 B, dn) embeddings, tg_dyg_backward the whole backward into a gradient block in the flat parameter's layout and,
+ * optionally, torch.optim.Adam's update.  poff: offsets (floats, multiples of 4) inside the flat parameter of
+ *   [time_encoder.w.weight, .bias, co-occurrence encoder layer 0 weight, bias, layer 2 weight, bias,
+ *    projection_layer node / edge / time / neighbor_co_occurrence (weight, bias each),
+ *    per transformer block: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, norm 0 weight, bias, norm 1 weight, bias,
+ *    linear 0 weight, bias, linear 1 weight, bias;  output_layer.weight, output_layer.bias].
+ * TG_ESHAPE from tg_dyg_arena_floats (-1) / tg_dyg_create for shapes the step does not cover (two sides of more than 32 positions, heads
+ * wider than 100 columns): the autograd path takes those. */
+typedef struct tg_dyg tg_dyg;
+typedef struct tg_dyg_cfg {
+    const tg_graph* graph;
+    const float* d_node; int64_t node_ld; const float* d_edge; int64_t edge_ld; int64_t num_edge_rows;
+    float* d_param; int64_t param_floats;
+    int64_t poff[64];
+    int32_t dn, de, dt_dim, channel, layers, heads, max_len, max_edges;      /* max_len = max_input_sequence_length, max_edges = B at most */
+} tg_dyg_cfg;
+int64_t tg_dyg_arena_floats(const tg_dyg_cfg* cfg);
+int tg_dyg_create(const tg_dyg_cfg* cfg, float* d_arena, int64_t arena_floats, tg_dyg** out);
+void tg_dyg_destroy(tg_dyg* st);
+/* offsets (floats from d_arena): [0] gradient block (flat-parameter layout), [1] embeddings (2 B, dn): source rows, then destination rows */
+int tg_dyg_regions(const tg_dyg* st, const float* d_arena, int64_t* off2);
+/* HOST ids (int64) / times (float64) of B edges; ws / wd: this batch's side widths (longest history of the side + 1, at most max_len --
+ * tg_host_count_before gives them without device work); dropout_p = 0 in eval mode, else seeds = 4 per block.  TG_ERANGE for an id
+ * outside the graph.  Nothing waits for the GPU. */
+int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h_dst, const double* h_t, int64_t B, int ws, int wd, float dropout_p,
+                   const uint64_t* seeds, void* stream, float** d_emb);
+/* d_demb (2 B, dn): gradient of the loss w.r.t. the embeddings of the forward in flight; adam (optional): the update, behind the backward */
+int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, const tg_adam_args* adam, float** d_grad);
 
 #ifdef __cplusplus
 }

@@ -220,3 +220,119 @@ def test_fused_self_attention_equals_batched_products(B, S, d, heads, p):
         assert float((res[0][0].double() - o).abs().max()) <= 1e-5 and float((res[0][1].double() - pr).abs().max()) <= 1e-6
         want = torch.cat([g_.grad.transpose(1, 2).reshape(B, S, d) for g_ in (q, k, v)], dim=-1)
         assert float((res[0][2].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def _flat_grads(m, st):
+    """per-tensor views of the native step's gradient block (laid out like the flat parameter)"""
+    base = st.flat.data_ptr()
+    out = {}
+    for k_, p in m.named_parameters():
+        o = (p.data_ptr() - base) // 4
+        out[k_] = st.grad[o:o + p.numel()].view(p.shape).cpu().numpy()
+    return out
+
+
+def test_dygformer_native_step_matches_reference_golden():
+    """the native step (tg_dyg_forward / tg_dyg_backward, every launch issued by the library) against the reference's golden vectors:
+    embeddings and every parameter gradient"""
+    g = load_golden("dyg_p1")
+    m = _model(g).train()
+    m.flatten_parameters()
+    st = m.enable_native_step(len(g["bs"]))
+    B = len(g["bs"])
+    emb = st.forward(g["bs"], g["bd"], g["bt"])
+    np.testing.assert_allclose(emb[:B].cpu().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(emb[B:].cpu().numpy(), g["d_emb"], atol=TOL)
+    r = torch.from_numpy(g["r"]).cuda()
+    st.backward(r.reshape(2 * B, -1).contiguous())
+    assert_grads_match(g, _flat_grads(m, st), atol=1e-4, rtol=1e-3)
+    assert m._flat_pack[0].grad.data_ptr() == st.grad.data_ptr()
+    # a smaller batch through the same object; an id outside the graph; a batch larger than the object was sized for
+    emb2 = st.forward(g["bs"][:4], g["bd"][:4], g["bt"][:4]).clone()
+    s4, d4 = m.compute_src_dst_node_temporal_embeddings(g["bs"][:4], g["bd"][:4], g["bt"][:4])
+    assert float((emb2 - torch.cat([s4, d4]).detach()).abs().max()) <= 2e-5
+    bad = g["bs"].copy()
+    bad[0] = 10 ** 6
+    with pytest.raises(IndexError):
+        st.forward(bad, g["bd"], g["bt"])
+    with pytest.raises(Exception):
+        st.forward(np.tile(g["bs"], 2), np.tile(g["bd"], 2), np.tile(g["bt"], 2))
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_dygformer_native_step_equals_autograd_step(dropout):
+    """config-4 shape: the native train_step against the autograd path on the same batch, weights and seeds -- embeddings, loss, every
+    gradient; then two optimizer steps each (torch.optim.Adam there, the library's update here)"""
+    from flid_amd import ops
+    from flid_amd.optim import FlatAdam
+    from flid_amd.synth import reddit_like
+    from flid_amd.models.DyGFormer import DyGFormer
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = reddit_like(num_edges=20000, num_users=1500, num_items=200, seed=4)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    p = O.seeded_like(O.dyg_shapes(172, 172, 100, 50, 1, 2), 91, 0.04)
+    ms = []
+    for _ in range(2):
+        m = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, 100, 50, 1, 2, 2, dropout, 32, "cuda:0").to("cuda:0").train()
+        m.load_state_dict(p)
+        ms.append(m)
+    ma, mn = ms
+    flat = mn.flatten_parameters()
+    mn.enable_native_step(200)
+    B = 200
+    torch.manual_seed(3)
+    rw = torch.randn(2 * B, 172, device="cuda:0")
+    rw_grad = rw / float(2 * B)
+
+    def loss_fn(emb):
+        return ops.weighted_sum(emb, rw, 1.0 / (2 * B)), rw_grad
+
+    opt_a = torch.optim.Adam(ma.parameters(), lr=1e-4)
+    opt_n = FlatAdam([flat], lr=1e-4)
+    for it, lo in enumerate((15000, 15200)):
+        sl = slice(lo, lo + B)
+        args = (data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl])
+        torch.manual_seed(11 + it)
+        s, d = ma.compute_src_dst_node_temporal_embeddings(*args)
+        ea = torch.cat([s, d])
+        la = (ea * rw).sum() / (2 * B)
+        opt_a.zero_grad(set_to_none=True)
+        la.backward()
+        torch.manual_seed(11 + it)
+        opt_n.zero_grad(set_to_none=True)
+        en, ln = mn.train_step(*args, loss_fn, optimizer=opt_n if it == 1 else None)
+        tol_e = 2e-5 if it == 0 else 2e-3                   # (step 1 runs on weights two different Adam kernels produced)
+        assert float((ea.detach() - en).abs().max()) <= tol_e, (it, float((ea.detach() - en).abs().max()))
+        assert abs(float(la) - float(ln)) <= 1e-5 * max(1.0, abs(float(la))) * (1 if it == 0 else 100)
+        if it == 0:
+            gn = _flat_grads(mn, mn._stepper)
+            for k_, q in ma.named_parameters():
+                ga = q.grad.cpu().numpy()
+                big = max(1e-6, float(np.abs(ga).max()))
+                assert float(np.abs(gn[k_] - ga).max()) <= 2e-4 * big, (k_, float(np.abs(gn[k_] - ga).max()), big)
+            opt_n.step()                                    # the library's stand-alone update on the native gradient
+        opt_a.step()
+    for (k_, qa), (_, qn) in zip(ma.named_parameters(), mn.named_parameters()):
+        # two Adam steps of lr 1e-4 each: entries whose gradient is rounding-level may differ by the whole step
+        assert float((qa.detach() - qn.detach()).abs().max()) <= 4.1e-4, k_
+
+
+def test_dygformer_native_step_refuses_uncovered_shapes():
+    from flid_amd._lib import TgShapeNotCovered
+    g = load_golden("dyg_p2")
+    m = _model(g).train()
+    m.flatten_parameters()
+    with pytest.raises(NotImplementedError):
+        m.enable_native_step(16)                             # patch size 2
+    from flid_amd.synth import reddit_like
+    from flid_amd.models.DyGFormer import DyGFormer
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = reddit_like(num_edges=2000, num_users=150, num_items=20, seed=4)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, 100, 50, 1, 2, 2, 0.1, 64, "cuda:0").to("cuda:0")
+    m.flatten_parameters()
+    with pytest.raises(TgShapeNotCovered):
+        m.enable_native_step(16)                             # two sides of 64 positions
+    with pytest.raises(RuntimeError):
+        DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, 100, 50, 1, 2, 2, 0.1, 32, "cuda:0").to("cuda:0").train_step(
+            data.src_node_ids[:4], data.dst_node_ids[:4], data.node_interact_times[:4], None)
