@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) dyg_cooc_bwd_kernel(const float* __restri
     }
 }
 
-struct BlockBuf { float *y1, *m1, *r1, *qkv, *prob, *att, *ao, *o1, *y2, *m2, *r2, *h, *hgd, *f, *out; };
+struct BlockBuf { float *y1, *m1, *r1, *qkv, *prob, *att, *ao, *o1, *y2, *m2, *r2, *h, *hgd, *out; };
 
 struct Arena {
     float* base; int64_t off = 0;
@@ -219,7 +219,7 @@ void layout(tg_dyg* st, float* base, int64_t* total) {
     for (BlockBuf& b : st->blk) {
         b.y1 = A.take(n * d); b.m1 = A.take(n); b.r1 = A.take(n); b.qkv = A.take(n * 3 * d); b.prob = A.take(B * H * S * S); b.att = A.take(n * d);
         b.ao = A.take(n * d); b.o1 = A.take(n * d); b.y2 = A.take(n * d); b.m2 = A.take(n); b.r2 = A.take(n); b.h = A.take(n * 4 * d);
-        b.hgd = A.take(n * 4 * d); b.f = A.take(n * d); b.out = A.take(n * d);
+        b.hgd = A.take(n * 4 * d); b.out = A.take(n * d);
     }
     st->means = A.take(2 * B * d); st->emb = A.take(2 * B * c.dn);
     st->d_means = A.take(2 * B * d); st->dxa = A.take(n * d); st->dxb = A.take(n * d); st->d_f = A.take(n * d); st->d_hgd = A.take(n * 4 * d);
@@ -385,10 +385,12 @@ extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h
         TG_TRY(tg_gemm_f32(0, 1, n, d, d, 1.f, b.att, d, P(st, blk_i(l, B_OUT_W)), d, b.ao, d, P(st, blk_i(l, B_OUT_B)), 0, 0, stream));
         TG_TRY(tg_dropout_add(b.ao, x, n * d, p, s1, b.o1, stream));
         TG_TRY(tg_add_layernorm_fwd(b.o1, nullptr, n, d, P(st, blk_i(l, B_LN2_G)), P(st, blk_i(l, B_LN2_B)), b.y2, b.m2, b.r2, stream));
+        // (the element-wise passes stay launches of their own: folded into the products' epilogues they cost those exactly what they
+        // cost alone -- measured, 3.028 vs 3.006 ms per step -- because the epilogue of a short-K product is on its critical path)
         TG_TRY(tg_gemm_f32(0, 1, n, 4 * d, d, 1.f, b.y2, d, P(st, blk_i(l, B_FC1_W)), d, b.h, 4 * d, P(st, blk_i(l, B_FC1_B)), 0, 0, stream));
         TG_TRY(tg_gelu_dropout_fwd(b.h, n * 4 * d, p, s2, b.hgd, stream));
-        TG_TRY(tg_gemm_f32(0, 1, n, d, 4 * d, 1.f, b.hgd, 4 * d, P(st, blk_i(l, B_FC2_W)), 4 * d, b.f, d, P(st, blk_i(l, B_FC2_B)), 0, 0, stream));
-        TG_TRY(tg_dropout_add(b.f, b.o1, n * d, p, s3, b.out, stream));
+        TG_TRY(tg_gemm_f32(0, 1, n, d, 4 * d, 1.f, b.hgd, 4 * d, P(st, blk_i(l, B_FC2_W)), 4 * d, b.ao, d, P(st, blk_i(l, B_FC2_B)), 0, 0, stream));
+        TG_TRY(tg_dropout_add(b.ao, b.o1, n * d, p, s3, b.out, stream));
         x = b.out;
     }
     // ---- per-side means over the patches and the output layer (:185-194) ----------------------------------------------------------
@@ -429,7 +431,11 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         const float* xin = l == 0 ? st->x0 : st->blk[(size_t)l - 1].out;
         const uint64_t* sd = st->seeds + 4 * l;
         const float* d_f = dcur;
-        if (p > 0.f) { TG_TRY(tg_dropout(dcur, n * d, p, sd[3], st->d_f, stream)); d_f = st->d_f; }
+        if (p > 0.f) {
+            // (below the top block the dropped copy came out of the block above's LayerNorm backward)
+            if (l == c.layers - 1) TG_TRY(tg_dropout(dcur, n * d, p, sd[3], st->d_f, stream));
+            d_f = st->d_f;
+        }
         TG_TRY(tg_gemm_f32(0, 0, n, 4 * d, d, 1.f, d_f, d, P(st, blk_i(l, B_FC2_W)), 4 * d, st->d_hgd, 4 * d, nullptr, 0, 0, stream));
         float* d_h = st->d_hgd;                                                         // element-wise, in place
         TG_TRY(tg_gelu_dropout_bwd(b.h, st->d_hgd, n * 4 * d, p, p > 0.f ? sd[2] : 0, d_h, stream));
@@ -443,14 +449,18 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         TG_TRY(tg_gemm_f32(0, 0, n, d, d, 1.f, d_ao, d, P(st, blk_i(l, B_OUT_W)), d, st->d_att, d, nullptr, 0, 0, stream));
         TG_TRY(tg_seq_attn_bwd(b.qkv, b.prob, st->d_att, B, S, d, H, p, p > 0.f ? sd[0] : 0, st->dqkv, stream));
         TG_TRY(tg_gemm_f32(0, 0, n, d, 3 * d, 1.f, st->dqkv, 3 * d, P(st, blk_i(l, B_IN_W)), d, st->d_y1, d, nullptr, 0, 0, stream));
-        TG_TRY(tg_add_layernorm_bwd_res(xin, nullptr, st->d_y1, n, d, P(st, blk_i(l, B_LN1_G)), b.m1, b.r1, st->d_o1, dnext, st->part, 0.f, 0, nullptr, stream));
-        TG_TRY(ln_param_grads(st, st->part, d, G(st, blk_i(l, B_LN1_G)), G(st, blk_i(l, B_LN1_B)), stream));
         const tg_wgrad_job jobs[4] = {
             {d_f, d, d, b.hgd, 4 * (int64_t)d, 4 * d, G(st, blk_i(l, B_FC2_W)), 4 * (int64_t)d, G(st, blk_i(l, B_FC2_B))},
             {d_h, 4 * (int64_t)d, 4 * d, b.y2, d, d, G(st, blk_i(l, B_FC1_W)), d, G(st, blk_i(l, B_FC1_B))},
             {d_ao, d, d, b.att, d, d, G(st, blk_i(l, B_OUT_W)), d, G(st, blk_i(l, B_OUT_B))},
             {st->dqkv, 3 * (int64_t)d, 3 * d, b.y1, d, d, G(st, blk_i(l, B_IN_W)), d, G(st, blk_i(l, B_IN_B))}};
         TG_TRY(wgrad(4, jobs, n, stream));
+        // d x = d o1 + dLN1(d y1); the block below wants dropout(d x) under ITS last seed (written into d_f: the weight gradients above were
+        // the last readers of this block's)
+        const bool below = p > 0.f && l > 0;
+        TG_TRY(tg_add_layernorm_bwd_res(xin, nullptr, st->d_y1, n, d, P(st, blk_i(l, B_LN1_G)), b.m1, b.r1, st->d_o1, dnext, st->part,
+                                        below ? p : 0.f, below ? st->seeds[4 * (l - 1) + 3] : 0, below ? st->d_f : nullptr, stream));
+        TG_TRY(ln_param_grads(st, st->part, d, G(st, blk_i(l, B_LN1_G)), G(st, blk_i(l, B_LN1_B)), stream));
         std::swap(dcur, dnext);
     }
     // ---- patch projection, time encoder, co-occurrence encoder ------------------------------------------------------------------------

@@ -163,6 +163,40 @@ def main():
         err = float((g_ - want).abs().max()) / max(1e-12, float(want.abs().max()))
         assert err <= 2e-4, f"rank {rank}: DyGFormer reduced gradient of parameter {i} off by {err:.2e}"
 
+    # ---- (iv-b) the same through the native step (csrc/tg_dyg.hip): every rank's train_step leaves its batch's gradient in the flat
+    # parameter's block, one in-place all-reduce of that block, then the library's Adam -- replicas stay identical
+    from flid_amd import ops
+    from flid_amd.optim import FlatAdam
+    flat = dyg.flatten_parameters()
+    stp = dyg.enable_native_step(200)
+    opt = FlatAdam([flat], lr=1e-4)
+    red_n = fdist.GradAllReducer([flat])
+
+    def native_grad(b):
+        sl = slice(3000 + 200 * b, 3200 + 200 * b)
+        rb = torch.cat([r_all[b, 0], r_all[b, 1]]).contiguous()
+        opt.zero_grad(set_to_none=True)
+        dyg.train_step(data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl],
+                       lambda emb: (ops.weighted_sum(emb, rb, 1.0 / 200.0), rb / 200.0))
+        return stp.grad.clone()
+    every_n = [native_grad(b) for b in range(world)]
+    native_grad(rank)
+    red_n.reduce(weight=1.0 / world)
+    want = sum(every_n) / world
+    err = float((flat.grad - want).abs().max()) / max(1e-12, float(want.abs().max()))
+    assert err <= 2e-4, f"rank {rank}: DyGFormer native step, reduced gradient off by {err:.2e}"
+    # (against the autograd path's gradients of (iv), tensor by tensor)
+    base = flat.data_ptr()
+    for i, (p_, e0) in enumerate(zip(params, every[rank])):
+        o = (p_.data_ptr() - base) // 4
+        gn = every_n[rank][o:o + p_.numel()].view(p_.shape)
+        err = float((gn - e0).abs().max()) / max(1e-12, float(e0.abs().max()))
+        assert err <= 2e-4, f"rank {rank}: DyGFormer native gradient of parameter {i} differs from autograd by {err:.2e}"
+    opt.step()
+    both = [torch.empty_like(flat.data) for _ in range(world)]
+    dist.all_gather(both, flat.data.contiguous())
+    assert all(torch.equal(both[0], b_) for b_ in both[1:]), "DyGFormer replicas diverged after the native step"
+
     dist.barrier()
     if rank == 0:
         print("DIST-GPU-OK", flush=True)
