@@ -15,11 +15,15 @@ python3 bench.py --model tgn --simulate-world 8 --no-cpu-baseline > $O/r04_tgn_s
 rocprofv3 --kernel-trace -d $O/kt_tgn -o tgn -- python3 bench.py --model tgn --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2> $O/kt_tgn.err
 python3 tools/rocpd_stats.py $O/kt_tgn/tgn_results.db --csv $O/r04_tgn_kernel_stats.csv --timeline > $O/r04_tgn_timeline.txt 2>&1
 python3 bench.py --model dygformer > $O/r04_dygformer_bench.json 2> $O/dyg.err
-rocprofv3 --kernel-trace -d $O/kt_dyg -o dyg -- python3 bench.py --model dygformer --steps 20 --warmup 6 --no-cpu-baseline > /dev/null 2> $O/kt_dyg.err
-python3 tools/rocpd_stats.py $O/kt_dyg/dyg_results.db --csv $O/r04_dygformer_kernel_stats.csv > /dev/null 2>&1
+python3 bench.py --model dygformer --python-step --no-cpu-baseline > $O/r04_dygformer_bench_autograd.json 2> $O/dyg_py.err
+rocprofv3 --kernel-trace -d $O/kt_dyg -o dyg -- python3 bench.py --model dygformer --steps 20 --warmup 6 --no-cpu-baseline --no-breakdown > /dev/null 2> $O/kt_dyg.err
+python3 tools/rocpd_stats.py $O/kt_dyg/dyg_results.db --csv $O/r04_dygformer_kernel_stats.csv --timeline > $O/r04_dygformer_timeline.txt 2>&1
+python3 tools/dyg_host_prof.py > $O/r04_dygformer_host_issue.txt 2> $O/dyg_host.err
 python3 bench.py --mode sweep > $O/r04_sweep_bench.json 2> $O/sweep.err
 python3 bench.py --mode fwd > $O/r04_fwd_bench.json 2> $O/fwd.err
 python3 bench.py --mode lp > $O/r04_lp_bench.json 2> $O/lp.err
 python3 bench.py --workload scale --no-cpu-baseline > $O/r04_scale_config5_bench.json 2> $O/scale.err
-rm -rf $O/kt $O/kt_tgn $O/kt_dyg gpurun_out/pmcs* $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+rocprofv3 --kernel-trace -d $O/kt_scale -o scale -- python3 bench.py --workload scale --steps 20 --warmup 6 --no-cpu-baseline --no-breakdown > /dev/null 2> $O/kt_scale.err
+python3 tools/rocpd_stats.py $O/kt_scale/scale_results.db --csv $O/r04_scale_config5_kernel_stats.csv --timeline > $O/r04_scale_config5_timeline.txt 2>&1
+rm -rf $O/kt $O/kt_tgn $O/kt_dyg $O/kt_scale gpurun_out/pmcs* $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 tail -c 300 $O/r04_headline_bench.json; tail -3 $O/traffic.log; grep -h "host issue" $O/*.err
