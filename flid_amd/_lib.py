@@ -76,6 +76,11 @@ class AdamArgs(C.Structure):
                 ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("step", c_i64)]
 
 
+class Pack32Job(C.Structure):
+    """struct tg_pack32_job"""
+    _fields_ = [("src", c_void), ("ld", c_i64), ("N", C.c_int32), ("K", C.c_int32), ("trans", C.c_int32), ("dst", c_void)]
+
+
 class DygCfg(C.Structure):
     """struct tg_dyg_cfg"""
     _fields_ = [("graph", c_void), ("d_node", c_void), ("node_ld", c_i64), ("d_edge", c_void), ("edge_ld", c_i64), ("num_edge_rows", c_i64),
@@ -106,6 +111,9 @@ SIGNATURES = {
     "tg_stepper_tgn_forward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), C.c_int, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void), C.c_int]),
     "tg_stepper_tgn_backward": (C.c_int, [c_void, C.c_int, C.POINTER(TgnBank), c_void, C.c_int, c_void, C.POINTER(AdamArgs), C.POINTER(c_void),
                                           GRAD_READY_FN, c_void]),
+    "tg_packed32_floats": (c_i64, [C.c_int, C.c_int]),
+    "tg_pack32_weights": (C.c_int, [C.c_int, c_void, c_void]),
+    "tg_gemm_pk_nt": (C.c_int, [c_i64, C.c_int, C.c_int, c_void, c_i64, c_void, c_void, c_i64, c_void, c_void]),
     "tg_dyg_arena_floats": (c_i64, [C.POINTER(DygCfg)]),
     "tg_dyg_create": (C.c_int, [C.POINTER(DygCfg), c_void, c_i64, C.POINTER(c_void)]),
     "tg_dyg_destroy": (None, [c_void]),

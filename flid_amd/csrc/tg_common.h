@@ -79,6 +79,9 @@ bool wspace_tail(const float* Wq, const float* Wk, const float* dP, const float*
 // tg_pack.hip: packed (split-bf16, MFMA fragment order) weights of the chain kernels
 int64_t packed_floats(int N, int K);
 int pack_weights(int njobs, const tg_pack_job* jobs, hipStream_t s);
+int64_t packed32_floats(int N, int K);
+int pack32_weights(int njobs, const tg_pack32_job* jobs, hipStream_t s);
+bool gemm_pk_nt(int64_t M, int N, int K, const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, const float* bias, hipStream_t s);
 // tg_chain.hip: everything behind the attention of a layer's forward as one launch
 bool chain_shape_ok(int H, int dn, int T, int de);
 int chain_hp(int H, int dn, int T);

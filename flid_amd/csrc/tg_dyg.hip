@@ -12,6 +12,7 @@
 // j - ws otherwise (the order the transformer reads them, DyGFormer.py:164-174).  X (n, Kp) = [node row | edge row | time encoding |
 // co-occurrence encoding | pad] per position; one product against the block-diagonal projection weight gives the (n, 4 C) tokens.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -150,7 +151,12 @@ __global__ void __launch_bounds__(256) dyg_cooc_bwd_kernel(const float* __restri
     }
 }
 
-struct BlockBuf { float *y1, *m1, *r1, *qkv, *prob, *att, *ao, *o1, *y2, *m2, *r2, *h, *hgd, *out; };
+struct BlockBuf {
+    float *y1, *m1, *r1, *qkv, *prob, *att, *ao, *o1, *y2, *m2, *r2, *h, *hgd, *out;
+    // pre-split weights of the products whose contraction is the token width d (tg_gemm_pk.hip): in_proj, out_proj, linear 0 forward;
+    // linear 1 and out_proj transposed for the input gradients d hgd = d f W2, d att = d ao Wo
+    float *pk_in, *pk_out, *pk_fc1, *pk_fc2t, *pk_outt;
+};
 
 struct Arena {
     float* base; int64_t off = 0;
@@ -179,6 +185,7 @@ struct tg_dyg {
     void* pinned = nullptr; int64_t stage_bytes = 0; hipEvent_t copied[RING] = {}; bool copy_pending[RING] = {}; int ring = 0;
     // the forward in flight
     bool fwd_pending = false; int64_t B = 0; int ws = 0, wd = 0; float p = 0.f; uint64_t seeds[32] = {};
+    bool use_pk = false;                  // this step's d-deep products run against the pre-split weights
 };
 
 namespace {
@@ -220,6 +227,10 @@ void layout(tg_dyg* st, float* base, int64_t* total) {
         b.y1 = A.take(n * d); b.m1 = A.take(n); b.r1 = A.take(n); b.qkv = A.take(n * 3 * d); b.prob = A.take(B * H * S * S); b.att = A.take(n * d);
         b.ao = A.take(n * d); b.o1 = A.take(n * d); b.y2 = A.take(n * d); b.m2 = A.take(n); b.r2 = A.take(n); b.h = A.take(n * 4 * d);
         b.hgd = A.take(n * 4 * d); b.out = A.take(n * d);
+        const bool pk = tg::packed32_floats(d, d) > 0;
+        b.pk_in = pk ? A.take(tg::packed32_floats(3 * d, d)) : nullptr; b.pk_out = pk ? A.take(tg::packed32_floats(d, d)) : nullptr;
+        b.pk_fc1 = pk ? A.take(tg::packed32_floats(4 * d, d)) : nullptr; b.pk_fc2t = pk ? A.take(tg::packed32_floats(4 * d, d)) : nullptr;
+        b.pk_outt = pk ? A.take(tg::packed32_floats(d, d)) : nullptr;
     }
     st->means = A.take(2 * B * d); st->emb = A.take(2 * B * c.dn);
     st->d_means = A.take(2 * B * d); st->dxa = A.take(n * d); st->dxb = A.take(n * d); st->d_f = A.take(n * d); st->d_hgd = A.take(n * 4 * d);
@@ -249,6 +260,13 @@ void derive(tg_dyg* st) {
 inline float* P(const tg_dyg* st, int i) { return st->c.d_param + st->c.poff[i]; }
 inline float* G(const tg_dyg* st, int i) { return st->gblock + st->c.poff[i]; }
 inline int blk_i(int l, int j) { return P_BLOCK0 + B_COUNT * l + j; }
+
+// C = A W^T (+ bias) (tb) or A W (W given K x N): against the pre-split copy of the weight where this step has one, else the general product
+int prod(const tg_dyg* st, const float* packed, int tb, int64_t M, int N, int K, const float* A, int64_t lda, const float* W, int64_t ldw, float* C,
+         int64_t ldc, const float* bias, void* stream) {
+    if (st->use_pk && packed && tg::gemm_pk_nt(M, N, K, A, lda, packed, C, ldc, bias, (hipStream_t)stream)) return tg::launch_status("gemm_pk_s_kernel");
+    return tg_gemm_f32(0, tb, M, N, K, 1.f, A, lda, W, ldw, C, ldc, bias, 0, 0, stream);
+}
 
 // weight (and bias) gradients: the grouped split-bf16 launch where it covers the shapes, else one exact product + one column sum per job
 int wgrad(int n, const tg_wgrad_job* jobs, int64_t rows, void* stream) {
@@ -373,6 +391,21 @@ extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h
     TG_TRY(tg_gemm_f32(0, 1, n, C, C, 1.f, st->hs, C, P(st, P_CO_W2), C, st->X + oo[3], Kp, st->b2x2, 0, 0, stream));
     TG_TRY(tg_gemm_f32(0, 1, n, d, Kp, 1.f, st->X, Kp, st->Wbd, Kp, st->x0, d, st->bbd, 0, 0, stream));
     // ---- transformer blocks (DyGFormer.py:418-461, pre-LN) ------------------------------------------------------------------------
+    static const bool no_pk = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_PK") && atoi(getenv("FLID_NO_PK")) != 0;
+    st->use_pk = !no_pk && tg_get_gemm_mode() != 0 && st->blk[0].pk_in != nullptr && d % 4 == 0 && c.layers <= 3;
+    if (st->use_pk) {                                   // the weights moved with the last update: split them again, one launch
+        tg_pack32_job jobs[16];
+        int nj = 0;
+        for (int l = 0; l < c.layers; ++l) {
+            const BlockBuf& b = st->blk[(size_t)l];
+            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_IN_W)), d, 3 * d, d, 0, b.pk_in};
+            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_OUT_W)), d, d, d, 0, b.pk_out};
+            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_FC1_W)), d, 4 * d, d, 0, b.pk_fc1};
+            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_FC2_W)), 4 * (int64_t)d, 4 * d, d, 1, b.pk_fc2t};
+            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_OUT_W)), d, d, d, 1, b.pk_outt};
+        }
+        TG_TRY(tg::pack32_weights(nj, jobs, s));
+    }
     const float p = dropout_p;
     const float* x = st->x0;
     for (int l = 0; l < c.layers; ++l) {
@@ -380,14 +413,14 @@ extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h
         const uint64_t* sd = seeds ? seeds + 4 * l : nullptr;
         const uint64_t s0 = p > 0.f ? sd[0] : 0, s1 = p > 0.f ? sd[1] : 0, s2 = p > 0.f ? sd[2] : 0, s3 = p > 0.f ? sd[3] : 0;
         TG_TRY(tg_add_layernorm_fwd(x, nullptr, n, d, P(st, blk_i(l, B_LN1_G)), P(st, blk_i(l, B_LN1_B)), b.y1, b.m1, b.r1, stream));
-        TG_TRY(tg_gemm_f32(0, 1, n, 3 * d, d, 1.f, b.y1, d, P(st, blk_i(l, B_IN_W)), d, b.qkv, 3 * d, P(st, blk_i(l, B_IN_B)), 0, 0, stream));
+        TG_TRY(prod(st, b.pk_in, 1, n, 3 * d, d, b.y1, d, P(st, blk_i(l, B_IN_W)), d, b.qkv, 3 * d, P(st, blk_i(l, B_IN_B)), stream));
         TG_TRY(tg_seq_attn_fwd(b.qkv, B, S, d, H, p, s0, b.att, b.prob, stream));
-        TG_TRY(tg_gemm_f32(0, 1, n, d, d, 1.f, b.att, d, P(st, blk_i(l, B_OUT_W)), d, b.ao, d, P(st, blk_i(l, B_OUT_B)), 0, 0, stream));
+        TG_TRY(prod(st, b.pk_out, 1, n, d, d, b.att, d, P(st, blk_i(l, B_OUT_W)), d, b.ao, d, P(st, blk_i(l, B_OUT_B)), stream));
         TG_TRY(tg_dropout_add(b.ao, x, n * d, p, s1, b.o1, stream));
         TG_TRY(tg_add_layernorm_fwd(b.o1, nullptr, n, d, P(st, blk_i(l, B_LN2_G)), P(st, blk_i(l, B_LN2_B)), b.y2, b.m2, b.r2, stream));
         // (the element-wise passes stay launches of their own: folded into the products' epilogues they cost those exactly what they
         // cost alone -- measured, 3.028 vs 3.006 ms per step -- because the epilogue of a short-K product is on its critical path)
-        TG_TRY(tg_gemm_f32(0, 1, n, 4 * d, d, 1.f, b.y2, d, P(st, blk_i(l, B_FC1_W)), d, b.h, 4 * d, P(st, blk_i(l, B_FC1_B)), 0, 0, stream));
+        TG_TRY(prod(st, b.pk_fc1, 1, n, 4 * d, d, b.y2, d, P(st, blk_i(l, B_FC1_W)), d, b.h, 4 * d, P(st, blk_i(l, B_FC1_B)), stream));
         TG_TRY(tg_gelu_dropout_fwd(b.h, n * 4 * d, p, s2, b.hgd, stream));
         TG_TRY(tg_gemm_f32(0, 1, n, d, 4 * d, 1.f, b.hgd, 4 * d, P(st, blk_i(l, B_FC2_W)), 4 * d, b.ao, d, P(st, blk_i(l, B_FC2_B)), 0, 0, stream));
         TG_TRY(tg_dropout_add(b.ao, b.o1, n * d, p, s3, b.out, stream));
@@ -436,7 +469,7 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
             if (l == c.layers - 1) TG_TRY(tg_dropout(dcur, n * d, p, sd[3], st->d_f, stream));
             d_f = st->d_f;
         }
-        TG_TRY(tg_gemm_f32(0, 0, n, 4 * d, d, 1.f, d_f, d, P(st, blk_i(l, B_FC2_W)), 4 * d, st->d_hgd, 4 * d, nullptr, 0, 0, stream));
+        TG_TRY(prod(st, b.pk_fc2t, 0, n, 4 * d, d, d_f, d, P(st, blk_i(l, B_FC2_W)), 4 * d, st->d_hgd, 4 * d, nullptr, stream));
         float* d_h = st->d_hgd;                                                         // element-wise, in place
         TG_TRY(tg_gelu_dropout_bwd(b.h, st->d_hgd, n * 4 * d, p, p > 0.f ? sd[2] : 0, d_h, stream));
         TG_TRY(tg_gemm_f32(0, 0, n, d, 4 * d, 1.f, d_h, 4 * d, P(st, blk_i(l, B_FC1_W)), d, st->d_y2, d, nullptr, 0, 0, stream));
@@ -446,7 +479,7 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
                                         p, p > 0.f ? sd[1] : 0, p > 0.f ? st->d_ao : nullptr, stream));
         if (p > 0.f) d_ao = st->d_ao;
         TG_TRY(ln_param_grads(st, st->part, d, G(st, blk_i(l, B_LN2_G)), G(st, blk_i(l, B_LN2_B)), stream));
-        TG_TRY(tg_gemm_f32(0, 0, n, d, d, 1.f, d_ao, d, P(st, blk_i(l, B_OUT_W)), d, st->d_att, d, nullptr, 0, 0, stream));
+        TG_TRY(prod(st, b.pk_outt, 0, n, d, d, d_ao, d, P(st, blk_i(l, B_OUT_W)), d, st->d_att, d, nullptr, stream));
         TG_TRY(tg_seq_attn_bwd(b.qkv, b.prob, st->d_att, B, S, d, H, p, p > 0.f ? sd[0] : 0, st->dqkv, stream));
         TG_TRY(tg_gemm_f32(0, 0, n, d, 3 * d, 1.f, st->dqkv, 3 * d, P(st, blk_i(l, B_IN_W)), d, st->d_y1, d, nullptr, 0, 0, stream));
         const tg_wgrad_job jobs[4] = {

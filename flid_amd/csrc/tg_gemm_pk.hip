@@ -1,0 +1,272 @@
+// Row-panel products against PRE-SPLIT weights:  C[M, N] = A[M, K] * W^T (+ bias), split-bf16 ("bf16x3", see tg_gemm_bf16x3.hip for the
+// arithmetic), for TALL activations against SMALL weights -- the products of DyGFormer's transformer blocks (38 400 rows against
+// 200 x 200 .. 800 x 200 weights) in the native step (tg_dyg.hip).
+//
+// replaces: aten::addmm behind the nn.Linear layers and nn.MultiheadAttention's projections of models/DyGFormer.py:418-461 and their
+//           input gradients.
+//
+// Why a second product kernel.  The tile kernel of tg_gemm_bf16x3.hip spends a K = 200 product in four costs of about equal size that
+// ADD instead of overlapping (prologue latency, LDS traffic of both operands, the C write, the MFMAs: DESIGN.md section 6).  Here
+//   * the A operand never touches LDS: a wave owns 32 rows, loads its MFMA fragments of a whole K chunk (<= 208) straight into registers
+//     and splits them ONCE (the tile kernel re-stages and re-splits a row panel for every 96 columns);
+//   * the weight is split and laid out in fragment order once per step (pack32_kernel); a workgroup's four waves share its 32-column
+//     tiles through a three-buffer LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no registers, no VALU, no LDS store
+//     instructions), one tile ahead of the MFMAs, one barrier per tile;
+//   * a tile of C leaves straight from the accumulators: one store instruction covers two 128-byte row segments.
+// K <= 208 only (one K chunk, any N).  A long-K form that kept the accumulators of up to 7 tiles while K chunks passed was built and
+// measured slower than the tile kernel (119 vs 80 us at 38 400 x 200 x 800: 370 registers, one workgroup per CU, 300 workgroups on 256
+// CUs); it is not kept.  Measured at 38 400 rows (tools/pk_bench.py): x 800 x 200 72 us (tile kernel 92), x 600 x 200 64 (78),
+// x 200 x 200 31 (35.5).  Without the C stores the 800-column product takes 50 us, with them 72-80: the 123 MB it writes are the floor
+// (~4 TB/s), the MFMAs (20 us) would hide under it -- what is left is the prologue (A rows from HBM, 26 splits per lane) per unit.
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "tg_common.h"
+#include "tg_split.h"
+
+namespace {
+
+using tgs::bf16x8;
+using tgs::f32x16;
+using tgs::split4;
+
+#ifndef FLID_PK_EXP
+#define FLID_PK_EXP 0
+#endif
+constexpr int PKS = 13;                       // 16-deep steps of one K chunk
+constexpr int KC = 16 * PKS;                  // 208
+constexpr int BLK = 1024;                     // one (step, plane) fragment block: 64 lanes x 8 bf16
+constexpr int STAGE = 2 * PKS * BLK;          // one 32-column tile x one K chunk, hi and lo planes: 26 KiB
+constexpr int NBUF = 3;
+
+// packed operand: [tile t][step s][plane hi, lo][lane][8 bf16]; lane l of (t, s) holds W[32 t + (l & 31)][16 s + 8 (l >> 5) + 0..7] -- the
+// B fragment of v_mfma_f32_32x32x16_bf16 -- zero beyond N or K.  Up to 16 weights per launch, one wave per fragment pair.
+struct Pack32Jobs { tg_pack32_job j[16]; int frag0[17]; int n; };
+__global__ void __launch_bounds__(256) pack32_kernel(Pack32Jobs jobs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = jobs.frag0[jobs.n];
+    for (int f = blockIdx.x * 4 + wave; f < total; f += gridDim.x * 4) {
+        int ji = 0;
+        while (ji + 1 < jobs.n && f >= jobs.frag0[ji + 1]) ++ji;
+        const tg_pack32_job J = jobs.j[ji];
+        const int fl = f - jobs.frag0[ji], s = fl % PKS, t = fl / PKS;
+        const int n = 32 * t + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q;
+            const bool ok = n < J.N && k < J.K;
+            v[q] = ok ? (J.trans ? J.src[(int64_t)k * J.ld + n] : J.src[(int64_t)n * J.ld + k]) : 0.f;
+        }
+        uint2 h0, l0, h1, l1;
+        split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+        split4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+        uint4* d = reinterpret_cast<uint4*>(J.dst) + ((int64_t)fl * 2) * 64 + lane;
+        d[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        d[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+// stage (chunk c, tile t) of the packed operand -> LDS buffer `buf`: 26 blocks of 1 KiB, wave w takes blocks w, w + 4, ... (every wave
+// issues the same number of copies; the surplus ones repeat block 25 with identical bytes)
+__device__ __forceinline__ void issue_stage(const uint4* __restrict__ Bp, int64_t stage_index, char* lds, int buf, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        int blk = wave + 4 * i;
+        if (blk > 2 * PKS - 1) blk = 2 * PKS - 1;
+        const uint4* g = Bp + (stage_index * (2 * PKS) + blk) * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(lds + buf * STAGE + blk * BLK), 16, 0, 0);
+    }
+}
+
+// this lane's A fragments: rows fixed, k = 16 s + 8 h + 0..7 for s = 0..12; loads unconditional (an offset past K
+// reads the row's start instead and is zeroed), split once
+__device__ __forceinline__ void load_a(const float* __restrict__ arow, int K, int h, bf16x8 (&ah)[PKS], bf16x8 (&al)[PKS]) {
+    float4 x[PKS], y[PKS];
+#pragma unroll
+    for (int s = 0; s < PKS; ++s) {
+        const int k = 16 * s + 8 * h;
+        x[s] = *reinterpret_cast<const float4*>(arow + (k < K ? k : 0));
+        y[s] = *reinterpret_cast<const float4*>(arow + (k + 4 < K ? k + 4 : 0));
+    }
+#pragma unroll
+    for (int s = 0; s < PKS; ++s) {
+        const int k = 16 * s + 8 * h;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 h0, l0, h1, l1;
+        split4(k < K ? x[s] : z, h0, l0);
+        split4(k + 4 < K ? y[s] : z, h1, l1);
+        ah[s] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        al[s] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    }
+}
+
+__device__ __forceinline__ void mma_stage(const char* __restrict__ stage, int lane, const bf16x8 (&ah)[PKS], const bf16x8 (&al)[PKS], f32x16& acc) {
+    const char* b = stage + lane * 16;
+#pragma unroll
+    for (int s = 0; s < PKS; ++s) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + s * 2 * BLK);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + s * 2 * BLK + BLK);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh, acc, 0, 0, 0);
+    }
+}
+
+template <int K_>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K_ * 0x55, 0xf, 0xf, false));
+}
+
+// The same tile as 16-byte stores: the four lanes of a quad hold a 4 (rows) x 4 (columns) block of every register group g = r >> 2;
+// transposed inside the quad (DPP broadcasts + selects), lane j of the quad owns row 8 g + 4 h + j, columns 4 (c >> 2) .. + 3: one store
+// instruction then covers 8 rows x 128 bytes instead of 2 rows.  Needs N % 4 == 0 and 16-byte aligned rows of C.
+__device__ __forceinline__ void store_tile4(const f32x16& acc, float* __restrict__ C, int64_t ldc, int64_t row0, int64_t M, int col_lane, int N,
+                                            const float* __restrict__ bias, int h) {
+    const int j = col_lane & 3, col4 = col_lane & ~3;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && col4 < N) b4 = *reinterpret_cast<const float4*>(bias + col4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // every lane of the quad sees lane k's four rows; it keeps the one of ITS row j: element (row j, column k of the quad)
+            const float t0 = k == 0 ? quad_bcast<0>(acc[4 * g + 0]) : k == 1 ? quad_bcast<1>(acc[4 * g + 0]) : k == 2 ? quad_bcast<2>(acc[4 * g + 0]) : quad_bcast<3>(acc[4 * g + 0]);
+            const float t1 = k == 0 ? quad_bcast<0>(acc[4 * g + 1]) : k == 1 ? quad_bcast<1>(acc[4 * g + 1]) : k == 2 ? quad_bcast<2>(acc[4 * g + 1]) : quad_bcast<3>(acc[4 * g + 1]);
+            const float t2 = k == 0 ? quad_bcast<0>(acc[4 * g + 2]) : k == 1 ? quad_bcast<1>(acc[4 * g + 2]) : k == 2 ? quad_bcast<2>(acc[4 * g + 2]) : quad_bcast<3>(acc[4 * g + 2]);
+            const float t3 = k == 0 ? quad_bcast<0>(acc[4 * g + 3]) : k == 1 ? quad_bcast<1>(acc[4 * g + 3]) : k == 2 ? quad_bcast<2>(acc[4 * g + 3]) : quad_bcast<3>(acc[4 * g + 3]);
+            w[k] = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
+        }
+        const int64_t row = row0 + 8 * g + 4 * h + j;
+        if (row < M && col4 < N)
+            *reinterpret_cast<float4*>(C + row * ldc + col4) = make_float4(w[0] + b4.x, w[1] + b4.y, w[2] + b4.z, w[3] + b4.w);
+    }
+}
+
+// accumulator layout of the 32x32 MFMA: lane (c = l & 31, h = l >> 5), register r -> row (r & 3) + 8 (r >> 2) + 4 h, column c
+__device__ __forceinline__ void store_tile(const f32x16& acc, float* __restrict__ C, int64_t ldc, int64_t row0, int64_t M, int col, int N,
+                                           const float* __restrict__ bias, int h) {
+    if (col >= N) return;
+    const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) C[row * ldc + col] = acc[r] + b;
+    }
+}
+
+// K <= 208: grid (row panels of 128, column units of `tpu` tiles)
+__global__ void __launch_bounds__(256) gemm_pk_s_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K, const uint4* __restrict__ Bp, int N,
+                                                        int ntiles, int tpu, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int vec) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int t0 = blockIdx.y * tpu, t1 = t0 + tpu < ntiles ? t0 + tpu : ntiles;
+    issue_stage(Bp, t0, lds, 0, wave, lane);
+    if (t0 + 1 < t1) issue_stage(Bp, t0 + 1, lds, 1, wave, lane);
+    int64_t row = row0 + (lane & 31);
+    if (row > M - 1) row = M - 1;
+    bf16x8 ah[PKS], al[PKS];
+    load_a(A + row * lda, K, h, ah, al);
+    // One barrier per tile, and no wait for the C stores: tile t's stores are issued one iteration late (behind the barrier of tile
+    // t + 1), so the queue of outstanding vector-memory operations at the top of iteration u is, oldest first,
+    //     [DMA of tile u + 1] [stores of tile u - 2 ... long done] [stores of tile u - 1] [DMA of tile u + 2 -- not yet issued]
+    // i.e. at the wait: DMA(u) (7, oldest), stores(u - 2) (4), DMA(u + 1) (7).  vmcnt(7) lets 7 stay outstanding: loads retire in
+    // order among themselves, so whichever way loads and stores interleave, 11 retirements include all 7 of DMA(u).
+    f32x16 prev;
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // tile t has landed for every wave; every wave is done reading tile t - 1
+        asm volatile("" ::: "memory");
+        if (t > t0) {
+            if (vec) store_tile4(prev, C, ldc, row0, M, 32 * (t - 1) + (lane & 31), N, bias, h);
+            else store_tile(prev, C, ldc, row0, M, 32 * (t - 1) + (lane & 31), N, bias, h);
+        }
+        if (t + 2 < t1) issue_stage(Bp, t + 2, lds, (t + 2 - t0) % NBUF, wave, lane);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_stage(lds + ((t - t0) % NBUF) * STAGE, lane, ah, al, acc);
+        prev = acc;
+    }
+    if (vec) store_tile4(prev, C, ldc, row0, M, 32 * (t1 - 1) + (lane & 31), N, bias, h);
+    else store_tile(prev, C, ldc, row0, M, 32 * (t1 - 1) + (lane & 31), N, bias, h);
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+namespace tg {
+
+int64_t packed32_floats(int N, int K) { return K > KC ? -1 : (int64_t)((N + 31) / 32) * (STAGE / 4); }
+
+int pack32_weights(int njobs, const tg_pack32_job* jobs, hipStream_t s) {
+    TG_REQUIRE(njobs >= 0 && njobs <= 16 && (njobs == 0 || jobs), "tg_pack32_weights: at most 16 jobs per launch");
+    if (njobs == 0) return TG_OK;
+    Pack32Jobs pj;
+    pj.n = njobs;
+    int total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        TG_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].N > 0 && jobs[i].K > 0 && jobs[i].K <= KC && al16(jobs[i].dst), "tg_pack32_weights: bad job (K <= 208)");
+        pj.j[i] = jobs[i];
+        pj.frag0[i] = total;
+        total += ((jobs[i].N + 31) / 32) * PKS;
+    }
+    pj.frag0[njobs] = total;
+    pack32_kernel<<<(unsigned)std::min((total + 3) / 4, 2048), 256, 0, s>>>(pj);
+    return launch_status("pack32_kernel");
+}
+
+// true = launched; false = shape / alignment not covered (the caller takes tg_gemm_f32 on the unpacked weight)
+bool gemm_pk_nt(int64_t M, int N, int K, const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, const float* bias, hipStream_t s) {
+    if (M < 1 || N < 1 || K < 4 || K > KC || K % 4 || lda % 4 || !al16(A) || !al16(packed)) return false;
+    const int ntiles = (N + 31) / 32;
+    const int64_t panels = (M + 127) / 128;
+    if (panels >= ((int64_t)1 << 31)) return false;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_pk_s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * STAGE) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_done = true;
+    }
+    const int vec = N % 4 == 0 && ldc % 4 == 0 && al16(C) && (!bias || al16(bias));
+    ProfScope prof("gemm", 2.0 * M * N * K, s);
+    // units per panel u: rounds of the grid over the chip's 512 workgroup slots x (tiles per unit + the prologue, which costs about
+    // six tiles' time: A rows from HBM, 26 splits per lane)
+    int tpu = ntiles;
+    int64_t best = -1;
+    static const int force_u = (getenv("FLID_GEMM_TUNE") && getenv("FLID_PK_UNITS")) ? atoi(getenv("FLID_PK_UNITS")) : 0;
+    for (int u = 1; u <= ntiles; ++u) {
+        const int per = (ntiles + u - 1) / u;
+        const int64_t cost = ((panels * ((ntiles + per - 1) / per) + 511) / 512) * (per + 6);
+        if (force_u ? u == force_u : (best < 0 || cost < best)) { best = cost; tpu = per; }
+    }
+    const dim3 grid((unsigned)panels, (unsigned)((ntiles + tpu - 1) / tpu));
+    gemm_pk_s_kernel<<<grid, 256, NBUF * STAGE, s>>>(A, lda, M, K, reinterpret_cast<const uint4*>(packed), N, ntiles, tpu, C, ldc, bias, vec);
+    return true;
+}
+
+}  // namespace tg
+
+extern "C" int64_t tg_packed32_floats(int N, int K) { return tg::packed32_floats(N, K); }
+
+extern "C" int tg_pack32_weights(int njobs, const tg_pack32_job* jobs, void* stream) { return tg::pack32_weights(njobs, jobs, (hipStream_t)stream); }
+
+extern "C" int tg_gemm_pk_nt(int64_t M, int N, int K, const float* d_A, int64_t lda, const void* d_packed, float* d_C, int64_t ldc, const float* d_bias,
+                             void* stream) {
+    TG_REQUIRE(d_A && d_packed && d_C && ldc >= N, "tg_gemm_pk_nt: arguments");
+    if (M == 0) return TG_OK;
+    if (!tg::gemm_pk_nt(M, N, K, d_A, lda, d_packed, d_C, ldc, d_bias, (hipStream_t)stream)) {
+        tg::set_error("tg_gemm_pk_nt: K <= 208, K and lda multiples of 4, 16-byte aligned operands");
+        return TG_ESHAPE;
+    }
+    return tg::launch_status("gemm_pk_s_kernel");
+}

@@ -250,7 +250,8 @@ def test_dygformer_native_step_matches_reference_golden():
     # a smaller batch through the same object; an id outside the graph; a batch larger than the object was sized for
     emb2 = st.forward(g["bs"][:4], g["bd"][:4], g["bt"][:4]).clone()
     s4, d4 = m.compute_src_dst_node_temporal_embeddings(g["bs"][:4], g["bd"][:4], g["bt"][:4])
-    assert float((emb2 - torch.cat([s4, d4]).detach()).abs().max()) <= 2e-5
+    # (the native step's d-deep products are split-bf16 against pre-split weights; the autograd path's few-row products exact fp32)
+    assert float((emb2 - torch.cat([s4, d4]).detach()).abs().max()) <= TOL
     bad = g["bs"].copy()
     bad[0] = 10 ** 6
     with pytest.raises(IndexError):
@@ -301,7 +302,7 @@ def test_dygformer_native_step_equals_autograd_step(dropout):
         torch.manual_seed(11 + it)
         opt_n.zero_grad(set_to_none=True)
         en, ln = mn.train_step(*args, loss_fn, optimizer=opt_n if it == 1 else None)
-        tol_e = 2e-5 if it == 0 else 2e-3                   # (step 1 runs on weights two different Adam kernels produced)
+        tol_e = 5e-5 if it == 0 else 2e-3                   # (two split-bf16 kernels; step 1 runs on weights two different Adam kernels produced)
         assert float((ea.detach() - en).abs().max()) <= tol_e, (it, float((ea.detach() - en).abs().max()))
         assert abs(float(la) - float(ln)) <= 1e-5 * max(1.0, abs(float(la))) * (1 if it == 0 else 100)
         if it == 0:

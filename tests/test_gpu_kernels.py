@@ -738,3 +738,28 @@ def test_weight_gradient_forms_agree():
     for form in (1, 2):
         assert float((res[form][0][0].double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
         assert float((res[form][0][1].double() - A.double().sum(0)).abs().max()) <= 3e-5 * float(A.double().sum(0).abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,trans", [(1000, 200, 200, 0), (777, 800, 200, 1), (2500, 600, 200, 0), (64, 24, 24, 0), (129, 50, 52, 1), (5000, 36, 208, 0)])
+def test_panel_product_against_presplit_weights(M, N, K, trans):
+    """tg_pack32_weights + tg_gemm_pk_nt (A fragments straight from global memory, the pre-split weight's tiles through the LDS-DMA
+    ring) against float64 and against the tile kernel's split-bf16 product of the same operands"""
+    from flid_amd import ops
+    from flid_amd._lib import Pack32Job, check, lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev)
+    w = (torch.randn(K, N, device=dev) if trans else torch.randn(N, K, device=dev)) * 0.1
+    b = torch.randn(N, device=dev)
+    pk = torch.empty(int(lib().tg_packed32_floats(N, K)), device=dev)
+    jobs = (Pack32Job * 1)(Pack32Job(w.data_ptr(), w.stride(0), N, K, trans, pk.data_ptr()))
+    check(lib().tg_pack32_weights(1, jobs, ops._stream()), "tg_pack32_weights")
+    c = torch.full((M, N), float("nan"), device=dev)
+    check(lib().tg_gemm_pk_nt(M, N, K, a.data_ptr(), K, pk.data_ptr(), c.data_ptr(), N, b.data_ptr(), ops._stream()), "tg_gemm_pk_nt")
+    wt = w.t() if trans else w
+    ref = a.double() @ wt.double().t() + b.double()
+    assert float((c.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    c2 = torch.empty(M, N, device=dev)
+    ops.gemm(a, wt.contiguous(), c2, tb=True, bias=b)
+    assert float((c - c2).abs().max()) <= 4e-5 * float(ref.abs().max())
+    assert int(lib().tg_packed32_floats(N, 300)) == -1                     # K > 208 is the tile kernel's
