@@ -120,6 +120,7 @@ SIGNATURES = {
     "tg_dyg_regions": (C.c_int, [c_void, c_void, C.POINTER(c_i64)]),
     "tg_dyg_forward": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_int, C.c_int, c_f32, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void)]),
     "tg_dyg_backward": (C.c_int, [c_void, c_void, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
+    "tg_add_layernorm_fwd_res": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void, c_f32, C.c_uint64, c_void, c_void, c_void, c_void, c_void]),
     "tg_add_layernorm_bwd_res": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_f32,
                                            C.c_uint64, c_void, c_void]),
     "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),

@@ -151,6 +151,24 @@ __global__ void __launch_bounds__(256) dyg_cooc_bwd_kernel(const float* __restri
     }
 }
 
+// gradient of the two per-side means (DyGFormer.py:185-187) at every position, and its dropped copy under the top block's last seed
+__global__ void __launch_bounds__(256) dyg_segmean_bwd_kernel(const float* __restrict__ d_means, int64_t B, int S, int d, int ws, float p, uint64_t seed,
+                                                              float* __restrict__ dx, float* __restrict__ dx_dropped) {
+    const int64_t total = B * S * d;
+    const float is = 1.f / (float)ws, id = 1.f / (float)(S - ws), scale = 1.f / (1.f - p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d);
+        const int64_t pos = i / d, b = pos / S;
+        const int j = (int)(pos - b * S);
+        const float v = j < ws ? d_means[b * d + c] * is : d_means[(B + b) * d + c] * id;
+        dx[i] = v;
+        if (dx_dropped) {
+            const float u = (float)(tg::mix32(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
+            dx_dropped[i] = u >= p ? v * scale : 0.f;
+        }
+    }
+}
+
 struct BlockBuf {
     float *y1, *m1, *r1, *qkv, *prob, *att, *ao, *o1, *y2, *m2, *r2, *h, *hgd, *out;
     // pre-split weights of the products whose contraction is the token width d (tg_gemm_pk.hip): in_proj, out_proj, linear 0 forward;
@@ -412,18 +430,24 @@ extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h
         BlockBuf& b = st->blk[(size_t)l];
         const uint64_t* sd = seeds ? seeds + 4 * l : nullptr;
         const uint64_t s0 = p > 0.f ? sd[0] : 0, s1 = p > 0.f ? sd[1] : 0, s2 = p > 0.f ? sd[2] : 0, s3 = p > 0.f ? sd[3] : 0;
-        TG_TRY(tg_add_layernorm_fwd(x, nullptr, n, d, P(st, blk_i(l, B_LN1_G)), P(st, blk_i(l, B_LN1_B)), b.y1, b.m1, b.r1, stream));
+        // (block l > 0: y1 came out of the pass that closed block l - 1)
+        if (l == 0) TG_TRY(tg_add_layernorm_fwd(x, nullptr, n, d, P(st, blk_i(l, B_LN1_G)), P(st, blk_i(l, B_LN1_B)), b.y1, b.m1, b.r1, stream));
         TG_TRY(prod(st, b.pk_in, 1, n, 3 * d, d, b.y1, d, P(st, blk_i(l, B_IN_W)), d, b.qkv, 3 * d, P(st, blk_i(l, B_IN_B)), stream));
         TG_TRY(tg_seq_attn_fwd(b.qkv, B, S, d, H, p, s0, b.att, b.prob, stream));
         TG_TRY(prod(st, b.pk_out, 1, n, d, d, b.att, d, P(st, blk_i(l, B_OUT_W)), d, b.ao, d, P(st, blk_i(l, B_OUT_B)), stream));
-        TG_TRY(tg_dropout_add(b.ao, x, n * d, p, s1, b.o1, stream));
-        TG_TRY(tg_add_layernorm_fwd(b.o1, nullptr, n, d, P(st, blk_i(l, B_LN2_G)), P(st, blk_i(l, B_LN2_B)), b.y2, b.m2, b.r2, stream));
+        // o1 = x + dropout(ao) and y2 = LayerNorm(o1) in one pass
+        TG_TRY(tg_add_layernorm_fwd_res(x, b.ao, n, d, P(st, blk_i(l, B_LN2_G)), P(st, blk_i(l, B_LN2_B)), p, s1, b.o1, b.y2, b.m2, b.r2, stream));
         // (the element-wise passes stay launches of their own: folded into the products' epilogues they cost those exactly what they
         // cost alone -- measured, 3.028 vs 3.006 ms per step -- because the epilogue of a short-K product is on its critical path)
         TG_TRY(prod(st, b.pk_fc1, 1, n, 4 * d, d, b.y2, d, P(st, blk_i(l, B_FC1_W)), d, b.h, 4 * d, P(st, blk_i(l, B_FC1_B)), stream));
         TG_TRY(tg_gelu_dropout_fwd(b.h, n * 4 * d, p, s2, b.hgd, stream));
         TG_TRY(tg_gemm_f32(0, 1, n, d, 4 * d, 1.f, b.hgd, 4 * d, P(st, blk_i(l, B_FC2_W)), 4 * d, b.ao, d, P(st, blk_i(l, B_FC2_B)), 0, 0, stream));
-        TG_TRY(tg_dropout_add(b.ao, b.o1, n * d, p, s3, b.out, stream));
+        if (l + 1 < c.layers) {                          // out = o1 + dropout(f) and the next block's y1 = LayerNorm(out) in one pass
+            BlockBuf& nb = st->blk[(size_t)l + 1];
+            TG_TRY(tg_add_layernorm_fwd_res(b.o1, b.ao, n, d, P(st, blk_i(l + 1, B_LN1_G)), P(st, blk_i(l + 1, B_LN1_B)), p, s3, b.out, nb.y1, nb.m1, nb.r1, stream));
+        } else {
+            TG_TRY(tg_dropout_add(b.ao, b.o1, n * d, p, s3, b.out, stream));
+        }
         x = b.out;
     }
     // ---- per-side means over the patches and the output layer (:185-194) ----------------------------------------------------------
@@ -456,19 +480,19 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         TG_TRY(wgrad(1, &j, 2 * B, stream));
     }
     float *dcur = st->dxa, *dnext = st->dxb;
-    TG_TRY(tg_segment_mean_bwd(st->d_means, B, S, d, 0, ws, dcur, stream));
-    TG_TRY(tg_segment_mean_bwd(st->d_means + B * d, B, S, d, ws, S, dcur, stream));
+    {
+        const int64_t tot = n * d;
+        dyg_segmean_bwd_kernel<<<(unsigned)std::min<int64_t>((tot + 255) / 256, tg::kMaxGridBlocks), 256, 0, s>>>(
+            st->d_means, B, S, d, ws, p, p > 0.f ? st->seeds[4 * (c.layers - 1) + 3] : 0, dcur, p > 0.f ? st->d_f : nullptr);
+        TG_TRY(tg::launch_status("dyg_segmean_bwd_kernel"));
+    }
     // ---- transformer blocks, last to first -------------------------------------------------------------------------------------------
     for (int l = c.layers - 1; l >= 0; --l) {
         BlockBuf& b = st->blk[(size_t)l];
         const float* xin = l == 0 ? st->x0 : st->blk[(size_t)l - 1].out;
         const uint64_t* sd = st->seeds + 4 * l;
         const float* d_f = dcur;
-        if (p > 0.f) {
-            // (below the top block the dropped copy came out of the block above's LayerNorm backward)
-            if (l == c.layers - 1) TG_TRY(tg_dropout(dcur, n * d, p, sd[3], st->d_f, stream));
-            d_f = st->d_f;
-        }
+        if (p > 0.f) d_f = st->d_f;      // the dropped copy came with dcur: from the means' backward (top block) or the block above's LayerNorm backward
         TG_TRY(prod(st, b.pk_fc2t, 0, n, 4 * d, d, d_f, d, P(st, blk_i(l, B_FC2_W)), 4 * d, st->d_hgd, 4 * d, nullptr, stream));
         float* d_h = st->d_hgd;                                                         // element-wise, in place
         TG_TRY(tg_gelu_dropout_bwd(b.h, st->d_hgd, n * 4 * d, p, p > 0.f ? sd[2] : 0, d_h, stream));

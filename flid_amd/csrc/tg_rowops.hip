@@ -45,15 +45,32 @@ __global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float* __re
 template <int MAXC>
 __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
         int cols, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-        float* __restrict__ mean, float* __restrict__ rstd) {
+        float* __restrict__ mean, float* __restrict__ rstd, float drop_p = 0.f, uint64_t drop_seed = 0, float* __restrict__ sum_out = nullptr) {
+    // drop_p > 0: b passes through dropout first (tg_dropout's mask of (drop_seed, flat index)); sum_out (optional) keeps a + dropout(b),
+    // the residual stream a pre-LN block hands on
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float drop_scale = 1.f / (1.f - drop_p);
     for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
         float x[MAXC];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = lane + 64 * i;
-            x[i] = c < cols ? a[r * cols + c] + (b ? b[r * cols + c] : 0.f) : 0.f;
+            float v = 0.f;
+            if (c < cols) {
+                const int64_t o = r * cols + c;
+                v = a[o];
+                if (b) {
+                    float bv = b[o];
+                    if (drop_p > 0.f) {
+                        const float u = (float)(tg::mix32(drop_seed ^ ((uint64_t)o * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
+                        bv = u >= drop_p ? bv * drop_scale : 0.f;
+                    }
+                    v += bv;
+                }
+                if (sum_out) sum_out[o] = v;
+            }
+            x[i] = v;
             s += x[i];
         }
         const float mu = tg::wave_sum(s) / cols;
@@ -432,6 +449,19 @@ extern "C" int tg_add_layernorm_fwd(const float* d_a, const float* d_b, int64_t 
     if (cols <= 64) add_ln_fwd_kernel<1><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
     else if (cols <= 320) add_ln_fwd_kernel<5><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
     else add_ln_fwd_kernel<16><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
+    return tg::launch_status("add_ln_fwd_kernel");
+}
+
+extern "C" int tg_add_layernorm_fwd_res(const float* d_a, const float* d_b, int64_t n, int cols, const float* d_gamma, const float* d_beta,
+                                        float drop_p, uint64_t drop_seed, float* d_sum, float* d_y, float* d_mean, float* d_rstd, void* stream) {
+    TG_REQUIRE(d_a && d_b && d_gamma && d_beta && d_y && d_mean && d_rstd, "tg_add_layernorm_fwd_res: null pointer");
+    TG_REQUIRE(cols > 0 && cols <= 1024 && drop_p >= 0.f && drop_p < 1.f, "tg_add_layernorm_fwd_res: cols must be in 1..1024, p in [0, 1)");
+    if (n == 0) return TG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = (unsigned)row_grid(n);
+    if (cols <= 64) add_ln_fwd_kernel<1><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, drop_p, drop_seed, d_sum);
+    else if (cols <= 320) add_ln_fwd_kernel<5><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, drop_p, drop_seed, d_sum);
+    else add_ln_fwd_kernel<16><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, drop_p, drop_seed, d_sum);
     return tg::launch_status("add_ln_fwd_kernel");
 }
 

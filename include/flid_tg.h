@@ -518,6 +518,11 @@ int tg_dropout_add(const float* d_x, const float* d_res, int64_t n, float p, uin
 /* out[i, :] = mean over positions [lo, hi) of x (n, s, d); backward writes dout/(hi-lo) into those positions of dx */
 int tg_segment_mean_fwd(const float* d_x, int64_t n, int s, int d, int lo, int hi, float* d_out, void* stream);
 int tg_segment_mean_bwd(const float* d_dout, int64_t n, int s, int d, int lo, int hi, float* d_dx, void* stream);
+/* tg_add_layernorm_fwd with the residual sum in front of it: d_sum (optional) = d_a + dropout(d_b) (mask as tg_dropout(drop_seed) on the
+ * flat index), d_y = LayerNorm(that sum) -- `outputs = inputs + dropout(h); norm(outputs)` of a pre-LN block (models/DyGFormer.py:448-461)
+ * in one pass */
+int tg_add_layernorm_fwd_res(const float* d_a, const float* d_b, int64_t n, int cols, const float* d_gamma, const float* d_beta, float drop_p,
+                             uint64_t drop_seed, float* d_sum, float* d_y, float* d_mean, float* d_rstd, void* stream);
 /* tg_add_layernorm_bwd with the residual branch joined: d_dx = d_dres (optional) + dLN(d_dy); d_dx_dropped (optional) = dropout(d_dx)
  * with tg_dropout's mask of (drop_seed, flat index) -- the gradient entering the dropout in front of a pre-LN block's residual sum */
 int tg_add_layernorm_bwd_res(const float* d_a, const float* d_b, const float* d_dy, int64_t n, int cols, const float* d_gamma,
