@@ -74,6 +74,7 @@ struct WTile {
     int64_t slab_off;           // floats, inside one slice of the workspace
     float* C; int64_t ldc;      // fold: C[m0.., n0..] += ...; colsum[m0..] += column ones_col
     float* colsum;
+    int trans;                  // the tile holds (B^T A): the fold writes element (m, n) to C[n * ldc + m] (job computed with its operands swapped)
 };
 constexpr int MAX_TILES = 24;
 struct WTiles { WTile t[MAX_TILES]; int n; };
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, int nsli
         for (int q = 0; q < 8; ++q) s += v[q];
     }
     for (; sl < nslices; ++sl) s += p[(int64_t)sl * slice_stride];
-    if (n < T.next) T.C[(int64_t)m * T.ldc + n] += s;
+    if (n < T.next) T.C[T.trans ? (int64_t)n * T.ldc + m : (int64_t)m * T.ldc + n] += s;
     else if (T.colsum) T.colsum[m] += s;
 }
 
@@ -356,13 +357,27 @@ bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t
     wt.n = 0;
     int64_t slab = 0;
     double flops = 0;
+    int swapped_sums[8], nswapped = 0;
     for (int i = 0; i < njobs; ++i) {
         const tg_wgrad_job& q = jobs[i];
         if (!(q.A && q.B && q.C && q.M >= 4 && q.N >= 4 && q.M % 4 == 0 && q.N % 4 == 0 && q.lda % 4 == 0 && q.ldb % 4 == 0 && al16(q.A) && al16(q.B)))
             return false;
         if (q.lda < q.M || q.ldb < q.N || q.ldc < q.N) return false;
-        const int nfull = q.N + (q.colsum_A ? 4 : 0);                       // the ones column takes a 4-column slot of its own
-        const int mb = (q.M + 31) / 32, nb = (nfull + 31) / 32;
+        // A tile costs its full 192 x 256 whatever it covers, so a job runs with its operands SWAPPED (C^T = B^T A, written back
+        // transposed by the fold) where that takes fewer tiles: 200 x 800 is 2 x 4 tiles as it stands, 5 x 1 swapped.  The ones column
+        // can only sum the columns of the tile's FIRST operand: a swapped job's bias sum is a launch of its own (below).
+        const int gm_s = ((q.M + 31) / 32 + TMB - 1) / TMB, gn_s = ((q.N + (q.colsum_A ? 4 : 0) + 31) / 32 + TNB - 1) / TNB;
+        const int gm_t = ((q.N + 31) / 32 + TMB - 1) / TMB, gn_t = ((q.M + 31) / 32 + TNB - 1) / TNB;
+        static const bool no_swap = getenv("FLID_GEMM_TUNE") && getenv("FLID_WG2_NOSWAP") && atoi(getenv("FLID_WG2_NOSWAP")) != 0;
+        // (the fold's transposed write-back is strided: swapping pays from about a third fewer tiles on -- 888 x 172 as 4 tiles instead
+        // of 5 was 20 us SLOWER on the headline step)
+        const bool swap = !no_swap && gm_t * gn_t * 10 <= gm_s * gn_s * 7;
+        const float *opA = swap ? q.B : q.A, *opB = swap ? q.A : q.B;
+        const int64_t ldA = swap ? q.ldb : q.lda, ldB = swap ? q.lda : q.ldb;
+        const int Mo = swap ? q.N : q.M, No = swap ? q.M : q.N;
+        float* cs = swap ? nullptr : q.colsum_A;
+        const int nfull = No + (cs ? 4 : 0);                                // the ones column takes a 4-column slot of its own
+        const int mb = (Mo + 31) / 32, nb = (nfull + 31) / 32;
         const int gm = (mb + TMB - 1) / TMB, gn = (nb + TNB - 1) / TNB;
         const int em = (mb + gm - 1) / gm * 32, en = (nb + gn - 1) / gn * 32;   // balanced extents (multiples of 32)
         for (int a = 0; a < gm; ++a)
@@ -370,18 +385,20 @@ bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t
                 if (wt.n >= MAX_TILES) return false;
                 WTile& T = wt.t[wt.n++];
                 const int m0 = a * em, n0 = b * en;
-                T.A = q.A + m0; T.B = q.B + n0; T.lda = q.lda; T.ldb = q.ldb;
-                T.mext = std::min(em, q.M - m0);
-                T.next = std::max(0, std::min(en, q.N - n0));
-                const bool has_ones = q.colsum_A && q.N >= n0 && q.N < n0 + en;
-                T.ones_col = has_ones ? q.N - n0 : -1;
+                T.A = opA + m0; T.B = opB + n0; T.lda = ldA; T.ldb = ldB;
+                T.mext = std::min(em, Mo - m0);
+                T.next = std::max(0, std::min(en, No - n0));
+                const bool has_ones = cs && No >= n0 && No < n0 + en;
+                T.ones_col = has_ones ? No - n0 : -1;
                 T.nw = T.next + (has_ones ? 4 : 0);
                 if (T.mext <= 0 || T.nw <= 0) { --wt.n; continue; }
                 T.slab_off = slab;
                 slab += (int64_t)T.mext * T.nw;
-                T.C = q.C + (int64_t)m0 * q.ldc + n0; T.ldc = q.ldc;
-                T.colsum = has_ones ? q.colsum_A + m0 : nullptr;
+                T.trans = swap ? 1 : 0;
+                T.C = swap ? q.C + (int64_t)n0 * q.ldc + m0 : q.C + (int64_t)m0 * q.ldc + n0; T.ldc = q.ldc;
+                T.colsum = has_ones ? cs + m0 : nullptr;
             }
+        if (swap && q.colsum_A) swapped_sums[nswapped++] = i;
         flops += 2.0 * q.M * q.N * rows;
     }
     slab = (slab + 3) / 4 * 4;
@@ -415,6 +432,10 @@ bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t
     unsigned extra_rows = 0;
     if (extra) { ex = *extra; extra_rows = ((unsigned)(ex.col_gx * ex.col_ny + ex.wq_n) + fold_gx - 1) / fold_gx; }
     wgrad2_fold_kernel<<<dim3(fold_gx, (unsigned)wt.n + extra_rows), 256, 0, s>>>(wt, (int)slices, ws, slab, ex);
+    for (int i = 0; i < nswapped; ++i) {
+        const tg_wgrad_job& q = jobs[swapped_sums[i]];
+        if (tg_colsum(q.A, q.lda, rows, q.M, q.colsum_A, 1, s) != TG_OK) return true;      // (launch errors surface at the caller's launch_status)
+    }
     return true;
 }
 

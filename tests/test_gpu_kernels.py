@@ -740,6 +740,29 @@ def test_weight_gradient_forms_agree():
         assert float((res[form][0][1].double() - A.double().sum(0)).abs().max()) <= 3e-5 * float(A.double().sum(0).abs().max()) + 1e-3
 
 
+def test_weight_gradient_jobs_with_swapped_operands():
+    """a grouped launch whose jobs take fewer 192 x 256 tiles with their operands swapped (200 x 800: 2 x 4 tiles as given, 5 x 1 as
+    B^T A written back transposed; the bias sum of such a job is a launch of its own) beside jobs that stay as they are -- DyGFormer's
+    four gradients of a block; into running gradients (accumulated)"""
+    from flid_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    rows, d = 3000, 200
+    d_f, hgd, d_h, y2 = torch.randn(rows, d, device=dev), torch.randn(rows, 4 * d, device=dev), torch.randn(rows, 4 * d, device=dev), torch.randn(rows, d, device=dev)
+    dqkv, y1 = torch.randn(rows, 3 * d, device=dev), torch.randn(rows, d, device=dev)
+    W2, b2 = torch.ones(d, 4 * d, device=dev), torch.ones(d, device=dev)          # start from 1: the launch accumulates
+    W1, b1 = torch.ones(4 * d, d, device=dev), torch.ones(4 * d, device=dev)
+    Wi, bi = torch.ones(3 * d, d, device=dev), torch.ones(3 * d, device=dev)
+    Wn = torch.ones(d, 4 * d, device=dev)                                          # the same swapped shape without a bias sum
+    ops.wgrad_group([(d_f, hgd, W2, b2), (d_h, y2, W1, b1), (dqkv, y1, Wi, bi), (d_f, hgd, Wn, None)])
+    for got, a, b_ in ((W2, d_f, hgd), (W1, d_h, y2), (Wi, dqkv, y1), (Wn, d_f, hgd)):
+        ref = 1.0 + a.double().t() @ b_.double()
+        assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    for got, a in ((b2, d_f), (b1, d_h), (bi, dqkv)):
+        ref = 1.0 + a.double().sum(0)
+        assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-3
+
+
 @pytest.mark.parametrize("M,N,K,trans", [(1000, 200, 200, 0), (777, 800, 200, 1), (2500, 600, 200, 0), (64, 24, 24, 0), (129, 50, 52, 1), (5000, 36, 208, 0)])
 def test_panel_product_against_presplit_weights(M, N, K, trans):
     """tg_pack32_weights + tg_gemm_pk_nt (A fragments straight from global memory, the pre-split weight's tiles through the LDS-DMA
