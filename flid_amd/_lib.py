@@ -122,7 +122,7 @@ SIGNATURES = {
     "tg_dyg_backward": (C.c_int, [c_void, c_void, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
     "tg_add_layernorm_fwd_res": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void, c_f32, C.c_uint64, c_void, c_void, c_void, c_void, c_void]),
     "tg_add_layernorm_bwd_res": (C.c_int, [c_void, c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_f32,
-                                           C.c_uint64, c_void, c_void]),
+                                           C.c_uint64, c_void, c_i64, c_void]),
     "tg_adam_f32": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_void]),
     "tg_time_bias_finish": (C.c_int, [c_void, c_void, c_void, C.c_int, c_void]),
     "tg_bce_logits": (C.c_int, [c_void, c_i64, c_i64, c_void, c_void, c_void]),

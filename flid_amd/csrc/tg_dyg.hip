@@ -255,7 +255,8 @@ void layout(tg_dyg* st, float* base, int64_t* total) {
     st->d_y2 = A.take(n * d); st->d_o1 = A.take(n * d); st->d_ao = A.take(n * d); st->d_att = A.take(n * d); st->dqkv = A.take(n * 3 * d);
     st->d_y1 = A.take(n * d);
     st->parts = tg_rowop_parts(n);
-    st->part = A.take(st->parts * 2 * d); st->d_tf = A.take(n * T); st->d_cf = A.take(n * C); st->d_hs = A.take(n * C);
+    st->part = A.take(st->parts * 4 * d);                       // [LN1: dgamma | dbeta][LN2: dgamma | dbeta] per row-op workgroup
+    st->d_tf = A.take(n * T); st->d_cf = A.take(n * C); st->d_hs = A.take(n * C);
     st->te_part = A.take(st->parts * 2 * T);
     // gradient block, zero-filled once per backward: [parameter gradients (flat layout) | d Wbd | d bbd]
     st->g_wbd = r4(c.param_floats);
@@ -298,13 +299,6 @@ int wgrad(int n, const tg_wgrad_job* jobs, int64_t rows, void* stream) {
         if (q.colsum_A) TG_TRY(tg_colsum(q.A, q.lda, rows, q.M, q.colsum_A, 1, stream));
     }
     return TG_OK;
-}
-
-// (dgamma | dbeta) partial slabs -> the two gradient tensors (one launch when they sit side by side in the flat layout)
-int ln_param_grads(const tg_dyg* st, const float* part, int cols, float* g_gamma, float* g_beta, void* stream) {
-    if (g_beta == g_gamma + cols) return tg_colsum(part, 2 * (int64_t)cols, st->parts, 2 * cols, g_gamma, 1, stream);
-    TG_TRY(tg_colsum(part, 2 * (int64_t)cols, st->parts, cols, g_gamma, 1, stream));
-    return tg_colsum(part + cols, 2 * (int64_t)cols, st->parts, cols, g_beta, 1, stream);
 }
 
 }  // namespace
@@ -499,10 +493,10 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         TG_TRY(tg_gemm_f32(0, 0, n, d, 4 * d, 1.f, d_h, 4 * d, P(st, blk_i(l, B_FC1_W)), d, st->d_y2, d, nullptr, 0, 0, stream));
         // d o1 = d out + dLN2(d y2); the gradient entering the attention branch is its dropout
         const float* d_ao = st->d_o1;
-        TG_TRY(tg_add_layernorm_bwd_res(b.o1, nullptr, st->d_y2, n, d, P(st, blk_i(l, B_LN2_G)), b.m2, b.r2, dcur, st->d_o1, st->part,
-                                        p, p > 0.f ? sd[1] : 0, p > 0.f ? st->d_ao : nullptr, stream));
+        // (both LayerNorms' partial sums of dgamma / dbeta side by side: one column-sum launch per block, below)
+        TG_TRY(tg_add_layernorm_bwd_res(b.o1, nullptr, st->d_y2, n, d, P(st, blk_i(l, B_LN2_G)), b.m2, b.r2, dcur, st->d_o1, st->part + 2 * d,
+                                        p, p > 0.f ? sd[1] : 0, p > 0.f ? st->d_ao : nullptr, 4 * (int64_t)d, stream));
         if (p > 0.f) d_ao = st->d_ao;
-        TG_TRY(ln_param_grads(st, st->part, d, G(st, blk_i(l, B_LN2_G)), G(st, blk_i(l, B_LN2_B)), stream));
         TG_TRY(prod(st, b.pk_outt, 0, n, d, d, d_ao, d, P(st, blk_i(l, B_OUT_W)), d, st->d_att, d, nullptr, stream));
         TG_TRY(tg_seq_attn_bwd(b.qkv, b.prob, st->d_att, B, S, d, H, p, p > 0.f ? sd[0] : 0, st->dqkv, stream));
         TG_TRY(tg_gemm_f32(0, 0, n, d, 3 * d, 1.f, st->dqkv, 3 * d, P(st, blk_i(l, B_IN_W)), d, st->d_y1, d, nullptr, 0, 0, stream));
@@ -516,8 +510,15 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         // the last readers of this block's)
         const bool below = p > 0.f && l > 0;
         TG_TRY(tg_add_layernorm_bwd_res(xin, nullptr, st->d_y1, n, d, P(st, blk_i(l, B_LN1_G)), b.m1, b.r1, st->d_o1, dnext, st->part,
-                                        below ? p : 0.f, below ? st->seeds[4 * (l - 1) + 3] : 0, below ? st->d_f : nullptr, stream));
-        TG_TRY(ln_param_grads(st, st->part, d, G(st, blk_i(l, B_LN1_G)), G(st, blk_i(l, B_LN1_B)), stream));
+                                        below ? p : 0.f, below ? st->seeds[4 * (l - 1) + 3] : 0, below ? st->d_f : nullptr, 4 * (int64_t)d, stream));
+        {
+            float* g4[4] = {G(st, blk_i(l, B_LN1_G)), G(st, blk_i(l, B_LN1_B)), G(st, blk_i(l, B_LN2_G)), G(st, blk_i(l, B_LN2_B))};
+            if (g4[1] == g4[0] + d && g4[2] == g4[1] + d && g4[3] == g4[2] + d) {
+                TG_TRY(tg_colsum(st->part, 4 * (int64_t)d, st->parts, 4 * d, g4[0], 1, stream));
+            } else {
+                for (int i = 0; i < 4; ++i) TG_TRY(tg_colsum(st->part + i * d, 4 * (int64_t)d, st->parts, d, g4[i], 1, stream));
+            }
+        }
         std::swap(dcur, dnext);
     }
     // ---- patch projection, time encoder, co-occurrence encoder ------------------------------------------------------------------------
@@ -529,8 +530,12 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
     }
     TG_TRY(tg_gemm_f32(0, 0, n, T, C, 1.f, dY + 2 * C, d, P(st, P_PT_W), T, st->d_tf, T, nullptr, 0, 0, stream));
     TG_TRY(tg_time_encode_bwd(st->dtv, st->mask, n, P(st, P_TE_W), P(st, P_TE_B), T, st->d_tf, st->te_part, stream));
-    TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, st->parts, T, G(st, P_TE_W), 1, stream));
-    TG_TRY(tg_colsum(st->te_part + T, 2 * (int64_t)T, st->parts, T, G(st, P_TE_B), 1, stream));
+    if (G(st, P_TE_B) == G(st, P_TE_W) + T) {
+        TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, st->parts, 2 * T, G(st, P_TE_W), 1, stream));
+    } else {
+        TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, st->parts, T, G(st, P_TE_W), 1, stream));
+        TG_TRY(tg_colsum(st->te_part + T, 2 * (int64_t)T, st->parts, T, G(st, P_TE_B), 1, stream));
+    }
     TG_TRY(tg_gemm_f32(0, 0, n, C, C, 1.f, dY + 3 * C, d, P(st, P_PC_W), C, st->d_cf, C, nullptr, 0, 0, stream));
     {
         const tg_wgrad_job j{st->d_cf, C, C, st->hs, C, C, G(st, P_CO_W2), C, G(st, P_CO_B2)};

@@ -96,7 +96,8 @@ template <int MAXC>
 __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
         const float* __restrict__ dy, int64_t n, int cols, const float* __restrict__ gamma, const float* __restrict__ mean,
         const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ part,
-        const float* __restrict__ dres = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0, float* __restrict__ dx_dropped = nullptr) {
+        const float* __restrict__ dres = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0, float* __restrict__ dx_dropped = nullptr,
+        int64_t part_ld = 0) {
     // dres (optional): dx = dres + dLN(dy) (the residual branch's gradient joins here); dx_dropped (optional): dropout(dx) with the mask
     // of (drop_seed, flat index) as tg_dropout draws it -- the gradient entering a dropout that sits in front of the residual sum
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < ROW_WAVES; ++w) s += red[w * 2 * cols + j];
-        part[(int64_t)blockIdx.x * 2 * cols + j] = s;
+        part[(int64_t)blockIdx.x * (part_ld > 0 ? part_ld : 2 * cols) + j] = s;
     }
 }
 
@@ -481,15 +482,16 @@ extern "C" int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const fl
 
 extern "C" int tg_add_layernorm_bwd_res(const float* d_a, const float* d_b, const float* d_dy, int64_t n, int cols, const float* d_gamma,
                                         const float* d_mean, const float* d_rstd, const float* d_dres, float* d_dx, float* d_dgb_part,
-                                        float drop_p, uint64_t drop_seed, float* d_dx_dropped, void* stream) {
+                                        float drop_p, uint64_t drop_seed, float* d_dx_dropped, int64_t part_ld, void* stream) {
     TG_REQUIRE(d_a && d_dy && d_gamma && d_mean && d_rstd && d_dx && d_dgb_part, "tg_add_layernorm_bwd_res: null pointer");
+    TG_REQUIRE(part_ld == 0 || part_ld >= 2 * cols, "tg_add_layernorm_bwd_res: part_ld");
     TG_REQUIRE(cols > 0 && cols <= 1024 && drop_p >= 0.f && drop_p < 1.f, "tg_add_layernorm_bwd_res: cols must be in 1..1024, p in [0, 1)");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)row_grid(n);
     const size_t lds = sizeof(float) * ROW_WAVES * 2 * cols;
-    if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped);
-    else if (cols <= 320) add_ln_bwd_kernel<5><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped);
-    else add_ln_bwd_kernel<16><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped);
+    if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped, part_ld);
+    else if (cols <= 320) add_ln_bwd_kernel<5><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped, part_ld);
+    else add_ln_bwd_kernel<16><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped, part_ld);
     return tg::launch_status("add_ln_bwd_kernel");
 }
 

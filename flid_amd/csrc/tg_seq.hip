@@ -12,10 +12,18 @@
 namespace {
 
 // one thread per (row, slot): counts of seq_a[row][slot] inside seq_a[row][:] and seq_b[row][:]  (widths <= a few dozen)
-__global__ void __launch_bounds__(256) cooc_kernel(const int32_t* __restrict__ a, int64_t lda, int wa, const int32_t* __restrict__ b,
-        int64_t ldb, int wb, int64_t n, float* __restrict__ out /* (n, wa, 2) */, int self_first) {
-    const int64_t total = n * wa;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+// (both sides in one launch: work items [0, n wa) are the source slots, the rest the destination slots)
+__global__ void __launch_bounds__(256) cooc_kernel(const int32_t* __restrict__ a0, int64_t lda0, int wa0, const int32_t* __restrict__ b0,
+        int64_t ldb0, int wb0, int64_t n, float* __restrict__ out_a /* (n, wa, 2) */, float* __restrict__ out_b /* (n, wb, 2) */) {
+    const int64_t na = n * wa0, total = na + n * wb0;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const bool first = i0 < na;
+        const int64_t i = first ? i0 : i0 - na;
+        const int32_t* a = first ? a0 : b0;
+        const int32_t* b = first ? b0 : a0;
+        const int64_t lda = first ? lda0 : ldb0, ldb = first ? ldb0 : lda0;
+        const int wa = first ? wa0 : wb0, wb = first ? wb0 : wa0;
+        float* out = first ? out_a : out_b;
         const int64_t r = i / wa;
         const int s = (int)(i - r * wa);
         const int32_t v = a[r * lda + s];
@@ -25,8 +33,8 @@ __global__ void __launch_bounds__(256) cooc_kernel(const int32_t* __restrict__ a
             for (int j = 0; j < wb; ++j) cb += b[r * ldb + j] == v;
         }
         // column order follows the reference: source rows are [in_src, in_dst], destination rows are [in_src, in_dst] too
-        out[i * 2 + 0] = (float)(self_first ? ca : cb);
-        out[i * 2 + 1] = (float)(self_first ? cb : ca);
+        out[i * 2 + 0] = (float)(first ? ca : cb);
+        out[i * 2 + 1] = (float)(first ? cb : ca);
     }
 }
 
@@ -169,8 +177,7 @@ extern "C" int tg_cooccurrence(const int32_t* d_a, int64_t lda, int wa, const in
     TG_REQUIRE(d_a && d_b && d_out_a && d_out_b && wa > 0 && wb > 0 && n >= 0, "tg_cooccurrence: arguments");
     if (n == 0) return TG_OK;
     hipStream_t s = (hipStream_t)stream;
-    cooc_kernel<<<ew_grid(n * wa), 256, 0, s>>>(d_a, lda, wa, d_b, ldb, wb, n, d_out_a, 1);
-    cooc_kernel<<<ew_grid(n * wb), 256, 0, s>>>(d_b, ldb, wb, d_a, lda, wa, n, d_out_b, 0);
+    cooc_kernel<<<ew_grid(n * (wa + wb)), 256, 0, s>>>(d_a, lda, wa, d_b, ldb, wb, n, d_out_a, d_out_b);
     return tg::launch_status("cooc_kernel");
 }
 

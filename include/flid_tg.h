@@ -524,10 +524,11 @@ int tg_segment_mean_bwd(const float* d_dout, int64_t n, int s, int d, int lo, in
 int tg_add_layernorm_fwd_res(const float* d_a, const float* d_b, int64_t n, int cols, const float* d_gamma, const float* d_beta, float drop_p,
                              uint64_t drop_seed, float* d_sum, float* d_y, float* d_mean, float* d_rstd, void* stream);
 /* tg_add_layernorm_bwd with the residual branch joined: d_dx = d_dres (optional) + dLN(d_dy); d_dx_dropped (optional) = dropout(d_dx)
- * with tg_dropout's mask of (drop_seed, flat index) -- the gradient entering the dropout in front of a pre-LN block's residual sum */
+ * with tg_dropout's mask of (drop_seed, flat index) -- the gradient entering the dropout in front of a pre-LN block's residual sum; part_ld
+ * (0 = 2 cols): row stride of d_dgb_part, so that several LayerNorms' partial sums sit side by side for ONE column-sum launch */
 int tg_add_layernorm_bwd_res(const float* d_a, const float* d_b, const float* d_dy, int64_t n, int cols, const float* d_gamma,
                              const float* d_mean, const float* d_rstd, const float* d_dres, float* d_dx, float* d_dgb_part,
-                             float drop_p, uint64_t drop_seed, float* d_dx_dropped, void* stream);
+                             float drop_p, uint64_t drop_seed, float* d_dx_dropped, int64_t part_ld, void* stream);
 
 /* ---- DyGFormer's training step as one native object (csrc/tg_dyg.hip) ----------------------------------------
  * replaces the host side of models/DyGFormer.py:60-194 compute_src_dst_node_temporal_embeddings (patch size 1) and the
