@@ -79,6 +79,13 @@ bool wspace_tail(const float* Wq, const float* Wk, const float* dP, const float*
 // tg_pack.hip: packed (split-bf16, MFMA fragment order) weights of the chain kernels
 int64_t packed_floats(int N, int K);
 int pack_weights(int njobs, const tg_pack_job* jobs, hipStream_t s);
+// (stepper-internal fusions of exported launches: tg_rowops.hip, tg_memory.hip)
+int scatter_add_rows2(const float* d_src, const float* d_src2, int64_t src_ld, const int32_t* d_idx, int64_t n, int cols, float* d_table, int64_t table_ld,
+                      hipStream_t s);
+int tgn_persist_index(const float* d_rows, int64_t rows_ld, const int32_t* d_row_of, const int32_t* d_nodes, const int32_t* d_has, const float* d_msg_time,
+                      float* d_memory, int64_t mem_ld, float* d_last_update, int64_t count, int d, int32_t* d_last_idx_ws, hipStream_t s);
+int msg_scatter_last_indexed(const int32_t* d_nodes, const float* d_msgs, int64_t msg_ld, const float* d_t32, int64_t count, int width, float* d_table,
+                             int64_t table_ld, int32_t* d_has, float* d_msg_time, int32_t* d_last_idx_ws, hipStream_t s);
 int64_t packed32_floats(int N, int K);
 int pack32_weights(int njobs, const tg_pack32_job* jobs, hipStream_t s);
 bool gemm_pk_nt(int64_t M, int N, int K, const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, const float* bias, hipStream_t s);

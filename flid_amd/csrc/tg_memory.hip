@@ -106,7 +106,49 @@ __global__ void __launch_bounds__(256) msg_scatter_last_kernel(const int32_t* __
     }
 }
 
+// tgn_persist_kernel's rows and msg_last_index_kernel's winner search as roles of one grid (they are independent: the stepper's state
+// advance is persist -> build messages -> scatter the last ones, and the winner index depends on the batch's node list alone)
+__global__ void __launch_bounds__(256) tgn_persist_index_kernel(const float* __restrict__ rows, int64_t rows_ld, const int32_t* __restrict__ row_of,
+        const int32_t* __restrict__ nodes, const int32_t* __restrict__ has, const float* __restrict__ msg_time, float* __restrict__ memory,
+        int64_t mem_ld, float* __restrict__ last_update, int64_t count, int d, int persist_blocks, int32_t* __restrict__ last_idx) {
+    if ((int)blockIdx.x >= persist_blocks) {
+        const int64_t nb = (int64_t)gridDim.x - persist_blocks;
+        for (int64_t i = ((int64_t)blockIdx.x - persist_blocks) * blockDim.x + threadIdx.x; i < count; i += nb * blockDim.x)
+            atomicMax(last_idx + nodes[i], (int32_t)i);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < count; i += (int64_t)persist_blocks * 4) {
+        const int64_t v = nodes[i];
+        if (!has[v]) continue;                                   // wave-uniform
+        const float* src = rows + (int64_t)row_of[i] * rows_ld;
+        for (int c = lane; c < d; c += 64) memory[v * mem_ld + c] = src[c];
+        if (lane == 0) last_update[v] = msg_time[v];
+    }
+}
+
 }  // namespace
+
+namespace tg {
+int tgn_persist_index(const float* d_rows, int64_t rows_ld, const int32_t* d_row_of, const int32_t* d_nodes, const int32_t* d_has, const float* d_msg_time,
+                      float* d_memory, int64_t mem_ld, float* d_last_update, int64_t count, int d, int32_t* d_last_idx_ws, hipStream_t s) {
+    TG_REQUIRE(d_rows && d_row_of && d_nodes && d_has && d_msg_time && d_memory && d_last_update && d_last_idx_ws && count >= 0 && d > 0, "tgn_persist_index: arguments");
+    if (count == 0) return TG_OK;
+    const int pb = (int)std::min<int64_t>((count + 3) / 4, tg::kMaxGridBlocks), ib = (int)std::min<int64_t>((count + 255) / 256, 64);
+    tgn_persist_index_kernel<<<(unsigned)(pb + ib), 256, 0, s>>>(d_rows, rows_ld, d_row_of, d_nodes, d_has, d_msg_time, d_memory, mem_ld, d_last_update, count,
+                                                                  d, pb, d_last_idx_ws);
+    return launch_status("tgn_persist_index_kernel");
+}
+// tg_msg_scatter_last behind tgn_persist_index: the winner index is in the workspace already
+int msg_scatter_last_indexed(const int32_t* d_nodes, const float* d_msgs, int64_t msg_ld, const float* d_t32, int64_t count, int width, float* d_table,
+                             int64_t table_ld, int32_t* d_has, float* d_msg_time, int32_t* d_last_idx_ws, hipStream_t s) {
+    TG_REQUIRE(d_nodes && d_msgs && d_t32 && d_table && d_has && d_msg_time && d_last_idx_ws && count >= 0 && width > 0, "msg_scatter_last_indexed: arguments");
+    if (count == 0) return TG_OK;
+    msg_scatter_last_kernel<<<(unsigned)std::min<int64_t>((count + 3) / 4, tg::kMaxGridBlocks), 256, 0, s>>>(d_nodes, d_msgs, msg_ld, d_t32, count, width,
+        d_table, table_ld, d_has, d_msg_time, d_last_idx_ws);
+    return launch_status("msg_scatter_last_kernel");
+}
+}  // namespace tg
 
 extern "C" int tg_tgn_persist(const float* d_rows, int64_t rows_ld, const int32_t* d_row_of, const int32_t* d_nodes, const int32_t* d_has,
                               const float* d_msg_time, float* d_memory, int64_t mem_ld, float* d_last_update, int64_t count, int d,

@@ -32,12 +32,14 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
 }
 
 __global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float* __restrict__ src, int64_t sld,
-        const int32_t* __restrict__ idx, int64_t n, int cols, float* __restrict__ table, int64_t tld) {
+        const int32_t* __restrict__ idx, int64_t n, int cols, float* __restrict__ table, int64_t tld, const float* __restrict__ src2 = nullptr) {
+    // src2 (optional, same layout as src): table[idx[r]] += src[r] + src2[r] -- two gradient streams into the same rows, one atomic each
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
         float* dst = table + (int64_t)idx[r] * tld;
         const float* s = src + r * sld;
-        for (int c = lane; c < cols; c += 64) atomicAdd(dst + c, s[c]);
+        const float* s2 = src2 ? src2 + r * sld : nullptr;
+        for (int c = lane; c < cols; c += 64) atomicAdd(dst + c, s2 ? s[c] + s2[c] : s[c]);
     }
 }
 
@@ -431,6 +433,16 @@ extern "C" int tg_gather_rows(const float* d_table, int64_t table_ld, const int3
     gather_rows_kernel<<<(unsigned)row_grid(n), 256, 0, (hipStream_t)stream>>>(d_table, table_ld, d_idx, n, cols, d_out, out_ld, vec);
     return tg::launch_status("gather_rows_kernel");
 }
+
+namespace tg {
+int scatter_add_rows2(const float* d_src, const float* d_src2, int64_t src_ld, const int32_t* d_idx, int64_t n, int cols, float* d_table, int64_t table_ld,
+                      hipStream_t s) {
+    TG_REQUIRE(d_src && d_src2 && d_idx && d_table && cols > 0 && n >= 0, "scatter_add_rows2: arguments");
+    if (n == 0) return TG_OK;
+    scatter_add_rows_kernel<<<(unsigned)row_grid(n), 256, 0, s>>>(d_src, src_ld, d_idx, n, cols, d_table, table_ld, d_src2);
+    return launch_status("scatter_add_rows_kernel");
+}
+}  // namespace tg
 
 extern "C" int tg_scatter_add_rows(const float* d_src, int64_t src_ld, const int32_t* d_idx, int64_t n, int cols,
                                    float* d_table, int64_t table_ld, void* stream) {

@@ -682,8 +682,7 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
     if (rc == TG_OK && grad_ready) grad_ready(user, g + st->poff[2], st->poff.back() - st->poff[2]);
     if (rc == TG_OK && pending) {
         // the merge layer's and the query's share of the gradient w.r.t. the roots' own rows, then the GRU
-        rc = tg_scatter_add_rows(t.d_own, D, s.rowmap, roots, D, d_table, D, stream);
-        if (rc == TG_OK) rc = tg_scatter_add_rows(t.d_raw, D, s.rowmap, roots, D, d_table, D, stream);
+        rc = tg::scatter_add_rows2(t.d_own, t.d_raw, D, s.rowmap, roots, D, d_table, D, (hipStream_t)stream);
         if (rc == TG_OK) rc = tg_gru_gates_bwd_masked(t.gi, t.gh, t.h_rows, d_table, s.uniq, bank->d_has, U, D, t.dgi, t.dgh, stream);
         if (rc == TG_OK) {
             const tg_wgrad_job jobs[2] = {{t.dgi, 3 * (int64_t)D, 3 * D, t.msg_rows, MD, MD, g + st->gru_off[0], MD, g + st->gru_off[2]},
@@ -698,12 +697,15 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
             if (viol) bank->past_violation = 1;
             const int32_t *batch_d = s.blob + s.off[5], *b_d = s.blob + s.off[1], *e_d = s.blob + s.off[2];
             const float* t32_d = reinterpret_cast<const float*>(s.blob + s.off[3]);
-            rc = tg_tgn_persist(t.rows, D, s.rowmap + roots, batch_d, bank->d_has, bank->d_msg_time, bank->d_mem, bank->mem_ld, bank->d_last_update, nb2, D, stream);
+            // (the "last message wins" index of the batch's node list rides in the persist launch: it needs nothing of it)
+            rc = tg::tgn_persist_index(t.rows, D, s.rowmap + roots, batch_d, bank->d_has, bank->d_msg_time, bank->d_mem, bank->mem_ld, bank->d_last_update, nb2,
+                                       D, bank->d_last_idx_ws, (hipStream_t)stream);
             if (rc == TG_OK)
                 rc = tg_build_messages(bank->d_mem, bank->mem_ld, bank->d_last_update, batch_d, b_d, t32_d, c.d_edge, c.edge_ld, e_d, c.d_param + st->poff[0],
                                        c.d_param + st->poff[1], nb2, D, c.de, c.dt_dim, t.msgs, stream);
             if (rc == TG_OK)
-                rc = tg_msg_scatter_last(batch_d, t.msgs, MD, t32_d, nb2, MD, bank->d_msg, bank->msg_ld, bank->d_has, bank->d_msg_time, bank->d_last_idx_ws, stream);
+                rc = tg::msg_scatter_last_indexed(batch_d, t.msgs, MD, t32_d, nb2, MD, bank->d_msg, bank->msg_ld, bank->d_has, bank->d_msg_time,
+                                                  bank->d_last_idx_ws, (hipStream_t)stream);
         }
     }
     return finish_backward(st, s, rc, stream, adam, d_grad);
