@@ -529,7 +529,11 @@ def main():
             try:
                 tj = json.load(open(tr))
                 if tj.get("_kernel_src_sha") == kernel_src_sha():
-                    roof["traffic"] = tj.get(args.roofline_kernel)
+                    # `traffic` = HBM bytes per launch, averaged over the family's launches as `achieved` is (the contract's figure);
+                    # the pass's details (raw counters, the layer-1 launch alone, the profiled command) beside it
+                    ent = tj.get(args.roofline_kernel) or {}
+                    roof["traffic"] = ent.get("hbm_bytes_per_launch")
+                    roof["traffic_detail"] = ent
                 else:
                     roof["traffic_stale"] = {"file": "profiles/traffic_r04.json", "kernel_src_sha": tj.get("_kernel_src_sha"),
                                              "current_kernel_src_sha": kernel_src_sha(),

@@ -970,7 +970,7 @@ struct DqBwdArgs {
     const void *pWk, *pWqT;           // packed per head Wk_h (N = hd, K = dk), heads back to back; Wq[:, :dn]^T (N = dn, K = H hp)
     float* dq;                        // (R, dq)
     float* d_own; int64_t d_own_ld; int d_own_acc;     // optional
-    float* dq_sum;                    // (dq) += column sums of dq (float atomics; zero on entry): what the time half of dWq needs
+    float* dq_sum;                    // (16-row blocks, dq) slab: row b = column sums of block b's dq rows (plain stores): what the time half of dWq needs
 };
 template <int HH, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) dq_bwd_kernel(DqBwdArgs a) {
@@ -1001,10 +1001,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dq_bwd_kernel(DqBwdArgs a) {
             if (col < hd && rok) st4(a.dq + rg * dq + mine * hd + col, v);
             if (a.dq_sum) {                                      // this block's 16 rows summed (rows past the end hold zeros)
                 const float s0 = rows16_sum(v.x), s1 = rows16_sum(v.y), s2 = rows16_sum(v.z), s3 = rows16_sum(v.w);
-                if ((w.lane & 15) == 0 && col < hd) {
-                    float* p = a.dq_sum + mine * hd + col;
-                    atomicAdd(p, s0); atomicAdd(p + 1, s1); atomicAdd(p + 2, s2); atomicAdd(p + 3, s3);
-                }
+                if ((w.lane & 15) == 0 && col < hd) st4(a.dq_sum + (int64_t)blockIdx.x * dq + mine * hd + col, make_float4(s0, s1, s2, s3));
             }
         }
     }
@@ -1127,10 +1124,10 @@ int qu_fwd(const tg_layer_desc* L, const void* pWq, const void* pWkT, hipStream_
     }
     return tg::launch_status("qu_fwd_kernel");
 }
-int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, float* dq_sum, hipStream_t s) {
+int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, float* dq_slab, hipStream_t s) {
     const tg_attn_desc& at = L->attn;
     DqBwdArgs a{at.m, at.heads, at.dn, at.dt_dim, at.de, chain_hp(at.heads, at.dn, at.dt_dim), Bw->du, pWk, pWqT, Bw->dq,
-                Bw->d_own, Bw->d_own_ld, 1, dq_sum};      // (d_own: the residual's share is already there, chain_bwd wrote or added it)
+                Bw->d_own, Bw->d_own_ld, 1, dq_slab};      // (d_own: the residual's share is already there, chain_bwd wrote or added it)
     const int dq = at.dn + at.dt_dim, dk = at.dn + at.de + at.dt_dim;
     ProfScope prof("gemm", 2.0 * at.m * ((double)dq * dk + (Bw->d_own ? (double)dq * at.dn : 0.0)), s);
     using G = Geo<1, 4>;

@@ -97,7 +97,7 @@ int chain_hpb(int H, int dn, int T);
 // the query side of a short (not merged) layer as one launch per direction: q -> u, dq -> d_own (tg_chain.hip)
 bool qu_shape_ok(int H, int dn, int T, int de);
 int qu_fwd(const tg_layer_desc* L, const void* pWq, const void* pWkT, hipStream_t s);
-int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, float* dq_sum, hipStream_t s);
+int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, float* dq_slab, hipStream_t s);
 int64_t chain_blocks(int64_t rows);
 int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, float* part, const void* pW2T, const void* pW1aT,
               const void* pWrT, const void* pWvT, hipStream_t s);
@@ -112,6 +112,7 @@ struct ColJob { const float* x; int64_t ld, n; int cols; SegDst d; };
 struct ColExtra {
     ColJob a, b; int groups_a, col_gx, col_ny;
     int wq_n, wq_gx, wq_dq, wq_T; const float *wq_sq, *wq_cosb, *wq_W; float *wq_dW, *wq_dcosb; int64_t wq_ld;
+    int wq_nb;                  // > 0: wq_sq is a slab of wq_nb partial rows (wq_time_slab_body), else the summed vector
 };
 // tg_wgrad.hip: big tiles + transposing LDS reads + slice fold; `extra` (optional): slab sums that ride in the fold launch
 bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s, const ColExtra* extra = nullptr);

@@ -224,12 +224,6 @@ int colsum_seg2(const ColJob& a, const ColJob& b, hipStream_t s) {
 
 using tg::WQT_ROWS;
 using tg::wq_time_body;
-__global__ void __launch_bounds__(64) wq_time_kernel(const float* __restrict__ sq, int dq, const float* __restrict__ cosb, int T,
-                                                     const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld,
-                                                     float* __restrict__ d_cosb) {
-    wq_time_body((int)blockIdx.x, (int)blockIdx.y, sq, dq, cosb, T, Wq_t, dWq_t, ld, d_cosb);
-}
-
 // The layer's PRELUDE in one launch: up to 10 small matrix transposes (weights, once per step): dst[c * ldd + r] = src[r * lds + c];
 // grid row n: cos(b) (the time encoding of a zero interval, models/TGAT.py:84-85; written out when cosb_out is set, else read from
 // mv_x) and the matrix-vector product mv_y[i] = sum_t mv_W[i * mv_ld + t] cos(b_t) (the constant half of the query, qb = Wq[:, dn:] cos b),
@@ -491,7 +485,7 @@ using tg::ub_bwd_body;
 // a few hundred KB of work).  Workgroups [0, n_head): the constant-part gradients of the query -- ub_bwd (merged projection,
 // head_mode 1: one workgroup per UBR query rows) or wq_time (head_mode 2: (T / 64) x (dq / 16) workgroups); the rest: the slab sums.
 struct TailArgs {
-    int head_mode, n_head, wq_gx;
+    int head_mode, n_head, wq_gx, wq_nb;       // wq_nb > 0: v is a slab of partial sums (wq_time_slab_body)
     const float *v, *qb, *Wk, *Wq, *cosb;        // v = dub (mode 1) or sum_rows dq (mode 2)
     int hd, dn, dq, dk, T;
     float *dWk, *dWq, *d_cosb;
@@ -500,9 +494,11 @@ struct TailArgs {
 };
 __global__ void __launch_bounds__(256) layer_tail_kernel(TailArgs t) {
     __shared__ float red[4][64];
+    __shared__ float red2[272];
     const int bid = (int)blockIdx.x;
     if (bid < t.n_head) {
         if (t.head_mode == 1) ub_bwd_body(bid, t.v, t.qb, t.Wk, t.Wq, t.cosb, t.hd, t.dn, t.dq, t.dk, t.T, t.dWk, t.dWq, t.d_cosb, &red[0][0]);
+        else if (t.wq_nb > 0) tg::wq_time_slab_body(bid % t.wq_gx, bid / t.wq_gx, t.v, t.wq_nb, t.dq, t.cosb, t.T, t.Wq + t.dn, t.dWq + t.dn, t.dq, t.d_cosb, red2);
         else wq_time_body(bid % t.wq_gx, bid / t.wq_gx, t.v, t.dq, t.cosb, t.T, t.Wq + t.dn, t.dWq + t.dn, t.dq, t.d_cosb);
         return;
     }
@@ -897,7 +893,8 @@ extern "C" int64_t tg_tgat_layer_part_floats(int64_t rows, int dn, int dq, int d
     const int64_t b = std::max<int64_t>(row_grid(rows), tg::chain_blocks(rows)) * 4 * dq;   // LayerNorm slabs (one per workgroup of the chain
                                                                                              // kernel when it runs: uncapped, rows / 64 from 8 192 rows)
     const int64_t c = (int64_t)tg_attn_bwd_parts(rows) * 2 * dt_dim; // time-encoder slabs
-    return 16 + a + b + c;                                            // disjoint regions: they are consumed concurrently
+    const int64_t d = ((rows + 15) / 16) * ((dq + 3) / 4 * 4);       // column sums of dq per 16-row block (layers whose query side is dq_bwd_kernel)
+    return 16 + a + b + c + d + 4;                                            // disjoint regions: they are consumed concurrently
     // (with merged projections the caller appends dq * heads * dk + heads * dk * dn + 32 floats: dV and dP)
 }
 
@@ -974,6 +971,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     float* part_relu = Bw->part;
     float* part_ln = part_relu + relu_blocks * dn;
     float* part_attn = part_ln + (int64_t)ln_grid * 4 * dq;
+    float* part_dq = part_attn + ((int64_t)attn_parts * 2 * T + 3) / 4 * 4;         // 16-byte aligned (dq % 4 == 0 where dq_bwd_kernel runs)
     const int64_t hk = (int64_t)H * dk;
     // zero-on-entry scratch (`vec`): [sum_rows dq (dq) or sum_rows du (H dk)] | dP (H dk, dn) (merged query side)
     float* vec_dq = vec;
@@ -1002,7 +1000,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             if (has_extra) TG_TRY(colsum_seg2(ex.a, ex.b, st));
             if (has_extra && ex.wq_n > 0) {            // the time half of dWq that would have ridden in the fold launch
                 TailArgs t{};
-                t.head_mode = 2; t.n_head = ex.wq_n; t.wq_gx = ex.wq_gx; t.v = ex.wq_sq; t.cosb = ex.wq_cosb; t.dq = ex.wq_dq; t.T = ex.wq_T;
+                t.head_mode = 2; t.n_head = ex.wq_n; t.wq_gx = ex.wq_gx; t.wq_nb = ex.wq_nb; t.v = ex.wq_sq; t.cosb = ex.wq_cosb; t.dq = ex.wq_dq; t.T = ex.wq_T;
                 t.Wq = ex.wq_W; t.dWq = ex.wq_dW; t.dn = 0; t.d_cosb = ex.wq_dcosb;
                 layer_tail_kernel<<<(unsigned)t.n_head, 256, 0, st>>>(t);
                 TG_TRY(tg::launch_status("layer_tail_kernel"));
@@ -1087,7 +1085,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         t.head_mode = head_mode;
         t.wq_gx = (T + 63) / 64;
         t.n_head = head_mode == 1 ? (dq + UBR - 1) / UBR : (T > 0 ? t.wq_gx * ((dq + WQT_ROWS - 1) / WQT_ROWS) : 0);
-        t.v = head_mode == 1 ? dub : vec_dq;
+        t.v = head_mode == 1 ? dub : (use_qu ? part_dq : vec_dq);
+        t.wq_nb = head_mode == 2 && use_qu ? (int)((R + 15) / 16) : 0;      // (the dq launch left per-block partial sums, not the vector)
         t.qb = Lc.qbias; t.Wk = P.Wk; t.Wq = P.Wq; t.cosb = Lc.cosb;
         t.hd = hd; t.dn = dn; t.dq = dq; t.dk = dk; t.T = T;
         t.dWk = G.Wk; t.dWq = G.Wq; t.d_cosb = Bc.d_cosb;
@@ -1161,9 +1160,9 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
         // ---- fused attention backward -------------------------------------------------------------------------------------------------
         TG_TRY(tg_attn_bwd(&a, L->u, L->agg, L->prob, Bw->dagg, Bw->du, Bw->dfeat, Bw->dfeat_ld, Bw->pad_row, nullptr, 0, part_attn, stream));
         // ---- key / query path --------------------------------------------------------------------------------------------------------
-        // dq_h = du_h Wk_h^T and d_own += dq Wq[:, :dn] in one launch, which also leaves sum_rows dq in `vec` (the weight-gradient launch's
-        // ones column delivered it before: the time half of dWq then had to wait for the fold)
-        if (use_qu) TG_TRY(tg::dq_bwd(L, Bw, pk.Wk, pk.WqT, vec_dq, s));
+        // dq_h = du_h Wk_h^T and d_own += dq Wq[:, :dn] in one launch, which also leaves the column sums of dq per 16-row block in `part_dq`
+        // (the weight-gradient launch's ones column delivered sum_rows dq before: the time half of dWq then had to wait for the fold)
+        if (use_qu) TG_TRY(tg::dq_bwd(L, Bw, pk.Wk, pk.WqT, part_dq, s));
         else TG_TRY(tg_gemm_f32_batched(0, 1, R, hd, dk, 1.f, Bw->du, hk, dk, P.Wk, dk, (int64_t)hd * dk, Bw->dq, dq, hd, H, nullptr, 0, 0, stream));
         TG_TRY(fork());                           // dres, dctx, du, dq are final: the attention block's five weight gradients in one launch
         {
@@ -1183,7 +1182,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             if (use_qu && T > 0 && !no_fold_wq) {
                 // ... and so does the time half of dWq (sum_rows dq came out of the dq launch): no tail launch
                 ce.wq_gx = (T + 63) / 64; ce.wq_n = ce.wq_gx * ((dq + WQT_ROWS - 1) / WQT_ROWS);
-                ce.wq_dq = dq; ce.wq_T = T; ce.wq_sq = vec_dq; ce.wq_cosb = Lc.cosb; ce.wq_W = P.Wq + dn; ce.wq_dW = G.Wq + dn;
+                ce.wq_dq = dq; ce.wq_T = T; ce.wq_sq = part_dq; ce.wq_nb = (int)((R + 15) / 16); ce.wq_cosb = Lc.cosb; ce.wq_W = P.Wq + dn; ce.wq_dW = G.Wq + dn;
                 ce.wq_dcosb = Bc.d_cosb; ce.wq_ld = dq;
                 TG_TRY(flush_wgrad(&ce));
             } else {

@@ -71,4 +71,42 @@ __device__ __forceinline__ void wq_time_body(int bx, int by, const float* __rest
     atomicAdd(d_cosb + c, acc);
 }
 
+// The same with sq given as per-workgroup partial sums (slab[b * dq + r], b < nb: what dq_bwd_kernel leaves, one row per 16-row block --
+// 75 workgroups adding into the same 272 addresses with float atomics cost the dq launch 16 us): all 256 threads sum the 16 rows this
+// workgroup needs, then the first 64 work as above.  red: 272 floats of LDS.  Every thread of the workgroup must call.
+__device__ __forceinline__ void wq_time_slab_body(int bx, int by, const float* __restrict__ slab, int nb, int dq, const float* __restrict__ cosb, int T,
+                                                  const float* __restrict__ Wq_t, float* __restrict__ dWq_t, int64_t ld, float* __restrict__ d_cosb,
+                                                  float* red) {
+    const int t = (int)threadIdx.x, r0 = by * WQT_ROWS;
+    {
+        const int r = r0 + (t & 15);
+        float s = 0.f;
+        if (r < dq)
+            for (int b = t >> 4; b < nb; b += 16) s += slab[(int64_t)b * dq + r];
+        red[t] = s;
+    }
+    __syncthreads();
+    if (t < 16) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k * 16 + t];
+        red[256 + t] = v;
+    }
+    __syncthreads();
+    const int c = bx * 64 + t;
+    if (t >= 64 || c >= T) return;
+    const float cb = cosb[c];
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < WQT_ROWS; ++j) {
+        const int r = r0 + j;
+        if (r < dq) {
+            const float v = red[256 + j];
+            dWq_t[(int64_t)r * ld + c] += v * cb;
+            acc = fmaf(v, Wq_t[(int64_t)r * ld + c], acc);
+        }
+    }
+    atomicAdd(d_cosb + c, acc);
+}
+
 }  // namespace tg

@@ -296,11 +296,15 @@ __global__ void __launch_bounds__(WNT, 2) wgrad2_kernel(WTiles tiles, int64_t R,
 __global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, int nslices, const float* __restrict__ ws, int64_t slice_stride, tg::ColExtra ex) {
     if ((int)blockIdx.y >= tiles.n) {
         __shared__ float red[4][64];
+        __shared__ float red2[272];
         const int c = ((int)blockIdx.y - tiles.n) * (int)gridDim.x + (int)blockIdx.x;
         const int ncol = ex.col_gx * ex.col_ny;
         if (c < ncol) tg::colsum_seg2_body(ex.a, ex.b, ex.groups_a, c % ex.col_gx, c / ex.col_gx, ex.col_ny, red);
-        else if (c - ncol < ex.wq_n)
-            tg::wq_time_body((c - ncol) % ex.wq_gx, (c - ncol) / ex.wq_gx, ex.wq_sq, ex.wq_dq, ex.wq_cosb, ex.wq_T, ex.wq_W, ex.wq_dW, ex.wq_ld, ex.wq_dcosb);
+        else if (c - ncol < ex.wq_n) {
+            if (ex.wq_nb > 0) tg::wq_time_slab_body((c - ncol) % ex.wq_gx, (c - ncol) / ex.wq_gx, ex.wq_sq, ex.wq_nb, ex.wq_dq, ex.wq_cosb, ex.wq_T, ex.wq_W,
+                                                    ex.wq_dW, ex.wq_ld, ex.wq_dcosb, red2);
+            else tg::wq_time_body((c - ncol) % ex.wq_gx, (c - ncol) / ex.wq_gx, ex.wq_sq, ex.wq_dq, ex.wq_cosb, ex.wq_T, ex.wq_W, ex.wq_dW, ex.wq_ld, ex.wq_dcosb);
+        }
         return;
     }
     const WTile T = tiles.t[blockIdx.y];

@@ -36,7 +36,7 @@ def main():
          "§5: what parity at realistic weights costs"),
         ("attn_bwd roofline (`roofline` object)", "%.2f TB/s on §8(d) bytes = **%.3f** of 8 TB/s; %.2f TB/s with the activation bytes"
          % (r["achieved"] / 1e3, r["frac"], r.get("achieved_incl_activations", 0) / 1e3),
-         "kernels unchanged since round 3; PMC traffic per launch %s (`profiles/traffic_r04.json`)" % ("%.0f MB" % (tr / 1e6) if tr else "see")),
+         "kernels unchanged since round 3; PMC traffic per launch %s (`profiles/traffic_r04.json`)" % ("%.0f MB" % ((tr["hbm_bytes_per_launch"] if isinstance(tr, dict) else tr) / 1e6) if tr else "see")),
         ("`dominant_family` (dense side)", "%.0f µs of the step (%.0f %%): %.1f GFLOP at %.1f TFLOP/s = %.2f of the f32-MFMA peak, %.3f of the bf16×3-equivalent peak"
          % (f.get("us_per_step", 0), 100 * f.get("share_of_step", 0), f.get("gflop_per_step", 0), f.get("tflops", 0), f.get("frac_of_f32_mfma_peak", 0),
             f.get("frac_of_bf16x3_peak", 0)), "chains + products + weight gradients, HIP events in an untimed second pass"),

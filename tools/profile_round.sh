@@ -19,6 +19,7 @@ python3 bench.py --model dygformer --python-step --no-cpu-baseline > $O/r04_dygf
 rocprofv3 --kernel-trace -d $O/kt_dyg -o dyg -- python3 bench.py --model dygformer --steps 20 --warmup 6 --no-cpu-baseline --no-breakdown > /dev/null 2> $O/kt_dyg.err
 python3 tools/rocpd_stats.py $O/kt_dyg/dyg_results.db --csv $O/r04_dygformer_kernel_stats.csv --timeline > $O/r04_dygformer_timeline.txt 2>&1
 python3 tools/dyg_host_prof.py > $O/r04_dygformer_host_issue.txt 2> $O/dyg_host.err
+python3 tools/pk_bench.py 2> /dev/null | grep "^R=" > $O/r04_pk_bench.txt
 python3 bench.py --mode sweep > $O/r04_sweep_bench.json 2> $O/sweep.err
 python3 bench.py --mode fwd > $O/r04_fwd_bench.json 2> $O/fwd.err
 python3 bench.py --mode lp > $O/r04_lp_bench.json 2> $O/lp.err
