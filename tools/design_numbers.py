@@ -29,7 +29,7 @@ def main():
     tr = r.get("traffic")
     rows = [
         ("headline, `python bench.py` (native stepper)", "**%s** (812 k, 0.739 ms)" % kv(h),
-         "%.1f %% of the path's HBM roofline (2 350 784 B per edge); main stream gap-free, 30 dispatches.  Same-box A/Bs of the round: 0.736 → 0.706 ms"
+         "%.1f %% of the path's HBM roofline (2 350 784 B per edge); main stream gap-free, 20 dispatches (+ the sampler's on the side stream).  Same-box A/Bs of the round: 0.736 → 0.70 ms"
          % (100 * h["path_roofline"]["hbm_frac"])),
         ("the same, `--python-step` (round 3's host path)", kv(load("r04_headline_bench_python_step.json")), "host issue with an idle GPU 403 µs per step against 171"),
         ("`exact_f32` / `strict` / `row_sharing_off`", " / ".join(kv(h.get(k)) for k in ("exact_f32", "strict", "row_sharing_off")),
@@ -49,8 +49,9 @@ def main():
          "one rank of 8: its 600-edge shard embedded, the replicated state advanced with all 4 800 edges — the extra cost against the line above stays "
          "below the 15 % at which VERDICT r03 #7 asked for a sharded advance"),
         ("DyGFormer (config 4), native step", "**%s** (150–158 k, 3.80–3.99 ms)" % kv(dyg),
-         "autograd path of the same build: %s.  GPU-bound (≈ 3.0 ms of kernels in 87 launches, host issues a step in 0.42 ms: "
-         "`profiles/r04_dygformer_timeline.txt`, `_host_issue.txt`): products 1.15 ms, weight gradients 0.58, attention core 0.38, element-wise passes 0.6"
+         "autograd path of the same build: %s.  GPU-bound (76 launches back to back, host issues a step in 0.40 ms: "
+         "`profiles/r04_dygformer_timeline.txt`, `_host_issue.txt`): products 0.98 ms (10 of 22 on `gemm_pk_s_kernel`), weight gradients 0.40, "
+         "attention core 0.38, element-wise passes 0.55"
          % kv(load("r04_dygformer_bench_autograd.json"))),
         ("CPU port (oracle, %s host threads)" % (h.get("cpu_baseline") or {}).get("cores", "?"),
          "%.0f (TGAT) edges/s" % (h.get("cpu_baseline") or {}).get("value", 0), "baseline only"),

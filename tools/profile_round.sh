@@ -1,11 +1,13 @@
 # Everything under profiles/r04_*: run on the GPU box from the repo root (bash tools/profile_round.sh), then copy gpurun_out/r04p/* into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04p; mkdir -p $O
-python3 bench.py --host-profile > $O/r04_headline_bench.json 2> $O/headline.err
 rocprofv3 --kernel-trace -d $O/kt -o headline -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-breakdown > $O/kt_bench.json 2> $O/kt.err
 python3 tools/rocpd_stats.py $O/kt/headline_results.db --csv $O/r04_headline_kernel_stats.csv --timeline > $O/r04_headline_timeline.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown > $O/pmc_$c.json 2> $O/pmc_$c.err; done
 python3 tools/traffic_from_pmc.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic_r04.json "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-breakdown" > $O/traffic.log 2>&1
+# (the headline line quotes the PMC traffic only from a file taken on the same kernel source: put it in place first)
+cp $O/traffic_r04.json profiles/traffic_r04.json
+python3 bench.py --host-profile > $O/r04_headline_bench.json 2> $O/headline.err
 KERNELS="chain_fwd chain_bwd wgrad2_kernel attn_bwd_fast attn_fwd_fast" bash tools/pmc_step.sh > $O/r04_pmc_sq.txt 2>&1
 python3 bench.py --gemm-mode 0 --no-cpu-baseline > $O/r04_headline_bench_exact_f32.json 2> $O/exact.err
 python3 bench.py --python-step --no-cpu-baseline --no-breakdown --host-profile > $O/r04_headline_bench_python_step.json 2> $O/pystep.err
