@@ -39,7 +39,7 @@ struct AssembleArgs {
     const double* t64;                                  // (>= B) query times
     const float* node; int64_t node_ld; const float* edge; int64_t edge_ld; int64_t num_edge_rows;
     const float *te_w, *te_b, *co_w0, *co_b0;
-    int64_t B; int ws, wd, wmax, dn, de, T, C, Kp;
+    int64_t B; int ws, wd, wmax, dn, de, T, C, Kp, Cp;  // Cp: row stride of hs (C rounded up to 4, pad columns zero)
     float *X, *hs, *dtv, *cnt; int32_t* mask;
 };
 
@@ -78,8 +78,9 @@ __global__ void __launch_bounds__(256) dyg_assemble_kernel(AssembleArgs a) {
         for (int c = lane; c < a.T; c += 64) x[o_t + c] = v == 0 ? 0.f : tg::cos_phase(fmaf(dt, a.te_w[c], a.te_b[c]));     // :266 zeroes padded slots
         for (int c = lane; c < a.C; c += 64) {
             const float w0 = a.co_w0[c], b0 = a.co_b0[c];
-            a.hs[p * a.C + c] = fmaxf(fmaf(c0, w0, b0), 0.f) + fmaxf(fmaf(c1, w0, b0), 0.f);
+            a.hs[p * a.Cp + c] = fmaxf(fmaf(c0, w0, b0), 0.f) + fmaxf(fmaf(c1, w0, b0), 0.f);
         }
+        for (int c = a.C + lane; c < a.Cp; c += 64) a.hs[p * a.Cp + c] = 0.f;
         for (int c = Kx + lane; c < a.Kp; c += 64) x[c] = 0.f;
         if (lane == 0) { a.dtv[p] = dt; a.mask[p] = v; a.cnt[2 * p] = c0; a.cnt[2 * p + 1] = c1; }
     }
@@ -105,9 +106,11 @@ __global__ void __launch_bounds__(256) dyg_wbd_kernel(WbdArgs a) {
 
 struct ProjGradArgs {
     float* G[4]; float* gb[4]; int k[4], off[4];
-    int C, Kp; const float *dWbd, *dbbd; float* g_co_b2;
+    int C, Kp, Cp; const float *dWbd, *dbbd; float* g_co_b2;
+    const float *w2s, *b2s; float* g_co_w2;      // the co-occurrence encoder's second layer: (Cp x Cp) gradient and column sums out of the grouped launch
 };
-// diagonal blocks of the block-diagonal weight's gradient -> the four projection layers' gradients; d b2 = 2 x (column sums of d cf)
+// diagonal blocks of the block-diagonal weight's gradient -> the four projection layers' gradients; the co-occurrence encoder's second
+// layer out of its padded scratch: d W2 = (d cf)^T hs, d b2 = 2 x (column sums of d cf)
 __global__ void __launch_bounds__(256) dyg_proj_grad_kernel(ProjGradArgs a) {
     const int64_t total = (int64_t)4 * a.C * a.Kp;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -116,7 +119,8 @@ __global__ void __launch_bounds__(256) dyg_proj_grad_kernel(ProjGradArgs a) {
         const int kk = k - a.off[c];
         if (kk >= 0 && kk < a.k[c]) a.G[c][(int64_t)rr * a.k[c] + kk] = a.dWbd[i];
         if (k == 0) a.gb[c][rr] = a.dbbd[r];
-        if (i < a.C) a.g_co_b2[i] *= 2.f;
+        if (i < a.C) a.g_co_b2[i] = 2.f * a.b2s[i];
+        if (i < (int64_t)a.C * a.C) { const int r2 = (int)(i / a.C), c2 = (int)(i - (int64_t)r2 * a.C); a.g_co_w2[i] = a.w2s[r2 * a.Cp + c2]; }
     }
 }
 
@@ -198,7 +202,8 @@ struct tg_dyg {
     std::vector<BlockBuf> blk;
     float *d_means = nullptr, *dxa = nullptr, *dxb = nullptr, *d_f = nullptr, *d_hgd = nullptr, *d_y2 = nullptr, *d_o1 = nullptr, *d_ao = nullptr,
           *d_att = nullptr, *dqkv = nullptr, *d_y1 = nullptr, *part = nullptr, *d_tf = nullptr, *d_cf = nullptr, *d_hs = nullptr, *te_part = nullptr;
-    float* gblock = nullptr; int64_t g_wbd = 0, g_bbd = 0, g_floats = 0;
+    float* gblock = nullptr; int64_t g_wbd = 0, g_bbd = 0, g_w2s = 0, g_b2s = 0, g_floats = 0;
+    int Cp = 0;
     // pinned staging ring
     void* pinned = nullptr; int64_t stage_bytes = 0; hipEvent_t copied[RING] = {}; bool copy_pending[RING] = {}; int ring = 0;
     // the forward in flight
@@ -237,7 +242,7 @@ void layout(tg_dyg* st, float* base, int64_t* total) {
     st->w_nbr = reinterpret_cast<int32_t*>(A.take(2 * B * wmax)); st->w_eid = reinterpret_cast<int32_t*>(A.take(2 * B * wmax));
     st->w_t = A.take(2 * B * wmax); st->w_len = reinterpret_cast<int32_t*>(A.take(2 * B));
     st->cnt_s = A.take(B * wmax * 2); st->cnt_d = A.take(B * wmax * 2);
-    st->X = A.take(n * st->Kp); st->hs = A.take(n * C); st->dtv = A.take(n); st->cnt = A.take(2 * n); st->mask = reinterpret_cast<int32_t*>(A.take(n));
+    st->X = A.take(n * st->Kp); st->hs = A.take(n * st->Cp); st->dtv = A.take(n); st->cnt = A.take(2 * n); st->mask = reinterpret_cast<int32_t*>(A.take(n));
     st->Wbd = A.take((int64_t)d * st->Kp); st->bbd = A.take(d); st->b2x2 = A.take(C);
     st->x0 = A.take(n * d);
     st->blk.resize((size_t)c.layers);
@@ -256,12 +261,14 @@ void layout(tg_dyg* st, float* base, int64_t* total) {
     st->d_y1 = A.take(n * d);
     st->parts = tg_rowop_parts(n);
     st->part = A.take(st->parts * 4 * d);                       // [LN1: dgamma | dbeta][LN2: dgamma | dbeta] per row-op workgroup
-    st->d_tf = A.take(n * T); st->d_cf = A.take(n * C); st->d_hs = A.take(n * C);
+    st->d_tf = A.take(n * T); st->d_cf = A.take(n * st->Cp); st->d_hs = A.take(n * C);      // (d_cf: pad columns zeroed once at creation)
     st->te_part = A.take(st->parts * 2 * T);
-    // gradient block, zero-filled once per backward: [parameter gradients (flat layout) | d Wbd | d bbd]
+    // gradient block, zero-filled once per backward: [parameter gradients (flat layout) | d Wbd | d bbd | d W2 (padded) | its column sums]
     st->g_wbd = r4(c.param_floats);
     st->g_bbd = st->g_wbd + r4((int64_t)d * st->Kp);
-    st->g_floats = st->g_bbd + r4(d);
+    st->g_w2s = st->g_bbd + r4(d);
+    st->g_b2s = st->g_w2s + r4((int64_t)st->Cp * st->Cp);
+    st->g_floats = st->g_b2s + r4(st->Cp);
     st->gblock = A.take(st->g_floats);
     *total = A.off;
 }
@@ -271,6 +278,7 @@ void derive(tg_dyg* st) {
     st->d = 4 * c.channel;
     st->Kx = c.dn + c.de + c.dt_dim + c.channel;
     st->Kp = (int)r4(st->Kx);
+    st->Cp = (int)r4(c.channel);
     st->wmax = c.max_len;                                     // patch size 1: a side is as wide as its longest sequence, at most max_len
     st->nmax = (int64_t)c.max_edges * 2 * st->wmax;
     st->nten = P_BLOCK0 + B_COUNT * c.layers + 2;
@@ -335,6 +343,7 @@ extern "C" int tg_dyg_create(const tg_dyg_cfg* cfg, float* d_arena, int64_t aren
     }
     for (hipEvent_t& e : st->copied)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); tg_dyg_destroy(st); tg::set_error("tg_dyg_create: event"); return TG_EHIP; }
+    if (hipMemset(st->d_cf, 0, sizeof(float) * (size_t)(st->nmax * st->Cp)) != hipSuccess) { (void)hipGetLastError(); tg_dyg_destroy(st); tg::set_error("tg_dyg_create: memset"); return TG_EHIP; }
     *out = st;
     return TG_OK;
 }
@@ -394,13 +403,13 @@ extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h
         a.nbr = st->w_nbr; a.eid = st->w_eid; a.tt = st->w_t; a.cnt_s = st->cnt_s; a.cnt_d = st->cnt_d; a.t64 = st->times;
         a.node = c.d_node; a.node_ld = c.node_ld; a.edge = c.d_edge; a.edge_ld = c.edge_ld; a.num_edge_rows = c.num_edge_rows;
         a.te_w = P(st, P_TE_W); a.te_b = P(st, P_TE_B); a.co_w0 = P(st, P_CO_W0); a.co_b0 = P(st, P_CO_B0);
-        a.B = B; a.ws = ws; a.wd = wd; a.wmax = wmax; a.dn = c.dn; a.de = c.de; a.T = T; a.C = C; a.Kp = Kp;
+        a.B = B; a.ws = ws; a.wd = wd; a.wmax = wmax; a.dn = c.dn; a.de = c.de; a.T = T; a.C = C; a.Kp = Kp; a.Cp = st->Cp;
         a.X = st->X; a.hs = st->hs; a.dtv = st->dtv; a.cnt = st->cnt; a.mask = st->mask;
         dyg_assemble_kernel<<<(unsigned)std::min<int64_t>((n + 3) / 4, 4 * tg::kMaxGridBlocks), 256, 0, s>>>(a);
         TG_TRY(tg::launch_status("dyg_assemble_kernel"));
     }
     // co-occurrence encoding = (h(c0) + h(c1)) W2^T + 2 b2, straight into its columns of X; then every channel's projection in one product
-    TG_TRY(tg_gemm_f32(0, 1, n, C, C, 1.f, st->hs, C, P(st, P_CO_W2), C, st->X + oo[3], Kp, st->b2x2, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 1, n, C, C, 1.f, st->hs, st->Cp, P(st, P_CO_W2), C, st->X + oo[3], Kp, st->b2x2, 0, 0, stream));
     TG_TRY(tg_gemm_f32(0, 1, n, d, Kp, 1.f, st->X, Kp, st->Wbd, Kp, st->x0, d, st->bbd, 0, 0, stream));
     // ---- transformer blocks (DyGFormer.py:418-461, pre-LN) ------------------------------------------------------------------------
     static const bool no_pk = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_PK") && atoi(getenv("FLID_NO_PK")) != 0;
@@ -524,11 +533,16 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
     // ---- patch projection, time encoder, co-occurrence encoder ------------------------------------------------------------------------
     const float* dY = dcur;
     const int oo[4] = {0, c.dn, c.dn + c.de, c.dn + c.de + T}, ko[4] = {c.dn, c.de, T, C};
-    {
-        const tg_wgrad_job j{dY, d, d, st->X, Kp, Kp, st->gblock + st->g_wbd, Kp, st->gblock + st->g_bbd};
-        TG_TRY(wgrad(1, &j, n, stream));
-    }
+    const int Cp = st->Cp;
     TG_TRY(tg_gemm_f32(0, 0, n, T, C, 1.f, dY + 2 * C, d, P(st, P_PT_W), T, st->d_tf, T, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 0, n, C, C, 1.f, dY + 3 * C, d, P(st, P_PC_W), C, st->d_cf, Cp, nullptr, 0, 0, stream));
+    {
+        // the block-diagonal projection weight's gradient and the co-occurrence encoder's second layer (operands padded to a multiple of 4
+        // columns, zero pads: 51 us as a split-K tile product + fold + column sums of its own) in one grouped launch
+        const tg_wgrad_job jobs[2] = {{dY, d, d, st->X, Kp, Kp, st->gblock + st->g_wbd, Kp, st->gblock + st->g_bbd},
+                                      {st->d_cf, Cp, Cp, st->hs, Cp, Cp, st->gblock + st->g_w2s, Cp, st->gblock + st->g_b2s}};
+        TG_TRY(wgrad(2, jobs, n, stream));
+    }
     TG_TRY(tg_time_encode_bwd(st->dtv, st->mask, n, P(st, P_TE_W), P(st, P_TE_B), T, st->d_tf, st->te_part, stream));
     if (G(st, P_TE_B) == G(st, P_TE_W) + T) {
         TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, st->parts, 2 * T, G(st, P_TE_W), 1, stream));
@@ -536,19 +550,15 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, st->parts, T, G(st, P_TE_W), 1, stream));
         TG_TRY(tg_colsum(st->te_part + T, 2 * (int64_t)T, st->parts, T, G(st, P_TE_B), 1, stream));
     }
-    TG_TRY(tg_gemm_f32(0, 0, n, C, C, 1.f, dY + 3 * C, d, P(st, P_PC_W), C, st->d_cf, C, nullptr, 0, 0, stream));
-    {
-        const tg_wgrad_job j{st->d_cf, C, C, st->hs, C, C, G(st, P_CO_W2), C, G(st, P_CO_B2)};
-        TG_TRY(wgrad(1, &j, n, stream));
-    }
-    TG_TRY(tg_gemm_f32(0, 0, n, C, C, 1.f, st->d_cf, C, P(st, P_CO_W2), C, st->d_hs, C, nullptr, 0, 0, stream));
+    TG_TRY(tg_gemm_f32(0, 0, n, C, C, 1.f, st->d_cf, Cp, P(st, P_CO_W2), C, st->d_hs, C, nullptr, 0, 0, stream));
     dyg_cooc_bwd_kernel<<<(unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64, 512)), 256, 0, s>>>(st->d_hs, st->cnt, n, C, P(st, P_CO_W0), P(st, P_CO_B0),
                                                                                                          G(st, P_CO_W0), G(st, P_CO_B0));
     TG_TRY(tg::launch_status("dyg_cooc_bwd_kernel"));
     {
         ProjGradArgs a{};
         for (int i = 0; i < 4; ++i) { a.G[i] = G(st, P_PN_W + 2 * i); a.gb[i] = G(st, P_PN_B + 2 * i); a.k[i] = ko[i]; a.off[i] = oo[i]; }
-        a.C = C; a.Kp = Kp; a.dWbd = st->gblock + st->g_wbd; a.dbbd = st->gblock + st->g_bbd; a.g_co_b2 = G(st, P_CO_B2);
+        a.C = C; a.Kp = Kp; a.Cp = Cp; a.dWbd = st->gblock + st->g_wbd; a.dbbd = st->gblock + st->g_bbd; a.g_co_b2 = G(st, P_CO_B2);
+        a.w2s = st->gblock + st->g_w2s; a.b2s = st->gblock + st->g_b2s; a.g_co_w2 = G(st, P_CO_W2);
         const int64_t tot = (int64_t)d * Kp;
         dyg_proj_grad_kernel<<<(unsigned)std::min<int64_t>((tot + 255) / 256, tg::kMaxGridBlocks), 256, 0, s>>>(a);
         TG_TRY(tg::launch_status("dyg_proj_grad_kernel"));
