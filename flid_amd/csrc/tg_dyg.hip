@@ -178,6 +178,8 @@ struct BlockBuf {
     // pre-split weights of the products whose contraction is the token width d (tg_gemm_pk.hip): in_proj, out_proj, linear 0 forward;
     // linear 1 and out_proj transposed for the input gradients d hgd = d f W2, d att = d ao Wo
     float *pk_in, *pk_out, *pk_fc1, *pk_fc2t, *pk_outt;
+    // ... and of the deep ones with d output columns: linear 1 forward (K = 4 d), d y2 = d h W1 (K = 4 d), d y1 = d qkv Wqkv (K = 3 d)
+    float *pk_fc2, *pk_fc1t, *pk_int;
 };
 
 struct Arena {
@@ -198,7 +200,7 @@ struct tg_dyg {
     double* times = nullptr; int32_t* ids = nullptr;
     int32_t *w_nbr = nullptr, *w_eid = nullptr, *w_len = nullptr, *mask = nullptr;
     float *w_t = nullptr, *cnt_s = nullptr, *cnt_d = nullptr, *X = nullptr, *hs = nullptr, *dtv = nullptr, *cnt = nullptr;
-    float *Wbd = nullptr, *bbd = nullptr, *b2x2 = nullptr, *x0 = nullptr, *means = nullptr, *emb = nullptr;
+    float *Wbd = nullptr, *bbd = nullptr, *b2x2 = nullptr, *x0 = nullptr, *means = nullptr, *emb = nullptr, *pk_wbd = nullptr;
     std::vector<BlockBuf> blk;
     float *d_means = nullptr, *dxa = nullptr, *dxb = nullptr, *d_f = nullptr, *d_hgd = nullptr, *d_y2 = nullptr, *d_o1 = nullptr, *d_ao = nullptr,
           *d_att = nullptr, *dqkv = nullptr, *d_y1 = nullptr, *part = nullptr, *d_tf = nullptr, *d_cf = nullptr, *d_hs = nullptr, *te_part = nullptr;
@@ -254,7 +256,11 @@ void layout(tg_dyg* st, float* base, int64_t* total) {
         b.pk_in = pk ? A.take(tg::packed32_floats(3 * d, d)) : nullptr; b.pk_out = pk ? A.take(tg::packed32_floats(d, d)) : nullptr;
         b.pk_fc1 = pk ? A.take(tg::packed32_floats(4 * d, d)) : nullptr; b.pk_fc2t = pk ? A.take(tg::packed32_floats(4 * d, d)) : nullptr;
         b.pk_outt = pk ? A.take(tg::packed32_floats(d, d)) : nullptr;
+        const bool pkl = pk && tg::packed32_floats(d, 4 * d) > 0;
+        b.pk_fc2 = pkl ? A.take(tg::packed32_floats(d, 4 * d)) : nullptr; b.pk_fc1t = pkl ? A.take(tg::packed32_floats(d, 4 * d)) : nullptr;
+        b.pk_int = pkl ? A.take(tg::packed32_floats(d, 3 * d)) : nullptr;
     }
+    st->pk_wbd = tg::packed32_floats(d, st->Kp) > 0 ? A.take(tg::packed32_floats(d, st->Kp)) : nullptr;
     st->means = A.take(2 * B * d); st->emb = A.take(2 * B * c.dn);
     st->d_means = A.take(2 * B * d); st->dxa = A.take(n * d); st->dxb = A.take(n * d); st->d_f = A.take(n * d); st->d_hgd = A.take(n * 4 * d);
     st->d_y2 = A.take(n * d); st->d_o1 = A.take(n * d); st->d_ao = A.take(n * d); st->d_att = A.take(n * d); st->dqkv = A.take(n * 3 * d);
@@ -399,6 +405,27 @@ extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h
         const int64_t tot = (int64_t)d * Kp;
         dyg_wbd_kernel<<<(unsigned)std::min<int64_t>((tot + 255) / 256, tg::kMaxGridBlocks), 256, 0, s>>>(w);
         TG_TRY(tg::launch_status("dyg_wbd_kernel"));
+        static const bool no_pk = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_PK") && atoi(getenv("FLID_NO_PK")) != 0;
+        st->use_pk = !no_pk && tg_get_gemm_mode() != 0 && st->blk[0].pk_in != nullptr && d % 4 == 0 && c.layers <= 3;
+        if (st->use_pk) {                               // the weights moved with the last update: split them again, one launch
+            tg_pack32_job jobs[32];
+            int nj = 0;
+            if (st->pk_wbd) jobs[nj++] = tg_pack32_job{st->Wbd, Kp, d, Kp, 0, st->pk_wbd};
+            for (int l = 0; l < c.layers; ++l) {
+                const BlockBuf& b = st->blk[(size_t)l];
+                jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_IN_W)), d, 3 * d, d, 0, b.pk_in};
+                jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_OUT_W)), d, d, d, 0, b.pk_out};
+                jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_FC1_W)), d, 4 * d, d, 0, b.pk_fc1};
+                jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_FC2_W)), 4 * (int64_t)d, 4 * d, d, 1, b.pk_fc2t};
+                jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_OUT_W)), d, d, d, 1, b.pk_outt};
+                if (b.pk_fc2) {
+                    jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_FC2_W)), 4 * (int64_t)d, d, 4 * d, 0, b.pk_fc2};
+                    jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_FC1_W)), d, d, 4 * d, 1, b.pk_fc1t};
+                    jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_IN_W)), d, d, 3 * d, 1, b.pk_int};
+                }
+            }
+            TG_TRY(tg::pack32_weights(nj, jobs, s));
+        }
         AssembleArgs a{};
         a.nbr = st->w_nbr; a.eid = st->w_eid; a.tt = st->w_t; a.cnt_s = st->cnt_s; a.cnt_d = st->cnt_d; a.t64 = st->times;
         a.node = c.d_node; a.node_ld = c.node_ld; a.edge = c.d_edge; a.edge_ld = c.edge_ld; a.num_edge_rows = c.num_edge_rows;
@@ -410,23 +437,8 @@ extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h
     }
     // co-occurrence encoding = (h(c0) + h(c1)) W2^T + 2 b2, straight into its columns of X; then every channel's projection in one product
     TG_TRY(tg_gemm_f32(0, 1, n, C, C, 1.f, st->hs, st->Cp, P(st, P_CO_W2), C, st->X + oo[3], Kp, st->b2x2, 0, 0, stream));
-    TG_TRY(tg_gemm_f32(0, 1, n, d, Kp, 1.f, st->X, Kp, st->Wbd, Kp, st->x0, d, st->bbd, 0, 0, stream));
+    TG_TRY(prod(st, st->pk_wbd, 1, n, d, Kp, st->X, Kp, st->Wbd, Kp, st->x0, d, st->bbd, stream));
     // ---- transformer blocks (DyGFormer.py:418-461, pre-LN) ------------------------------------------------------------------------
-    static const bool no_pk = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_PK") && atoi(getenv("FLID_NO_PK")) != 0;
-    st->use_pk = !no_pk && tg_get_gemm_mode() != 0 && st->blk[0].pk_in != nullptr && d % 4 == 0 && c.layers <= 3;
-    if (st->use_pk) {                                   // the weights moved with the last update: split them again, one launch
-        tg_pack32_job jobs[16];
-        int nj = 0;
-        for (int l = 0; l < c.layers; ++l) {
-            const BlockBuf& b = st->blk[(size_t)l];
-            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_IN_W)), d, 3 * d, d, 0, b.pk_in};
-            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_OUT_W)), d, d, d, 0, b.pk_out};
-            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_FC1_W)), d, 4 * d, d, 0, b.pk_fc1};
-            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_FC2_W)), 4 * (int64_t)d, 4 * d, d, 1, b.pk_fc2t};
-            jobs[nj++] = tg_pack32_job{P(st, blk_i(l, B_OUT_W)), d, d, d, 1, b.pk_outt};
-        }
-        TG_TRY(tg::pack32_weights(nj, jobs, s));
-    }
     const float p = dropout_p;
     const float* x = st->x0;
     for (int l = 0; l < c.layers; ++l) {
@@ -444,7 +456,7 @@ extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h
         // cost alone -- measured, 3.028 vs 3.006 ms per step -- because the epilogue of a short-K product is on its critical path)
         TG_TRY(prod(st, b.pk_fc1, 1, n, 4 * d, d, b.y2, d, P(st, blk_i(l, B_FC1_W)), d, b.h, 4 * d, P(st, blk_i(l, B_FC1_B)), stream));
         TG_TRY(tg_gelu_dropout_fwd(b.h, n * 4 * d, p, s2, b.hgd, stream));
-        TG_TRY(tg_gemm_f32(0, 1, n, d, 4 * d, 1.f, b.hgd, 4 * d, P(st, blk_i(l, B_FC2_W)), 4 * d, b.ao, d, P(st, blk_i(l, B_FC2_B)), 0, 0, stream));
+        TG_TRY(prod(st, b.pk_fc2, 1, n, d, 4 * d, b.hgd, 4 * d, P(st, blk_i(l, B_FC2_W)), 4 * d, b.ao, d, P(st, blk_i(l, B_FC2_B)), stream));
         if (l + 1 < c.layers) {                          // out = o1 + dropout(f) and the next block's y1 = LayerNorm(out) in one pass
             BlockBuf& nb = st->blk[(size_t)l + 1];
             TG_TRY(tg_add_layernorm_fwd_res(b.o1, b.ao, n, d, P(st, blk_i(l + 1, B_LN1_G)), P(st, blk_i(l + 1, B_LN1_B)), p, s3, b.out, nb.y1, nb.m1, nb.r1, stream));
@@ -499,7 +511,7 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         TG_TRY(prod(st, b.pk_fc2t, 0, n, 4 * d, d, d_f, d, P(st, blk_i(l, B_FC2_W)), 4 * d, st->d_hgd, 4 * d, nullptr, stream));
         float* d_h = st->d_hgd;                                                         // element-wise, in place
         TG_TRY(tg_gelu_dropout_bwd(b.h, st->d_hgd, n * 4 * d, p, p > 0.f ? sd[2] : 0, d_h, stream));
-        TG_TRY(tg_gemm_f32(0, 0, n, d, 4 * d, 1.f, d_h, 4 * d, P(st, blk_i(l, B_FC1_W)), d, st->d_y2, d, nullptr, 0, 0, stream));
+        TG_TRY(prod(st, b.pk_fc1t, 0, n, d, 4 * d, d_h, 4 * d, P(st, blk_i(l, B_FC1_W)), d, st->d_y2, d, nullptr, stream));
         // d o1 = d out + dLN2(d y2); the gradient entering the attention branch is its dropout
         const float* d_ao = st->d_o1;
         // (both LayerNorms' partial sums of dgamma / dbeta side by side: one column-sum launch per block, below)
@@ -508,7 +520,7 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         if (p > 0.f) d_ao = st->d_ao;
         TG_TRY(prod(st, b.pk_outt, 0, n, d, d, d_ao, d, P(st, blk_i(l, B_OUT_W)), d, st->d_att, d, nullptr, stream));
         TG_TRY(tg_seq_attn_bwd(b.qkv, b.prob, st->d_att, B, S, d, H, p, p > 0.f ? sd[0] : 0, st->dqkv, stream));
-        TG_TRY(tg_gemm_f32(0, 0, n, d, 3 * d, 1.f, st->dqkv, 3 * d, P(st, blk_i(l, B_IN_W)), d, st->d_y1, d, nullptr, 0, 0, stream));
+        TG_TRY(prod(st, b.pk_int, 0, n, d, 3 * d, st->dqkv, 3 * d, P(st, blk_i(l, B_IN_W)), d, st->d_y1, d, nullptr, stream));
         const tg_wgrad_job jobs[4] = {
             {d_f, d, d, b.hgd, 4 * (int64_t)d, 4 * d, G(st, blk_i(l, B_FC2_W)), 4 * (int64_t)d, G(st, blk_i(l, B_FC2_B))},
             {d_h, 4 * (int64_t)d, 4 * d, b.y2, d, d, G(st, blk_i(l, B_FC1_W)), d, G(st, blk_i(l, B_FC1_B))},

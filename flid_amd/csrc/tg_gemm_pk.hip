@@ -42,8 +42,10 @@ constexpr int STAGE = 2 * PKS * BLK;          // one 32-column tile x one K chun
 constexpr int NBUF = 3;
 
 // packed operand: [tile t][step s][plane hi, lo][lane][8 bf16]; lane l of (t, s) holds W[32 t + (l & 31)][16 s + 8 (l >> 5) + 0..7] -- the
-// B fragment of v_mfma_f32_32x32x16_bf16 -- zero beyond N or K.  Up to 16 weights per launch, one wave per fragment pair.
-struct Pack32Jobs { tg_pack32_job j[16]; int frag0[17]; int n; };
+// B fragment of v_mfma_f32_32x32x16_bf16 -- zero beyond N or K.  Up to 32 weights per launch, one wave per fragment pair.
+// (deep form, job.K > 208: [stage s = k / 32][tile t][step 2][plane hi, lo][lane][8 bf16] -- one 32-deep stage of ALL tiles contiguous, what
+// gemm_pk_l_kernel's LDS-DMA copies per iteration; fragment pairs are numbered (s, t, step))
+struct Pack32Jobs { tg_pack32_job j[32]; int frag0[33]; int n; };
 __global__ void __launch_bounds__(256) pack32_kernel(Pack32Jobs jobs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = jobs.frag0[jobs.n];
@@ -51,8 +53,11 @@ __global__ void __launch_bounds__(256) pack32_kernel(Pack32Jobs jobs) {
         int ji = 0;
         while (ji + 1 < jobs.n && f >= jobs.frag0[ji + 1]) ++ji;
         const tg_pack32_job J = jobs.j[ji];
-        const int fl = f - jobs.frag0[ji], s = fl % PKS, t = fl / PKS;
-        const int n = 32 * t + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+        const int fl = f - jobs.frag0[ji];
+        int t, k16;                                               // 32-column tile, 16-deep step of the contraction
+        if (J.K > KC) { const int nt = (J.N + 31) / 32; k16 = (fl / (2 * nt)) * 2 + (fl & 1); t = (fl >> 1) % nt; }
+        else { k16 = fl % PKS; t = fl / PKS; }
+        const int n = 32 * t + (lane & 31), k0 = 16 * k16 + 8 * (lane >> 5);
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -198,25 +203,117 @@ __global__ void __launch_bounds__(256) gemm_pk_s_kernel(const float* __restrict_
     else store_tile(prev, C, ldc, row0, M, 32 * (t1 - 1) + (lane & 31), N, bias, h);
 }
 
+// ---- deep contraction (K > 208), narrow output (N <= 224): the accumulators of all (up to 7) column tiles stay in registers while the
+// contraction passes in 32-deep stages; a stage = this lane's A fragments of 32 k (4 x 16-byte loads straight from global memory, split in
+// registers) + the 32-deep slice of ALL tiles of the pre-split weight (NT x 4 KiB, LDS-DMA into a two-buffer ring).  The loads of stage
+// i + 1 are issued before the MFMAs of stage i and waited for after them; two workgroups per CU cover each other's waits.
+constexpr int LSTEP = 4 * BLK;                // one tile's share of a stage: 2 steps x (hi, lo)
+
+template <int NT>
+__device__ __forceinline__ void issue_stage_l(const uint4* __restrict__ Bp, int64_t stage, char* lds, int buf, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {                         // NT x 4 blocks of 1 KiB, wave w takes blocks w, w + 4, ...
+        const int blk = wave + 4 * i;
+        const uint4* g = Bp + (stage * (NT * 4) + blk) * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(lds + buf * (NT * LSTEP) + blk * BLK), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void load_a_stage(const float* __restrict__ arow, int K, int stage, int h, float4 (&raw)[4]) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int k = 32 * stage + 16 * st + 8 * h;
+        raw[2 * st] = *reinterpret_cast<const float4*>(arow + (k < K ? k : 0));
+        raw[2 * st + 1] = *reinterpret_cast<const float4*>(arow + (k + 4 < K ? k + 4 : 0));
+    }
+}
+__device__ __forceinline__ void split_a_stage(const float4 (&raw)[4], int K, int stage, int h, bf16x8 (&ah)[2], bf16x8 (&al)[2]) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int k = 32 * stage + 16 * st + 8 * h;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 h0, l0, h1, l1;
+        split4(k < K ? raw[2 * st] : z, h0, l0);
+        split4(k + 4 < K ? raw[2 * st + 1] : z, h1, l1);
+        ah[st] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        al[st] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2) gemm_pk_l_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K, const uint4* __restrict__ Bp, int N,
+                                                           int nst, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int vec) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x NT x 4 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    int64_t row = row0 + (lane & 31);
+    if (row > M - 1) row = M - 1;
+    const float* arow = A + row * lda;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    issue_stage_l<NT>(Bp, 0, lds, 0, wave, lane);
+    float4 raw[4];
+    bf16x8 ah[2], al[2];
+    load_a_stage(arow, K, 0, h, raw);
+    split_a_stage(raw, K, 0, h, ah, al);
+    for (int i = 0; i < nst; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // stage i has landed for every wave; every wave is done reading stage i - 1
+        asm volatile("" ::: "memory");
+        const bool more = i + 1 < nst;
+        if (more) {
+            issue_stage_l<NT>(Bp, i + 1, lds, (i + 1) & 1, wave, lane);
+            load_a_stage(arow, K, i + 1, h, raw);
+        }
+        const char* b = lds + (i & 1) * (NT * LSTEP) + lane * 16;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK + BLK);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bh, acc[t], 0, 0, 0);
+            }
+        if (more) split_a_stage(raw, K, i + 1, h, ah, al);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (vec) store_tile4(acc[t], C, ldc, row0, M, 32 * t + (lane & 31), N, bias, h);
+        else store_tile(acc[t], C, ldc, row0, M, 32 * t + (lane & 31), N, bias, h);
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
 namespace tg {
 
-int64_t packed32_floats(int N, int K) { return K > KC ? -1 : (int64_t)((N + 31) / 32) * (STAGE / 4); }
+int64_t packed32_floats(int N, int K) {
+    const int nt = (N + 31) / 32;
+    if (K <= KC) return (int64_t)nt * (STAGE / 4);
+    return nt <= 7 ? (int64_t)((K + 31) / 32) * nt * (LSTEP / 4) : -1;          // deep form: N <= 224
+}
 
 int pack32_weights(int njobs, const tg_pack32_job* jobs, hipStream_t s) {
-    TG_REQUIRE(njobs >= 0 && njobs <= 16 && (njobs == 0 || jobs), "tg_pack32_weights: at most 16 jobs per launch");
+    TG_REQUIRE(njobs >= 0 && njobs <= 32 && (njobs == 0 || jobs), "tg_pack32_weights: at most 32 jobs per launch");
     if (njobs == 0) return TG_OK;
     Pack32Jobs pj;
     pj.n = njobs;
     int total = 0;
     for (int i = 0; i < njobs; ++i) {
-        TG_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].N > 0 && jobs[i].K > 0 && jobs[i].K <= KC && al16(jobs[i].dst), "tg_pack32_weights: bad job (K <= 208)");
+        TG_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].N > 0 && jobs[i].K > 0 && al16(jobs[i].dst) && packed32_floats(jobs[i].N, jobs[i].K) > 0,
+                   "tg_pack32_weights: bad job (K <= 208, or N <= 224)");
         pj.j[i] = jobs[i];
         pj.frag0[i] = total;
-        total += ((jobs[i].N + 31) / 32) * PKS;
+        const int nt = (jobs[i].N + 31) / 32;
+        total += jobs[i].K <= KC ? nt * PKS : ((jobs[i].K + 31) / 32) * nt * 2;
     }
     pj.frag0[njobs] = total;
     pack32_kernel<<<(unsigned)std::min((total + 3) / 4, 2048), 256, 0, s>>>(pj);
@@ -225,8 +322,9 @@ int pack32_weights(int njobs, const tg_pack32_job* jobs, hipStream_t s) {
 
 // true = launched; false = shape / alignment not covered (the caller takes tg_gemm_f32 on the unpacked weight)
 bool gemm_pk_nt(int64_t M, int N, int K, const float* A, int64_t lda, const void* packed, float* C, int64_t ldc, const float* bias, hipStream_t s) {
-    if (M < 1 || N < 1 || K < 4 || K > KC || K % 4 || lda % 4 || !al16(A) || !al16(packed)) return false;
+    if (M < 1 || N < 1 || K < 4 || K % 4 || lda % 4 || !al16(A) || !al16(packed)) return false;
     const int ntiles = (N + 31) / 32;
+    if (K > KC && ntiles > 7) return false;
     const int64_t panels = (M + 127) / 128;
     if (panels >= ((int64_t)1 << 31)) return false;
     static bool attr_done = false;
@@ -239,6 +337,17 @@ bool gemm_pk_nt(int64_t M, int N, int K, const float* A, int64_t lda, const void
     }
     const int vec = N % 4 == 0 && ldc % 4 == 0 && al16(C) && (!bias || al16(bias));
     ProfScope prof("gemm", 2.0 * M * N * K, s);
+    if (K > KC) {
+        const int nst = (K + 31) / 32;
+        const uint4* Bp = reinterpret_cast<const uint4*>(packed);
+#define PK_L(NTV) gemm_pk_l_kernel<NTV><<<(unsigned)panels, 256, 2 * NTV * LSTEP, s>>>(A, lda, M, K, Bp, N, nst, C, ldc, bias, vec)
+        switch (ntiles) {
+            case 1: PK_L(1); break; case 2: PK_L(2); break; case 3: PK_L(3); break; case 4: PK_L(4); break;
+            case 5: PK_L(5); break; case 6: PK_L(6); break; default: PK_L(7); break;
+        }
+#undef PK_L
+        return true;
+    }
     // units per panel u: rounds of the grid over the chip's 512 workgroup slots x (tiles per unit + the prologue, which costs about
     // six tiles' time: A rows from HBM, 26 splits per lane)
     int tpu = ntiles;
@@ -265,7 +374,7 @@ extern "C" int tg_gemm_pk_nt(int64_t M, int N, int K, const float* d_A, int64_t 
     TG_REQUIRE(d_A && d_packed && d_C && ldc >= N, "tg_gemm_pk_nt: arguments");
     if (M == 0) return TG_OK;
     if (!tg::gemm_pk_nt(M, N, K, d_A, lda, d_packed, d_C, ldc, d_bias, (hipStream_t)stream)) {
-        tg::set_error("tg_gemm_pk_nt: K <= 208, K and lda multiples of 4, 16-byte aligned operands");
+        tg::set_error("tg_gemm_pk_nt: K <= 208 or N <= 224, K and lda multiples of 4, 16-byte aligned operands");
         return TG_ESHAPE;
     }
     return tg::launch_status("gemm_pk_s_kernel");

@@ -338,12 +338,12 @@ typedef struct tg_pack_job {
 } tg_pack_job;
 int64_t tg_packed_floats(int N, int K);
 int tg_pack_weights(int njobs, const tg_pack_job* jobs, void* stream);
-/* Row-panel product against a PRE-SPLIT weight (csrc/tg_gemm_pk.hip): tg_pack32_weights splits up to 16 weights W (N x K, K <= 208;
+/* Row-panel product against a PRE-SPLIT weight (csrc/tg_gemm_pk.hip): tg_pack32_weights splits up to 32 weights W (N x K with K <= 208, or N <= 224 with any K;
  * trans: given as K x N) into bf16 hi / lo in the fragment order of v_mfma_f32_32x32x16_bf16, tg_packed32_floats(N, K) floats each
- * (-1 for K > 208), once per optimizer step; tg_gemm_pk_nt: C[M, N] = A[M, K] * W^T (+ bias[N]), A straight from global memory into
+ * (-1 for a weight that is both deeper than 208 and wider than 224), once per optimizer step; tg_gemm_pk_nt: C[M, N] = A[M, K] * W^T (+ bias[N]), A straight from global memory into
  * MFMA fragments (split once per row panel), the weight's 32-column tiles through an LDS ring filled by LDS-DMA.  Replaces aten::addmm
- * behind the nn.Linear layers of models/DyGFormer.py:418-461 and their input gradients where the contraction is 200 wide (38 400 rows
- * against 200..800 columns).  K, lda multiples of 4, 16-byte aligned operands -- TG_ESHAPE otherwise (nothing launched: tg_gemm_f32). */
+ * behind the nn.Linear layers of models/DyGFormer.py:418-461 and their input gradients (38 400 rows against 200..800-wide weights: a contraction of at most 208 with any
+ * width, or a deeper one with at most 224 output columns, whose accumulators stay in registers while 32-deep stages pass).  K, lda multiples of 4, 16-byte aligned operands -- TG_ESHAPE otherwise (nothing launched: tg_gemm_f32). */
 typedef struct tg_pack32_job { const float* src; int64_t ld; int32_t N, K, trans; void* dst; } tg_pack32_job;
 int64_t tg_packed32_floats(int N, int K);
 int tg_pack32_weights(int njobs, const tg_pack32_job* jobs, void* stream);

@@ -763,7 +763,8 @@ def test_weight_gradient_jobs_with_swapped_operands():
         assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-3
 
 
-@pytest.mark.parametrize("M,N,K,trans", [(1000, 200, 200, 0), (777, 800, 200, 1), (2500, 600, 200, 0), (64, 24, 24, 0), (129, 50, 52, 1), (5000, 36, 208, 0)])
+@pytest.mark.parametrize("M,N,K,trans", [(1000, 200, 200, 0), (777, 800, 200, 1), (2500, 600, 200, 0), (64, 24, 24, 0), (129, 50, 52, 1), (5000, 36, 208, 0),
+                                         (1000, 200, 800, 0), (3000, 200, 600, 1), (515, 200, 496, 0), (300, 224, 212, 1), (257, 20, 1000, 0)])
 def test_panel_product_against_presplit_weights(M, N, K, trans):
     """tg_pack32_weights + tg_gemm_pk_nt (A fragments straight from global memory, the pre-split weight's tiles through the LDS-DMA
     ring) against float64 and against the tile kernel's split-bf16 product of the same operands"""
@@ -785,4 +786,4 @@ def test_panel_product_against_presplit_weights(M, N, K, trans):
     c2 = torch.empty(M, N, device=dev)
     ops.gemm(a, wt.contiguous(), c2, tb=True, bias=b)
     assert float((c - c2).abs().max()) <= 4e-5 * float(ref.abs().max())
-    assert int(lib().tg_packed32_floats(N, 300)) == -1                     # K > 208 is the tile kernel's
+    assert int(lib().tg_packed32_floats(256, 300)) == -1                   # deep AND wide (K > 208, N > 224) is the tile kernel's

@@ -35,7 +35,7 @@ def pack32(w, trans=False):
     return out
 
 
-for N, K in [(600, 200), (200, 200), (800, 200)]:
+for N, K in [(600, 200), (200, 200), (800, 200), (200, 800), (200, 496), (200, 600)]:
     a = torch.randn(R, K, device=dev)
     w = torch.randn(N, K, device=dev) * 0.05
     b = torch.randn(N, device=dev)
