@@ -13,11 +13,17 @@
 //     tiles through a three-buffer LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no registers, no VALU, no LDS store
 //     instructions), one tile ahead of the MFMAs, one barrier per tile;
 //   * a tile of C leaves straight from the accumulators: one store instruction covers two 128-byte row segments.
-// K <= 208 only (one K chunk, any N).  A long-K form that kept the accumulators of up to 7 tiles while K chunks passed was built and
-// measured slower than the tile kernel (119 vs 80 us at 38 400 x 200 x 800: 370 registers, one workgroup per CU, 300 workgroups on 256
-// CUs); it is not kept.  Measured at 38 400 rows (tools/pk_bench.py): x 800 x 200 72 us (tile kernel 92), x 600 x 200 64 (78),
-// x 200 x 200 31 (35.5).  Without the C stores the 800-column product takes 50 us, with them 72-80: the 123 MB it writes are the floor
-// (~4 TB/s), the MFMAs (20 us) would hide under it -- what is left is the prologue (A rows from HBM, 26 splits per lane) per unit.
+// Two forms.  K <= 208, any N (gemm_pk_s_kernel): the A fragments of the whole contraction live in registers (loaded from global memory in
+// fragment shape, once per unit of column tiles), the weight's 32-column tiles (26 KiB) pass through a three-buffer ring.  K > 208,
+// N <= 224 (gemm_pk_l_kernel): the accumulators of all column tiles live in registers and the contraction passes in 32-deep stages of
+// both operands through three-buffer rings -- A as raw fp32 rows in full 128-byte lines (swizzled through the source address, split when
+// the fragments are read), the weight's stage slice of all tiles (28 KiB).
+// Measured at 38 400 rows (tools/pk_bench.py, profiles/r04_pk_bench.txt; tile kernel in brackets): x 800 x 200 72 us (92), x 600 x 200 64
+// (78), x 200 x 200 31 (35.5); x 200 x 800 65 (82), x 200 x 600 51 (64), x 200 x 496 46 (57).  What bounds them: without the C stores the
+// 800-column product takes 50 us, with them 72-80 -- the 123 MB it writes are the floor (~4 TB/s); the deep form takes 37 us without its
+// MFMAs and 65 with them, on three different A paths (fragment-shaped loads to registers one stage ahead; the same by hand-counted inline-asm
+// loads two stages ahead; LDS-DMA of full lines two stages ahead): the matrix pipe's 28 us ADD to the memory time although the generated
+// code waits only for the stage it reads (vmcnt(10), no compiler-inserted vmcnt(0) in the loop) -- not understood; DESIGN.md section 9.
 #include <math.h>
 #include <stdlib.h>
 
@@ -204,83 +210,106 @@ __global__ void __launch_bounds__(256) gemm_pk_s_kernel(const float* __restrict_
 }
 
 // ---- deep contraction (K > 208), narrow output (N <= 224): the accumulators of all (up to 7) column tiles stay in registers while the
-// contraction passes in 32-deep stages; a stage = this lane's A fragments of 32 k (4 x 16-byte loads straight from global memory, split in
-// registers) + the 32-deep slice of ALL tiles of the pre-split weight (NT x 4 KiB, LDS-DMA into a two-buffer ring).  The loads of stage
-// i + 1 are issued before the MFMAs of stage i and waited for after them; two workgroups per CU cover each other's waits.
+// contraction passes in 32-deep stages; a stage = 32 k of this wave's 32 rows of A (raw fp32, 4 KiB, split when the fragments are read) +
+// the 32-deep slice of ALL tiles of the pre-split weight (NT x 4 KiB), both by LDS-DMA into three-buffer rings.
 constexpr int LSTEP = 4 * BLK;                // one tile's share of a stage: 2 steps x (hi, lo)
 
-template <int NT>
+// LDS-DMA of one stage of the deep form: NT x 4 blocks of 1 KiB over NWV waves, every wave the same number of copies (the surplus ones
+// repeat the last block with identical bytes) so that the counted waits below hold for every wave
+template <int NT, int NWV>
 __device__ __forceinline__ void issue_stage_l(const uint4* __restrict__ Bp, int64_t stage, char* lds, int buf, int wave, int lane) {
+    constexpr int PER = (NT * 4 + NWV - 1) / NWV;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {                         // NT x 4 blocks of 1 KiB, wave w takes blocks w, w + 4, ...
-        const int blk = wave + 4 * i;
+    for (int i = 0; i < PER; ++i) {
+        int blk = wave + NWV * i;
+        if (blk > NT * 4 - 1) blk = NT * 4 - 1;
         const uint4* g = Bp + (stage * (NT * 4) + blk) * 64 + lane;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(lds + buf * (NT * LSTEP) + blk * BLK), 16, 0, 0);
     }
 }
 
-__device__ __forceinline__ void load_a_stage(const float* __restrict__ arow, int K, int stage, int h, float4 (&raw)[4]) {
+// A rows of one 32-deep stage by LDS-DMA into THIS WAVE's region: 32 rows x 128 bytes = four copies of 1 KiB, each lane one 16-byte chunk
+// of a full 128-byte line (fragment-shaped loads straight to registers -- 64 scattered 16-byte pieces per instruction -- ran the deep
+// form at 1.9 TB/s of A traffic: address-processing bound).  The LDS image is row-major with the eight 16-byte slots of a row permuted
+// through the SOURCE address (slot p of row r holds chunk p ^ (r & 7)), so that the fragment reads below are conflict-free.  A chunk
+// past K comes from a block of zeros.
+__device__ __forceinline__ void issue_a_stage(const float* __restrict__ A, int64_t lda, int64_t M, int K, int64_t wrow0, int stage, char* region,
+                                              const float* __restrict__ zeros, int lane) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        const int k = 32 * stage + 16 * st + 8 * h;
-        raw[2 * st] = *reinterpret_cast<const float4*>(arow + (k < K ? k : 0));
-        raw[2 * st + 1] = *reinterpret_cast<const float4*>(arow + (k + 4 < K ? k + 4 : 0));
+    for (int j = 0; j < 4; ++j) {
+        int64_t row = wrow0 + 8 * j + (lane >> 3);
+        if (row > M - 1) row = M - 1;
+        const int rl = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ (rl & 7);
+        const int k = 32 * stage + 4 * c;
+        const float* g = k < K ? A + row * lda + k : zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(region + j * BLK), 16, 0, 0);
     }
 }
-__device__ __forceinline__ void split_a_stage(const float4 (&raw)[4], int K, int stage, int h, bf16x8 (&ah)[2], bf16x8 (&al)[2]) {
+// lane (r = l & 31, h = l >> 5), step st: k = 16 st + 8 h + 0..7 = chunks 4 st + 2 h and + 1 of row r
+__device__ __forceinline__ void read_a_stage(const char* __restrict__ region, int lane, bf16x8 (&ah)[2], bf16x8 (&al)[2]) {
+    const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-        const int k = 32 * stage + 16 * st + 8 * h;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = 4 * st + 2 * h;
+        const float4 x = *reinterpret_cast<const float4*>(region + r * 128 + ((c0 ^ (r & 7)) << 4));
+        const float4 y = *reinterpret_cast<const float4*>(region + r * 128 + (((c0 + 1) ^ (r & 7)) << 4));
         uint2 h0, l0, h1, l1;
-        split4(k < K ? raw[2 * st] : z, h0, l0);
-        split4(k + 4 < K ? raw[2 * st + 1] : z, h1, l1);
+        split4(x, h0, l0);
+        split4(y, h1, l1);
         ah[st] = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
         al[st] = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
     }
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256, 2) gemm_pk_l_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K, const uint4* __restrict__ Bp, int N,
-                                                           int nst, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int vec) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x NT x 4 KiB
+// NWV waves x 32 rows per workgroup (the launcher picks NWV so that the row panels fit the chip in one round: one workgroup per CU);
+// three LDS buffers in rotation for both operands: stage i + 2 is issued at the top of stage i, the waits are counted by hand
+template <int NT, int NWV>
+__global__ void __launch_bounds__(64 * NWV, 1) gemm_pk_l_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int K, const uint4* __restrict__ Bp,
+                                                                int N, int nst, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int vec,
+                                                                const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // 3 x NT x 4 KiB of B, then NWV x 3 x 4 KiB of A
+    constexpr int OPS = (NT * 4 + NWV - 1) / NWV + 4;               // vector-memory operations a wave issues per stage
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
-    int64_t row = row0 + (lane & 31);
-    if (row > M - 1) row = M - 1;
-    const float* arow = A + row * lda;
+    const int64_t row0 = (int64_t)blockIdx.x * (32 * NWV) + wave * 32;
+    char* aring = lds + 3 * NT * LSTEP + wave * (3 * 4 * BLK);
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    issue_stage_l<NT>(Bp, 0, lds, 0, wave, lane);
-    float4 raw[4];
-    bf16x8 ah[2], al[2];
-    load_a_stage(arow, K, 0, h, raw);
-    split_a_stage(raw, K, 0, h, ah, al);
+    issue_stage_l<NT, NWV>(Bp, 0, lds, 0, wave, lane);
+    issue_a_stage(A, lda, M, K, row0, 0, aring, zeros, lane);
+    if (nst > 1) {
+        issue_stage_l<NT, NWV>(Bp, 1, lds, 1, wave, lane);
+        issue_a_stage(A, lda, M, K, row0, 1, aring + 4 * BLK, zeros, lane);
+    }
     for (int i = 0; i < nst; ++i) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(OPS) : "memory");      // everything but stage i + 1's copies has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // stage i has landed for every wave; every wave is done reading stage i - 1
         asm volatile("" ::: "memory");
-        const bool more = i + 1 < nst;
-        if (more) {
-            issue_stage_l<NT>(Bp, i + 1, lds, (i + 1) & 1, wave, lane);
-            load_a_stage(arow, K, i + 1, h, raw);
+        if (i + 2 < nst) {
+            issue_stage_l<NT, NWV>(Bp, i + 2, lds, (i + 2) % 3, wave, lane);
+            issue_a_stage(A, lda, M, K, row0, i + 2, aring + ((i + 2) % 3) * (4 * BLK), zeros, lane);
         }
-        const char* b = lds + (i & 1) * (NT * LSTEP) + lane * 16;
+        bf16x8 ah[2], al[2];
+        read_a_stage(aring + (i % 3) * (4 * BLK), lane, ah, al);
+        const char* b = lds + (i % 3) * (NT * LSTEP) + lane * 16;
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK + BLK);
+                const int tt = FLID_PK_EXP == 5 ? 0 : t;      // (timing experiment 5: one B fragment pair per step; 6: no MFMAs; 7: no A/B waits)
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + tt * LSTEP + st * 2 * BLK);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + tt * LSTEP + st * 2 * BLK + BLK);
+                if (FLID_PK_EXP == 6) { acc[t][0] += __builtin_bit_cast(float4, bh).x + __builtin_bit_cast(float4, bl).y + __builtin_bit_cast(float4, ah[st]).z; continue; }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], bh, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bl, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bh, acc[t], 0, 0, 0);
             }
-        if (more) split_a_stage(raw, K, i + 1, h, ah, al);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -340,12 +369,27 @@ bool gemm_pk_nt(int64_t M, int N, int K, const float* A, int64_t lda, const void
     if (K > KC) {
         const int nst = (K + 31) / 32;
         const uint4* Bp = reinterpret_cast<const uint4*>(packed);
-#define PK_L(NTV) gemm_pk_l_kernel<NTV><<<(unsigned)panels, 256, 2 * NTV * LSTEP, s>>>(A, lda, M, K, Bp, N, nst, C, ldc, bias, vec)
+        const float* zeros = zero_block();                  // chunks past K are copied from it
+        if (!zeros) return false;
+        // waves (32 rows each) per workgroup: the fewest of 4 / 5 / 6 whose row panels fit the chip's 256 CUs in ONE round (one
+        // workgroup per CU: 84 KiB of LDS for the weight's ring + 12 KiB per wave for its rows), else 6
+        int nwv = 4;
+        while (nwv < 6 && (M + 32 * nwv - 1) / (32 * nwv) > 256) ++nwv;
+        const unsigned grid = (unsigned)((M + 32 * nwv - 1) / (32 * nwv));
+#define PK_LW(NTV, NWVV) do { \
+            static bool attr_l = false;      /* (one per instantiation: every expansion has its own) */ \
+            if (!attr_l) { \
+                if (hipFuncSetAttribute((const void*)gemm_pk_l_kernel<NTV, NWVV>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * NTV * LSTEP + NWVV * 12 * BLK) != hipSuccess) { \
+                    (void)hipGetLastError(); return false; } \
+                attr_l = true; } \
+            gemm_pk_l_kernel<NTV, NWVV><<<grid, 64 * NWVV, 3 * NTV * LSTEP + NWVV * 12 * BLK, s>>>(A, lda, M, K, Bp, N, nst, C, ldc, bias, vec, zeros); } while (0)
+#define PK_L(NTV) do { if (nwv == 4) PK_LW(NTV, 4); else if (nwv == 5) PK_LW(NTV, 5); else PK_LW(NTV, 6); } while (0)
         switch (ntiles) {
             case 1: PK_L(1); break; case 2: PK_L(2); break; case 3: PK_L(3); break; case 4: PK_L(4); break;
             case 5: PK_L(5); break; case 6: PK_L(6); break; default: PK_L(7); break;
         }
 #undef PK_L
+#undef PK_LW
         return true;
     }
     // units per panel u: rounds of the grid over the chip's 512 workgroup slots x (tiles per unit + the prologue, which costs about
