@@ -35,7 +35,10 @@ def pack32(w, trans=False):
     return out
 
 
-for N, K in [(600, 200), (200, 200), (800, 200), (200, 800), (200, 496), (200, 600)]:
+SHAPES = [(600, 200), (200, 200), (800, 200), (200, 800), (200, 496), (200, 600)]
+if os.environ.get("PK_SHAPES"):                                      # e.g. PK_SHAPES=888x172,516x172
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["PK_SHAPES"].split(",")]
+for N, K in SHAPES:
     a = torch.randn(R, K, device=dev)
     w = torch.randn(N, K, device=dev) * 0.05
     b = torch.randn(N, device=dev)
