@@ -22,7 +22,7 @@
 // (78), x 200 x 200 31 (35.5); x 200 x 800 65 (82), x 200 x 600 51 (64), x 200 x 496 46 (57).  What bounds them: without the C stores the
 // 800-column product takes 50 us, with them 72-80 -- the 123 MB it writes are the floor (~4 TB/s); the deep form takes 37 us without its
 // MFMAs and 65 with them, on three different A paths (fragment-shaped loads to registers one stage ahead; the same by hand-counted inline-asm
-// loads two stages ahead; LDS-DMA of full lines two stages ahead): the matrix pipe's 28 us ADD to the memory time although the generated
+// loads two stages ahead; LDS-DMA of full lines two stages ahead, issued in front of or behind the stage's MFMAs): the matrix pipe's 28 us ADD to the memory time although the generated
 // code waits only for the stage it reads (vmcnt(10), no compiler-inserted vmcnt(0) in the loop) -- not understood; DESIGN.md section 9.
 #include <math.h>
 #include <stdlib.h>
