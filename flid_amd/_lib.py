@@ -168,6 +168,7 @@ SIGNATURES = {
     "tg_set_gemm_mode": (None, [C.c_int]),
     "tg_get_gemm_mode": (C.c_int, []),
     "tg_set_gemm_mode_thread": (None, [C.c_int]),
+    "tg_get_gemm_mode_thread": (C.c_int, []),
     "tg_gemm_f32_batched": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_void,
                                       c_i64, c_i64, C.c_int, c_void, C.c_int, C.c_int, c_void]),
     "tg_gemm_f32_batched2": (C.c_int, [C.c_int, C.c_int, c_i64, c_i64, c_i64, c_f32, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64,

@@ -583,3 +583,4 @@ extern "C" int tg_wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows,
 extern "C" void tg_set_gemm_mode(int mode) { g_gemm_mode = mode; }
 extern "C" int tg_get_gemm_mode(void) { return gemm_mode(); }
 extern "C" void tg_set_gemm_mode_thread(int mode) { t_gemm_mode = mode; }
+extern "C" int tg_get_gemm_mode_thread(void) { return t_gemm_mode; }

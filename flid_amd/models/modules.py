@@ -22,12 +22,13 @@ class _exact_products:
     def __enter__(self):
         if self.on:
             from .._lib import lib
+            self.prev = lib().tg_get_gemm_mode_thread()      # (scopes nest: the enclosing override comes back on exit)
             lib().tg_set_gemm_mode_thread(0)        # this thread's calls only: other issuing threads keep the process-wide mode
 
     def __exit__(self, *exc):
         if self.on:
             from .._lib import lib
-            lib().tg_set_gemm_mode_thread(-1)
+            lib().tg_set_gemm_mode_thread(self.prev)
         return False
 
 

@@ -392,6 +392,7 @@ int tg_get_gemm_mode(void);
 /* override for the CALLING THREAD only (mode as tg_set_gemm_mode; -1 = follow the process-wide mode): per-call precision without
  * touching what other issuing threads see */
 void tg_set_gemm_mode_thread(int mode);
+int tg_get_gemm_mode_thread(void);      /* the calling thread's override as set (-1 = none): save / restore around a scoped override */
 
 /* strided-batched form: problem b uses A + b*stride_a, B + b*stride_b, C + b*stride_c (bias + b*N).  One launch for the
  * per-head products of models/modules.py:186-197 (head h = column / row block h of the projection weights). */
