@@ -214,38 +214,34 @@ __global__ void __launch_bounds__(256) gemm_pk_s_kernel(const float* __restrict_
 // the 32-deep slice of ALL tiles of the pre-split weight (NT x 4 KiB), both by LDS-DMA into three-buffer rings.
 constexpr int LSTEP = 4 * BLK;                // one tile's share of a stage: 2 steps x (hi, lo)
 
-// LDS-DMA of one stage of the deep form: NT x 4 blocks of 1 KiB over NWV waves, every wave the same number of copies (the surplus ones
-// repeat the last block with identical bytes) so that the counted waits below hold for every wave
+// LDS-DMA of one stage of the deep form.  The per-lane parts of every copy's address are 32-bit byte offsets computed ONCE (voff_b: this
+// wave's blocks of the stage slice -- NT x 4 blocks of 1 KiB dealt over NWV waves, every wave the same number of copies, the surplus ones
+// repeating the last block with identical bytes so that the counted waits hold for every wave; voff_a: row and swizzled chunk of each of the
+// four A copies); a stage then only moves two wave-uniform base pointers (scalar ALU) -- computed per copy, the 64-bit address arithmetic
+// was ~100 vector instructions per stage in front of the MFMAs, on SIMDs that carry one or two waves.
+// A: 32 rows x 128 bytes of this wave's rows = four copies of 1 KiB, each lane one 16-byte chunk of a full 128-byte line
+// (fragment-shaped loads straight to registers -- 64 scattered 16-byte pieces per instruction -- are address-processing bound).  The LDS
+// image is row-major with the eight 16-byte slots of a row permuted through the SOURCE address (slot p of row r holds chunk p ^ (r & 7)),
+// so that the fragment reads below are conflict-free.  In the last stage a chunk past K comes from a block of zeros (TAIL).
 template <int NT, int NWV>
-__device__ __forceinline__ void issue_stage_l(const uint4* __restrict__ Bp, int64_t stage, char* lds, int buf, int wave, int lane) {
+__device__ __forceinline__ void issue_stage_l(const char* __restrict__ bstage, const uint32_t (&voff_b)[(NT * 4 + NWV - 1) / NWV], char* ldsb, int wave) {
     constexpr int PER = (NT * 4 + NWV - 1) / NWV;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         int blk = wave + NWV * i;
         if (blk > NT * 4 - 1) blk = NT * 4 - 1;
-        const uint4* g = Bp + (stage * (NT * 4) + blk) * 64 + lane;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(lds + buf * (NT * LSTEP) + blk * BLK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bstage + voff_b[i]),
+                                         (__attribute__((address_space(3))) void*)(ldsb + blk * BLK), 16, 0, 0);
     }
 }
-
-// A rows of one 32-deep stage by LDS-DMA into THIS WAVE's region: 32 rows x 128 bytes = four copies of 1 KiB, each lane one 16-byte chunk
-// of a full 128-byte line (fragment-shaped loads straight to registers -- 64 scattered 16-byte pieces per instruction -- ran the deep
-// form at 1.9 TB/s of A traffic: address-processing bound).  The LDS image is row-major with the eight 16-byte slots of a row permuted
-// through the SOURCE address (slot p of row r holds chunk p ^ (r & 7)), so that the fragment reads below are conflict-free.  A chunk
-// past K comes from a block of zeros.
-__device__ __forceinline__ void issue_a_stage(const float* __restrict__ A, int64_t lda, int64_t M, int K, int64_t wrow0, int stage, char* region,
-                                              const float* __restrict__ zeros, int lane) {
+template <bool TAIL>
+__device__ __forceinline__ void issue_a_stage(const char* __restrict__ astage, const uint32_t (&voff_a)[4], int kleft, int chunk, char* region,
+                                              const float* __restrict__ zeros) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int64_t row = wrow0 + 8 * j + (lane >> 3);
-        if (row > M - 1) row = M - 1;
-        const int rl = 8 * j + (lane >> 3);
-        const int c = (lane & 7) ^ (rl & 7);
-        const int k = 32 * stage + 4 * c;
-        const float* g = k < K ? A + row * lda + k : zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(region + j * BLK), 16, 0, 0);
+        const char* g = astage + voff_a[j];
+        if (TAIL && 4 * chunk >= kleft) g = reinterpret_cast<const char*>(zeros);      // (chunk = this lane's swizzled chunk of row 8 j + ..: see the caller)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(region + j * BLK), 16, 0, 0);
     }
 }
 // lane (r = l & 31, h = l >> 5), step st: k = 16 st + 8 h + 0..7 = chunks 4 st + 2 h and + 1 of row r
@@ -271,30 +267,51 @@ __global__ void __launch_bounds__(64 * NWV, 1) gemm_pk_l_kernel(const float* __r
                                                                 int N, int nst, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int vec,
                                                                 const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 3 x NT x 4 KiB of B, then NWV x 3 x 4 KiB of A
-    constexpr int OPS = (NT * 4 + NWV - 1) / NWV + 4;               // vector-memory operations a wave issues per stage
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    constexpr int PER = (NT * 4 + NWV - 1) / NWV;
+    constexpr int OPS = PER + 4;                                    // vector-memory operations a wave issues per stage
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // (scalar: LDS destinations and block numbers stay on the scalar ALU)
     const int64_t row0 = (int64_t)blockIdx.x * (32 * NWV) + wave * 32;
     char* aring = lds + 3 * NT * LSTEP + wave * (3 * 4 * BLK);
+    // per-lane address parts, once
+    uint32_t voff_b[PER], voff_a[4];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int blk = wave + NWV * i;
+        if (blk > NT * 4 - 1) blk = NT * 4 - 1;
+        voff_b[i] = (uint32_t)((blk * 64 + lane) * 16);
+    }
+    // A copy j covers rows 8 j .. 8 j + 7 of the wave's 32; every one of them has (row & 7) = lane >> 3, so the swizzled chunk is the same
+    // for the four copies
+    const int chunk = (lane & 7) ^ ((lane >> 3) & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int64_t row = row0 + 8 * j + (lane >> 3);
+        if (row > M - 1) row = M - 1;
+        voff_a[j] = (uint32_t)((row * lda + 4 * chunk) * 4);        // (the launcher checks M lda < 2^30)
+    }
+    const char* a0 = reinterpret_cast<const char*>(A);
+    const char* b0 = reinterpret_cast<const char*>(Bp);
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    issue_stage_l<NT, NWV>(Bp, 0, lds, 0, wave, lane);
-    issue_a_stage(A, lda, M, K, row0, 0, aring, zeros, lane);
-    if (nst > 1) {
-        issue_stage_l<NT, NWV>(Bp, 1, lds, 1, wave, lane);
-        issue_a_stage(A, lda, M, K, row0, 1, aring + 4 * BLK, zeros, lane);
-    }
+    const bool ktail = (K & 31) != 0;                               // only the last stage can hold chunks past K
+    auto issue = [&](int st) {
+        issue_stage_l<NT, NWV>(b0 + (int64_t)st * (NT * LSTEP), voff_b, lds + (st % 3) * (NT * LSTEP), wave);
+        char* region = aring + (st % 3) * (4 * BLK);
+        if (ktail && st == nst - 1) issue_a_stage<true>(a0 + (int64_t)st * 128, voff_a, K - 32 * st, chunk, region, zeros);
+        else issue_a_stage<false>(a0 + (int64_t)st * 128, voff_a, 32, chunk, region, zeros);
+    };
+    issue(0);
+    if (nst > 1) issue(1);
     for (int i = 0; i < nst; ++i) {
         if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(OPS) : "memory");      // everything but stage i + 1's copies has landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // stage i has landed for every wave; every wave is done reading stage i - 1
         asm volatile("" ::: "memory");
-        if (i + 2 < nst) {
-            issue_stage_l<NT, NWV>(Bp, i + 2, lds, (i + 2) % 3, wave, lane);
-            issue_a_stage(A, lda, M, K, row0, i + 2, aring + ((i + 2) % 3) * (4 * BLK), zeros, lane);
-        }
+        if (i + 2 < nst) issue(i + 2);
         bf16x8 ah[2], al[2];
         read_a_stage(aring + (i % 3) * (4 * BLK), lane, ah, al);
         const char* b = lds + (i % 3) * (NT * LSTEP) + lane * 16;
@@ -302,10 +319,8 @@ __global__ void __launch_bounds__(64 * NWV, 1) gemm_pk_l_kernel(const float* __r
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int tt = FLID_PK_EXP == 5 ? 0 : t;      // (timing experiment 5: one B fragment pair per step; 6: no MFMAs; 7: no A/B waits)
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + tt * LSTEP + st * 2 * BLK);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + tt * LSTEP + st * 2 * BLK + BLK);
-                if (FLID_PK_EXP == 6) { acc[t][0] += __builtin_bit_cast(float4, bh).x + __builtin_bit_cast(float4, bl).y + __builtin_bit_cast(float4, ah[st]).z; continue; }
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK + BLK);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], bh, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bl, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bh, acc[t], 0, 0, 0);
@@ -367,6 +382,7 @@ bool gemm_pk_nt(int64_t M, int N, int K, const float* A, int64_t lda, const void
     const int vec = N % 4 == 0 && ldc % 4 == 0 && al16(C) && (!bias || al16(bias));
     ProfScope prof("gemm", 2.0 * M * N * K, s);
     if (K > KC) {
+        if (M * lda >= ((int64_t)1 << 30)) return false;   // (32-bit byte offsets of the A copies)
         const int nst = (K + 31) / 32;
         const uint4* Bp = reinterpret_cast<const uint4*>(packed);
         const float* zeros = zero_block();                  // chunks past K are copied from it
