@@ -486,6 +486,7 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
     const int d = st->d, C = c.channel, T = c.dt_dim, H = c.heads, ws = st->ws, wd = st->wd, S = ws + wd, Kp = st->Kp;
     const int64_t B = st->B, n = B * S;
     const float p = st->p;
+    const int64_t parts = tg_rowop_parts(n);           // slab rows THIS batch's row-wise launches write (the regions are sized for the largest batch)
     if (hipMemsetAsync(st->gblock, 0, sizeof(float) * (size_t)st->g_floats, s) != hipSuccess) { (void)hipGetLastError(); return TG_EHIP; }
     // ---- output layer, per-side means ------------------------------------------------------------------------------------------------
     const int io = P_BLOCK0 + B_COUNT * c.layers;
@@ -535,9 +536,9 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
         {
             float* g4[4] = {G(st, blk_i(l, B_LN1_G)), G(st, blk_i(l, B_LN1_B)), G(st, blk_i(l, B_LN2_G)), G(st, blk_i(l, B_LN2_B))};
             if (g4[1] == g4[0] + d && g4[2] == g4[1] + d && g4[3] == g4[2] + d) {
-                TG_TRY(tg_colsum(st->part, 4 * (int64_t)d, st->parts, 4 * d, g4[0], 1, stream));
+                TG_TRY(tg_colsum(st->part, 4 * (int64_t)d, parts, 4 * d, g4[0], 1, stream));
             } else {
-                for (int i = 0; i < 4; ++i) TG_TRY(tg_colsum(st->part + i * d, 4 * (int64_t)d, st->parts, d, g4[i], 1, stream));
+                for (int i = 0; i < 4; ++i) TG_TRY(tg_colsum(st->part + i * d, 4 * (int64_t)d, parts, d, g4[i], 1, stream));
             }
         }
         std::swap(dcur, dnext);
@@ -557,10 +558,10 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
     }
     TG_TRY(tg_time_encode_bwd(st->dtv, st->mask, n, P(st, P_TE_W), P(st, P_TE_B), T, st->d_tf, st->te_part, stream));
     if (G(st, P_TE_B) == G(st, P_TE_W) + T) {
-        TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, st->parts, 2 * T, G(st, P_TE_W), 1, stream));
+        TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, parts, 2 * T, G(st, P_TE_W), 1, stream));
     } else {
-        TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, st->parts, T, G(st, P_TE_W), 1, stream));
-        TG_TRY(tg_colsum(st->te_part + T, 2 * (int64_t)T, st->parts, T, G(st, P_TE_B), 1, stream));
+        TG_TRY(tg_colsum(st->te_part, 2 * (int64_t)T, parts, T, G(st, P_TE_W), 1, stream));
+        TG_TRY(tg_colsum(st->te_part + T, 2 * (int64_t)T, parts, T, G(st, P_TE_B), 1, stream));
     }
     TG_TRY(tg_gemm_f32(0, 0, n, C, C, 1.f, st->d_cf, Cp, P(st, P_CO_W2), C, st->d_hs, C, nullptr, 0, 0, stream));
     dyg_cooc_bwd_kernel<<<(unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64, 512)), 256, 0, s>>>(st->d_hs, st->cnt, n, C, P(st, P_CO_W0), P(st, P_CO_B0),

@@ -337,3 +337,41 @@ def test_dygformer_native_step_refuses_uncovered_shapes():
     with pytest.raises(RuntimeError):
         DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, 100, 50, 1, 2, 2, 0.1, 32, "cuda:0").to("cuda:0").train_step(
             data.src_node_ids[:4], data.dst_node_ids[:4], data.node_interact_times[:4], None)
+
+
+def test_dygformer_native_step_on_empty_and_short_histories():
+    """the stream's first edges: no node has a history (both sides one position wide: the node itself), then a few edges later (ragged,
+    short windows) -- native forward / backward against the autograd path"""
+    from flid_amd.synth import reddit_like
+    from flid_amd.models.DyGFormer import DyGFormer
+    from flid_amd.utils.utils import get_neighbor_sampler
+    data = reddit_like(num_edges=3000, num_users=300, num_items=40, seed=7)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    p = O.seeded_like(O.dyg_shapes(172, 172, 100, 50, 1, 2), 17, 0.05)
+    ma = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, 100, 50, 1, 2, 2, 0.0, 32, "cuda:0").to("cuda:0").train()
+    mn = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, 100, 50, 1, 2, 2, 0.0, 32, "cuda:0").to("cuda:0").train()
+    ma.load_state_dict(p)
+    mn.load_state_dict(p)
+    mn.flatten_parameters()
+    st = mn.enable_native_step(64)
+    t0 = float(data.node_interact_times[0])
+    cases = [(data.src_node_ids[:5], data.dst_node_ids[:5], np.full(5, t0)),           # nothing strictly before the first time stamp
+             (data.src_node_ids[40:104], data.dst_node_ids[40:104], data.node_interact_times[40:104]),
+             (data.src_node_ids[2990:2991], data.dst_node_ids[2990:2991], data.node_interact_times[2990:2991])]   # one edge, long histories
+    for src, dst, t in cases:
+        B = len(src)
+        s, d = ma.compute_src_dst_node_temporal_embeddings(src, dst, t)
+        ea = torch.cat([s, d])
+        torch.manual_seed(B)
+        r = torch.randn(2 * B, 172, device="cuda:0")
+        for q in ma.parameters():
+            q.grad = None
+        (ea * r).sum().backward()
+        en = st.forward(src, dst, t)
+        assert float((ea.detach() - en).abs().max()) <= TOL, B
+        st.backward(r.contiguous())
+        gn = _flat_grads(mn, st)
+        for k_, q in ma.named_parameters():
+            ga = q.grad.cpu().numpy()
+            big = max(1e-6, float(np.abs(ga).max()))
+            assert float(np.abs(gn[k_] - ga).max()) <= 5e-4 * big + 1e-6, (B, k_, float(np.abs(gn[k_] - ga).max()), big)
