@@ -789,3 +789,37 @@ def test_native_step_slots_errors_and_prefetch_order():
             assert float((flat.grad - ref[1]).abs().max()) <= 2e-6 * float(ref[1].abs().max())
     for j in jobs:
         st.release(j)
+
+
+def test_native_step_small_batch_after_large_one():
+    """one native object, a full batch and then a much smaller one (every slab / scratch region is sized for the largest batch: what a
+    smaller batch's launches do not write must not be read): the small batch's embeddings and gradient == the Python engine's on a fresh
+    model with the same weights"""
+    from flid_amd import engine, ops
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.utils.utils import get_neighbor_sampler
+    g = load_golden("tgat_L2_K20")
+    dev = torch.device("cuda:0")
+    dn, de, dt, _, k = [int(v) for v in g["dims"]]
+    B = len(g["bs"])
+    small = slice(0, max(1, B // 5))
+    res = []
+    for native in (False, True):
+        smp = get_neighbor_sampler(_Data(g), "recent", seed=0)
+        torch.manual_seed(3)
+        m = TGAT(g["node_feat"], g["edge_feat"], smp, dt, 2, 2, 0.0, "cuda:0").to(dev).train()
+        flat = m.flatten_parameters()
+        if native:
+            m.enable_native_step(2 * B, k)
+        rec = []
+        for sl in (slice(0, B), small):
+            n = 2 * len(g["bs"][sl])
+            w = torch.from_numpy(np.random.RandomState(n).standard_normal((n, dn)).astype(np.float32)).to(dev)
+            flat.grad = None
+            job = m.prepare_batch_finish(m.prepare_batch_begin(g["bs"][sl], g["bd"][sl], g["bt"][sl], k))
+            emb, loss = m.train_step(job, lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w), k)
+            rec.append((emb.clone(), flat.grad.clone()))
+        res.append(rec)
+    for (ea, ga), (en, gn) in zip(res[0], res[1]):
+        assert torch.equal(ea, en), float((ea - en).abs().max())
+        assert float((ga - gn).abs().max()) <= 2e-6 * float(ga.abs().max())

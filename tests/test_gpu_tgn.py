@@ -422,3 +422,44 @@ def test_prepare_batch_rejects_ids_beyond_the_graph_and_counts_history_on_the_ho
     times = data.node_interact_times[2000:2600]
     want = np.array([O.history_end(adj, int(v), t) for v, t in zip(ids, times)])
     assert np.array_equal(sampler.graph.count_before_host(ids, times), want)
+
+
+def test_tgn_native_step_ragged_batch_sizes():
+    """the same two paths over chronological batches of DIFFERENT sizes through one native object (12, 3, 12, 5, 1, 9 edges: every slab and
+    scratch region is sized for the largest; a smaller batch must not read what its launches did not write)"""
+    from flid_amd import ops
+    from flid_amd.optim import FlatAdam
+    g = load_golden("tgn_small")
+    sizes = [12, 3, 12, 5, 1, 9]
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    assert bounds[-1] <= len(g["src"])
+    dn = g["node_feat"].shape[1]
+    res = []
+    for native in (False, True):
+        m, p, k = _model(g)
+        flat = m.flatten_parameters()
+        opt = FlatAdam([flat], lr=1e-7)
+        m.memory_bank.__init_memory_bank__()
+        if native:
+            m.enable_native_step(max(sizes), k)
+        rec = []
+        for b in range(len(sizes)):
+            sl = slice(int(bounds[b]), int(bounds[b + 1]))
+            w = torch.from_numpy(np.random.RandomState(b).standard_normal((2 * sizes[b], dn)).astype(np.float32)).cuda()
+            loss_fn = lambda e, w=w: (ops.weighted_sum(e, w, 0.5), 0.5 * w)
+            opt.zero_grad(set_to_none=True)
+            job = m.prepare_batch_finish(m.prepare_batch_begin(g["src"][sl], g["dst"][sl], g["t"][sl], k, edge_ids=g["eid"][sl]))
+            if native:
+                emb, loss = m.train_step(job, g["eid"][sl], loss_fn, k, optimizer=opt)
+            else:
+                emb, loss = m.train_step(job, g["eid"][sl], loss_fn, k)
+                opt.step()
+            bank = m.memory_bank
+            rec.append((emb.clone(), float(loss), flat.grad.clone(), bank.node_memories.data.clone(), bank._msg.clone(), bank._has.copy()))
+        res.append(rec)
+    for b, (x, y) in enumerate(zip(*res)):
+        assert float((x[0] - y[0]).abs().max()) <= 1e-5, (b, float((x[0] - y[0]).abs().max()))
+        assert abs(x[1] - y[1]) <= 1e-5 * max(1.0, abs(x[1])), b
+        scale = max(1.0, float(x[2].abs().max()))
+        assert float((x[2] - y[2]).abs().max()) <= 2e-5 * scale, (b, float((x[2] - y[2]).abs().max()), scale)
+        assert torch.allclose(x[3], y[3], atol=1e-5) and torch.allclose(x[4], y[4], atol=1e-5) and np.array_equal(x[5], y[5]), b
