@@ -649,6 +649,9 @@ def bench_memory_or_sequence_model(args):
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.gemm_mode is not None:
+        from flid_amd._lib import lib as _l
+        _l().tg_set_gemm_mode(args.gemm_mode)
     assert args.workload == "reddit", "tgn / dygformer are benchmarked on the Reddit-shape graph (BASELINE configs[2], [3])"
     data = reddit_like(seed=0)
     n_train = int(0.7 * data.num_interactions)
@@ -900,7 +903,7 @@ def bench_memory_or_sequence_model(args):
         metric = "edges/sec (temporal-embedding fwd+bwd), %s Reddit, 1/2/4/8 MI355X" % {"dygformer": "DyGFormer", "tcl": "TCL", "graphmixer": "GraphMixer"}[args.model]
     out = {"metric": metric, "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": DTYPE, "data": "synthetic",
+           "dtype": DTYPE if args.gemm_mode != 0 else "f32 (exact f32-input MFMA products)", "data": "synthetic",
            "config": {"workload": f"Reddit-shape synthetic (10984 nodes, 672447 edges, 172-d edge feats) + {desc}, batch 600 edges/GPU, "
                                   f"dropout {args.dropout:.2f}, host numpy ids per call, fwd+bwd+Adam ({('fused step, native stepper' if native else 'fused step') if fused else 'autograd'}{', neg-then-pos warm-up step' if tgn_lp else ''})",
                       "batch_per_gpu": BATCH, "global_batch": BATCH * wsim, "parallelism": f"dp{world}"},

@@ -13,11 +13,13 @@ python3 bench.py --gemm-mode 0 --no-cpu-baseline > $O/r04_headline_bench_exact_f
 python3 bench.py --python-step --no-cpu-baseline --no-breakdown --host-profile > $O/r04_headline_bench_python_step.json 2> $O/pystep.err
 python3 bench.py --model tgn > $O/r04_tgn_bench.json 2> $O/tgn.err
 python3 bench.py --model tgn --mode lp > $O/r04_tgn_lp_bench.json 2> $O/tgn_lp.err
+python3 bench.py --model tgn --gemm-mode 0 --no-cpu-baseline > $O/r04_tgn_bench_exact_f32.json 2> $O/tgn_exact.err
 python3 bench.py --model tgn --simulate-world 8 --no-cpu-baseline > $O/r04_tgn_simulate_world8_bench.json 2> $O/tgn_sim.err
 rocprofv3 --kernel-trace -d $O/kt_tgn -o tgn -- python3 bench.py --model tgn --steps 40 --warmup 10 --no-cpu-baseline > /dev/null 2> $O/kt_tgn.err
 python3 tools/rocpd_stats.py $O/kt_tgn/tgn_results.db --csv $O/r04_tgn_kernel_stats.csv --timeline > $O/r04_tgn_timeline.txt 2>&1
 python3 bench.py --model dygformer > $O/r04_dygformer_bench.json 2> $O/dyg.err
 python3 bench.py --model dygformer --python-step --no-cpu-baseline > $O/r04_dygformer_bench_autograd.json 2> $O/dyg_py.err
+python3 bench.py --model dygformer --gemm-mode 0 --no-cpu-baseline > $O/r04_dygformer_bench_exact_f32.json 2> $O/dyg_exact.err
 rocprofv3 --kernel-trace -d $O/kt_dyg -o dyg -- python3 bench.py --model dygformer --steps 20 --warmup 6 --no-cpu-baseline --no-breakdown > /dev/null 2> $O/kt_dyg.err
 python3 tools/rocpd_stats.py $O/kt_dyg/dyg_results.db --csv $O/r04_dygformer_kernel_stats.csv --timeline > $O/r04_dygformer_timeline.txt 2>&1
 python3 tools/dyg_host_prof.py > $O/r04_dygformer_host_issue.txt 2> $O/dyg_host.err
