@@ -164,3 +164,30 @@ def test_dygformer_b600_matches_reference():
     rr = torch.from_numpy(r).cuda()
     ((s * rr[0]).sum() + (d * rr[1]).sum()).backward()
     assert_grads_match(g, {k_: v.grad.cpu().numpy() for k_, v in m.named_parameters()}, atol=1e-4, rtol=1e-3)
+
+
+def test_dygformer_b600_native_step_matches_reference():
+    """the same fixture through the native step (tg_dyg.hip: 19 of its 22 products against pre-split weights, tg_gemm_pk.hip): the
+    reference's own embeddings and gradients at B = 600 in the default product mode"""
+    from flid_amd.models.DyGFormer import DyGFormer
+    from flid_amd.utils.utils import get_neighbor_sampler
+    g = load_golden("dyg_B600")
+    data, p, (bs, bd, bt), r = fullsize.dyg_case(g)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = DyGFormer(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, channel_embedding_dim=50, patch_size=1,
+                  num_layers=2, num_heads=2, dropout=0.0, max_input_sequence_length=32, device="cuda:0")
+    m.load_state_dict(p)
+    m = m.to("cuda:0").train()
+    flat = m.flatten_parameters()
+    st = m.enable_native_step(len(bs))
+    B = len(bs)
+    emb = st.forward(bs, bd, bt)
+    np.testing.assert_allclose(emb[:B].cpu().numpy(), g["s_emb"], atol=TOL)
+    np.testing.assert_allclose(emb[B:].cpu().numpy(), g["d_emb"], atol=TOL)
+    st.backward(torch.from_numpy(r).cuda().reshape(2 * B, -1).contiguous())
+    base = flat.data_ptr()
+    grads = {}
+    for k_, q in m.named_parameters():
+        o = (q.data_ptr() - base) // 4
+        grads[k_] = st.grad[o:o + q.numel()].view(q.shape).cpu().numpy()
+    assert_grads_match(g, grads, atol=1e-4, rtol=1e-3)
