@@ -41,6 +41,15 @@ using tgs::split4;
 #ifndef FLID_PK_EXP
 #define FLID_PK_EXP 0
 #endif
+#ifndef FLID_PK_STAMPS
+#define FLID_PK_STAMPS 0   // 1: wave 0 of workgroup 0 of the deep form records cycle counts per loop phase (tools/pk_stamps.py)
+#endif
+#if FLID_PK_STAMPS
+__device__ unsigned long long g_pk_stamps[8];
+#define PK_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); g_pk_stamps[k] += t_ - t_last; t_last = t_; } } while (0)
+#else
+#define PK_STAMP(k) do {} while (0)
+#endif
 constexpr int PKS = 13;                       // 16-deep steps of one K chunk
 constexpr int KC = 16 * PKS;                  // 208
 constexpr int BLK = 1024;                     // one (step, plane) fragment block: 64 lanes x 8 bf16
@@ -117,13 +126,20 @@ __device__ __forceinline__ void load_a(const float* __restrict__ arow, int K, in
 
 __device__ __forceinline__ void mma_stage(const char* __restrict__ stage, int lane, const bf16x8 (&ah)[PKS], const bf16x8 (&al)[PKS], f32x16& acc) {
     const char* b = stage + lane * 16;
+    // the tile's 26 fragment reads in front of its 39 MFMAs (a read pair in front of every three MFMAs exposed one LDS round trip each)
+    bf16x8 bh[PKS], bl[PKS];
 #pragma unroll
     for (int s = 0; s < PKS; ++s) {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + s * 2 * BLK);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + s * 2 * BLK + BLK);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh, acc, 0, 0, 0);
+        bh[s] = *reinterpret_cast<const bf16x8*>(b + s * 2 * BLK);
+        bl[s] = *reinterpret_cast<const bf16x8*>(b + s * 2 * BLK + BLK);
+    }
+#pragma unroll
+    for (int s = 0; s < PKS; ++s) {
+        // (one accumulation chain: three chains -- one per split term, summed at the end -- issue faster in isolation, 33 against 52 cycles
+        // per MFMA in tools/micro/mfma_rate.hip, but their 32 extra registers cost the kernel its second workgroup per CU: 68 -> 113 us)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[s], acc, 0, 0, 0);
     }
 }
 
@@ -306,25 +322,52 @@ __global__ void __launch_bounds__(64 * NWV, 1) gemm_pk_l_kernel(const float* __r
     };
     issue(0);
     if (nst > 1) issue(1);
+#if FLID_PK_STAMPS
+    unsigned long long t_last = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int q = 0; q < 8; ++q) g_pk_stamps[q] = 0;
+#endif
     for (int i = 0; i < nst; ++i) {
+        PK_STAMP(0);
         if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(OPS) : "memory");      // everything but stage i + 1's copies has landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PK_STAMP(1);
         __builtin_amdgcn_s_barrier();                      // stage i has landed for every wave; every wave is done reading stage i - 1
         asm volatile("" ::: "memory");
-        if (i + 2 < nst) issue(i + 2);
+        PK_STAMP(2);
+        // (the A fragment reads in front of the copies' issue: behind 11-14 LDS-DMA instructions they took ~1 000 cycles per stage)
         bf16x8 ah[2], al[2];
         read_a_stage(aring + (i % 3) * (4 * BLK), lane, ah, al);
+#if FLID_PK_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        PK_STAMP(3);
+        if (i + 2 < nst) issue(i + 2);
+        PK_STAMP(4);
         const char* b = lds + (i % 3) * (NT * LSTEP) + lane * 16;
+        // all fragment reads of a step in front of its MFMAs (read-then-multiply per tile left one LDS round trip exposed in front of
+        // every three MFMAs -- 14 per stage, with one wave per SIMD and nothing to hide them: the loop ran at a third of the matrix rate
+        // with its copies switched off)
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 bh[NT], bl[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK + BLK);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bh, acc[t], 0, 0, 0);
+                if (FLID_PK_EXP == 10) { bh[t] = al[st]; bl[t] = ah[st]; continue; }     // (timing experiment: no B fragment reads)
+                bh[t] = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK);
+                bl[t] = *reinterpret_cast<const bf16x8*>(b + t * LSTEP + st * 2 * BLK + BLK);
             }
+            // term-major: consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bh[t], acc[t], 0, 0, 0);
+        }
+#if FLID_PK_STAMPS
+        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[NT - 1][15]) : "memory");      // (the MFMAs' results are needed here)
+#endif
+        PK_STAMP(5);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -425,6 +468,9 @@ bool gemm_pk_nt(int64_t M, int N, int K, const float* A, int64_t lda, const void
 
 }  // namespace tg
 
+#if FLID_PK_STAMPS
+extern "C" int tg_pk_stamps_read(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pk_stamps), 64) == hipSuccess ? 0 : -2; }
+#endif
 extern "C" int64_t tg_packed32_floats(int N, int K) { return tg::packed32_floats(N, K); }
 
 extern "C" int tg_pack32_weights(int njobs, const tg_pack32_job* jobs, void* stream) { return tg::pack32_weights(njobs, jobs, (hipStream_t)stream); }
