@@ -136,7 +136,8 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ stage, int la
 #pragma unroll
     for (int s = 0; s < PKS; ++s) {
         // (one accumulation chain: three chains -- one per split term, summed at the end -- issue faster in isolation, 33 against 52 cycles
-        // per MFMA in tools/micro/mfma_rate.hip, but their 32 extra registers cost the kernel its second workgroup per CU: 68 -> 113 us)
+        // per MFMA in tools/micro/mfma_rate.hip, but their 32 extra registers cost the kernel its second workgroup per CU: 68 -> 113 us;
+        // two chains, which fit: 72 -> 74 us -- the chain is not what this kernel waits for)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[s], acc, 0, 0, 0);
