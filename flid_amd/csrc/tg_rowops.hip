@@ -4,6 +4,7 @@
 //   tg_add_layernorm_*    <- models/modules.py:238        layer_norm(output + residual), eps 1e-5
 //   tg_time_encode        <- models/modules.py:28-40      cos(w t + b)
 #include <math.h>
+#include <stdlib.h>
 
 #include "tg_common.h"
 
@@ -537,7 +538,10 @@ extern "C" int tg_colsum(const float* d_x, int64_t ld, int64_t n, int cols, floa
     if (!accumulate) TG_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(float) * cols, s));
     if (n == 0) return TG_OK;
     const int col_groups = (cols + 63) / 64;
-    const int64_t max_slices = std::max<int64_t>(64, std::min<int64_t>(512, 2048 / col_groups));
+    // ~512 workgroups in all: every slice ends in one float atomic per column, and 512 slices adding into the same 64 addresses were most
+    // of the launch (the column sums of a 38 400 x 200 operand: 21 us)
+    static const int tune = (getenv("FLID_GEMM_TUNE") && getenv("FLID_COLSUM_WGS")) ? atoi(getenv("FLID_COLSUM_WGS")) : 0;
+    const int64_t max_slices = std::max<int64_t>(16, std::min<int64_t>(512, (tune > 0 ? tune : 512) / col_groups));
     const int slices = (int)std::min<int64_t>(max_slices, std::max<int64_t>(1, n / 32));
     colsum_atomic_kernel<<<dim3(col_groups, slices), 256, 0, s>>>(d_x, ld, n, cols, d_out);
     return tg::launch_status("colsum_atomic_kernel");
