@@ -50,7 +50,7 @@ def main():
          "one rank of 8: its 600-edge shard embedded, the replicated state advanced with all 4 800 edges — the extra cost against the line above stays "
          "below the 15 % at which VERDICT r03 #7 asked for a sharded advance"),
         ("DyGFormer (config 4), native step", "**%s** (150–158 k, 3.80–3.99 ms)" % kv(dyg),
-         "autograd path of the same build: %s; `--gemm-mode 0` (exact fp32 products): %s.  GPU-bound (76 launches back to back, host issues a step in 0.40 ms: "
+         "autograd path of the same build: %s; `--gemm-mode 0` (exact fp32 products): %s.  GPU-bound (69 launches back to back, host issues a step in 0.40 ms: "
          "`profiles/r04_dygformer_timeline.txt`, `_host_issue.txt`): products 0.85 ms (19 of 22 against pre-split weights, `tg_gemm_pk.hip`), weight gradients 0.40, "
          "attention core 0.38, element-wise passes 0.55"
          % (kv(load("r04_dygformer_bench_autograd.json")), kv(load("r04_dygformer_bench_exact_f32.json")))),
