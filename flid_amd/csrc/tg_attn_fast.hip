@@ -45,52 +45,62 @@ __device__ __forceinline__ void st4(float* __restrict__ p, const float (&v)[4]) 
 }
 __device__ __forceinline__ void zero4(float (&v)[4]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
 
-// which 16-byte chunks of a neighbor row z = [node row | edge row] this lane owns, and where they come from
+// Lane l owns chunk l (16 bytes) of the node row AND chunk l of the edge row of every neighbor: each of the two loads of a slot then
+// has ONE wave-uniform base (a scalar register pair) plus the lane's constant offset -- no per-lane pointer select, no 64-bit vector
+// adds.  Rows of up to 64 chunks (256 floats) each; a lane past the row's end re-reads chunk 0: real, finite data that only ever meets
+// a zero u / dagg in that lane and is never stored (a predicated load cost six instructions of mask handling and zero fill).
 struct LaneMap {
-    bool has[2];        // chunk slot i (chunk index lane + 64 i) exists
-    bool node[2];       // ... and lies in the node row (else the edge row)
-    int col[2];         // first column inside its table row
-    int ucol[2];        // first column inside u / agg / du (feature part)
+    bool has[2];        // this lane owns a chunk of the node row [0] / edge row [1]
+    int col[2];         // its first column inside the table row (0 when it owns none)
+    int ucol[2];        // first column inside u / agg / du
 };
 __device__ __forceinline__ LaneMap lane_map(const tg_attn_desc& a, int lane) {
     LaneMap m;
-    const int nch = (a.dn + a.de) >> 2, ndn = a.dn >> 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = lane + kWave * i;
-        m.has[i] = c < nch;
-        m.node[i] = c < ndn;
-        m.col[i] = (m.node[i] ? c : c - ndn) * 4;
-        m.ucol[i] = c * 4;
-    }
+    m.has[0] = 4 * lane < a.dn;
+    m.has[1] = 4 * lane < a.de;
+    m.col[0] = m.has[0] ? 4 * lane : 0;
+    m.col[1] = m.has[1] ? 4 * lane : 0;
+    m.ucol[0] = 4 * lane;
+    m.ucol[1] = a.dn + 4 * lane;
     return m;
 }
 
-__device__ __forceinline__ void issue_row(const tg_attn_desc& a, const LaneMap& m, bool live, int64_t fi, int64_t ei, float (&z)[2][4]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (live && m.has[i]) {
-            const float* p = m.node[i] ? a.d_feat + fi * a.feat_ld + m.col[i] : a.d_edge + ei * a.edge_ld + m.col[i];
-            ld4(p, z[i]);
-        } else {
-            zero4(z[i]);
-        }
-    }
+__device__ __forceinline__ void issue_row(const tg_attn_desc& a, const LaneMap& m, int64_t fi, int64_t ei, float (&z)[2][4]) {
+    ld4(a.d_feat + fi * a.feat_ld + m.col[0], z[0]);
+    ld4(a.d_edge + ei * a.edge_ld + m.col[1], z[1]);
+}
+
+__device__ __forceinline__ int rl(int v, int s) { return __builtin_amdgcn_readlane(v, s); }
+__device__ __forceinline__ float rlf(float v, int s) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), s)); }
+// lane s of v := the wave-uniform x.  v_writelane_b32 has no builtin, and on gfx9 it may name only one scalar register: the lane select
+// goes through M0 (compiler-reserved, so saved and restored inside the statement).
+__device__ __forceinline__ float wlf(float x, int s, float v) {
+    const int xb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x));
+    int keep;
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(v), "=&s"(keep) : "s"(xb), "s"(s));
+    return v;
 }
 
 inline int64_t fast_grid(int64_t m) { return tg::attn_grid_blocks(m); }
 
+constexpr float kLog2e = 1.4426950408889634f;
+
 // ------------------------------------------------------------------------------------------------ forward
+// The slot loop is software-pipelined through two register sets with STATIC counts: every trip issues the rows of the next batch
+// unconditionally (past the end it re-reads the last slots, L1 hits) so that hipcc can wait with vmcnt(2 RB) instead of vmcnt(0) -- with
+// a conditional issue it drained the batch it had just sent, every trip.
 template <int H, int RB>
 __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_fwd_fast_kernel(tg_attn_desc a, const float* __restrict__ u, float* __restrict__ agg,
                                                                   float* __restrict__ prob) {
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // (uniform: row arithmetic on the scalar unit)
     const int nfe = a.dn + a.de, dk = nfe + a.dt_dim, k = a.k, T = a.dt_dim;
     const LaneMap m = lane_map(a, lane);
     const bool ht0 = lane < T, ht1 = lane + kWave < T;
+    // a lane past T computes cos(0) = 1 against a zero u and stores nothing
     const float w0 = ht0 ? a.d_te_w[lane] : 0.f, b0 = ht0 ? a.d_te_b[lane] : 0.f;
     const float w1 = ht1 ? a.d_te_w[lane + kWave] : 0.f, b1 = ht1 ? a.d_te_b[lane + kWave] : 0.f;
     const bool two_t = T > kWave;
+    const float scale2 = a.scale * kLog2e;          // scores in base-2 units: exp2 of a difference, no multiply per slot
 
     for (int64_t row = (int64_t)blockIdx.x * WPB + wave; row < a.m; row += (int64_t)gridDim.x * WPB) {
         const int64_t mo = row * k + lane;
@@ -101,16 +111,17 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_fwd_fast_kerne
         auto issue = [&](float (&zb)[RB][2][4], int sb) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int s = sb + r;
-                const bool live = s < k;
-                const int ss = live ? s : 0;
-                issue_row(a, m, live, __builtin_amdgcn_readlane(my_f, ss), __builtin_amdgcn_readlane(my_e, ss), zb[r]);
+                const int ss = sb + r < k ? sb + r : k - 1;
+                issue_row(a, m, rl(my_f, ss), rl(my_e, ss), zb[r]);
             }
         };
         issue(zA, 0);
-        float uh[H][2][4], ut[H][2], acc[H][2][4], at[H][2], mx[H], den[H], keep_score[H];
+        float uh[H][2][4], ut[H][2], acc[H][2][4], at[H][2], mx[H], den[H], raw[H], keep[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) {
+            // the dropout decisions of this instance, slot s on lane s: ONE hash per lane and head instead of one per slot on every lane
+            // (64-bit multiplies on the vector ALU: a third of the kernel's issue slots before)
+            keep[h] = sl ? tg::dropout_keep_scale(a.seed, a.row0 + row, h, lane, a.dropout_p) : 0.f;
             const float* ur = u + (row * H + h) * dk;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -120,21 +131,19 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_fwd_fast_kerne
             ut[h][0] = ht0 ? ur[nfe + lane] : 0.f;
             ut[h][1] = ht1 ? ur[nfe + lane + kWave] : 0.f;
             at[h][0] = at[h][1] = 0.f;
-            mx[h] = -INFINITY; den[h] = 0.f; keep_score[h] = 0.f;
+            mx[h] = -INFINITY; den[h] = 0.f; raw[h] = 0.f;
         }
         auto compute = [&](float (&zb)[RB][2][4], int sb) {
             float zt[RB][2], part[RB * H];
             int nb[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int s = sb + r;
-                const bool live = s < k;
-                const int ss = live ? s : 0;
-                nb[r] = __builtin_amdgcn_readlane(my_n, ss);
-                const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), ss));
-                zt[r][0] = (live && ht0) ? tg::cos_phase(fmaf(dt, w0, b0)) : 0.f;
+                const int ss = sb + r < k ? sb + r : k - 1;
+                nb[r] = rl(my_n, ss);
+                const float dt = rlf(my_dt, ss);
+                zt[r][0] = tg::cos_phase(fmaf(dt, w0, b0));
                 zt[r][1] = 0.f;
-                if (two_t) zt[r][1] = (live && ht1) ? tg::cos_phase(fmaf(dt, w1, b1)) : 0.f;
+                if (two_t) zt[r][1] = tg::cos_phase(fmaf(dt, w1, b1));
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
                     float p = ut[h][0] * zt[r][0];
@@ -153,11 +162,11 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_fwd_fast_kerne
                 if (s >= k) break;                     // wave-uniform
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    float sc = part[r * H + h] * a.scale;
-                    if (nb[r] == 0) sc = -1e10f;                                        // modules.py:221
-                    if (lane == s) keep_score[h] = sc;
+                    raw[h] = wlf(part[r * H + h], s, raw[h]);         // the unscaled score of slot s, kept on lane s (-> prob at the end)
+                    float sc = part[r * H + h] * scale2;
+                    if (nb[r] == 0) sc = -1e10f * kLog2e;                               // modules.py:221
                     if (sc > mx[h]) {                  // wave-uniform: the running maximum moves, rescale what was gathered so far
-                        const float corr = __expf(mx[h] - sc);
+                        const float corr = __builtin_amdgcn_exp2f(mx[h] - sc);
                         den[h] *= corr;
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
@@ -166,9 +175,9 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_fwd_fast_kerne
                         at[h][0] *= corr; at[h][1] *= corr;
                         mx[h] = sc;
                     }
-                    const float pe = __expf(sc - mx[h]);
+                    const float pe = __builtin_amdgcn_exp2f(sc - mx[h]);
                     den[h] += pe;
-                    const float wgt = pe * tg::dropout_keep_scale(a.seed, a.row0 + row, h, s, a.dropout_p);
+                    const float wgt = pe * rlf(keep[h], s);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -179,16 +188,18 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_fwd_fast_kerne
             }
         };
         for (int sb = 0; sb < k; sb += 2 * RB) {
-            if (sb + RB < k) issue(zB, sb + RB);
+            issue(zB, sb + RB);
             compute(zA, sb);
-            if (sb + RB >= k) break;
-            if (sb + 2 * RB < k) issue(zA, sb + 2 * RB);
+            issue(zA, sb + 2 * RB);
             compute(zB, sb + RB);
         }
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const float inv = 1.f / den[h];
-            if (sl) prob[(row * H + h) * k + lane] = __expf(keep_score[h] - mx[h]) * inv;
+            if (sl) {
+                const float sc = my_n == 0 ? -1e10f * kLog2e : raw[h] * scale2;
+                prob[(row * H + h) * k + lane] = __builtin_amdgcn_exp2f(sc - mx[h]) * inv;
+            }
             float* ar = agg + (row * H + h) * dk;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -213,10 +224,11 @@ template <int H, int RB, bool DF, bool DE>
 __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kernel(tg_attn_desc a, const float* __restrict__ u, const float* __restrict__ agg,
         const float* __restrict__ prob, const float* __restrict__ dagg, float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld,
         int64_t pad_row, float* __restrict__ dedge, int64_t dedge_ld, float* __restrict__ dte_part) {
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // (uniform: row arithmetic on the scalar unit)
     const int nfe = a.dn + a.de, dk = nfe + a.dt_dim, k = a.k, T = a.dt_dim;
     const LaneMap m = lane_map(a, lane);
     const bool ht0 = lane < T, ht1 = lane + kWave < T;
+    // a lane past T evaluates phase 0 against zero u / dagg: every gradient it forms is an exact zero
     const float w0 = ht0 ? a.d_te_w[lane] : 0.f, b0 = ht0 ? a.d_te_b[lane] : 0.f;
     const float w1 = ht1 ? a.d_te_w[lane + kWave] : 0.f, b1 = ht1 ? a.d_te_b[lane + kWave] : 0.f;
     const bool two_t = T > kWave;
@@ -225,8 +237,8 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
     const int wmax = a.dn > a.de ? a.dn : a.de;
     float* tr = red + WPB * (2 * T + a.dn) + wave * wmax;
     float gw[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f};
-    float dpad[2][4];
-    zero4(dpad[0]); zero4(dpad[1]);
+    float dpad[4];
+    zero4(dpad);
 
     for (int64_t row = (int64_t)blockIdx.x * WPB + wave; row < a.m; row += (int64_t)gridDim.x * WPB) {
         const int64_t mo = row * k + lane;
@@ -237,25 +249,24 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
         auto issue = [&](float (&zb)[RB][2][4], int sb) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int s = sb + r;
-                const bool live = s < k;
-                const int ss = live ? s : 0;
-                issue_row(a, m, live, __builtin_amdgcn_readlane(my_f, ss), __builtin_amdgcn_readlane(my_e, ss), zb[r]);
+                const int ss = sb + r < k ? sb + r : k - 1;
+                issue_row(a, m, rl(my_f, ss), rl(my_e, ss), zb[r]);
             }
         };
         issue(zA, 0);
-        float my_p[H];
+        float my_p[H], my_pd[H];
         float uh[H][2][4], ut[H][2], dg[H][2][4], dgt[H][2], dacc[H][2][4], dat[H][2], cterm[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             my_p[h] = sl ? prob[(row * H + h) * k + lane] : 0.f;
+            my_pd[h] = sl ? my_p[h] * tg::dropout_keep_scale(a.seed, a.row0 + row, h, lane, a.dropout_p) : 0.f;   // slot s on lane s, hashed once
             const int64_t o = (row * H + h) * dk;
             float p = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float ag[4];
                 if (m.has[i]) {
-                    ld4(u + o + m.ucol[i], uh[h][i]);
+                    if (DF || DE) ld4(u + o + m.ucol[i], uh[h][i]);
                     ld4(dagg + o + m.ucol[i], dg[h][i]);
                     ld4(agg + o + m.ucol[i], ag);
                 } else {
@@ -281,18 +292,14 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
             int64_t fis[RB], eis[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int s = sb + r;
-                const bool live = s < k;
-                const int ss = live ? s : 0;
-                nb[r] = __builtin_amdgcn_readlane(my_n, ss);
-                fis[r] = __builtin_amdgcn_readlane(my_f, ss);
-                eis[r] = __builtin_amdgcn_readlane(my_e, ss);
-                dts[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_dt), ss));
-                float s0, c0, s1 = 0.f, c1 = 0.f;
-                tg::sincos_phase(fmaf(dts[r], w0, b0), &s0, &c0);
-                if (two_t) tg::sincos_phase(fmaf(dts[r], w1, b1), &s1, &c1);
-                zt[r][0] = (live && ht0) ? c0 : 0.f;  sn[r][0] = (live && ht0) ? s0 : 0.f;
-                zt[r][1] = (live && ht1) ? c1 : 0.f;  sn[r][1] = (live && ht1) ? s1 : 0.f;
+                const int ss = sb + r < k ? sb + r : k - 1;
+                nb[r] = rl(my_n, ss);
+                fis[r] = rl(my_f, ss);
+                eis[r] = rl(my_e, ss);
+                dts[r] = rlf(my_dt, ss);
+                tg::sincos_phase(fmaf(dts[r], w0, b0), &sn[r][0], &zt[r][0]);
+                sn[r][1] = 0.f; zt[r][1] = 0.f;
+                if (two_t) tg::sincos_phase(fmaf(dts[r], w1, b1), &sn[r][1], &zt[r][1]);
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
                     float p = dgt[h][0] * zt[r][0];
@@ -312,8 +319,8 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
                 float pd[H], dsc[H];
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    const float pr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_p[h]), s));
-                    pd[h] = pr * tg::dropout_keep_scale(a.seed, a.row0 + row, h, s, a.dropout_p);
+                    const float pr = rlf(my_p[h], s);
+                    pd[h] = rlf(my_pd[h], s);
                     dsc[h] = nb[r] == 0 ? 0.f : (pd[h] * part[r * H + h] - pr * cterm[h]) * a.scale;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -344,17 +351,13 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
                             dz[i][e] = v;
                         }
                     if (DF && nb[r] == 0 && pad_row >= 0) {         // wave-uniform: every padded slot gathers the same row
+                        if (m.has[0])
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            if (m.has[i] && m.node[i])
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) dpad[i][e] += dz[i][e];
+                            for (int e = 0; e < 4; ++e) dpad[e] += dz[0][e];
                     } else if (DF) {
                         // transpose through LDS: lane l then owns columns l, l+64, ... and one atomic instruction covers 256
                         // contiguous bytes of the destination row
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            if (m.has[i] && m.node[i]) st4(tr + m.col[i], dz[i]);
+                        if (m.has[0]) st4(tr + m.col[0], dz[0]);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -365,9 +368,7 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
                     if constexpr (DE) {
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            if (m.has[i] && !m.node[i]) st4(tr + m.col[i], dz[i]);
+                        if (m.has[1]) st4(tr + m.col[1], dz[1]);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -381,10 +382,9 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
             }
         };
         for (int sb = 0; sb < k; sb += 2 * RB) {
-            if (sb + RB < k) issue(zB, sb + RB);
+            issue(zB, sb + RB);
             compute(zA, sb);
-            if (sb + RB >= k) break;
-            if (sb + 2 * RB < k) issue(zA, sb + 2 * RB);
+            issue(zA, sb + 2 * RB);
             compute(zB, sb + RB);
         }
 #pragma unroll
@@ -403,9 +403,7 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
     if (ht1) { red[wave * 2 * T + lane + kWave] = gw[1]; red[wave * 2 * T + T + lane + kWave] = gb[1]; }
     float* redp = red + WPB * 2 * T;
     if (DF && pad_row >= 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (m.has[i] && m.node[i]) st4(redp + wave * a.dn + m.col[i], dpad[i]);
+        if (m.has[0]) st4(redp + wave * a.dn + m.col[0], dpad);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < 2 * T; j += blockDim.x) {
@@ -427,7 +425,7 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool shape_ok(const tg_attn_desc& a) {
-    return a.dn % 4 == 0 && a.de % 4 == 0 && (a.dn + a.de) / 4 <= 2 * kWave && a.dt_dim <= 2 * kWave && a.dt_dim % 4 == 0 &&
+    return a.dn % 4 == 0 && a.de % 4 == 0 && a.dn / 4 <= kWave && a.de / 4 <= kWave && a.de > 0 && a.dt_dim <= 2 * kWave && a.dt_dim % 4 == 0 &&
            a.k <= kWave && (a.heads == 1 || a.heads == 2) && a.feat_ld % 4 == 0 && a.edge_ld % 4 == 0 && aligned16(a.d_feat) &&
            aligned16(a.d_edge);
 }

@@ -120,6 +120,10 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
                   float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s);
+// tg_attn_ring.hip: the LDS-ring kernels; nparts = slab rows of dte the caller allocated (tg_attn_bwd_parts)
+int attn_fwd_ring(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);
+int attn_bwd_ring(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du, float* dfeat,
+                  int64_t dfeat_ld, int64_t pad_row, float* dte, int nparts, hipStream_t s);
 
 // ---- wave64 helpers -------------------------------------------------------------------------------
 // DPP lane exchange inside the VALU (no LDS crossbar): quad swaps, 8- and 16-lane mirrors, then the two row broadcasts
