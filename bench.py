@@ -876,6 +876,23 @@ def bench_memory_or_sequence_model(args):
                      "allreduce_ms": round((time.perf_counter() - t_ar) / 20 * 1e3, 4), "allreduce_floats": int(gbuf.numel()),
                      "overlap": ("attention + merge layer block reduced under the GRU backward and the state advance (GradAllReducer.segment_ready)"
                                  if (args.model == "tgn" and native) else "none (one flat-bucket all-reduce between backward and optimizer)")}
+    if args.model == "tgn" and native and (world > 1 or wsim > 1) and not tgn_lp:
+        # every rank advances the REPLICATED memory / message state with the whole global batch (no exchange step) -- what
+        # that costs a rank, from HIP events around the advance's launches in a few extra steps behind the timed region
+        ops.profile_enable("tgn_advance")
+        ops.profile_collect("tgn_advance")
+        n_adv = min(10, args.steps)
+        for s in range(total_steps, total_steps + n_adv):
+            step(s)
+        adv_ms, adv_edges, adv_cnt = ops.profile_collect("tgn_advance")
+        ops.profile_enable(False)
+        adv = {"state_advance_ms_per_step": round(adv_ms / max(1, adv_cnt), 4), "edges_filed_per_step": int(adv_edges / max(1, adv_cnt)),
+               "state_advance_share_of_step": round(adv_ms / max(1, adv_cnt) / (elapsed / args.steps * 1e3), 4),
+               "note": "replicated state advance over the whole global batch on every rank (no memory / message exchange); HIP events, untimed extra steps"}
+        if dist_info is not None:
+            dist_info["tgn_state_advance"] = adv
+        else:
+            dist_info = {"rccl_ranks": world, "tgn_state_advance": adv}
     value = args.steps * BATCH * world / elapsed
     secs = max(ms * 1e-3, 1e-12)
     if args.model == "tgn":
@@ -907,7 +924,10 @@ def bench_memory_or_sequence_model(args):
            "config": {"workload": f"Reddit-shape synthetic (10984 nodes, 672447 edges, 172-d edge feats) + {desc}, batch 600 edges/GPU, "
                                   f"dropout {args.dropout:.2f}, host numpy ids per call, fwd+bwd+Adam ({('fused step, native stepper' if native else 'fused step') if fused else 'autograd'}{', neg-then-pos warm-up step' if tgn_lp else ''})",
                       "batch_per_gpu": BATCH, "global_batch": BATCH * wsim, "parallelism": f"dp{world}"},
-           "path_roofline": path, "roofline": roof, "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 4)}
+           "path_roofline": path, "roofline": roof,
+           # wall time until the host had ISSUED the timed steps: with a GPU-bound step this is queue back-pressure (~ the step time), not
+           # the host's own cost -- that is the idle-GPU figure of tools/*_host_prof.py (profiles/*_host_issue.txt)
+           "host_issue_wall_ms_per_step_incl_queue_backpressure": round(host_issue / args.steps * 1e3, 4)}
     if dist_info is not None:
         out["distributed"] = dist_info
     if wsim != world:

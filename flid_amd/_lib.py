@@ -104,6 +104,7 @@ SIGNATURES = {
     "tg_stepper_prepare_begin": (C.c_int, [c_void, C.c_int, c_void, c_void, c_i64]),
     "tg_stepper_prepare_finish": (C.c_int, [c_void, C.c_int, C.POINTER(c_i64)]),
     "tg_stepper_release": (C.c_int, [c_void, C.c_int]),
+    "tg_stepper_set_graph": (C.c_int, [c_void, c_void]),
     "tg_stepper_slot_view": (C.c_int, [c_void, C.c_int, C.POINTER(c_void), C.POINTER(c_i64)]),
     "tg_stepper_forward": (C.c_int, [c_void, C.c_int, C.c_int, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void)]),
     "tg_stepper_backward": (C.c_int, [c_void, C.c_int, c_void, c_void, GRAD_READY_FN, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "tg_dyg_create": (C.c_int, [C.POINTER(DygCfg), c_void, c_i64, C.POINTER(c_void)]),
     "tg_dyg_destroy": (None, [c_void]),
     "tg_dyg_regions": (C.c_int, [c_void, c_void, C.POINTER(c_i64)]),
+    "tg_dyg_set_graph": (C.c_int, [c_void, c_void]),
     "tg_dyg_forward": (C.c_int, [c_void, c_void, c_void, c_void, c_i64, C.c_int, C.c_int, c_f32, C.POINTER(C.c_uint64), c_void, C.POINTER(c_void)]),
     "tg_dyg_backward": (C.c_int, [c_void, c_void, c_void, C.POINTER(AdamArgs), C.POINTER(c_void)]),
     "tg_add_layernorm_fwd_res": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void, c_f32, C.c_uint64, c_void, c_void, c_void, c_void, c_void]),

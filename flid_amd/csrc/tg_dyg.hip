@@ -362,6 +362,13 @@ extern "C" int tg_dyg_regions(const tg_dyg* st, const float* d_arena, int64_t* o
     return TG_OK;
 }
 
+// as tg_stepper_set_graph: the model's sampler was swapped (models/DyGFormer.py:308-317 as called from PTCL/M_step.py:34, :200)
+extern "C" int tg_dyg_set_graph(tg_dyg* st, const tg_graph* graph) {
+    TG_REQUIRE(st && graph, "tg_dyg_set_graph: null pointer");
+    st->c.graph = graph;
+    return TG_OK;
+}
+
 extern "C" int tg_dyg_forward(tg_dyg* st, const int64_t* h_src, const int64_t* h_dst, const double* h_t, int64_t B, int ws, int wd,
                               float dropout_p, const uint64_t* seeds, void* stream, float** d_emb) {
     TG_REQUIRE(st && h_src && h_dst && h_t, "tg_dyg_forward: null pointer");

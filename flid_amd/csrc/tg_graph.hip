@@ -27,8 +27,8 @@ const float* zero_block() {
 }
 
 struct ProfRec { std::string tag; double units; hipEvent_t a, b; };
-static int g_prof_mask = 0;   // bit 0 attn_fwd, bit 1 attn_bwd, bit 2 gemm
-static int prof_bit(const char* tag) { return tag[0] == 'g' ? 4 : (tag[5] == 'f' ? 1 : 2); }
+static int g_prof_mask = 0;   // bit 0 attn_fwd, bit 1 attn_bwd, bit 2 gemm, bit 3 tgn_advance
+static int prof_bit(const char* tag) { return tag[0] == 't' ? 8 : tag[0] == 'g' ? 4 : (tag[5] == 'f' ? 1 : 2); }
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mutex;          // launches come from two host threads (tg_layer.hip: SideIssuer)
 ProfScope::ProfScope(const char* tag_, double units_, hipStream_t s) : tag(tag_), units(units_), a(nullptr), b(nullptr), stream(s) {

@@ -14,6 +14,9 @@
 #include <thread>
 #include <vector>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "tg_common.h"
 #include "tg_pack.h"
 #include "tg_colsum.h"
@@ -653,6 +656,23 @@ private:
 };
 SideIssuer g_issuer;
 bool g_issue_thread = true;
+// What a layer's forward decided (chain launch / short-layer query launch / merged projection), by the layer's weight buffer: the
+// backward reads the saved activations accordingly (`res` holds the NORMALISED LayerNorm input behind a chain forward, `q` does not exist
+// behind a merged one), so a switch flipped between the two calls (tg_set_layer_chain, tg_set_layer_merged, tg_set_gemm_mode, the row
+// threshold) must be an error, not a silently different meaning.
+std::mutex g_fwd_mode_mutex;
+std::unordered_map<const void*, int> g_fwd_mode;
+void note_forward_mode(const void* key, bool use_chain, bool use_qu, bool merged) {
+    std::lock_guard<std::mutex> g(g_fwd_mode_mutex);
+    if (g_fwd_mode.size() > 4096) g_fwd_mode.clear();          // (keys are long-lived arena addresses; a leak guard, not a cache policy)
+    g_fwd_mode[key] = (use_chain ? 1 : 0) | (use_qu ? 2 : 0) | (merged ? 4 : 0);
+}
+int forward_mode(const void* key) {
+    std::lock_guard<std::mutex> g(g_fwd_mode_mutex);
+    const auto it = g_fwd_mode.find(key);
+    return it == g_fwd_mode.end() ? -1 : it->second;
+}
+
 bool g_merged = true;      // merged projections (merge_weights_body); false = the reference's four separate products per layer
 // the weight-space work of the merged form (one merge kernel forward, ~6 small launches backward) is a fixed cost per layer call:
 // it pays from a few thousand rows on (TGAT layer 1: 12 k rows), not for the 1 200-row root layer or a TGN batch
@@ -725,6 +745,7 @@ static int layer_fwd_impl(const tg_layer_desc* L, void* stream, int mode, Prelud
     const bool merged = g_merged && R >= kMergedMinRows;
     static const bool no_qu = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_QU") && atoi(getenv("FLID_NO_QU")) != 0;       // A/B timing
     const bool use_qu = !no_qu && use_chain && !merged && tg::qu_shape_ok(H, dn, T, a.de) && a16(L->q) && a16(L->u) && a16(L->qbias);
+    if (mode != 1) note_forward_mode(L->wT, use_chain, use_qu, merged);
     if (use_chain) {
         const int hp = tg::chain_hp(H, dn, T), yc = (dq + 31) / 32, rc = (dn + 31) / 32;
         tg_pack_job jobs[20];
@@ -927,8 +948,16 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
                "tg_tgat_layer_bwd: backward buffers must be 16-byte aligned (the layer's forward ran the chain kernel)");
     const bool merged = g_merged && R >= kMergedMinRows;
     static const bool no_qu = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_QU") && atoi(getenv("FLID_NO_QU")) != 0;
-    const bool use_qu = !no_qu && use_chain && !merged && tg::qu_shape_ok(H, dn, T, a.de) && a16(L->q) && a16(L->u) && a16(L->qbias) && a16(Bw->du) &&
-                        a16(Bw->dq) && (!Bw->d_own || (a16(Bw->d_own) && Bw->d_own_ld % 4 == 0));          // = the forward's decision (+ this call's buffers)
+    const bool use_qu_fwd = !no_qu && use_chain && !merged && tg::qu_shape_ok(H, dn, T, a.de) && a16(L->q) && a16(L->u) && a16(L->qbias);
+    TG_REQUIRE(!use_qu_fwd || (a16(Bw->du) && a16(Bw->dq) && (!Bw->d_own || (a16(Bw->d_own) && Bw->d_own_ld % 4 == 0))),
+               "tg_tgat_layer_bwd: du / dq / d_own must be 16-byte aligned (the layer's forward ran the query-side chain launch)");
+    const bool use_qu = use_qu_fwd;
+    {
+        const int fm = forward_mode(L->wT);
+        TG_REQUIRE(fm < 0 || fm == ((use_chain ? 1 : 0) | (use_qu ? 2 : 0) | (merged ? 4 : 0)),
+                   "tg_tgat_layer_bwd: the layer's forward ran in another mode (chain / query-side launch / merged projection): a switch "
+                   "(tg_set_layer_chain, tg_set_layer_merged, tg_set_merged_min_rows, tg_set_gemm_mode) changed between forward and backward");
+    }
     const bool overlap = g_overlap && g_side.init();
     // where everything that only feeds parameter gradients goes: re-pointed by every fork()
     void* wstream = stream;

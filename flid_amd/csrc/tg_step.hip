@@ -401,6 +401,16 @@ extern "C" int tg_stepper_release(tg_stepper* st, int slot) {
     return TG_OK;
 }
 
+// The trainers swap the model's neighbor sampler between the train graph and the full graph every epoch (PTCL/EM_warmup.py:118, :296;
+// PTCL/M_step.py:34, :200): the object follows.  Only between batches: no slot may hold a batch in preparation or a forward without
+// its backward (tg_stepper_release first).  The new graph must cover the same id space (the arena is sized by roots, not by nodes).
+extern "C" int tg_stepper_set_graph(tg_stepper* st, const tg_graph* graph) {
+    TG_REQUIRE(st && graph, "tg_stepper_set_graph: null pointer");
+    for (const Slot& s : st->slots) TG_REQUIRE(s.state == Slot::FREE, "tg_stepper_set_graph: a slot still holds a batch (release it first)");
+    st->c.graph = graph;
+    return TG_OK;
+}
+
 // device views of a prepared slot for tests / other consumers: ids_all, S_nbr, S_eid, S_t, S_dt, child (pointers), pad row
 extern "C" int tg_stepper_slot_view(const tg_stepper* st, int slot, void** p6, int64_t* pad_row) {
     TG_REQUIRE(st && p6 && slot >= 0 && slot < (int)st->slots.size(), "tg_stepper_slot_view: slot");
@@ -691,6 +701,8 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
         }
     }
     if (rc == TG_OK && positive) {
+        // (units: the edges whose state the advance files -- on a data-parallel rank the WHOLE global batch, section 7 of DESIGN.md)
+        tg::ProfScope prof("tgn_advance", (double)(s.nb), (hipStream_t)stream);
         int viol = 0;
         rc = tg_tgn_host_advance(s.h_u.data(), s.h_newt.data(), s.h_nu, bank->h_has, bank->h_msg_time, bank->h_last, bank->num_nodes, &viol);
         if (rc == TG_OK) {

@@ -228,3 +228,6 @@ class DyGFormer(nn.Module):
         if self.neighbor_sampler.sample_neighbor_strategy in ['uniform', 'time_interval_aware']:
             assert self.neighbor_sampler.seed is not None
             self.neighbor_sampler.reset_random_state()
+        st = getattr(self, "_stepper", None)          # the native step follows the sampler (PTCL/M_step.py:34, :200)
+        if st is not None:
+            st.rebind(neighbor_sampler.graph)

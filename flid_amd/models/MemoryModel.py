@@ -450,7 +450,7 @@ class MemoryModel(torch.nn.Module):
         import ctypes as C
         from .._lib import check, lib
         st = getattr(self, "_stepper", None)
-        if st is not None and int(num_neighbors) == st.k:
+        if st is not None and self.training and int(num_neighbors) == st.k:
             assert int(num_neighbors) > 0, 'Number of sampled neighbors for each node should be greater than 0!'
             return st.begin_tgn(src_node_ids, dst_node_ids, node_interact_times, edge_ids, shard)
         dev = self.node_raw_features.device
@@ -629,6 +629,12 @@ class MemoryModel(torch.nn.Module):
         if self.embedding_module.neighbor_sampler.sample_neighbor_strategy in ['uniform', 'time_interval_aware']:
             assert self.embedding_module.neighbor_sampler.seed is not None
             self.embedding_module.neighbor_sampler.reset_random_state()
+        st = getattr(self, "_stepper", None)          # the native step follows the sampler (PTCL/EM_warmup.py:118, :296)
+        if st is not None:
+            if neighbor_sampler.sample_neighbor_strategy == "recent":
+                st.rebind(neighbor_sampler.graph)
+            else:
+                self._stepper = None
 
 
 def compute_src_dst_node_time_shifts(src_node_ids: np.ndarray, dst_node_ids: np.ndarray, node_interact_times: np.ndarray):

@@ -113,7 +113,8 @@ class TGAT(nn.Module):
         # (PTCL/M_step.py:285: the destination rows the reference computes there are never read), half the roots of a step
         assert roots in ("both", "src")
         st = getattr(self, "_stepper", None)
-        if st is not None and not torch.is_tensor(src_node_ids) and num_neighbors == st.k:
+        # (the native object serves training steps; an eval-time prefetch takes the engine's path, whose job the autograd-facing call accepts)
+        if st is not None and self.training and not torch.is_tensor(src_node_ids) and num_neighbors == st.k:
             return st.begin([np.asarray(src_node_ids)] if roots == "src" else [np.asarray(src_node_ids), np.asarray(dst_node_ids)],
                             node_interact_times)
         if not torch.is_tensor(src_node_ids):
@@ -143,7 +144,7 @@ class TGAT(nn.Module):
         int64 / float64 in; the embedding block of the prepared batch is the lists' rows one after the other."""
         from .. import ops
         st = getattr(self, "_stepper", None)
-        if st is not None and num_neighbors == st.k:
+        if st is not None and self.training and num_neighbors == st.k:
             return st.begin([np.asarray(a) for a in id_lists], node_interact_times)
         graph = self.neighbor_sampler.graph
         arrs = [np.asarray(a) for a in id_lists]
@@ -222,3 +223,10 @@ class TGAT(nn.Module):
         if self.neighbor_sampler.sample_neighbor_strategy in ['uniform', 'time_interval_aware']:
             assert self.neighbor_sampler.seed is not None
             self.neighbor_sampler.reset_random_state()
+        # the native step follows the sampler (the trainers alternate train-graph / full-graph samplers every epoch, PTCL/EM_warmup.py:118, :296)
+        st = getattr(self, "_stepper", None)
+        if st is not None:
+            if neighbor_sampler.sample_neighbor_strategy == "recent":
+                st.rebind(neighbor_sampler.graph)
+            else:
+                self._stepper = None

@@ -422,7 +422,7 @@ def weighted_sum(a: torch.Tensor, w: torch.Tensor, scale: float = 1.0, out: Opti
     return out
 
 
-PROFILE_TAGS = {"attn_fwd": 1, "attn_bwd": 2, "gemm": 4}
+PROFILE_TAGS = {"attn_fwd": 1, "attn_bwd": 2, "gemm": 4, "tgn_advance": 8}
 
 
 def profile_enable(on):

@@ -55,6 +55,12 @@ class FlatAdam(torch.optim.Optimizer):
                                 float(group["eps"]), float(group["weight_decay"]), int(st["step"]))
         raise RuntimeError("FlatAdam.native_args: not a parameter of this optimizer")
 
+    def native_rollback(self, p):
+        """the native call that was to issue native_args()'s update failed: the step was not taken"""
+        st = self.state.get(p)
+        if st and st.get("step", 0) > 0:
+            st["step"] -= 1
+
     def zero_grad(self, set_to_none: bool = True):
         """as torch.optim.Optimizer.zero_grad, without its profiler context (~10 us of host time per step)"""
         for group in self.param_groups:

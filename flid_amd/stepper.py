@@ -73,6 +73,7 @@ class Stepper:
         self.grad = self.arena[off[0]:off[0] + self.flat.numel()]        # parameter gradients, laid out like the flat parameter
         self._emb_off, self.dn, self.max_roots, self.nslots = int(off[2]), int(cfg.dn), int(max_roots), int(slots)
         self._next = 0
+        self._grad_pending = False           # a backward without an update left its gradient in the block
         self._seeds = (C.c_uint64 * (2 * self.num_layers))()
         self._rows = (C.c_int64 * 2)()
         self._emb_views = {}
@@ -86,10 +87,28 @@ class Stepper:
             except Exception:
                 pass
 
+    def rebind(self, graph):
+        """the model's neighbor sampler was swapped (set_neighbor_sampler: the trainers alternate between the train-graph and the
+        full-graph sampler every epoch, PTCL/EM_warmup.py:118, :296): drop every prepared batch and sample from `graph` from now on"""
+        if graph is self.graph:
+            return
+        self.reset()
+        check(lib().tg_stepper_set_graph(self._h, graph.handle), "tg_stepper_set_graph")
+        self.graph = graph
+        self.cfg.graph = graph.handle
+
+    def _check_graph(self):
+        m = self.model
+        sampler = m.embedding_module.neighbor_sampler if self.tgn else m.neighbor_sampler
+        if sampler.graph is not self.graph:
+            raise RuntimeError("the native stepper samples from another graph than the model's current neighbor sampler "
+                               "(set_neighbor_sampler() rebinds it; the sampler object was replaced behind the model's back)")
+
     # ---- preparation (side stream of the native object) ---------------------------------------------------------------------------
     def begin(self, id_lists, node_interact_times) -> StepJob:
         """id_lists: host int64 arrays that share `node_interact_times` ([src, dst], [src], [src, dst, negative dst]); the embedding block
         of the step holds their rows one after the other"""
+        self._check_graph()
         ids = np.ascontiguousarray(np.concatenate(id_lists) if len(id_lists) > 1 else id_lists[0], dtype=np.int64)
         t = np.ascontiguousarray(node_interact_times, dtype=np.float64)
         times = np.ascontiguousarray(np.tile(t, len(id_lists))) if len(id_lists) > 1 else t
@@ -124,27 +143,55 @@ class Stepper:
             emb = self._emb_views[job.n] = self.arena[self._emb_off:self._emb_off + job.n * self.dn].view(job.n, self.dn)
         return emb
 
+    def _ready_callback(self, grad_ready):
+        """the C callback around `grad_ready`: an exception raised inside it (an RCCL / gloo error in segment_ready) cannot cross the C
+        frame -- ctypes would print and swallow it -- so it is kept and re-raised once the C call has returned"""
+        if grad_ready is None:
+            return GRAD_READY_FN(), None
+        g, base, box = self.grad, self.grad.data_ptr(), []
+
+        def _cb(_user, seg_ptr, floats):
+            if box:
+                return
+            try:
+                o = (seg_ptr - base) // 4
+                grad_ready(g[o:o + floats])
+            except BaseException as e:          # noqa: BLE001 (relayed below)
+                box.append(e)
+        return GRAD_READY_FN(_cb), box
+
+    def _earlier_grad(self, optimizer, cb_given, accumulate, who):
+        """the flat parameter's .grad as the caller left it: None / this object's block (-> None) / another tensor (the step's gradient is
+        added to it afterwards, as autograd accumulates).  The block is rewritten by every step (its zero fill rides in the forward's
+        first launch), so a second backward into it without an update in between would silently drop the first: refuse that."""
+        prev = self.flat.grad
+        if prev is not None and prev.data_ptr() == self.grad.data_ptr():
+            if optimizer is None and not accumulate and self._grad_pending:
+                raise RuntimeError(f"{who}: the flat parameter's .grad still holds the previous step's gradient block, which this step "
+                                   "rewrites -- zero_grad(set_to_none=True) after the optimizer's step (or pass optimizer= so that the "
+                                   "update runs inside the call); gradients of several batches add up only with accumulate=True (TGN)")
+            prev = None
+        if prev is not None and (optimizer is not None or cb_given):
+            raise RuntimeError(f"{who}: zero_grad(set_to_none=True) first (the update / the reduction runs on this step's gradient block)")
+        return prev
+
     def backward(self, job: StepJob, d_emb: torch.Tensor, grad_ready=None, optimizer=None):
         """leaves the step's gradient in `self.grad` (and in the flat parameter's .grad); optimizer (a FlatAdam over the flat parameter):
         its update is issued right behind the last layer's backward, in the same call"""
         assert d_emb.is_contiguous() and d_emb.dtype == torch.float32 and d_emb.numel() == job.n * self.dn
-        cb, adam = None, None
-        if grad_ready is not None:
-            g, base = self.grad, self.grad.data_ptr()
-
-            def _cb(_user, seg_ptr, floats):
-                o = (seg_ptr - base) // 4
-                grad_ready(g[o:o + floats])
-            cb = GRAD_READY_FN(_cb)
-        prev = self.flat.grad
-        if prev is not None and prev.data_ptr() == self.grad.data_ptr():
-            prev = None
-        if prev is not None and (optimizer is not None or cb is not None):
-            raise RuntimeError("Stepper.backward: zero_grad(set_to_none=True) first (the update / the reduction runs on this step's gradient block)")
-        if optimizer is not None:
-            adam = optimizer.native_args(self.flat)
-        check(lib().tg_stepper_backward(self._h, job.slot, d_emb.data_ptr(), ops._stream(), cb if cb is not None else GRAD_READY_FN(),
-                                        None, None if adam is None else C.byref(adam), None), "tg_stepper_backward")
+        cb, box = self._ready_callback(grad_ready)
+        prev = self._earlier_grad(optimizer, grad_ready is not None, False, "Stepper.backward")
+        adam = None if optimizer is None else optimizer.native_args(self.flat)
+        try:
+            check(lib().tg_stepper_backward(self._h, job.slot, d_emb.data_ptr(), ops._stream(), cb, None, None if adam is None else C.byref(adam),
+                                            None), "tg_stepper_backward")
+        except BaseException:
+            if optimizer is not None:
+                optimizer.native_rollback(self.flat)            # the update was not issued: the bias correction's step count goes back
+            raise
+        if box:
+            raise box[0]
+        self._grad_pending = optimizer is None
         if prev is None:
             self.flat.grad = self.grad
         else:
@@ -152,6 +199,7 @@ class Stepper:
 
     # ---- TGN: the memory stage around the layer (tg_stepper_tgn_*) -------------------------------------------------------------------
     def begin_tgn(self, src, dst, t, edge_ids=None, shard=None) -> StepJob:
+        self._check_graph()
         src, dst = np.ascontiguousarray(src, dtype=np.int64), np.ascontiguousarray(dst, dtype=np.int64)
         t = np.ascontiguousarray(t, dtype=np.float64)
         eid = None if edge_ids is None else np.ascontiguousarray(edge_ids, dtype=np.int64)
@@ -192,28 +240,24 @@ class Stepper:
         grad_ready(segment): called with the layer's finished gradient block while the GRU's backward and the state advance are still
         being issued (a data-parallel caller starts its reduction there)"""
         assert d_emb.is_contiguous() and d_emb.dtype == torch.float32 and d_emb.numel() == job.n * self.dn
-        cb = GRAD_READY_FN()
-        if grad_ready is not None:
-            g_, base_ = self.grad, self.grad.data_ptr()
-
-            def _cb(_user, seg_ptr, floats):
-                o = (seg_ptr - base_) // 4
-                grad_ready(g_[o:o + floats])
-            cb = GRAD_READY_FN(_cb)
-        prev = self.flat.grad
-        if prev is not None and prev.data_ptr() == self.grad.data_ptr():
-            prev = None
-        if prev is not None and optimizer is not None:
-            raise RuntimeError("Stepper.backward_tgn: zero_grad(set_to_none=True) first (the update runs on this step's gradient block)")
+        cb, box = self._ready_callback(grad_ready)
+        prev = self._earlier_grad(optimizer, grad_ready is not None, accumulate, "Stepper.backward_tgn")
         adam = None if optimizer is None else optimizer.native_args(self.flat)
         bank = self._bank()
         try:
             check(lib().tg_stepper_tgn_backward(self._h, job.slot, C.byref(bank), d_emb.data_ptr(),
                                                 int(bool(positive)) | (2 if accumulate else 0) | (4 if more else 0), ops._stream(),
                                                 None if adam is None else C.byref(adam), None, cb, None), "tg_stepper_tgn_backward")
+        except BaseException:
+            if optimizer is not None:
+                optimizer.native_rollback(self.flat)
+            raise
         finally:
             if bank.past_violation:
                 self.model.memory_bank._past_violation = True
+        if box:
+            raise box[0]
+        self._grad_pending = optimizer is None
         if prev is None:
             self.flat.grad = self.grad
         else:
@@ -221,17 +265,31 @@ class Stepper:
 
     def step_tgn(self, job: StepJob, loss_fn, positive: bool = True, optimizer=None, accumulate: bool = False, more: bool = False,
                  grad_ready=None):
-        emb = self.forward_tgn(job, keep_grad=accumulate)
-        loss, d_emb = loss_fn(emb)
-        self.backward_tgn(job, d_emb, positive=positive, optimizer=optimizer, accumulate=accumulate, more=more, grad_ready=grad_ready)
+        try:
+            emb = self.forward_tgn(job, keep_grad=accumulate)
+            loss, d_emb = loss_fn(emb)
+            self.backward_tgn(job, d_emb, positive=positive, optimizer=optimizer, accumulate=accumulate, more=more, grad_ready=grad_ready)
+        except BaseException:
+            self._release_quietly(job)              # (a slot only becomes free behind its backward: do not leak it)
+            raise
         return emb, loss
 
     def step(self, job: StepJob, loss_fn, grad_ready=None, optimizer=None):
         """forward, `loss_fn(emb) -> (loss, d loss / d emb)`, backward (+ update): (embeddings, loss)"""
-        emb = self.forward(job)
-        loss, d_emb = loss_fn(emb)
-        self.backward(job, d_emb, grad_ready=grad_ready, optimizer=optimizer)
+        try:
+            emb = self.forward(job)
+            loss, d_emb = loss_fn(emb)
+            self.backward(job, d_emb, grad_ready=grad_ready, optimizer=optimizer)
+        except BaseException:
+            self._release_quietly(job)
+            raise
         return emb, loss
+
+    def _release_quietly(self, job: StepJob):
+        try:
+            self.release(job)
+        except Exception:
+            pass
 
 
 class DygStepper:
@@ -280,6 +338,8 @@ class DygStepper:
         self._emb_off, self.dn, self.max_edges = int(off[1]), int(cfg.dn), int(max_batch_edges)
         self._seeds = (C.c_uint64 * (4 * model.num_layers))()
         self._emb_views = {}
+        self._last_B = 0
+        self._grad_pending = False
         self.keep = (node, edge, self.flat)
 
     def __del__(self):
@@ -290,13 +350,24 @@ class DygStepper:
             except Exception:
                 pass
 
+    def rebind(self, graph):
+        """the model's neighbor sampler was swapped (set_neighbor_sampler): later batches read their histories from `graph`"""
+        if graph is self.graph:
+            return
+        check(lib().tg_dyg_set_graph(self._h, graph.handle), "tg_dyg_set_graph")
+        self.graph = graph
+        self.cfg.graph = graph.handle
+
     def forward(self, src_node_ids, dst_node_ids, node_interact_times) -> torch.Tensor:
         """(2 B, dn): source embeddings, then destination embeddings"""
         m = self.model
+        if m.neighbor_sampler.graph is not self.graph:
+            raise RuntimeError("the native DyGFormer step reads another graph than the model's current neighbor sampler (set_neighbor_sampler() rebinds it)")
         src = np.ascontiguousarray(src_node_ids, dtype=np.int64)
         dst = np.ascontiguousarray(dst_node_ids, dtype=np.int64)
         t = np.ascontiguousarray(node_interact_times, dtype=np.float64)
         B, L = len(src), m.max_input_sequence_length
+        self._last_B = B
         # every side is as wide as ITS longest sequence of the batch (the node itself + its history, at most L): host binary searches
         ws, wd = (int(np.minimum(self.graph.count_before_host(ids, t), L - 1).max()) + 1 for ids in (src, dst))
         p = float(m.dropout) if m.training else 0.0
@@ -314,14 +385,24 @@ class DygStepper:
     def backward(self, d_emb: torch.Tensor, optimizer=None):
         """leaves the step's gradient in `self.grad` (= the flat parameter's .grad); optimizer (a FlatAdam over the flat parameter): its
         update is issued right behind the backward, in the same call"""
-        assert d_emb.is_contiguous() and d_emb.dtype == torch.float32
+        assert d_emb.is_contiguous() and d_emb.dtype == torch.float32 and d_emb.numel() == 2 * self._last_B * self.dn, \
+            "d_emb must be the (2 B, dn) gradient of the last forward's embedding block"
         prev = self.flat.grad
         if prev is not None and prev.data_ptr() == self.grad.data_ptr():
+            if optimizer is None and self._grad_pending:
+                raise RuntimeError("DygStepper.backward: the flat parameter's .grad still holds the previous step's gradient block, which this "
+                                   "step rewrites -- zero_grad(set_to_none=True) after the optimizer's step, or pass optimizer=")
             prev = None
         if prev is not None and optimizer is not None:
             raise RuntimeError("DygStepper.backward: zero_grad(set_to_none=True) first (the update runs on this step's gradient block)")
         adam = None if optimizer is None else optimizer.native_args(self.flat)
-        check(lib().tg_dyg_backward(self._h, d_emb.data_ptr(), ops._stream(), None if adam is None else C.byref(adam), None), "tg_dyg_backward")
+        try:
+            check(lib().tg_dyg_backward(self._h, d_emb.data_ptr(), ops._stream(), None if adam is None else C.byref(adam), None), "tg_dyg_backward")
+        except BaseException:
+            if optimizer is not None:
+                optimizer.native_rollback(self.flat)
+            raise
+        self._grad_pending = optimizer is None
         if prev is None:
             self.flat.grad = self.grad
         else:

@@ -29,9 +29,10 @@ typedef struct tg_graph tg_graph; /* opaque: device CSR of time-sorted incidence
 const char* tg_last_error(void);
 int tg_version(void);
 
-/* optional HIP-event timing of the kernel families "attn_fwd", "attn_bwd" (units = algorithmic bytes) and "gemm"
- * (units = flops), recorded on the launch stream; tg_profile_collect synchronises the device.
- * mask: bit 0 = attn_fwd, bit 1 = attn_bwd, bit 2 = gemm (7 = all, 0 = off). */
+/* optional HIP-event timing of the kernel families "attn_fwd", "attn_bwd" (units = algorithmic bytes), "gemm"
+ * (units = flops) and "tgn_advance" (the state advance behind a positive TGN step, units = edges filed), recorded on the
+ * launch stream; tg_profile_collect synchronises the device.
+ * mask: bit 0 = attn_fwd, bit 1 = attn_bwd, bit 2 = gemm, bit 3 = tgn_advance (0 = off). */
 void tg_profile_enable(int mask);
 int tg_profile_collect(const char* tag, double* ms, double* units, int64_t* count, int reset);
 
@@ -272,6 +273,9 @@ int tg_stepper_prepare_begin(tg_stepper* st, int slot, const int64_t* h_ids, con
 /* a step later: reads the distinct-row count (pinned word) and issues the level-1 lookups; rows2 (optional) = {roots, distinct level-1 rows} */
 int tg_stepper_prepare_finish(tg_stepper* st, int slot, int64_t* rows2);
 int tg_stepper_release(tg_stepper* st, int slot);
+/* the model's neighbor sampler was swapped (set_neighbor_sampler: models/TGAT.py:146-155, models/MemoryModel.py:717-726, called every
+ * epoch by PTCL/EM_warmup.py:118, :296 and PTCL/M_step.py:34, :200): later batches are sampled from `graph`.  Every slot must be free. */
+int tg_stepper_set_graph(tg_stepper* st, const tg_graph* graph);
 /* device pointers of a prepared slot: {ids_all, S_nbr, S_eid, S_t, S_dt, child}; *pad_row = frontier row of the padding pair or -1 */
 int tg_stepper_slot_view(const tg_stepper* st, int slot, void** p6, int64_t* pad_row);
 /* seeds: 2 per layer (attention dropout, residual dropout), layer 1 first; may be NULL in eval mode.  *d_emb: (roots, dn) */
@@ -555,6 +559,8 @@ int tg_dyg_create(const tg_dyg_cfg* cfg, float* d_arena, int64_t arena_floats, t
 void tg_dyg_destroy(tg_dyg* st);
 /* offsets (floats from d_arena): [0] gradient block (flat-parameter layout), [1] embeddings (2 B, dn): source rows, then destination rows */
 int tg_dyg_regions(const tg_dyg* st, const float* d_arena, int64_t* off2);
+/* models/DyGFormer.py:308-317 (set_neighbor_sampler): later batches read their histories from `graph` */
+int tg_dyg_set_graph(tg_dyg* st, const tg_graph* graph);
 /* HOST ids (int64) / times (float64) of B edges; ws / wd: this batch's side widths (longest history of the side + 1, at most max_len --
  * tg_host_count_before gives them without device work); dropout_p = 0 in eval mode, else seeds = 4 per block.  TG_ERANGE for an id
  * outside the graph.  Nothing waits for the GPU. */

@@ -31,3 +31,34 @@ def test_two_rccl_ranks_match_single_process():
     r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + "\n" + r.stderr[-4000:]
     assert "DIST-GPU-OK" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["tgat", "tgn", "dygformer"])
+def test_bench_two_ranks_prints_one_line(model):
+    """the program the driver launches at N > 1: `bench.py --gpus 2` as a child (it spawns torch.distributed.run itself, before any GPU call),
+    two ranks -- sharing the one GPU over gloo on a 1-GPU box, as above -- through the native steps with the gradient hand-over from C
+    (PTCL/EM_warmup.py:126-238 sharded by edges).  ONE JSON line on stdout: whole-job edges/s, every rank's ms per step, the
+    collective's own time; TGN additionally the share of a step that the replicated state advance takes."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if torch.cuda.device_count() < 2:
+        env.update(FLID_BENCH_SHARE_GPU="1", FLID_DIST_BACKEND="gloo")
+    port = {"tgat": 29611, "tgn": 29612, "dygformer": 29613}[model]
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-breakdown",
+           "--model", model, "--master-port", str(port)]
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + "\n" + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    dist = d["distributed"]
+    assert dist["rccl_ranks"] == 2 and len(dist["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in dist["per_rank_ms_per_step"])
+    assert dist["allreduce_ms"] > 0 and dist["allreduce_floats"] > 900_000
+    # whole-job value = the edges all ranks processed / the slowest rank's time
+    per_gpu = d["config"]["batch_per_gpu"] if "batch_per_gpu" in d["config"] else 600
+    assert abs(d["value"] - 2 * per_gpu * 3 / (max(dist["per_rank_ms_per_step"]) * 3e-3)) <= 0.02 * d["value"]
+    if model == "tgn":
+        adv = dist["tgn_state_advance"]
+        assert adv["edges_filed_per_step"] == 2 * 600 and 0 < adv["state_advance_share_of_step"] < 1

@@ -42,6 +42,71 @@ def test_tgat_b600_realistic_weights_exact_products_strict():
     _b600_case("tgat_B600_full", True, exact=True)
 
 
+@pytest.mark.parametrize("native", [False, True], ids=["engine", "native_step"])
+def test_tgat_b600_default_dispatch_error_is_a_few_relu_flips_and_nothing_else(native):
+    """What holds the DEFAULT (split-bf16) dispatch at realistic weights, where single ReLU units flip and the per-entry bound has to be
+    loose: the backward is linear in the upstream gradient r, and a flipped unit changes every gradient tensor by ONE direction times a
+    scalar that depends on r.  So over K = 12 random r on the same forward, the differences default - exact (exact mode is pinned to the
+    reference at 1e-4 max|g| on every entry, test above) must lie, tensor by tensor, in a subspace of at most 8 dimensions (one per
+    flipped unit) up to the products' rounding noise.  Any systematic error -- a tensor scaled by 1.005, a dropped term, a wrong
+    accumulation -- is a full-rank perturbation and fails; the test scales one tensor by 1.005 itself to show that it would.
+    (models/modules.py:58-69: the merge layers whose units flip.)"""
+    from flid_amd import engine
+    from flid_amd._lib import lib
+    g = load_golden("tgat_B600_full")
+    data, p, (bs, bd, bt), _ = fullsize.tgat_case(g)
+    K, MAX_FLIPS = 12, 8
+    B = len(bs)
+    rs = [torch.from_numpy(np.random.RandomState(100 + i).standard_normal((2 * B, 172)).astype(np.float32)).cuda() for i in range(K)]
+
+    def grads(mode):
+        lib().tg_set_gemm_mode(mode)
+        try:
+            m = _tgat(data, p)
+            flat = m.flatten_parameters()
+            if native:
+                m.enable_native_step(2 * B, 20)
+            out = []
+            for r in rs:
+                flat.grad = None
+                if native:
+                    job = m.prepare_batch_finish(m.prepare_batch_begin(bs, bd, bt, 20))
+                    m.train_step(job, lambda e: (None, r), 20)
+                else:
+                    s_, d_ = m.compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=bd, node_interact_times=bt, num_neighbors=20)
+                    ((s_ * r[:B]).sum() + (d_ * r[B:]).sum()).backward()
+                out.append(flat.grad.detach().double().clone())
+            named = [m.time_encoder.w.weight, m.time_encoder.w.bias] + m._layer_params()
+            offs, _ = engine.block_layout(named)
+            names = {id(v): k_ for k_, v in m.named_parameters()}
+            return torch.stack(out), [(names[id(q)], o, q.numel()) for o, q in zip(offs, named)]
+        finally:
+            lib().tg_set_gemm_mode(1)
+
+    G1, layout = grads(1)
+    G0, _ = grads(0)
+
+    def tail(D, ref):
+        """the (MAX_FLIPS + 1)-th singular value of D's rows, relative to the rms row norm of `ref`"""
+        ev = torch.linalg.eigvalsh(D @ D.T).clamp_min(0).sqrt().flip(0)
+        return float(ev[MAX_FLIPS]) / float(ref.pow(2).sum(1).mean().sqrt()), [float(x) for x in ev]
+
+    worst = 0.0
+    for name, o, n in layout:
+        d, ref = (G1 - G0)[:, o:o + n], G0[:, o:o + n]
+        t, ev = tail(d, ref)
+        worst = max(worst, t)
+        # (2e-4 of the tensor's gradient norm: the products' rounding noise measures 1e-5..4e-5; a 0.5 % systematic error would leave 5e-3)
+        assert t <= 2e-4, (name, t, ev)
+        # ... and the flips themselves stay small: no direction carries more than 3 % of the gradient's norm
+        assert ev[0] / float(ref.pow(2).sum(1).mean().sqrt()) <= 3e-2, (name, ev[0])
+    # sensitivity: the same check on a default-mode gradient with ONE weight tensor scaled by 1.005 must fail
+    name, o, n = next(x for x in layout if x[0] == "temporal_conv_layers.0.value_projection.weight")
+    bad = G1[:, o:o + n] * 1.005
+    t, _ = tail(bad - G0[:, o:o + n], G0[:, o:o + n])
+    assert t > 2e-3, ("a 0.5 % scaling error would not be caught", t, worst)
+
+
 def _b600_case(name, flat, exact):
     from flid_amd import engine
     from flid_amd._lib import lib
@@ -136,6 +201,66 @@ def test_tgn_b600_sequence_matches_reference():
         mem = bank.node_memories.detach().cpu()
         np.testing.assert_allclose(mem.numpy()[g[f"touched{j}"]], g[f"mem{j}"], atol=TOL)
         # (the whole table's sum after 330 batches of GRU updates: 1.9 M entries, |sum| ~ 6e3 -- 2e-5 of it)
+        assert abs(mem.double().sum().item() - g[f"memsum{j}"][0]) < 2e-5 * max(1.0, abs(float(g[f"memsum{j}"][0])))
+        assert np.array_equal(bank.node_last_updated_times.detach().cpu().numpy(), g[f"lu{j}"])
+        raw = bank.node_raw_messages
+        has = np.zeros(mem.shape[0], dtype=bool)
+        has[[nid for nid, lst in raw.items() if len(lst)]] = True
+        assert np.array_equal(has, g[f"has{j}"])
+        ids = np.nonzero(has)[0]
+        sums = torch.stack([raw[int(i)][-1][0] for i in ids]).double().sum(1).cpu().numpy()
+        np.testing.assert_allclose(sums, g[f"pmsum{j}"][ids], atol=2e-3)
+        assert all(raw[int(i)][-1][1] == g[f"pt{j}"][i] for i in ids)
+
+
+def test_tgn_b600_native_step_matches_reference():
+    """the same fixture through the NATIVE step (csrc/tg_step.hip tg_stepper_tgn_*: the path `bench.py --model tgn` times): 330 warm-up
+    batches, then per recorded batch the warm-up's pair -- negatives (no state advance, `more`), then positives (`accumulate`) -- as two
+    native calls that add into one gradient block (models/MemoryModel.py:96-189 under PTCL/EM_warmup.py:159-231).  Against the reference's
+    own numbers: the four embedding blocks, EVERY parameter gradient (kink-free weights: strict), memory / last-update / pending
+    messages after each batch."""
+    from flid_amd import engine
+    from flid_amd.models.MemoryModel import MemoryModel
+    from flid_amd.utils.utils import get_neighbor_sampler
+    g = load_golden("tgn_B600x3")
+    data, p = fullsize.tgn_case(g)
+    sampler = get_neighbor_sampler(data, "recent", seed=0)
+    m = MemoryModel(data.node_raw_features, data.edge_raw_features, sampler, time_feat_dim=100, model_name="TGN", num_layers=1,
+                    num_heads=2, dropout=0.0, device="cuda:0")
+    sd = dict(p)
+    sd["embedding_module.time_encoder.w.weight"], sd["embedding_module.time_encoder.w.bias"] = p["time_encoder.w.weight"], p["time_encoder.w.bias"]
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    flat = m.flatten_parameters()
+    m.enable_native_step(fullsize.B, 20)
+    bank = m.memory_bank
+    bank.__init_memory_bank__()
+    step = int(g["step"])
+    B = fullsize.B
+    zero = torch.zeros(2 * B, 172, device="cuda")
+    for j, (bs, bd, bt, be), neg, r in fullsize.tgn_batches(g, data):
+        flat.grad = None
+        if j is None:                      # warm-up: positives only, the state advances (a zero upstream gradient: nothing to compare)
+            job = m.prepare_batch_finish(m.prepare_batch_begin(bs, bd, bt, 20, edge_ids=be))
+            m.train_step(job, be, lambda e: (None, zero), 20)
+            continue
+        rr = torch.from_numpy(r).cuda()
+        r_neg, r_pos = rr[:2].reshape(2 * B, -1).contiguous(), rr[2:].reshape(2 * B, -1).contiguous()
+        jn = m.prepare_batch_finish(m.prepare_batch_begin(bs, neg, bt, 20))
+        jp = m.prepare_batch_finish(m.prepare_batch_begin(bs, bd, bt, 20, edge_ids=be))
+        en, _ = m.train_step(jn, None, lambda e: (None, r_neg), 20, edges_are_positive=False, more=True)
+        en = en.clone()
+        ep, _ = m.train_step(jp, be, lambda e: (None, r_pos), 20, accumulate=True)
+        named = m._trainable()
+        offs, _ = engine.block_layout(named)
+        by_id = {id(q): flat.grad[o:o + q.numel()].view(q.shape) for o, q in zip(offs, named)}
+        grads = {k_: by_id[id(v)].cpu().numpy() for k_, v in m.named_parameters() if id(v) in by_id}
+        assert "memory_updater.memory_updater.weight_ih" in grads
+        assert_grads_match(fullsize.tgn_grads_view(g, j), grads, atol=1e-4, strict=True)
+        for mine, key in ((en[:B], "ns"), (en[B:], "nd"), (ep[:B], "ps"), (ep[B:], "pd")):
+            np.testing.assert_allclose(mine.cpu().numpy()[::step], g[f"{key}{j}"], atol=TOL, err_msg=f"{key}{j}")
+        mem = bank.node_memories.detach().cpu()
+        np.testing.assert_allclose(mem.numpy()[g[f"touched{j}"]], g[f"mem{j}"], atol=TOL)
         assert abs(mem.double().sum().item() - g[f"memsum{j}"][0]) < 2e-5 * max(1.0, abs(float(g[f"memsum{j}"][0])))
         assert np.array_equal(bank.node_last_updated_times.detach().cpu().numpy(), g[f"lu{j}"])
         raw = bank.node_raw_messages

@@ -823,3 +823,66 @@ def test_native_step_small_batch_after_large_one():
     for (ea, ga), (en, gn) in zip(res[0], res[1]):
         assert torch.equal(ea, en), float((ea - en).abs().max())
         assert float((ga - gn).abs().max()) <= 2e-6 * float(ga.abs().max())
+
+
+def test_native_stepper_follows_set_neighbor_sampler_and_eval_prefetch_stays_on_the_engine():
+    """The trainers alternate between the train-graph and the full-graph sampler every epoch (PTCL/EM_warmup.py:118, :296; PTCL/M_step.py:34,
+    :200).  set_neighbor_sampler() rebinds the native object: a step after the swap samples from the NEW graph (== the Python engine on
+    that graph), a prepared batch of the old graph is dropped, a sampler replaced behind the model's back is refused, a second backward
+    into the gradient block without an update or zero_grad is refused, and in eval mode prepare_batch_begin hands out an engine job that
+    compute_src_dst_node_temporal_embeddings accepts."""
+    from flid_amd import ops
+    from flid_amd.models.TGAT import TGAT
+    from flid_amd.stepper import StepJob
+    from flid_amd.synth import wikipedia_like
+    from flid_amd.utils.utils import get_neighbor_sampler
+    dev = torch.device("cuda:0")
+    data = wikipedia_like(num_edges=6000, seed=2)
+    n_tr = 3000
+    s_train = get_neighbor_sampler(data.slice(0, n_tr), "recent", seed=0)
+    s_full = get_neighbor_sampler(data, "recent", seed=1)
+    k = 10
+    sl = slice(5200, 5260)                                  # beyond the train graph: histories differ between the two samplers
+    bs, bd, bt = data.src_node_ids[sl], data.dst_node_ids[sl], data.node_interact_times[sl]
+    n = 2 * len(bs)
+    w = torch.from_numpy(np.random.RandomState(1).standard_normal((n, 172)).astype(np.float32)).to(dev)
+    loss_fn = lambda e: (ops.weighted_sum(e, w, 0.5), 0.5 * w)
+
+    def model(sampler):
+        torch.manual_seed(11)
+        m = TGAT(data.node_raw_features, data.edge_raw_features, sampler, 100, 2, 2, 0.0, "cuda:0").to(dev).train()
+        return m, m.flatten_parameters()
+
+    ref = {}
+    for name, smp in (("train", s_train), ("full", s_full)):               # the Python engine on each graph
+        m, flat = model(smp)
+        emb, _ = m.train_step(m.prepare_batch_finish(m.prepare_batch_begin(bs, bd, bt, k)), loss_fn, k)
+        ref[name] = (emb.clone(), flat.grad.clone())
+    assert float((ref["train"][0] - ref["full"][0]).abs().max()) > 1e-3    # the graphs do give different embeddings here
+
+    m, flat = model(s_train)
+    st = m.enable_native_step(n, k)
+    stale = m.prepare_batch_begin(bs, bd, bt, k)                           # prepared on the train graph, never used
+    assert isinstance(stale, StepJob)
+    emb, _ = m.train_step(m.prepare_batch_finish(m.prepare_batch_begin(bs, bd, bt, k)), loss_fn, k)
+    assert torch.equal(emb, ref["train"][0])
+    with pytest.raises(RuntimeError, match="zero_grad"):                  # the block still holds that step's gradient
+        m.train_step(m.prepare_batch_finish(m.prepare_batch_begin(bs, bd, bt, k)), loss_fn, k)
+    flat.grad = None
+    m.set_neighbor_sampler(s_full)
+    assert st.graph is s_full.graph
+    emb, _ = m.train_step(m.prepare_batch_finish(m.prepare_batch_begin(bs, bd, bt, k)), loss_fn, k)
+    assert torch.equal(emb, ref["full"][0])
+    assert float((flat.grad - ref["full"][1]).abs().max()) <= 2e-6 * float(ref["full"][1].abs().max())
+    flat.grad = None
+    # eval: the prefetch goes to the engine, and the autograd-facing call takes its job
+    m.eval()
+    job = m.prepare_batch_begin(bs, bd, bt, k)
+    assert not isinstance(job, StepJob)
+    with torch.no_grad():
+        se, de = m.compute_src_dst_node_temporal_embeddings(m.prepare_batch_finish(job), None, None, k)
+    assert float((torch.cat([se, de]) - ref["full"][0]).abs().max()) <= 1e-5
+    m.train()
+    m.neighbor_sampler = s_train                                            # behind the model's back
+    with pytest.raises(RuntimeError, match="another graph"):
+        m.prepare_batch_begin(bs, bd, bt, k)

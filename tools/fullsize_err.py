@@ -26,5 +26,9 @@ for name in sys.argv[1:] or ["tgat_B600_full", "tgat_B600_kinkfree"]:
         for k in sorted(x for x in g if x.startswith("g:")):
             big = max(1.0, float(np.abs(g[k]).max()))
             err = np.abs(mine[k].astype(np.float64) - g[k])
-            print(f"  {k[2:]:55s} max|g| {big:10.3f}  max err/max|g| {err.max() / big:9.2e}  > 1e-4: {int((err > 1e-4 * big).sum()):5d} / {err.size}")
+            gs = "gs:" + k[2:]
+            rl2 = float(np.sqrt((err ** 2).sum() / max(1e-30, (g[k].astype(np.float64) ** 2).sum())))
+            print(f"  {k[2:]:55s} max|g| {big:10.3f}  max err/max|g| {err.max() / big:9.2e}  > 1e-4: {int((err > 1e-4 * big).sum()):5d} / {err.size}"
+                  f"  median {np.median(err) / big:8.1e}  p99 {np.quantile(err, 0.99) / big:8.1e}  rel-L2(sample) {rl2:8.1e}"
+                  f"  sum err {abs(mine[gs][0] - g[gs][0]) / max(1.0, np.sqrt(g[gs][1])):8.1e}  sumsq rel {abs(mine[gs][1] - g[gs][1]) / max(1.0, g[gs][1]):8.1e}")
 lib().tg_set_gemm_mode(1)
