@@ -90,8 +90,9 @@ def main():
     ap.add_argument("--no-flat", action="store_true", help="per-tensor parameters / gradients / Adam as in the reference's trainers")
     ap.add_argument("--gemm-mode", type=int, default=None, help="tg_set_gemm_mode override (experiments)")
     ap.add_argument("--trace-steps", action="store_true", help="per-step GPU times (events) to stderr")
-    ap.add_argument("--event-every", type=int, default=4, help="HIP events around the roofline kernel's launches in every n-th timed step "
-                    "(an event pair costs ~12 us of stream idle time per launch; 1 = every step)")
+    ap.add_argument("--event-every", type=int, default=10, help="HIP events around the roofline kernel's launches in every n-th timed step "
+                    "(an event pair costs ~10 us of stream idle time per launch -- round 5, kernel trace: +20 us on a step that carries them, "
+                    "whatever n; 1 = every step)")
     ap.add_argument("--host-profile", action="store_true", help="host issue cost per phase of a fused step (GPU idle at each step start) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the untimed per-family profiling pass")

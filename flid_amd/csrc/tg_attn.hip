@@ -502,7 +502,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // bit 0: forward on tg_attn_fast.hip, bit 1: backward, bit 2: the fast forward also where the one-instance-per-workgroup (SPLIT)
 // form of the generic kernel would run (launches of <= 4096 instances); bit 3 / 4: forward / backward on the LDS-ring kernels
 // (tg_attn_ring.hip) wherever they cover the shape.  tg_set_attn_fast() is for A/B tests and timing.
-int g_fast = 3;
+int g_fast = 7;
 
 int check_desc(const tg_attn_desc* a) {
     TG_REQUIRE(a, "tg_attn: null descriptor");

@@ -38,6 +38,12 @@
 #ifndef FLID_CHAIN_X4
 #define FLID_CHAIN_X4 1   // keep the lo * lo term (see step()); 0: three terms, as the launch-per-product kernels
 #endif
+#ifndef FLID_CHAIN_ROT
+#define FLID_CHAIN_ROT 0   // 1: every workgroup walks a product's contraction from its own starting group (see Wave::rot_seed).  Measured
+                           // (round 5): chain_fwd 71.8 -> 67.3 us, chain_bwd 74.7 -> 71.6 us at 13.6 k rows -- and OFF all the same: a row's
+                           // rounding then depends on the row block it sits in, and with row sharing the rows of a call are numbered in
+                           // the hash set's arrival order, so two identical calls stopped being bit-identical
+#endif
 #ifndef FLID_CHAIN_EXP
 #define FLID_CHAIN_EXP 0   // timing experiments only (results wrong): 1 no steady-state weight loads, 2 no MFMAs, 3 all fragment reads from one chunk
 #endif
@@ -79,8 +85,15 @@ struct Wave {
     bf16x8 b0h[2][NTW], b0l[2][NTW], b1h[2][NTW], b1l[2][NTW];
     const uint4* bptr[NTW];
     int S, t0, tcnt;          // current product: steps, first tile of this wave (inside its operand), tiles it owns
+    // Every workgroup of a launch streams the SAME packed weights, and they all start together: walking the contraction in the same
+    // order they ask the XCD's L2 for the same lines at the same time (one or two of its 16 channels busy, the rest idle).  So workgroup
+    // b starts a product's contraction at group (b / 8) mod ngroups and wraps around: the 32 CUs of an XCD spread over the whole operand.
+    // (The order of a row's partial sums then depends on its row block -- fixed per row, so results stay reproducible run to run.)
+    int rot_seed = 0, rot = 0, ng = 1;
+    __device__ __forceinline__ int Gr(int i) const { const int x = i + rot; return x >= ng ? x - ng : x; }
+    __device__ __forceinline__ int Gx(int i) const { return i < ng ? Gr(i) : ng; }     // past the end: a group of zero rows
     bool pre = false;         // the first weight group of the product about to begin() is already on its way into b0 (prefetch())
-#if FLID_CHAIN_STAMPS == 2
+#if FLID_CHAIN_STAMPS >= 2
     unsigned long long* fine = nullptr;     // diagnostic: stamps inside run_panel (one product only)
     int fine_i = 0;
     __device__ __forceinline__ void fstamp() {
@@ -96,6 +109,8 @@ struct Wave {
     // the product's nt column tiles are dealt in blocks to waves [w0, w0 + nw); `packed` = that operand
     __device__ __forceinline__ void begin(const void* packed, int nt, int steps, int w0 = 0, int nw = NW) {
         S = steps;
+        ng = (steps + 1) >> 1;
+        rot = FLID_CHAIN_ROT ? rot_seed % ng : 0;
         const int cpw = (nt + nw - 1) / nw;
         t0 = (wave - w0) * cpw;
         tcnt = nt - t0 < cpw ? nt - t0 : cpw;
@@ -119,9 +134,10 @@ struct Wave {
     __device__ __forceinline__ void prefetch(const void* packed, int nt, int steps, int w0 = 0, int nw = NW) {
         const int cpw = (nt + nw - 1) / nw;
         const int pt0 = (wave - w0) * cpw;
+        const int g0 = FLID_CHAIN_ROT ? rot_seed % ((steps + 1) >> 1) : 0;      // the group that product starts with (begin() computes the same)
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            const int sc = sl < steps ? sl : steps - 1;
+            const int sc = 2 * g0 + sl < steps ? 2 * g0 + sl : steps - 1;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 int t = pt0 + j;
@@ -213,28 +229,28 @@ struct Wave {
     // ---- product whose rows come from the LDS panel: chunks [chunk0, chunk0 + S).  No barrier inside.
     template <int NT>
     __device__ __forceinline__ void run_panel(int chunk0) {
-        const int ngroups = (S + 1) >> 1;
         const char* base = lds + chunk0 * G::CHUNK;
         fstamp();
-        if (!pre) loadB<NT>(b0h, b0l, 0);                      // (uniform: set by prefetch() at compile-time-known call sites)
+        if (!pre) loadB<NT>(b0h, b0l, Gr(0));                   // (uniform: set by prefetch() at compile-time-known call sites)
         pre = false;
         fstamp();
-        for (int g = 0; g < ngroups; g += 2) {
-            loadB<NT>(b1h, b1l, g + 1);
+        for (int g = 0; g < ng; g += 2) {
+            const int g0 = Gr(g), g1 = g + 1 < ng ? Gr(g + 1) : g0, g2 = g + 2 < ng ? Gr(g + 2) : g0;
+            loadB<NT>(b1h, b1l, g1);
             fstamp();
-            step<NT>(base + (2 * g) * G::CHUNK, b0h[0], b0l[0]);
+            step<NT>(base + (2 * g0) * G::CHUNK, b0h[0], b0l[0]);
             spread_loads<NT, 4 * NT>();
             fstamp();
-            if (2 * g + 1 < S) step<NT>(base + (2 * g + 1) * G::CHUNK, b0h[1], b0l[1]);
+            if (2 * g0 + 1 < S) step<NT>(base + (2 * g0 + 1) * G::CHUNK, b0h[1], b0l[1]);
             fstamp();
             fstamp();
-            if (2 * g + 2 < S) {                                 // (uniform; the loads of group g + 2 inside the block whose MFMAs hide them)
-                loadB<NT>(b0h, b0l, g + 2);
-                step<NT>(base + (2 * g + 2) * G::CHUNK, b1h[0], b1l[0]);
+            if (g + 1 < ng) {                                  // (uniform; the loads of group g + 2 inside the block whose MFMAs hide them)
+                loadB<NT>(b0h, b0l, g2);
+                step<NT>(base + (2 * g1) * G::CHUNK, b1h[0], b1l[0]);
                 spread_loads<NT, 4 * NT>();
             }
             fstamp();
-            if (2 * g + 3 < S) step<NT>(base + (2 * g + 3) * G::CHUNK, b1h[1], b1l[1]);
+            if (g + 1 < ng && 2 * g1 + 1 < S) step<NT>(base + (2 * g1 + 1) * G::CHUNK, b1h[1], b1l[1]);
             fstamp();
         }
     }
@@ -285,32 +301,40 @@ struct Wave {
                 }
             }
         };
-        const int ngroups = (S + 1) >> 1;
+        const int ngroups = ng;
         float4 ra0[HH][PER], ra1[HH][PER];
-        loadA(ra0, 0);
-        loadB<NT>(b0h, b0l, 0);
-        loadA(ra1, 1);
-        writeA(0, ra0, 0);
-        loadA(ra0, 2);
+        fstamp();
+        loadA(ra0, Gx(0));
+        loadB<NT>(b0h, b0l, Gr(0));
+        loadA(ra1, Gx(1));
+        writeA(0, ra0, Gx(0));
+        loadA(ra0, Gx(2));
         __syncthreads();
+        fstamp();
         const char* r0 = lds + (2 * mine) * 2 * G::CHUNK, *r1 = r0 + 2 * G::CHUNK;
         for (int g = 0; g < ngroups; g += 2) {
-            writeA(1, ra1, g + 1);
-            loadA(ra1, g + 3);
-            loadB<NT>(b1h, b1l, g + 1);
+            writeA(1, ra1, Gx(g + 1));
+            fstamp();
+            loadA(ra1, Gx(g + 3));
+            loadB<NT>(b1h, b1l, g + 1 < ngroups ? Gr(g + 1) : Gr(g));
             step<NT>(r0, b0h[0], b0l[0]);
             spread_loads<NT, 4 * NT + HH * PER>();
             step<NT>(r0 + G::CHUNK, b0h[1], b0l[1]);        // (a step past the end of K multiplies zero rows)
+            fstamp();
             __syncthreads();
-            writeA(0, ra0, g + 2);
+            fstamp();
+            writeA(0, ra0, Gx(g + 2));
+            fstamp();
             if (g + 1 < ngroups) {                              // (uniform; past the last group nothing more is needed)
-                loadA(ra0, g + 4);
-                loadB<NT>(b0h, b0l, g + 2);
+                loadA(ra0, Gx(g + 4));
+                loadB<NT>(b0h, b0l, g + 2 < ngroups ? Gr(g + 2) : Gr(g));
                 step<NT>(r1, b1h[0], b1l[0]);
                 spread_loads<NT, 4 * NT + HH * PER>();
                 step<NT>(r1 + G::CHUNK, b1h[1], b1l[1]);
             }
+            fstamp();
             __syncthreads();
+            fstamp();
         }
     }
     // coordinates of acc[rb][j]: row (inside the block) and first of its 4 columns (inside the wave's operand)
@@ -378,6 +402,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
     w.wave = threadIdx.x >> 6;
     w.row0 = (int64_t)blockIdx.x * ROWS;
     w.R = a.R;
+    w.rot_seed = blockIdx.x >> 3;
     const int lane = w.lane, tid = threadIdx.x;
     const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
     const int ychunks = (dq + 31) >> 5, rchunks = (a.dn + 31) >> 5;
@@ -414,7 +439,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs
         const int64_t wv_stride = (int64_t)((hd + 15) / 16) * ((dk + 31) / 32) * 512;   // floats per packed head (tg_packed_floats(hd, dk))
         const int mine = HH == 2 ? w.wave / (NW / 2) : 0;
         w.begin(reinterpret_cast<const float*>(a.pWv) + mine * wv_stride, ht, (dk + 31) >> 5, HH == 2 ? (NW / 2) * mine : 0, NW / HH);
+#if FLID_CHAIN_STAMPS == 3
+        w.fine = a.dbg ? a.dbg + blockIdx.x * 16 : nullptr;
+        w.fine_i = 0;
+#endif
         w.template run_stream<NTW, HH>(a.agg, (int64_t)HH * dk, dk, dk, mine);
+#if FLID_CHAIN_STAMPS == 3
+        w.fine = nullptr;
+#endif
         STAMP();
         w.template prefetch<NTW>(a.pWr, (dq + 15) >> 4, (HH * a.hp + 31) >> 5);
 #pragma unroll
@@ -651,6 +683,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
     w.wave = threadIdx.x >> 6;
     w.row0 = (int64_t)blockIdx.x * ROWS;
     w.R = a.R;
+    w.rot_seed = blockIdx.x >> 3;
     const int lane = w.lane, tid = threadIdx.x;
     const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
     const int nchunks_dn = (a.dn + 31) >> 5, nchunks_dq = (dq + 31) >> 5;
@@ -914,7 +947,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) qu_fwd_kernel(QuFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     Wave<1, NW, NTD> w;
     w.lds = lds; w.lane = threadIdx.x & 63; w.wave = threadIdx.x >> 6;
-    w.row0 = (int64_t)blockIdx.x * 16; w.R = a.R;
+    w.row0 = (int64_t)blockIdx.x * 16; w.R = a.R; w.rot_seed = blockIdx.x >> 3;
     const int tid = threadIdx.x;
     const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
     const int r = w.out_row(0);
@@ -979,7 +1012,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dq_bwd_kernel(DqBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     Wave<1, NW> w;
     w.lds = lds; w.lane = threadIdx.x & 63; w.wave = threadIdx.x >> 6;
-    w.row0 = (int64_t)blockIdx.x * 16; w.R = a.R;
+    w.row0 = (int64_t)blockIdx.x * 16; w.R = a.R; w.rot_seed = blockIdx.x >> 3;
     const int tid = threadIdx.x;
     const int dq = a.dn + a.T, hd = dq / HH, dk = a.dn + a.de + a.T;
     const int r = w.out_row(0);

@@ -116,6 +116,10 @@ struct ColExtra {
 };
 // tg_wgrad.hip: big tiles + transposing LDS reads + slice fold; `extra` (optional): slab sums that ride in the fold launch
 bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s, const ColExtra* extra = nullptr);
+// the NEXT wgrad_group2 call of this thread is kept back and leaves in the launch of the call after it on the same stream (one product
+// launch + one fold for both groups); wgrad_flush_deferred launches a kept-back group that nothing picked up
+void wgrad_defer_next(bool on);
+int wgrad_flush_deferred(hipStream_t s);
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);   // tg_gemm_bf16x3.hip; false = shapes not covered
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,

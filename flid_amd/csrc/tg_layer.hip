@@ -1127,6 +1127,12 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             return tg::launch_status("layer_tail_kernel");
         });
     };
+    // Only the short-layer form below (query-side launch, the time half of dWq in the fold) leaves nothing behind its grouped launch that
+    // reads the launch's results inside this call: every other form cancels a deferral the caller asked for (tg::wgrad_defer_next).
+    {
+        static const bool no_fold_wq0 = getenv("FLID_GEMM_TUNE") && getenv("FLID_NO_FOLD_WQ") && atoi(getenv("FLID_NO_FOLD_WQ")) != 0;
+        if (merged || !use_qu || T <= 0 || overlap || !g_wgrad_grouped || no_fold_wq0 || (Bw->finish_time_bias && T > 0)) tg::wgrad_defer_next(false);
+    }
     if (merged) {
         // ---- output projection + value path (the reference's two products; weight gradients in one grouped launch) ------------------
         if (!use_chain) {

@@ -509,8 +509,10 @@ namespace {
 struct BaseGrad { float* d_table; int64_t pad_row; float* d_own; float* d_raw; };
 
 // the layers' backward calls; `fill_extra` floats behind the lower layers' gradient rows are zeroed with the gradient block
+// defer_last: the LAST layer's weight gradients are kept back too (the caller has another grouped launch coming on this stream that carries
+// them: TGN's GRU) -- the caller then owns the final tg::wgrad_flush_deferred
 int run_backward(tg_stepper* st, Slot& s, const float* d_demb, void* stream, tg_grad_ready_fn grad_ready, void* user, bool fuse_tb,
-                 const BaseGrad& bg, int64_t fill_extra, bool accumulate = false) {
+                 const BaseGrad& bg, int64_t fill_extra, bool accumulate = false, bool defer_last = false) {
     const tg_stepper_cfg& c = st->c;
     const int L = c.layers, dn = c.dn;
     hipStream_t ms = (hipStream_t)stream;
@@ -554,7 +556,11 @@ int run_backward(tg_stepper* st, Slot& s, const float* d_demb, void* stream, tg_
         }
         bw.defer_join = (l > 1 && !grad_ready) ? 1 : 0;
         bw.finish_time_bias = (l == 1 && !fuse_tb) ? 1 : 0;
+        // An upper layer's weight gradients (1 200 rows: a ~19 + 12 us latency chain on a fraction of the chip) ride in the grouped launch
+        // of the layer below -- unless a data-parallel caller wants this layer's block now (grad_ready).
+        tg::wgrad_defer_next(!grad_ready && (l > 1 || defer_last));
         rc = tg_tgat_layer_bwd(&st->desc[(size_t)l - 1], &bw, stream);
+        tg::wgrad_defer_next(false);
         if (rc == TG_OK && grad_ready && l >= 2) {
             const int64_t lo = st->poff[2 + (size_t)(l - 1) * 11], hi = l < L ? st->poff[2 + (size_t)l * 11] : st->poff.back();
             grad_ready(user, g + lo, hi - lo);
@@ -562,7 +568,8 @@ int run_backward(tg_stepper* st, Slot& s, const float* d_demb, void* stream, tg_
         dH = dH_prev;
     }
     const int rj = tg_side_join(stream);          // queued side-stream products must not outlive this call's operands
-    return rc != TG_OK ? rc : rj;
+    const int rf = defer_last ? (int)TG_OK : tg::wgrad_flush_deferred((hipStream_t)stream);      // (nothing picked a kept-back group up: it leaves alone)
+    return rc != TG_OK ? rc : (rj != TG_OK ? rj : rf);
 }
 
 int finish_backward(tg_stepper* st, Slot& s, int rc, void* stream, const tg_adam_args* adam, float** d_grad) {
@@ -684,9 +691,10 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
     TG_REQUIRE(!(more && adam), "tg_stepper_tgn_backward: the update belongs to the LAST backward of a step");
     TG_REQUIRE(!(grad_ready && (adam || more)), "tg_stepper_tgn_backward: grad_ready is for the last backward of a step, before a reduction (no update here)");
     // (fuse_tb argument: true also when more backward calls follow -- d b is finished once, on the summed d cos b, by the last call)
+    // (with pending messages the GRU's grouped weight-gradient launch follows and carries the layer's along)
     int rc = run_backward(st, s, d_demb, stream, nullptr, nullptr, adam != nullptr || more,
                           pending ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw} : BaseGrad{nullptr, 0, nullptr, nullptr}, pending ? r4(U * D) : 0,
-                          accumulate);
+                          accumulate, pending && !grad_ready);
     // the attention + merge layer's block is final (the time encoder's two tensors in front of it are not: d b is finished below / by the
     // caller's update): a data-parallel caller starts reducing it under the GRU's backward and the state advance
     if (rc == TG_OK && grad_ready) grad_ready(user, g + st->poff[2], st->poff.back() - st->poff[2]);
@@ -699,6 +707,10 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
                                           {t.dgh, 3 * (int64_t)D, 3 * D, t.h_rows, D, D, g + st->gru_off[1], D, g + st->gru_off[3]}};
             rc = tg_wgrad_group(2, jobs, U, stream);
         }
+    }
+    if (pending && !grad_ready) {                      // (safety net: an error path above may have left the layer's group kept back)
+        const int rf = tg::wgrad_flush_deferred((hipStream_t)stream);
+        if (rc == TG_OK) rc = rf;
     }
     if (rc == TG_OK && positive) {
         // (units: the edges whose state the advance files -- on a data-parallel rank the WHOLE global batch, section 7 of DESIGN.md)

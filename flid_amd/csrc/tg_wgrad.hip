@@ -75,9 +75,19 @@ struct WTile {
     float* C; int64_t ldc;      // fold: C[m0.., n0..] += ...; colsum[m0..] += column ones_col
     float* colsum;
     int trans;                  // the tile holds (B^T A): the fold writes element (m, n) to C[n * ldc + m] (job computed with its operands swapped)
+    int nsl;                    // K slices of this tile's group (what the fold adds up)
 };
-constexpr int MAX_TILES = 24;
+constexpr int MAX_TILES = 34;   // (kernel arguments stay under 4 KB: 34 x 88 B + two ColExtra)
 struct WTiles { WTile t[MAX_TILES]; int n; };
+static_assert(sizeof(WTile) == 88, "WTile grew: re-check the kernel argument block");
+// Up to two GROUPS of jobs in one launch: each group contracts over its own rows (a 13.6 k-row layer and the 1 200-row layer above it;
+// TGN's layer and its GRU).  The grid is `cap` blocks per XCD (block b runs on XCD b % 8: observed, used for speed only); group 0 takes
+// slices s = x, x + 8, ... of all its tiles on XCD x (a slice's row range is pulled into ONE L2), group 1 fills what is left, in order.
+struct WGroups {
+    int n, cap;
+    int tile0[2], ntiles[2], nslices[2];
+    int64_t rows[2], rps[2];
+};
 
 // 8 bf16 of one MFMA operand fragment from a [k][column] image: two transposing reads (k = 8 h + 0..3, 8 h + 4..7)
 __device__ __forceinline__ bf16x8 frag_tr(const char* p, int stride) {
@@ -88,18 +98,37 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* p, int stride) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ void __launch_bounds__(WNT, 2) wgrad2_kernel(WTiles tiles, int64_t R, int64_t rows_per_slice, int nslices, float* __restrict__ ws,
-                                                         int64_t slice_stride) {
+__global__ void __launch_bounds__(WNT, 2) wgrad2_kernel(WTiles tiles, WGroups gr, float* __restrict__ ws, int64_t slice_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    int t, slice;
-    if ((nslices & 7) == 0) {                       // all tiles of a K slice on one XCD: its L2 pulls that row range of the operands once
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        t = j % tiles.n;
-        slice = xcd + 8 * (j / tiles.n);
+    int t, slice, gi = 0;
+    if (gr.n == 1) {
+        const int nslices = gr.nslices[0], nt = gr.ntiles[0];
+        if ((nslices & 7) == 0) {                   // all tiles of a K slice on one XCD: its L2 pulls that row range of the operands once
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            t = j % nt;
+            slice = xcd + 8 * (j / nt);
+        } else {
+            t = blockIdx.x % nt;
+            slice = blockIdx.x / nt;
+        }
     } else {
-        t = blockIdx.x % tiles.n;
-        slice = blockIdx.x / tiles.n;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int nt0 = gr.ntiles[0], s0 = gr.nslices[0];
+        const int c0 = nt0 * ((s0 + 7 - x) >> 3);                    // group 0's blocks on this XCD
+        if (j < c0) {
+            t = j % nt0;
+            slice = x + 8 * (j / nt0);
+        } else {
+            int before = 0;                                          // group 1's blocks on the XCDs in front of this one
+            for (int y = 0; y < x; ++y) before += gr.cap - nt0 * ((s0 + 7 - y) >> 3);
+            const int idx = before + (j - c0), nt1 = gr.ntiles[1];
+            if (idx >= nt1 * gr.nslices[1]) return;                  // (a block nobody needs: the grid is a whole number of blocks per XCD)
+            gi = 1;
+            t = gr.tile0[1] + idx % nt1;
+            slice = idx / nt1;
+        }
     }
+    const int64_t R = gr.rows[gi], rows_per_slice = gr.rps[gi];
     const WTile T = tiles.t[t];
     const int64_t kbeg = (int64_t)slice * rows_per_slice;
     const int64_t kend = kbeg + rows_per_slice < R ? kbeg + rows_per_slice : R;
@@ -293,18 +322,24 @@ __global__ void __launch_bounds__(WNT, 2) wgrad2_kernel(WTiles tiles, int64_t R,
 // C += sum over slices (fixed order); the ones column lands in colsum.  One element per thread, the slices' loads independent.
 // Grid rows behind the tiles' (blockIdx.y >= tiles.n) are the caller's slab sums (tg::ColExtra): independent of the fold, they used to
 // be a part of the layer's tail launch that could only start after it.
-__global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, int nslices, const float* __restrict__ ws, int64_t slice_stride, tg::ColExtra ex) {
+__global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, const float* __restrict__ ws, int64_t slice_stride, tg::ColExtra ex0, tg::ColExtra ex1,
+                                                          int rows0) {
     if ((int)blockIdx.y >= tiles.n) {
         __shared__ float red[4][64];
         __shared__ float red2[272];
-        const int c = ((int)blockIdx.y - tiles.n) * (int)gridDim.x + (int)blockIdx.x;
-        const int ncol = ex.col_gx * ex.col_ny;
-        if (c < ncol) tg::colsum_seg2_body(ex.a, ex.b, ex.groups_a, c % ex.col_gx, c / ex.col_gx, ex.col_ny, red);
-        else if (c - ncol < ex.wq_n) {
-            if (ex.wq_nb > 0) tg::wq_time_slab_body((c - ncol) % ex.wq_gx, (c - ncol) / ex.wq_gx, ex.wq_sq, ex.wq_nb, ex.wq_dq, ex.wq_cosb, ex.wq_T, ex.wq_W,
-                                                    ex.wq_dW, ex.wq_ld, ex.wq_dcosb, red2);
-            else tg::wq_time_body((c - ncol) % ex.wq_gx, (c - ncol) / ex.wq_gx, ex.wq_sq, ex.wq_dq, ex.wq_cosb, ex.wq_T, ex.wq_W, ex.wq_dW, ex.wq_ld, ex.wq_dcosb);
-        }
+        // the two groups' slab sums: grid rows [tiles.n, tiles.n + rows0) belong to the first, the rest to the second.  (Two branches, not
+        // a reference picked by a condition: a select between two argument structs makes hipcc copy both to scratch.)
+        auto run = [&](const tg::ColExtra& ex, int c) {
+            const int ncol = ex.col_gx * ex.col_ny;
+            if (c < ncol) tg::colsum_seg2_body(ex.a, ex.b, ex.groups_a, c % ex.col_gx, c / ex.col_gx, ex.col_ny, red);
+            else if (c - ncol < ex.wq_n) {
+                if (ex.wq_nb > 0) tg::wq_time_slab_body((c - ncol) % ex.wq_gx, (c - ncol) / ex.wq_gx, ex.wq_sq, ex.wq_nb, ex.wq_dq, ex.wq_cosb, ex.wq_T, ex.wq_W,
+                                                        ex.wq_dW, ex.wq_ld, ex.wq_dcosb, red2);
+                else tg::wq_time_body((c - ncol) % ex.wq_gx, (c - ncol) / ex.wq_gx, ex.wq_sq, ex.wq_dq, ex.wq_cosb, ex.wq_T, ex.wq_W, ex.wq_dW, ex.wq_ld, ex.wq_dcosb);
+            }
+        };
+        if ((int)blockIdx.y < tiles.n + rows0) run(ex0, ((int)blockIdx.y - tiles.n) * (int)gridDim.x + (int)blockIdx.x);
+        else run(ex1, ((int)blockIdx.y - tiles.n - rows0) * (int)gridDim.x + (int)blockIdx.x);
         return;
     }
     const WTile T = tiles.t[blockIdx.y];
@@ -314,6 +349,7 @@ __global__ void __launch_bounds__(256) wgrad2_fold_kernel(WTiles tiles, int nsli
     const int m = (int)(e / T.nw), n = (int)(e - (int64_t)m * T.nw);
     if (n >= T.next && n != T.ones_col) return;
     const float* p = ws + T.slab_off + e;
+    const int nslices = T.nsl;
     float s = 0.f;
     int sl = 0;
     for (; sl + 8 <= nslices; sl += 8) {
@@ -354,16 +390,13 @@ bool g_wgrad2 = true;
 
 namespace tg {
 
-// false = a job's shape / alignment is not covered or no workspace (nothing launched): the caller takes the first form
-bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s, const ColExtra* extra) {
-    if (!g_wgrad2 || njobs < 1 || njobs > 8 || rows < 1) return false;
-    WTiles wt;
-    wt.n = 0;
-    int64_t slab = 0;
-    double flops = 0;
-    int swapped_sums[8], nswapped = 0;
-    for (int i = 0; i < njobs; ++i) {
-        const tg_wgrad_job& q = jobs[i];
+namespace {
+struct WGroupIn { int njobs; const tg_wgrad_job* jobs; int64_t rows; const ColExtra* extra; };
+
+// the tiles of one group's jobs appended to wt; false = a job's shape / alignment is not covered or the tile table is full
+bool build_tiles(const WGroupIn& gin, WTiles& wt, int64_t& slab, double& flops, int* swapped_sums, int& nswapped) {
+    for (int i = 0; i < gin.njobs; ++i) {
+        const tg_wgrad_job& q = gin.jobs[i];
         if (!(q.A && q.B && q.C && q.M >= 4 && q.N >= 4 && q.M % 4 == 0 && q.N % 4 == 0 && q.lda % 4 == 0 && q.ldb % 4 == 0 && al16(q.A) && al16(q.B)))
             return false;
         if (q.lda < q.M || q.ldb < q.N || q.ldc < q.N) return false;
@@ -399,26 +432,80 @@ bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t
                 T.slab_off = slab;
                 slab += (int64_t)T.mext * T.nw;
                 T.trans = swap ? 1 : 0;
+                T.nsl = 1;
                 T.C = swap ? q.C + (int64_t)n0 * q.ldc + m0 : q.C + (int64_t)m0 * q.ldc + n0; T.ldc = q.ldc;
                 T.colsum = has_ones ? cs + m0 : nullptr;
             }
         if (swap && q.colsum_A) swapped_sums[nswapped++] = i;
-        flops += 2.0 * q.M * q.N * rows;
+        flops += 2.0 * q.M * q.N * gin.rows;
+    }
+    return true;
+}
+
+// One or two groups as ONE product launch + ONE fold launch.  false = not covered / no workspace (nothing launched).
+bool launch_groups(int ng, const WGroupIn* gin, hipStream_t s) {
+    WTiles wt;
+    wt.n = 0;
+    WGroups gr{};
+    gr.n = ng;
+    int64_t slab = 0;
+    double flops = 0;
+    int swapped[2][8], nswapped[2] = {0, 0};
+    for (int g = 0; g < ng; ++g) {
+        gr.tile0[g] = wt.n;
+        if (gin[g].njobs < 1 || gin[g].njobs > 8 || gin[g].rows < 1) return false;
+        if (!build_tiles(gin[g], wt, slab, flops, swapped[g], nswapped[g])) return false;
+        gr.ntiles[g] = wt.n - gr.tile0[g];
+        gr.rows[g] = gin[g].rows;
+        if (gr.ntiles[g] < 1) return false;
     }
     slab = (slab + 3) / 4 * 4;
-    // K slices: ~256 workgroups (one per CU: 128 KB of LDS each); a multiple of 8 pins each slice to an XCD
-    int64_t slices = std::max<int64_t>(1, 256 / wt.n);
-    if (slices >= 8) slices = slices / 8 * 8;
-    const int64_t max_slices = std::max<int64_t>(1, rows / (2 * CK));
-    if (slices > max_slices) slices = max_slices;
     static const bool tuning = getenv("FLID_GEMM_TUNE") != nullptr;
-    if (tuning) if (const char* e = getenv("FLID_WG2_SLICES")) { const int v = atoi(e); if (v >= 1) slices = v; }
-    int64_t rps = ((rows + slices - 1) / slices + CK - 1) / CK * CK;
-    slices = (rows + rps - 1) / rps;
-    if (slices >= 8 && slices % 8) {                    // keep the XCD pinning: round the slice count up to a multiple of 8 (empty tails are legal)
-        slices = (slices + 7) / 8 * 8;
+    int64_t slices[2] = {1, 1};
+    if (ng == 1) {
+        // K slices: ~256 workgroups (one per CU: 128 KB of LDS each); a multiple of 8 pins each slice to an XCD
+        int64_t sl = std::max<int64_t>(1, 256 / wt.n);
+        if (sl >= 8) sl = sl / 8 * 8;
+        const int64_t max_slices = std::max<int64_t>(1, gr.rows[0] / (2 * CK));
+        if (sl > max_slices) sl = max_slices;
+        if (tuning) if (const char* e = getenv("FLID_WG2_SLICES")) { const int v = atoi(e); if (v >= 1) sl = v; }
+        int64_t rps = ((gr.rows[0] + sl - 1) / sl + CK - 1) / CK * CK;
+        sl = (gr.rows[0] + rps - 1) / rps;
+        if (sl >= 8 && sl % 8) sl = (sl + 7) / 8 * 8;      // keep the XCD pinning: round the slice count up to a multiple of 8 (empty tails are legal)
+        slices[0] = sl;
+        gr.rps[0] = rps;
+        gr.cap = 0;
+    } else {
+        // 256 workgroups in all (one per CU: 128 KB of LDS each), all resident at once: the launch lasts as long as its longest workgroup,
+        // i.e. the largest number of 32-row chunks any slice contracts over.  Try every slice count of the smaller group, give the rest
+        // of the chip to the larger one, keep the split with the fewest chunks per workgroup.
+        int64_t best = -1;
+        for (int64_t s1 = 1; s1 <= 16; ++s1) {
+            if (s1 > std::max<int64_t>(1, gr.rows[1] / (2 * CK)) || gr.ntiles[1] * s1 >= 256) break;
+            int64_t s0 = (256 - gr.ntiles[1] * s1) / gr.ntiles[0];
+            s0 = std::max<int64_t>(1, std::min<int64_t>(s0, std::max<int64_t>(1, gr.rows[0] / (2 * CK))));
+            const int64_t c0 = ((gr.rows[0] + s0 - 1) / s0 + CK - 1) / CK, c1 = ((gr.rows[1] + s1 - 1) / s1 + CK - 1) / CK;
+            const int64_t t = std::max(c0, c1);
+            if (best < 0 || t < best) { best = t; slices[0] = s0; slices[1] = s1; }
+        }
+        for (int g = 0; g < 2; ++g) {
+            gr.rps[g] = ((gr.rows[g] + slices[g] - 1) / slices[g] + CK - 1) / CK * CK;
+            slices[g] = (gr.rows[g] + gr.rps[g] - 1) / gr.rps[g];
+        }
+        int cap = (int)((gr.ntiles[0] * slices[0] + gr.ntiles[1] * slices[1] + 7) / 8);
+        cap = std::max<int>(cap, gr.ntiles[0] * (int)((slices[0] + 7) / 8));
+        // (group 1's blocks must fit behind group 0's on the eight XCDs)
+        int room = 0;
+        for (int x = 0; x < 8; ++x) room += cap - gr.ntiles[0] * (int)((slices[0] + 7 - x) >> 3);
+        if (room < gr.ntiles[1] * slices[1]) cap += (int)((gr.ntiles[1] * slices[1] - room + 7) / 8);
+        gr.cap = cap;
     }
-    float* ws = workspace((size_t)(slices * slab), s);
+    for (int g = 0; g < ng; ++g) {
+        gr.nslices[g] = (int)slices[g];
+        for (int t = gr.tile0[g]; t < gr.tile0[g] + gr.ntiles[g]; ++t) wt.t[t].nsl = (int)slices[g];
+    }
+    const int64_t max_sl = std::max(slices[0], ng > 1 ? slices[1] : (int64_t)1);
+    float* ws = workspace((size_t)(max_sl * slab), s);
     if (!ws) return false;
     ProfScope prof("gemm", flops, s);
     static bool attr_set = false;
@@ -429,18 +516,84 @@ bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t
         }
         attr_set = true;
     }
-    wgrad2_kernel<<<(unsigned)(wt.n * slices), WNT, 2 * STAGE, s>>>(wt, rows, rps, (int)slices, ws, slab);
+    const unsigned grid = ng == 1 ? (unsigned)(wt.n * slices[0]) : (unsigned)(8 * gr.cap);
+    wgrad2_kernel<<<grid, WNT, 2 * STAGE, s>>>(wt, gr, ws, slab);
     if (hipGetLastError() != hipSuccess) return false;
     const unsigned fold_gx = (TM * (TN + 4) + 255) / 256;
-    ColExtra ex{};
-    unsigned extra_rows = 0;
-    if (extra) { ex = *extra; extra_rows = ((unsigned)(ex.col_gx * ex.col_ny + ex.wq_n) + fold_gx - 1) / fold_gx; }
-    wgrad2_fold_kernel<<<dim3(fold_gx, (unsigned)wt.n + extra_rows), 256, 0, s>>>(wt, (int)slices, ws, slab, ex);
-    for (int i = 0; i < nswapped; ++i) {
-        const tg_wgrad_job& q = jobs[swapped_sums[i]];
-        if (tg_colsum(q.A, q.lda, rows, q.M, q.colsum_A, 1, s) != TG_OK) return true;      // (launch errors surface at the caller's launch_status)
-    }
+    ColExtra ex[2] = {ColExtra{}, ColExtra{}};
+    unsigned extra_rows[2] = {0, 0};
+    for (int g = 0; g < ng; ++g)
+        if (gin[g].extra) { ex[g] = *gin[g].extra; extra_rows[g] = ((unsigned)(ex[g].col_gx * ex[g].col_ny + ex[g].wq_n) + fold_gx - 1) / fold_gx; }
+    wgrad2_fold_kernel<<<dim3(fold_gx, (unsigned)wt.n + extra_rows[0] + extra_rows[1]), 256, 0, s>>>(wt, ws, slab, ex[0], ex[1], (int)extra_rows[0]);
+    for (int g = 0; g < ng; ++g)
+        for (int i = 0; i < nswapped[g]; ++i) {
+            const tg_wgrad_job& q = gin[g].jobs[swapped[g][i]];
+            if (tg_colsum(q.A, q.lda, gin[g].rows, q.M, q.colsum_A, 1, s) != TG_OK) return true;      // (launch errors surface at the caller's launch_status)
+        }
     return true;
+}
+
+// A group kept back (wgrad_defer_next): it leaves with the NEXT group on the same stream -- the 1 200-row root layer's weight gradients
+// in the launch of the 13.6 k-row layer below it, TGN's layer in its GRU's.  Such a group alone is a latency chain of ~19 + 12 us (product
+// launch + fold) on a fraction of the chip; riding along it costs the big launch a few workgroups.
+struct Deferred {
+    bool valid = false;
+    hipStream_t stream = nullptr;
+    tg_wgrad_job jobs[8];
+    int njobs = 0;
+    int64_t rows = 0;
+    ColExtra extra{};
+    bool has_extra = false;
+};
+thread_local Deferred t_deferred;
+thread_local bool t_defer_next = false;
+}  // namespace
+
+void wgrad_defer_next(bool on) { t_defer_next = on; }
+
+// a kept-back group that nothing picked up leaves by itself
+int wgrad_flush_deferred(hipStream_t s) {
+    t_defer_next = false;
+    if (!t_deferred.valid) return TG_OK;
+    Deferred d = t_deferred;
+    t_deferred.valid = false;
+    const WGroupIn g{d.njobs, d.jobs, d.rows, d.has_extra ? &d.extra : nullptr};
+    if (!launch_groups(1, &g, d.stream)) { set_error("tg_wgrad: a deferred group could not be launched"); return TG_ESHAPE; }
+    (void)s;
+    return launch_status("wgrad2_kernel");
+}
+
+// false = a job's shape / alignment is not covered or no workspace (nothing launched): the caller takes the first form
+bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s, const ColExtra* extra) {
+    if (!g_wgrad2 || njobs < 1 || njobs > 8 || rows < 1) return false;
+    if (t_defer_next) {
+        t_defer_next = false;
+        if (t_deferred.valid && wgrad_flush_deferred(s) != TG_OK) return false;
+        // keep it only if it is launchable at all (a dry run of the tiling)
+        WTiles wt; wt.n = 0;
+        int64_t slab = 0; double fl = 0; int sw[8], nsw = 0;
+        const WGroupIn probe{njobs, jobs, rows, extra};
+        if (!build_tiles(probe, wt, slab, fl, sw, nsw)) return false;
+        t_deferred.valid = true; t_deferred.stream = s; t_deferred.njobs = njobs; t_deferred.rows = rows;
+        for (int i = 0; i < njobs; ++i) t_deferred.jobs[i] = jobs[i];
+        t_deferred.has_extra = extra != nullptr;
+        if (extra) t_deferred.extra = *extra;
+        return true;
+    }
+    if (t_deferred.valid && t_deferred.stream == s) {
+        Deferred d = t_deferred;
+        t_deferred.valid = false;
+        // the group with more work first (it gets the XCD-pinned slices)
+        const WGroupIn mine{njobs, jobs, rows, extra}, kept{d.njobs, d.jobs, d.rows, d.has_extra ? &d.extra : nullptr};
+        const WGroupIn both[2] = {rows >= d.rows ? mine : kept, rows >= d.rows ? kept : mine};
+        static const bool no_merge = getenv("FLID_GEMM_TUNE") && getenv("FLID_WG2_NOMERGE") && atoi(getenv("FLID_WG2_NOMERGE")) != 0;
+        if (!no_merge && launch_groups(2, both, s)) return true;
+        if (!launch_groups(1, &kept, s)) return false;         // (too many tiles for one table: one after the other)
+        return launch_groups(1, &mine, s);
+    }
+    if (t_deferred.valid && wgrad_flush_deferred(s) != TG_OK) return false;
+    const WGroupIn g{njobs, jobs, rows, extra};
+    return launch_groups(1, &g, s);
 }
 
 }  // namespace tg

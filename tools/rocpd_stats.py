@@ -42,6 +42,12 @@ def main():
         print(f"{t[1]:6d} x {t[3] / 1e3:9.1f} us = {t[2] / 1e6:9.3f} ms {t[4]:6.2f}%  {short(t[0])}")
     if args.timeline:
         idx = [i for i, r in enumerate(rows) if args.marker in r[0]]
+        if len(idx) >= 4:
+            # the period of every step (end of one marker launch to the end of the next): what the bench's wall clock averages over
+            per = [(rows[idx[i + 1]][2] - rows[idx[i]][2]) / 1e3 for i in range(len(idx) - 1)]
+            tail = per[len(per) // 2:]
+            print(f"--- step periods (second half of the run, {len(tail)} steps): mean {sum(tail) / len(tail):.1f} us  min {min(tail):.1f}  max {max(tail):.1f}"
+                  f"   [{' '.join('%.0f' % x for x in tail[-12:])}]")
         if len(idx) >= 3:
             a, b = idx[-3], idx[-2]
             t0 = rows[a][2]
