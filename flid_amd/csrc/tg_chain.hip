@@ -68,10 +68,10 @@ struct Geo {
     static constexpr int LDS_BYTES = PAR_OFF + (3 * 320 + 2 * 192) * 4;
     static constexpr int RPP = 4 * NW;               // rows per pass when a product streams its rows (16 float4 per row and group)
     static constexpr int PER = ROWS / RPP;           // float4 per thread, operand and group
-    static constexpr int NTW = NW == 8 ? 3 : 5;      // most column tiles a wave owns in any product of a chain
+    static constexpr int NTW = NW == 16 ? 2 : NW == 8 ? 3 : 5;      // most column tiles a wave owns in any product of a chain (<= 20 / NW ... 18 tiles)
     static_assert(ROWS % RPP == 0, "row passes must tile the block");
 };
-static_assert(Geo<4, 8>::LDS_BYTES <= 163840, "one workgroup must fit the CU's LDS");
+static_assert(Geo<4, 16>::LDS_BYTES <= 163840 && Geo<4, 8>::LDS_BYTES <= 163840, "one workgroup must fit the CU's LDS");
 
 // state of one wave inside a chain
 template <int RB, int NW, int NTW_ = Geo<RB, NW>::NTW>
@@ -394,7 +394,7 @@ struct ChainFwdArgs {
 template <int RB, int HH, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) chain_fwd_kernel(ChainFwdArgs a) {
     using G = Geo<RB, NW>;
-    constexpr int ROWS = G::ROWS, NTH = G::NTH, NTW = G::NTW, NTF = NW == 8 ? 2 : 3;
+    constexpr int ROWS = G::ROWS, NTH = G::NTH, NTW = G::NTW, NTF = NW == 16 ? 1 : NW == 8 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     Wave<RB, NW> w;
     w.lds = lds;
@@ -674,8 +674,8 @@ struct ChainBwdArgs {
 template <int RB, int HH, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs a) {
     using G = Geo<RB, NW>;
-    constexpr int ROWS = G::ROWS, NTH = G::NTH, NTW = G::NTW, NTF = NW == 8 ? 2 : 3;
-    constexpr int NTD = NW == 8 ? 4 : 7;                       // tiles per wave of the widest product (dagg_h: dk columns in one pass)
+    constexpr int ROWS = G::ROWS, NTH = G::NTH, NTW = G::NTW, NTF = NW == 16 ? 1 : NW == 8 ? 2 : 3;
+    constexpr int NTD = NW == 16 ? 2 : NW == 8 ? 4 : 7;                       // tiles per wave of the widest product (dagg_h: dk columns in one pass)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     Wave<RB, NW, NTD> w;
     w.lds = lds;
@@ -1128,8 +1128,13 @@ int chain_fwd(const tg_layer_desc* L, const void* pWv, const void* pWr, const vo
     // 64-row blocks once they fill the chip; fewer rows take 16-row blocks (a workgroup streams all the weights whatever its height)
     static const bool force_rb1 = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_CHAIN_RB1") != nullptr;
     const bool tall = at.m >= 64 * 128 && !force_rb1;
-    if (at.heads == 2) return tall ? launch_fwd<4, 2, 4>(a, s) : launch_fwd<1, 2, 4>(a, s);
-    return tall ? launch_fwd<4, 1, 4>(a, s) : launch_fwd<1, 1, 4>(a, s);
+    // tall launches: 8 waves (two per SIMD).  The products are bound by the CU's weight stream whatever the wave count, but the epilogues
+    // between them (LayerNorm, dropout, split + panel stores, the global stores) are vector-ALU work that one wave per SIMD issues at
+    // half the rate of two: round 5, same box, 78.1 -> 69.0 us forward and 76.0 -> 68.5 us backward at 13.6 k rows (round 3 measured the
+    // 8-wave form equal: the epilogues were a smaller share of a longer launch then).  FLID_CHAIN_NW4=1 (tuning mode): 4 waves.
+    static const bool nw4 = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_CHAIN_NW4") != nullptr;
+    if (at.heads == 2) return tall ? (nw4 ? launch_fwd<4, 2, 4>(a, s) : launch_fwd<4, 2, 8>(a, s)) : launch_fwd<1, 2, 4>(a, s);
+    return tall ? (nw4 ? launch_fwd<4, 1, 4>(a, s) : launch_fwd<4, 1, 8>(a, s)) : launch_fwd<1, 1, 4>(a, s);
 }
 
 int chain_hpb(int H, int dn, int T) { const int hd = (dn + T) / H; return (hd + 31) / 32 * 32; }
@@ -1198,8 +1203,9 @@ int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, 
     const double macs = (double)at.dn * at.dn + (double)dq * at.dn + (double)dq * dq + (double)dk * dq;
     ProfScope prof("gemm", 2.0 * at.m * macs, s);
     const bool tall = at.m >= 64 * 128;
-    if (at.heads == 2) return tall ? launch_bwd<4, 2, 4>(a, s) : launch_bwd<1, 2, 4>(a, s);
-    return tall ? launch_bwd<4, 1, 4>(a, s) : launch_bwd<1, 1, 4>(a, s);
+    static const bool nw4 = getenv("FLID_GEMM_TUNE") != nullptr && getenv("FLID_CHAIN_NW4") != nullptr;
+    if (at.heads == 2) return tall ? (nw4 ? launch_bwd<4, 2, 4>(a, s) : launch_bwd<4, 2, 8>(a, s)) : launch_bwd<1, 2, 4>(a, s);
+    return tall ? (nw4 ? launch_bwd<4, 1, 4>(a, s) : launch_bwd<4, 1, 8>(a, s)) : launch_bwd<1, 1, 4>(a, s);
 }
 
 }  // namespace tg
