@@ -487,7 +487,9 @@ def main():
             return {"value": round(n_leg * BATCH / dt_, 1), "ms_per_step": round(dt_ / n_leg * 1e3, 4), "steps": n_leg}
         _lib_().tg_set_gemm_mode(0)
         try:
-            exact_f32 = dict(short_leg(), note="tg_set_gemm_mode(0): every product exact fp32 (f32-input MFMA), as the reference's mm")
+            exact_f32 = dict(short_leg(), note="tg_set_gemm_mode(0): every forward and input-gradient product exact fp32 (f32-input MFMA), as the reference's mm; "
+                                                  "the weight gradients leave in the grouped split-bf16x3 launch in this mode too (as in earlier rounds: "
+                                                  "tg_set_wgrad_grouped(0) would make them exact products as well)")
             _eng.DEDUPE = False
             strict = dict(short_leg(), note="exact fp32 products AND engine.DEDUPE = False (24 000 layer-1 instances, per-root dropout "
                                             "masks): the reference's arithmetic and recursion, row for row")

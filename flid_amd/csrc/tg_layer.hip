@@ -1025,7 +1025,10 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
             tg_wgrad_job q[8];
             const int n = (int)jobs.size();
             for (int i = 0; i < n; ++i) q[i] = tg_wgrad_job{jobs[i].A, jobs[i].lda, jobs[i].M, jobs[i].B, jobs[i].ldb, jobs[i].N, jobs[i].C, jobs[i].ldc, jobs[i].cs};
-            if (g_wgrad_grouped && tg_get_gemm_mode() != 0 && tg::wgrad_group2(n, q, R, st, has_extra ? &ex : nullptr)) return tg::launch_status("wgrad kernel");
+            // (both grouped forms are split-bf16 launches; the exact-product mode took the FIRST form here -- 122 + 30 us per 13.6 k-row layer
+            // against 57 + 13 -- for no gain in exactness: it takes the second like the default mode.  tg_set_wgrad_grouped(0) is the
+            // switch for one exact product + one column sum per gradient.)
+            if (g_wgrad_grouped && tg::wgrad_group2(n, q, R, st, has_extra ? &ex : nullptr)) return tg::launch_status("wgrad kernel");
             if (has_extra) TG_TRY(colsum_seg2(ex.a, ex.b, st));
             if (has_extra && ex.wq_n > 0) {            // the time half of dWq that would have ridden in the fold launch
                 TailArgs t{};
