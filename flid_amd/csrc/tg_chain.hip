@@ -39,10 +39,10 @@
 #define FLID_CHAIN_X4 1   // keep the lo * lo term (see step()); 0: three terms, as the launch-per-product kernels
 #endif
 #ifndef FLID_CHAIN_ROT
-#define FLID_CHAIN_ROT 0   // 1: every workgroup walks a product's contraction from its own starting group (see Wave::rot_seed).  Measured
-                           // (round 5): chain_fwd 71.8 -> 67.3 us, chain_bwd 74.7 -> 71.6 us at 13.6 k rows -- and OFF all the same: a row's
-                           // rounding then depends on the row block it sits in, and with row sharing the rows of a call are numbered in
-                           // the hash set's arrival order, so two identical calls stopped being bit-identical
+#define FLID_CHAIN_ROT 1   // every workgroup walks a product's contraction from its own starting group (see Wave::rot_seed): chain_fwd
+                           // 71.8 -> 67.3 us, chain_bwd 74.7 -> 71.6 us at 13.6 k rows (round 5, 4-wave form).  A row's rounding then depends
+                           // on the row block it sits in -- reproducible run to run because the shared rows of a call are numbered in the
+                           // order of their first occurrence (tg_dedupe_pairs), not in the hash set's arrival order as before.  0: all from k = 0
 #endif
 #ifndef FLID_CHAIN_EXP
 #define FLID_CHAIN_EXP 0   // timing experiments only (results wrong): 1 no steady-state weight loads, 2 no MFMAs, 3 all fragment reads from one chunk

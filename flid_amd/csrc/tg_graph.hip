@@ -274,14 +274,23 @@ __global__ void __launch_bounds__(256) first_hop_window_kernel(const int64_t* __
 }
 
 // ---- distinct (node id, float32 time) pairs of a sampled level ----------------------------------------------------------------
-// Open-addressing hash set in global memory: the first slot to claim a key owns it and draws the next compact row index.
+// Open-addressing hash set in global memory for WHICH pairs are distinct; the compact row numbers are given out in the order of the
+// pairs' FIRST OCCURRENCE in the input (round 5).  Before, the slot that claimed a key drew the next number from an atomic counter:
+// the numbering followed the arrival order of the claims, two identical calls numbered their rows differently, and anything that
+// depends on a row's POSITION (which workgroup a row lands in) could not be allowed to touch its value.  Three passes:
+//   insert : claim / find the pair's slot; vals[slot] = min over its occurrences of the input index (atomicMin)
+//   rank   : occurrence i is a first one iff vals[pos[i]] == i; per 4096-slot tile the first ones are ranked (wave ballots) and counted
+//   number : a first occurrence's number = the counts of the tiles in front + its rank
+//            (as ONE workgroup walking the tiles this took 60 us -- six dependent round trips per tile -- and a 16-wave workgroup parked
+//            on a CU for that long stretched whichever main-stream launch had workgroups there: the root attention backward 23 -> 34 us)
+//   lookup : every slot's row = the number of its pair
 __device__ __forceinline__ uint32_t hash_pair(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
     return (uint32_t)k;
 }
 __global__ void __launch_bounds__(256) dedupe_insert_kernel(const int32_t* __restrict__ ids, const float* __restrict__ t, int64_t n,
         uint32_t mask, unsigned long long* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ pos,
-        int32_t* __restrict__ out_ids, float* __restrict__ out_t, int32_t* __restrict__ count_pad) {
+        int32_t* __restrict__ count_pad) {
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + threadIdx.x;
         const bool in = i < n;
@@ -289,18 +298,11 @@ __global__ void __launch_bounds__(256) dedupe_insert_kernel(const int32_t* __res
         const float tt = in ? t[i] : 0.f;
         const unsigned long long key = ((unsigned long long)(uint32_t)id << 32) | (unsigned long long)__float_as_uint(tt);
         // The padding pair (0, +0.0f) is a fifth of all slots: it bypasses the table (thousands of CAS on one slot would
-        // serialise); one lane per wave claims its row through count_pad[1] (-1 = unclaimed, -2 = being claimed).
+        // serialise); the first padding lane of each wave (the wave's smallest index) reports it to count_pad[2]
         const bool is_pad = in && key == 0ULL;
         const unsigned long long pad_lanes = __ballot(is_pad);
         if (is_pad) {
-            if ((int)(threadIdx.x & 63) == __ffsll((long long)pad_lanes) - 1) {
-                if (atomicCAS(&count_pad[1], -1, -2) == -1) {
-                    const int32_t idx = atomicAdd(&count_pad[0], 1);
-                    out_ids[idx] = 0;
-                    out_t[idx] = 0.f;
-                    atomicExch(&count_pad[1], idx);
-                }
-            }
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)pad_lanes) - 1) atomicMin(&count_pad[2], (int32_t)i);
             pos[i] = -1;
             continue;
         }
@@ -308,30 +310,87 @@ __global__ void __launch_bounds__(256) dedupe_insert_kernel(const int32_t* __res
         uint32_t h = hash_pair(key) & mask;
         while (true) {
             const unsigned long long prev = atomicCAS(&keys[h], ~0ULL, key);
-            if (prev == ~0ULL) {                       // this slot owns the pair
-                const int32_t idx = atomicAdd(&count_pad[0], 1);
-                vals[h] = idx;
-                out_ids[idx] = id;
-                out_t[idx] = tt;
-                break;
-            }
-            if (prev == key) break;
+            if (prev == ~0ULL || prev == key) break;      // this slot holds the pair now
             h = (h + 1) & mask;
         }
+        atomicMin(&vals[h], (int32_t)i);
         pos[i] = (int32_t)h;
     }
+}
+constexpr int kNumberThreads = 1024;
+constexpr int kNumberTile = 4 * kNumberThreads;     // input slots per workgroup of the two numbering passes
+constexpr int kNumberMaxBlocks = 1024;              // their totals live behind the hash set's values: vals[capacity + block]
+// pass 1: rank[i] = rank of slot i among the first occurrences of its 4096-slot tile (-1: not a first occurrence); totals[tile]
+__global__ void __launch_bounds__(kNumberThreads) dedupe_rank_kernel(int64_t n, const int32_t* __restrict__ pos, const int32_t* __restrict__ vals,
+                                                                   const int32_t* __restrict__ count_pad, int32_t* __restrict__ rank,
+                                                                   int32_t* __restrict__ totals) {
+    __shared__ int32_t wtot[kNumberThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t pad_first = count_pad[2];
+    const unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+    const int64_t i = (int64_t)blockIdx.x * kNumberTile + 4 * tid;
+    int32_t h[4];
+    bool f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = i + e < n ? pos[i + e] : -2;
+    int32_t lower = 0, total = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = h[e] == -2 ? false : (h[e] < 0 ? pad_first == (int32_t)(i + e) : vals[h[e]] == (int32_t)(i + e));
+        const unsigned long long m = __ballot(f[e]);
+        lower += __popcll(m & below);                            // first occurrences held by lower lanes (all of their four slots come first)
+        total += __popcll(m);
+    }
+    if (lane == 0) wtot[wave] = total;
+    __syncthreads();
+    int32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kNumberThreads / 64; ++w) { const int32_t v = wtot[w]; all += v; before += w < wave ? v : 0; }
+    int32_t r = before + lower;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (i + e < n) rank[i + e] = f[e] ? r++ : -1;
+    if (tid == 0) totals[blockIdx.x] = all;
+}
+// pass 2: the first occurrences take the numbers (totals of the tiles in front) + rank; a number overwrites the slot's first-occurrence
+// index TAGGED (negative): nothing compares it with an index any more, the tag only keeps the lookup's meaning of the field explicit
+__global__ void __launch_bounds__(kNumberThreads) dedupe_number_kernel(const int32_t* __restrict__ ids, const float* __restrict__ t, int64_t n,
+        const int32_t* __restrict__ pos, int32_t* __restrict__ vals, const int32_t* __restrict__ rank, const int32_t* __restrict__ totals,
+        int32_t* __restrict__ out_ids, float* __restrict__ out_t, int32_t* __restrict__ count_pad) {
+    __shared__ int32_t part[kNumberThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t s = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += kNumberThreads) s += totals[b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    int32_t offset = 0;
+#pragma unroll
+    for (int w = 0; w < kNumberThreads / 64; ++w) offset += part[w];
+    const int64_t i = (int64_t)blockIdx.x * kNumberTile + 4 * tid;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i + e >= n) break;
+        const int32_t r = rank[i + e];
+        if (r < 0) continue;
+        const int32_t idx = offset + r, h = pos[i + e];
+        if (h < 0) { count_pad[1] = idx; out_ids[idx] = 0; out_t[idx] = 0.f; }
+        else { out_ids[idx] = ids[i + e]; out_t[idx] = t[i + e]; vals[h] = idx - 0x40000000; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) count_pad[0] = offset + totals[blockIdx.x];
 }
 __global__ void __launch_bounds__(256) dedupe_lookup_kernel(const int32_t* __restrict__ pos, const int32_t* __restrict__ vals, int64_t n,
                                                             int32_t offset, const int32_t* __restrict__ count_pad,
                                                             int32_t* __restrict__ inv) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        inv[i] = (pos[i] < 0 ? count_pad[1] : vals[pos[i]]) + offset;
+        inv[i] = (pos[i] < 0 ? count_pad[1] : vals[pos[i]] + 0x40000000) + offset;
 }
 
-// empty hash set + (count, pad row) = (0, -1): one launch instead of three memsets
-__global__ void __launch_bounds__(256) dedupe_init_kernel(unsigned long long* __restrict__ keys, int64_t capacity, int32_t* __restrict__ count_pad) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x) keys[i] = ~0ULL;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { count_pad[0] = 0; count_pad[1] = -1; }
+// empty hash set (no key, first occurrence = none) + (count, pad row, first padding slot) = (0, -1, none): one launch
+__global__ void __launch_bounds__(256) dedupe_init_kernel(unsigned long long* __restrict__ keys, int32_t* __restrict__ vals, int64_t capacity,
+                                                          int32_t* __restrict__ count_pad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x) { keys[i] = ~0ULL; vals[i] = 0x7fffffff; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { count_pad[0] = 0; count_pad[1] = -1; count_pad[2] = 0x7fffffff; }
 }
 
 inline int grid_for(int64_t work_items, int64_t per_block) {
@@ -597,10 +656,17 @@ extern "C" int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n
     TG_REQUIRE(d_ids && d_t && d_keys_ws && d_vals_ws && d_pos_ws && d_out_ids && d_out_t && d_out_row && d_count_pad, "tg_dedupe_pairs: null pointer");
     TG_REQUIRE(n >= 0 && capacity >= 2 * n && (capacity & (capacity - 1)) == 0 && capacity <= ((int64_t)1 << 31), "tg_dedupe_pairs: capacity must be a power of two >= 2n");
     hipStream_t s = (hipStream_t)stream;
-    dedupe_init_kernel<<<grid_for(capacity, 1024), 256, 0, s>>>((unsigned long long*)d_keys_ws, capacity, d_count_pad);   // pad row = -1 until seen
+    TG_REQUIRE(n < 0x40000000, "tg_dedupe_pairs: more than 2^30 slots");
+    dedupe_init_kernel<<<grid_for(capacity, 1024), 256, 0, s>>>((unsigned long long*)d_keys_ws, d_vals_ws, capacity, d_count_pad);   // pad row = -1 until seen
     if (n == 0) return tg::launch_status("dedupe_init_kernel");
     dedupe_insert_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_ids, d_t, n, (uint32_t)(capacity - 1), (unsigned long long*)d_keys_ws, d_vals_ws,
-                                                          d_pos_ws, d_out_ids, d_out_t, d_count_pad);
+                                                          d_pos_ws, d_count_pad);
+    const unsigned nb = (unsigned)((n + kNumberTile - 1) / kNumberTile);
+    TG_REQUIRE(nb <= (unsigned)kNumberMaxBlocks, "tg_dedupe_pairs: more than 4 M slots");
+    int32_t* totals = d_vals_ws + capacity;           // (the values workspace is capacity + 1024 ints)
+    // (the slots' rows double as the scratch of the ranks: the lookup pass overwrites them last)
+    dedupe_rank_kernel<<<nb, kNumberThreads, 0, s>>>(n, d_pos_ws, d_vals_ws, d_count_pad, d_out_row, totals);
+    dedupe_number_kernel<<<nb, kNumberThreads, 0, s>>>(d_ids, d_t, n, d_pos_ws, d_vals_ws, d_out_row, totals, d_out_ids, d_out_t, d_count_pad);
     dedupe_lookup_kernel<<<grid_for(n, 256), 256, 0, s>>>(d_pos_ws, d_vals_ws, n, row_offset, d_count_pad, d_out_row);
     return tg::launch_status("dedupe kernels");
 }

@@ -126,7 +126,7 @@ int layout(tg_stepper* st, float* base, int64_t* total) {
         }
         st->ded_cap = tg_dedupe_capacity(total);
         st->ded_keys = A.take(2 * st->ded_cap);
-        st->ded_vals = reinterpret_cast<int32_t*>(A.take(st->ded_cap));
+        st->ded_vals = reinterpret_cast<int32_t*>(A.take(st->ded_cap + 1024));
         st->ded_pos = reinterpret_cast<int32_t*>(A.take(total));
         TgnBuf& t = st->tb;
         const int64_t U = total, D = dn, MD = st->md;
@@ -149,7 +149,7 @@ int layout(tg_stepper* st, float* base, int64_t* total) {
     if (!c.tgn) {
         st->ded_cap = tg_dedupe_capacity(c.max_roots * k);
         st->ded_keys = A.take(2 * st->ded_cap);
-        st->ded_vals = reinterpret_cast<int32_t*>(A.take(st->ded_cap));
+        st->ded_vals = reinterpret_cast<int32_t*>(A.take(st->ded_cap + 1024));
         st->ded_pos = reinterpret_cast<int32_t*>(A.take(c.max_roots * k));
     }
     st->cosb = A.take(T);

@@ -129,7 +129,8 @@ class TemporalGraph:
         key = (str(dev), int(_stream() or 0))
         ws = self._dedupe_ws.get(key)
         if ws is None or ws[0].numel() < cap or ws[2].numel() < n:
-            ws = (torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+            # (values: capacity + 1024 ints -- the numbering passes keep their per-tile totals behind the table, include/flid_tg.h)
+            ws = (torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap + 1024, dtype=torch.int32, device=dev),
                   torch.empty(max(n, 1), dtype=torch.int32, device=dev))
             self._dedupe_ws[key] = ws
         return cap, ws
@@ -137,15 +138,15 @@ class TemporalGraph:
     def dedupe_pairs_async(self, ids: torch.Tensor, t32: torch.Tensor, row_offset: int, out_ids: torch.Tensor, out_t: torch.Tensor,
                            row: torch.Tensor):
         """distinct (id, float32 time) pairs of a sampled level, written into caller buffers (each at least len(ids) long):
-        out_ids / out_t = the pairs in arrival order, row[i] = row_offset + index of slot i's pair.  Returns the DEVICE tensor
+        out_ids / out_t = the pairs in the order of their first occurrence in `ids`, row[i] = row_offset + index of slot i's pair.  Returns the DEVICE tensor
         (count, index of the padding pair or -1): nothing is read back here.  The hash-set workspace is per graph object AND per
         stream (calls on two streams do not share it)."""
         n, dev = ids.numel(), ids.device
         cap, ws = self._dedupe_ws_for(n, dev)
-        cp = torch.empty(2, dtype=torch.int32, device=dev)
+        cp = torch.empty(4, dtype=torch.int32, device=dev)        # (count, padding row, scratch, scratch)
         check(lib().tg_dedupe_pairs(_p(ids), _p(t32), n, cap, _p(ws[0]), _p(ws[1]), _p(ws[2]), int(row_offset), _p(out_ids), _p(out_t),
                                     _p(row), _p(cp), _stream()), "tg_dedupe_pairs")
-        return cp
+        return cp[:2]
 
     def dedupe_pairs(self, ids: torch.Tensor, t32: torch.Tensor, row_offset: int):
         """as dedupe_pairs_async with fresh buffers and ONE 8-byte readback: (uniq_ids i32, uniq_t f32, row_of_slot i32, pad_row or -1)"""

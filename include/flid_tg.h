@@ -64,9 +64,11 @@ int tg_sample_recent(const tg_graph* g, const int32_t* d_ids, const double* d_ti
 
 /* Distinct (node id, float32 time) pairs of a sampled level (flid_amd/engine.py row sharing): the embedding of a node at a
  * time is a function of that pair only, so repeated pairs inside a batch are computed once.  n input slots; outputs: the
- * distinct pairs (d_out_ids / d_out_t, at most n, in arrival order), d_out_row[i] = row_offset + index of slot i's pair,
- * d_count_pad[0] = number of distinct pairs, d_count_pad[1] = index of the padding pair (0, 0.0f) or -1.
- * Workspaces: keys (capacity x 8 B), vals / pos (capacity, n int32); capacity = tg_dedupe_capacity(n) (power of two >= 2n). */
+ * distinct pairs (d_out_ids / d_out_t, at most n, in the order of their FIRST OCCURRENCE among the input slots: the same input gives the
+ * same numbering, run after run), d_out_row[i] = row_offset + index of slot i's pair,
+ * d_count_pad (4 ints): [0] = number of distinct pairs, [1] = index of the padding pair (0, 0.0f) or -1, [2..3] scratch.
+ * Workspaces: keys (capacity x 8 B), vals (capacity + 1024 int32), pos (n int32); capacity = tg_dedupe_capacity(n) (power of two >= 2n);
+ * n <= 4 M slots per call. */
 int64_t tg_dedupe_capacity(int64_t n);
 int tg_dedupe_pairs(const int32_t* d_ids, const float* d_t, int64_t n, int64_t capacity, void* d_keys_ws, int32_t* d_vals_ws,
                     int32_t* d_pos_ws, int32_t row_offset, int32_t* d_out_ids, float* d_out_t, int32_t* d_out_row,
