@@ -124,6 +124,9 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
                   float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s);
+// tg_gemm.hip: two X W^T + b products of the same M x N as one launch (TGN's two GRU gate products); false = issue them one by one
+bool gemm_pair_nt(int64_t M, int64_t N, int64_t K1, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C1, const float* bias1,
+                  int64_t K2, const float* A2, int64_t lda2, const float* B2, int64_t ldb2, float* C2, const float* bias2, int64_t ldc, hipStream_t s);
 // tg_attn_ring.hip: the LDS-ring kernels; nparts = slab rows of dte the caller allocated (tg_attn_bwd_parts)
 int attn_fwd_ring(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);
 int attn_bwd_ring(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du, float* dfeat,

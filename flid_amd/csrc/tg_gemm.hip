@@ -28,6 +28,8 @@ namespace tg {
 bool gemm_direct_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
                     hipStream_t s, const float* mask, int64_t ldm, bool b_kc = true);
+bool gemm_bf16x3_nt_pair(int64_t M, int64_t N, int64_t K1, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C1, const float* bias1,
+                         int64_t K2, const float* A2, int64_t lda2, const float* B2, int64_t ldb2, float* C2, const float* bias2, int64_t ldc, hipStream_t s);
 bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, int nbatch, const float* bias, int relu, int accumulate,
                     hipStream_t s, const float* mask, int64_t ldm);
@@ -569,6 +571,16 @@ extern "C" int tg_gemm_f32_nt_masked(int64_t M, int64_t N, int64_t K, const floa
     TG_REQUIRE(d_Y && ldy >= N, "tg_gemm_f32_nt_masked: mask matrix");
     return gemm_impl(0, 1, M, N, K, 1.f, d_A, lda, 0, d_B, ldb, 0, d_C, ldc, 0, 1, nullptr, 0, 0, (hipStream_t)stream, 1, 0, 0, 0, d_Y, ldy);
 }
+
+namespace tg {
+// Two products of the same M x N with k-contiguous operands (X W^T + b) as one launch where both would take the split-bf16 tile kernel
+// anyway (default product mode, more tiles than the direct kernel serves); false = the caller issues them one by one
+bool gemm_pair_nt(int64_t M, int64_t N, int64_t K1, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C1, const float* bias1,
+                  int64_t K2, const float* A2, int64_t lda2, const float* B2, int64_t ldb2, float* C2, const float* bias2, int64_t ldc, hipStream_t s) {
+    if (gemm_mode() < 1 || ((M + 31) / 32) * ((N + 31) / 32) <= 800) return false;
+    return gemm_bf16x3_nt_pair(M, N, K1, A1, lda1, B1, ldb1, C1, bias1, K2, A2, lda2, B2, ldb2, C2, bias2, ldc, s);
+}
+}  // namespace tg
 
 extern "C" int tg_wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, void* stream) {
     TG_REQUIRE(jobs && njobs >= 1 && njobs <= 8 && rows >= 0, "tg_wgrad_group: arguments");

@@ -123,7 +123,7 @@ template <int TNW>
 __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
         const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, const float* __restrict__ bias, int relu,
         int accumulate, int gx, int gy, int64_t strideA, int64_t strideB, int64_t strideC, const float* __restrict__ zeros, int vec_c,
-        const float* __restrict__ mask, int64_t ldm) {
+        const float* __restrict__ mask, int64_t ldm, int64_t K2, int64_t lda2, int64_t ldb2, const float* __restrict__ bias2) {
     constexpr int BNt = 32 * TNW;
     constexpr int FA = BM * ROW_BYTES, FB = BNt * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * (FA + FB)];
@@ -136,7 +136,11 @@ __global__ void __launch_bounds__(NT) gemm_bf16x3_nt_kernel(int64_t M, int64_t N
     const int by = swz / gx, bx = swz % gx;
     const int batch = blockIdx.z;
     A += batch * strideA; B += batch * strideB; C += batch * strideC;
-    if (bias) bias += batch * (int64_t)N;
+    // K2 > 0: a PAIR of products with the same M and N but their own contraction depth, leading dimensions and bias (batch 1 takes the
+    // second set): the two GRU gate products of a TGN step as one launch (gemm_bf16x3_nt_pair)
+    if (K2 > 0) {
+        if (batch == 1) { K = K2; lda = lda2; ldb = ldb2; bias = bias2; }
+    } else if (bias) bias += batch * (int64_t)N;
 
     const int64_t bm = (int64_t)by * BM, bn = (int64_t)bx * BNt;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -746,9 +750,35 @@ bool gemm_bf16x3_nt(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     ProfScope prof("gemm", 2.0 * M * N * K * nbatch, s);
     const dim3 grid((unsigned)(gx * gy), 1, (unsigned)nbatch);
     if (tnw == 3)
-        gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c, mask, ldm);
+        gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c, mask, ldm, 0, 0, 0, nullptr);
     else
-        gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c, mask, ldm);
+        gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, (int)gx, (int)gy, strideA, strideB, strideC, zeros, vec_c, mask, ldm, 0, 0, 0, nullptr);
+    return true;
+}
+
+// C1 = A1 B1^T + bias1 (K1 deep) and C2 = A2 B2^T + bias2 (K2 deep), both M x N, as ONE launch (grid z = 2): two dependent-latency chains of
+// a few hundred workgroups each run side by side instead of one after the other.  false = not covered (the caller issues two products).
+bool gemm_bf16x3_nt_pair(int64_t M, int64_t N, int64_t K1, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C1, const float* bias1,
+                         int64_t K2, const float* A2, int64_t lda2, const float* B2, int64_t ldb2, float* C2, const float* bias2, int64_t ldc, hipStream_t s) {
+    if (!(al16(A1) && al16(B1) && al16(A2) && al16(B2) && lda1 % 4 == 0 && ldb1 % 4 == 0 && lda2 % 4 == 0 && ldb2 % 4 == 0 && K1 % 4 == 0 && K2 % 4 == 0)) return false;
+    if (M < 1 || N < 1 || K1 < 8 || K2 < 8) return false;
+    // (operands of one allocation each: the second problem is addressed as an element offset from the first)
+    if ((reinterpret_cast<uintptr_t>(A1) | reinterpret_cast<uintptr_t>(A2) | reinterpret_cast<uintptr_t>(B1) | reinterpret_cast<uintptr_t>(B2) |
+         reinterpret_cast<uintptr_t>(C1) | reinterpret_cast<uintptr_t>(C2)) & 3) return false;
+    const int64_t pad3 = (N + 95) / 96 * 96, pad2 = (N + 63) / 64 * 64;
+    const int tnw = pad3 * 100 <= pad2 * 108 ? 3 : 2;
+    const int64_t gx = (N + 32 * tnw - 1) / (32 * tnw), gy = (M + BM - 1) / BM;
+    if (gx * gy >= ((int64_t)1 << 30)) return false;
+    const float* zeros = zero_block();
+    if (!zeros) return false;
+    const int vec_c = N % 4 == 0 && ldc % 4 == 0 && al16(C1) && al16(C2) && (!bias1 || al16(bias1)) && (!bias2 || al16(bias2));
+    ProfScope prof("gemm", 2.0 * M * N * (K1 + K2), s);
+    const dim3 grid((unsigned)(gx * gy), 1, 2);
+    const int64_t sA = A2 - A1, sB = B2 - B1, sC = C2 - C1;
+    if (tnw == 3)
+        gemm_bf16x3_nt_kernel<3><<<grid, NT, 0, s>>>(M, N, K1, A1, lda1, B1, ldb1, C1, ldc, bias1, 0, 0, (int)gx, (int)gy, sA, sB, sC, zeros, vec_c, nullptr, 0, K2, lda2, ldb2, bias2);
+    else
+        gemm_bf16x3_nt_kernel<2><<<grid, NT, 0, s>>>(M, N, K1, A1, lda1, B1, ldb1, C1, ldc, bias1, 0, 0, (int)gx, (int)gy, sA, sB, sC, zeros, vec_c, nullptr, 0, K2, lda2, ldb2, bias2);
     return true;
 }
 
