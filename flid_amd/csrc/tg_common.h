@@ -124,6 +124,10 @@ bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t 
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
                   float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s);
+// tg_memory.hip: a positive TGN batch's new raw messages, only each node's last one, built straight into the pending-message table
+int build_scatter_last(const float* d_mem, int64_t mem_ld, const float* d_last_update, const int32_t* d_a_ids, const int32_t* d_b_ids, const float* d_t32,
+                       const float* d_edge, int64_t edge_ld, const int32_t* d_eids, const float* d_te_w, const float* d_te_b, int64_t n, int d, int de, int T,
+                       float* d_table, int64_t table_ld, int32_t* d_has, float* d_msg_time, int32_t* d_last_idx_ws, hipStream_t s);
 // tg_gemm.hip: two X W^T + b products of the same M x N as one launch (TGN's two GRU gate products); false = issue them one by one
 bool gemm_pair_nt(int64_t M, int64_t N, int64_t K1, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C1, const float* bias1,
                   int64_t K2, const float* A2, int64_t lda2, const float* B2, int64_t ldb2, float* C2, const float* bias2, int64_t ldc, hipStream_t s);

@@ -106,6 +106,27 @@ __global__ void __launch_bounds__(256) msg_scatter_last_kernel(const int32_t* __
     }
 }
 
+// build_messages_kernel + msg_scatter_last_kernel as one launch: only a node's LAST message of the batch is ever read, so only those are built,
+// straight into the node's row of the pending-message table (the winner index comes from tgn_persist_index_kernel's launch)
+__global__ void __launch_bounds__(256) build_scatter_last_kernel(const float* __restrict__ mem, int64_t mem_ld,
+        const float* __restrict__ last_update, const int32_t* __restrict__ a_ids, const int32_t* __restrict__ b_ids,
+        const float* __restrict__ t32, const float* __restrict__ edge, int64_t edge_ld, const int32_t* __restrict__ eids,
+        const float* __restrict__ te_w, const float* __restrict__ te_b, int64_t n, int d, int de, int T, float* __restrict__ table,
+        int64_t table_ld, int32_t* __restrict__ has, float* __restrict__ msg_time, int32_t* __restrict__ last_idx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        const int64_t a = a_ids[r];
+        if (last_idx[a] != (int32_t)r) continue;                 // wave-uniform: not the last entry of its node
+        const int64_t b = b_ids[r], e = eids[r];
+        const float dt = t32[r] - last_update[a];                       // float32 - float32, MemoryModel.py:255-257
+        float* o = table + a * table_ld;
+        for (int c = lane; c < d; c += 64) { o[c] = mem[a * mem_ld + c]; o[d + c] = mem[b * mem_ld + c]; }
+        for (int c = lane; c < T; c += 64) o[2 * d + c] = tg::cos_phase(fmaf(dt, te_w[c], te_b[c]));
+        for (int c = lane; c < de; c += 64) o[2 * d + T + c] = edge[e * edge_ld + c];
+        if (lane == 0) { has[a] = 1; msg_time[a] = t32[r]; last_idx[a] = -1; }      // the workspace is left all -1 for the next call
+    }
+}
+
 // tgn_persist_kernel's rows and msg_last_index_kernel's winner search as roles of one grid (they are independent: the stepper's state
 // advance is persist -> build messages -> scatter the last ones, and the winner index depends on the batch's node list alone)
 __global__ void __launch_bounds__(256) tgn_persist_index_kernel(const float* __restrict__ rows, int64_t rows_ld, const int32_t* __restrict__ row_of,
@@ -138,6 +159,19 @@ int tgn_persist_index(const float* d_rows, int64_t rows_ld, const int32_t* d_row
     tgn_persist_index_kernel<<<(unsigned)(pb + ib), 256, 0, s>>>(d_rows, rows_ld, d_row_of, d_nodes, d_has, d_msg_time, d_memory, mem_ld, d_last_update, count,
                                                                   d, pb, d_last_idx_ws);
     return launch_status("tgn_persist_index_kernel");
+}
+// models/MemoryModel.py:233-278 (new raw messages) + :177-180, :312-320 (only the last one per node is ever read) behind
+// tgn_persist_index: the winners' messages, built in place
+int build_scatter_last(const float* d_mem, int64_t mem_ld, const float* d_last_update, const int32_t* d_a_ids, const int32_t* d_b_ids, const float* d_t32,
+                       const float* d_edge, int64_t edge_ld, const int32_t* d_eids, const float* d_te_w, const float* d_te_b, int64_t n, int d, int de, int T,
+                       float* d_table, int64_t table_ld, int32_t* d_has, float* d_msg_time, int32_t* d_last_idx_ws, hipStream_t s) {
+    TG_REQUIRE(d_mem && d_last_update && d_a_ids && d_b_ids && d_t32 && d_edge && d_eids && d_te_w && d_te_b && d_table && d_has && d_msg_time && d_last_idx_ws,
+               "build_scatter_last: null pointer");
+    TG_REQUIRE(n >= 0 && d > 0 && de >= 0 && T > 0 && table_ld >= 2 * d + T + de, "build_scatter_last: sizes");
+    if (n == 0) return TG_OK;
+    build_scatter_last_kernel<<<(unsigned)std::min<int64_t>((n + 3) / 4, tg::kMaxGridBlocks), 256, 0, s>>>(d_mem, mem_ld, d_last_update, d_a_ids, d_b_ids, d_t32,
+        d_edge, edge_ld, d_eids, d_te_w, d_te_b, n, d, de, T, d_table, table_ld, d_has, d_msg_time, d_last_idx_ws);
+    return launch_status("build_scatter_last_kernel");
 }
 // tg_msg_scatter_last behind tgn_persist_index: the winner index is in the workspace already
 int msg_scatter_last_indexed(const int32_t* d_nodes, const float* d_msgs, int64_t msg_ld, const float* d_t32, int64_t count, int width, float* d_table,

@@ -724,12 +724,10 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
             // (the "last message wins" index of the batch's node list rides in the persist launch: it needs nothing of it)
             rc = tg::tgn_persist_index(t.rows, D, s.rowmap + roots, batch_d, bank->d_has, bank->d_msg_time, bank->d_mem, bank->mem_ld, bank->d_last_update, nb2,
                                        D, bank->d_last_idx_ws, (hipStream_t)stream);
-            if (rc == TG_OK)
-                rc = tg_build_messages(bank->d_mem, bank->mem_ld, bank->d_last_update, batch_d, b_d, t32_d, c.d_edge, c.edge_ld, e_d, c.d_param + st->poff[0],
-                                       c.d_param + st->poff[1], nb2, D, c.de, c.dt_dim, t.msgs, stream);
-            if (rc == TG_OK)
-                rc = tg::msg_scatter_last_indexed(batch_d, t.msgs, MD, t32_d, nb2, MD, bank->d_msg, bank->msg_ld, bank->d_has, bank->d_msg_time,
-                                                  bank->d_last_idx_ws, (hipStream_t)stream);
+            if (rc == TG_OK)      // the new raw messages: only each node's last one, built straight into its row of the pending-message table
+                rc = tg::build_scatter_last(bank->d_mem, bank->mem_ld, bank->d_last_update, batch_d, b_d, t32_d, c.d_edge, c.edge_ld, e_d, c.d_param + st->poff[0],
+                                            c.d_param + st->poff[1], nb2, D, c.de, c.dt_dim, bank->d_msg, bank->msg_ld, bank->d_has, bank->d_msg_time,
+                                            bank->d_last_idx_ws, (hipStream_t)stream);
         }
     }
     return finish_backward(st, s, rc, stream, adam, d_grad);
