@@ -527,7 +527,7 @@ def main():
                 "instances_per_launch_avg": round(inst / max(1, cnt), 1)}
         # PMC passes of the same command (tools/traffic_from_pmc.py, separate rocprofv3 --pmc runs): reported only when they were
         # taken on THIS source of the attention kernels; a file from another build is named, not quoted
-        tr = os.path.join(REPO, "profiles", "traffic_r04.json")
+        tr = os.path.join(REPO, "profiles", "traffic_r05.json")
         if os.path.exists(tr) and args.workload == "wikipedia" and args.mode == "train":
             try:
                 tj = json.load(open(tr))
@@ -538,7 +538,7 @@ def main():
                     roof["traffic"] = ent.get("hbm_bytes_per_launch")
                     roof["traffic_detail"] = ent
                 else:
-                    roof["traffic_stale"] = {"file": "profiles/traffic_r04.json", "kernel_src_sha": tj.get("_kernel_src_sha"),
+                    roof["traffic_stale"] = {"file": "profiles/traffic_r05.json", "kernel_src_sha": tj.get("_kernel_src_sha"),
                                              "current_kernel_src_sha": kernel_src_sha(),
                                              "note": "PMC passes taken on another build of the attention kernels: not quoted"}
             except Exception:
