@@ -917,9 +917,16 @@ def bench_memory_or_sequence_model(args):
                 "achieved": round(units / secs / 1e12, 2), "peak": round(MFMA_F32_PEAK / 1e12, 1), "unit": "TFLOP/s",
                 "frac": round(units / secs / MFMA_F32_PEAK, 4), "traffic": None, "launches": cnt, "avg_launch_ms": round(ms / max(1, cnt), 4),
                 "gflop_per_step": round(units / unit_steps / 1e9, 2), "measured_over": f"{prof_steps} steps behind the timed region"}
+        if args.gemm_mode != 0:
+            # `frac` prices the reference's fp32 flops against the f32-input MFMA peak (what a plain fp32 mm could reach); the kernels
+            # that ran issue three bf16 MFMAs per product term set, so the peak THEY could reach is 2.5 PFLOP/s / 3
+            roof["frac_bf16x3_equivalent"] = round(units / secs / (BF16_PEAK / 3), 4)
+            roof["peak_bf16x3_equivalent"] = round(BF16_PEAK / 3 / 1e12, 1)
         flops_edge = units / (unit_steps * BATCH)
         path = {"flops_per_edge_fwd_bwd": round(flops_edge, 1), "mfma_frac": round(value / world * flops_edge / MFMA_F32_PEAK, 4),
                 "edges_per_s_at_100pct": round(MFMA_F32_PEAK / max(flops_edge, 1.0), 1)}
+        if args.gemm_mode != 0:
+            path["mfma_frac_bf16x3_equivalent"] = round(value / world * flops_edge / (BF16_PEAK / 3), 4)
         metric = "edges/sec (temporal-embedding fwd+bwd), %s Reddit, 1/2/4/8 MI355X" % {"dygformer": "DyGFormer", "tcl": "TCL", "graphmixer": "GraphMixer"}[args.model]
     out = {"metric": metric, "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) dyg_cooc_bwd_kernel(const float* __restri
 __global__ void __launch_bounds__(256) dyg_segmean_bwd_kernel(const float* __restrict__ d_means, int64_t B, int S, int d, int ws, float p, uint64_t seed,
                                                               float* __restrict__ dx, float* __restrict__ dx_dropped) {
     const int64_t total = B * S * d;
-    const float is = 1.f / (float)ws, id = 1.f / (float)(S - ws), scale = 1.f / (1.f - p);
+    const float is = 1.f / (float)ws, id = 1.f / (float)(S - ws);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % d);
         const int64_t pos = i / d, b = pos / S;
@@ -167,8 +167,7 @@ __global__ void __launch_bounds__(256) dyg_segmean_bwd_kernel(const float* __res
         const float v = j < ws ? d_means[b * d + c] * is : d_means[(B + b) * d + c] * id;
         dx[i] = v;
         if (dx_dropped) {
-            const float u = (float)(tg::mix32(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
-            dx_dropped[i] = u >= p ? v * scale : 0.f;
+            dx_dropped[i] = v * tg::res_keep_scale(seed, i, p);
         }
     }
 }

@@ -6,6 +6,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <initializer_list>
+
 #include "tg_common.h"
 
 namespace {
@@ -52,7 +54,6 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const float* __restrict
     // drop_p > 0: b passes through dropout first (tg_dropout's mask of (drop_seed, flat index)); sum_out (optional) keeps a + dropout(b),
     // the residual stream a pre-LN block hands on
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float drop_scale = 1.f / (1.f - drop_p);
     for (int64_t r = (int64_t)blockIdx.x * ROW_WAVES + wave; r < n; r += (int64_t)gridDim.x * ROW_WAVES) {
         float x[MAXC];
         float s = 0.f;
@@ -66,8 +67,7 @@ __global__ void __launch_bounds__(256) add_ln_fwd_kernel(const float* __restrict
                 if (b) {
                     float bv = b[o];
                     if (drop_p > 0.f) {
-                        const float u = (float)(tg::mix32(drop_seed ^ ((uint64_t)o * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
-                        bv = u >= drop_p ? bv * drop_scale : 0.f;
+                        bv *= tg::res_keep_scale(drop_seed, o, drop_p);
                     }
                     v += bv;
                 }
@@ -104,7 +104,6 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
     // dres (optional): dx = dres + dLN(dy) (the residual branch's gradient joins here); dx_dropped (optional): dropout(dx) with the mask
     // of (drop_seed, flat index) as tg_dropout draws it -- the gradient entering a dropout that sits in front of the residual sum
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float drop_scale = 1.f / (1.f - drop_p);
     extern __shared__ float red[];   // ROW_WAVES * 2 * cols
     float dgam[MAXC], dbet[MAXC], gm[MAXC];
 #pragma unroll
@@ -139,8 +138,7 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
                 if (dres) v += dres[o];
                 dx[o] = v;
                 if (dx_dropped) {
-                    const float u = (float)(tg::mix32(drop_seed ^ ((uint64_t)o * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
-                    dx_dropped[o] = u >= drop_p ? v * drop_scale : 0.f;
+                    dx_dropped[o] = v * tg::res_keep_scale(drop_seed, o, drop_p);
                 }
             }
         }
@@ -157,6 +155,146 @@ __global__ void __launch_bounds__(256) add_ln_bwd_kernel(const float* __restrict
         for (int w = 0; w < ROW_WAVES; ++w) s += red[w * 2 * cols + j];
         part[(int64_t)blockIdx.x * (part_ld > 0 ? part_ld : 2 * cols) + j] = s;
     }
+}
+
+// The same two passes for rows of at most 256 floats, a multiple of 4, 16-byte aligned (DyGFormer's 200-wide tokens): lane l owns
+// columns [4 l, 4 l + 4) as ONE 16-byte access per operand, two rows per wave in flight, one 64-bit hash per four dropout decisions.
+// (One float per lane and access, one row at a time: 35 us per pass over 38 400 x 200, 3.5 TB/s.)  Same grid, same wave -> row map
+// and the same `part` layout as the kernels above.
+__device__ __forceinline__ float4 ldv(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stv(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
+
+__global__ void __launch_bounds__(256) add_ln_fwd4_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+        int cols, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+        float* __restrict__ mean, float* __restrict__ rstd, float drop_p, uint64_t drop_seed, float* __restrict__ sum_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = 4 * lane;
+    const bool ok = c < cols;
+    float gm[4], bt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gm[j] = ok ? gamma[c + j] : 0.f; bt[j] = ok ? beta[c + j] : 0.f; }
+    const int64_t stride = (int64_t)gridDim.x * ROW_WAVES;
+    const float inv = 1.f / (float)cols;
+    for (int64_t r0 = (int64_t)blockIdx.x * ROW_WAVES + wave; r0 < n; r0 += 2 * stride) {
+        const int64_t r1 = r0 + stride;
+        const bool has1 = r1 < n;
+        const int64_t o0 = r0 * cols + c, o1 = (has1 ? r1 : r0) * cols + c;
+        float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0, b0 = x0, b1 = x0;
+        if (ok) {
+            x0 = ldv(a + o0); x1 = ldv(a + o1);
+            if (b) { b0 = ldv(b + o0); b1 = ldv(b + o1); }
+        }
+        if (b && ok) {
+            float k0[4], k1[4];
+            tg::res_keep_scale4(drop_seed, o0, drop_p, k0);
+            tg::res_keep_scale4(drop_seed, o1, drop_p, k1);
+            x0 = make_float4(x0.x + b0.x * k0[0], x0.y + b0.y * k0[1], x0.z + b0.z * k0[2], x0.w + b0.w * k0[3]);
+            x1 = make_float4(x1.x + b1.x * k1[0], x1.y + b1.y * k1[1], x1.z + b1.z * k1[2], x1.w + b1.w * k1[3]);
+        }
+        if (sum_out && ok) { stv(sum_out + o0, x0); if (has1) stv(sum_out + o1, x1); }
+        const float mu0 = tg::wave_sum(sum4(x0)) * inv, mu1 = tg::wave_sum(sum4(x1)) * inv;
+        float4 d0 = make_float4(x0.x - mu0, x0.y - mu0, x0.z - mu0, x0.w - mu0), d1 = make_float4(x1.x - mu1, x1.y - mu1, x1.z - mu1, x1.w - mu1);
+        if (!ok) { d0 = make_float4(0.f, 0.f, 0.f, 0.f); d1 = d0; }
+        const float v0 = fmaf(d0.x, d0.x, fmaf(d0.y, d0.y, fmaf(d0.z, d0.z, d0.w * d0.w)));
+        const float v1 = fmaf(d1.x, d1.x, fmaf(d1.y, d1.y, fmaf(d1.z, d1.z, d1.w * d1.w)));
+        const float rs0 = rsqrtf(tg::wave_sum(v0) * inv + 1e-5f), rs1 = rsqrtf(tg::wave_sum(v1) * inv + 1e-5f);
+        if (ok) {
+            stv(y + o0, make_float4(d0.x * rs0 * gm[0] + bt[0], d0.y * rs0 * gm[1] + bt[1], d0.z * rs0 * gm[2] + bt[2], d0.w * rs0 * gm[3] + bt[3]));
+            if (has1) stv(y + o1, make_float4(d1.x * rs1 * gm[0] + bt[0], d1.y * rs1 * gm[1] + bt[1], d1.z * rs1 * gm[2] + bt[2], d1.w * rs1 * gm[3] + bt[3]));
+        }
+        if (lane == 0) {
+            mean[r0] = mu0; rstd[r0] = rs0;
+            if (has1) { mean[r1] = mu1; rstd[r1] = rs1; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) add_ln_bwd4_kernel(const float* __restrict__ a, const float* __restrict__ b,
+        const float* __restrict__ dy, int64_t n, int cols, const float* __restrict__ gamma, const float* __restrict__ mean,
+        const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ part,
+        const float* __restrict__ dres, float drop_p, uint64_t drop_seed, float* __restrict__ dx_dropped, int64_t part_ld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = 4 * lane;
+    const bool ok = c < cols;
+    extern __shared__ float red[];   // ROW_WAVES * 2 * cols
+    float gm[4], dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gm[j] = ok ? gamma[c + j] : 0.f;
+    const int64_t stride = (int64_t)gridDim.x * ROW_WAVES;
+    const float inv = 1.f / (float)cols;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t r0 = (int64_t)blockIdx.x * ROW_WAVES + wave; r0 < n; r0 += 2 * stride) {
+        const int64_t r1 = r0 + stride;
+        const bool has1 = r1 < n;
+        const int64_t q1 = has1 ? r1 : r0;
+        const int64_t o0 = r0 * cols + c, o1 = q1 * cols + c;
+        float4 d0 = z, d1 = z, x0 = z, x1 = z, e0 = z, e1 = z;
+        if (ok) {
+            d0 = ldv(dy + o0); d1 = ldv(dy + o1);
+            x0 = ldv(a + o0); x1 = ldv(a + o1);
+            if (b) {
+                const float4 t0 = ldv(b + o0), t1 = ldv(b + o1);
+                x0 = make_float4(x0.x + t0.x, x0.y + t0.y, x0.z + t0.z, x0.w + t0.w);
+                x1 = make_float4(x1.x + t1.x, x1.y + t1.y, x1.z + t1.z, x1.w + t1.w);
+            }
+            if (dres) { e0 = ldv(dres + o0); e1 = ldv(dres + o1); }
+        }
+        if (!has1) d1 = z;
+        const float mu0 = mean[r0], rs0 = rstd[r0], mu1 = mean[q1], rs1 = rstd[q1];
+        float xh0[4] = {(x0.x - mu0) * rs0, (x0.y - mu0) * rs0, (x0.z - mu0) * rs0, (x0.w - mu0) * rs0};
+        float xh1[4] = {(x1.x - mu1) * rs1, (x1.y - mu1) * rs1, (x1.z - mu1) * rs1, (x1.w - mu1) * rs1};
+        const float dv0[4] = {d0.x, d0.y, d0.z, d0.w}, dv1[4] = {d1.x, d1.y, d1.z, d1.w};
+        float g0[4], g1[4], s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!ok) { xh0[j] = 0.f; xh1[j] = 0.f; }
+            g0[j] = dv0[j] * gm[j]; g1[j] = dv1[j] * gm[j];
+            s10 += g0[j]; s11 += g1[j];
+            s20 = fmaf(g0[j], xh0[j], s20); s21 = fmaf(g1[j], xh1[j], s21);
+            dgam[j] = fmaf(dv0[j], xh0[j], dgam[j]); dbet[j] += dv0[j];
+            dgam[j] = fmaf(dv1[j], xh1[j], dgam[j]); dbet[j] += dv1[j];
+        }
+        const float m10 = tg::wave_sum(s10) * inv, m20 = tg::wave_sum(s20) * inv, m11 = tg::wave_sum(s11) * inv, m21 = tg::wave_sum(s21) * inv;
+        if (ok) {
+            const float4 v0 = make_float4(rs0 * (g0[0] - m10 - xh0[0] * m20) + e0.x, rs0 * (g0[1] - m10 - xh0[1] * m20) + e0.y,
+                                          rs0 * (g0[2] - m10 - xh0[2] * m20) + e0.z, rs0 * (g0[3] - m10 - xh0[3] * m20) + e0.w);
+            stv(dx + o0, v0);
+            if (dx_dropped) {
+                float k[4];
+                tg::res_keep_scale4(drop_seed, o0, drop_p, k);
+                stv(dx_dropped + o0, make_float4(v0.x * k[0], v0.y * k[1], v0.z * k[2], v0.w * k[3]));
+            }
+            if (has1) {
+                const float4 v1 = make_float4(rs1 * (g1[0] - m11 - xh1[0] * m21) + e1.x, rs1 * (g1[1] - m11 - xh1[1] * m21) + e1.y,
+                                              rs1 * (g1[2] - m11 - xh1[2] * m21) + e1.z, rs1 * (g1[3] - m11 - xh1[3] * m21) + e1.w);
+                stv(dx + o1, v1);
+                if (dx_dropped) {
+                    float k[4];
+                    tg::res_keep_scale4(drop_seed, o1, drop_p, k);
+                    stv(dx_dropped + o1, make_float4(v1.x * k[0], v1.y * k[1], v1.z * k[2], v1.w * k[3]));
+                }
+            }
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[wave * 2 * cols + c + j] = dgam[j]; red[wave * 2 * cols + cols + c + j] = dbet[j]; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * cols; j += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < ROW_WAVES; ++w) s += red[w * 2 * cols + j];
+        part[(int64_t)blockIdx.x * (part_ld > 0 ? part_ld : 2 * cols) + j] = s;
+    }
+}
+
+inline bool al16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+inline bool ln4_ok(int cols, std::initializer_list<const void*> ps) {
+    if (cols > 256 || (cols & 3)) return false;
+    for (const void* q : ps) if (q && !al16p(q)) return false;
+    return true;
 }
 
 __global__ void __launch_bounds__(256) relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, int64_t numel) {
@@ -460,7 +598,8 @@ extern "C" int tg_add_layernorm_fwd(const float* d_a, const float* d_b, int64_t 
     if (n == 0) return TG_OK;
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)row_grid(n);
-    if (cols <= 64) add_ln_fwd_kernel<1><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
+    if (ln4_ok(cols, {d_a, d_b, d_y})) add_ln_fwd4_kernel<<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, 0.f, 0, nullptr);
+    else if (cols <= 64) add_ln_fwd_kernel<1><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
     else if (cols <= 320) add_ln_fwd_kernel<5><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
     else add_ln_fwd_kernel<16><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd);
     return tg::launch_status("add_ln_fwd_kernel");
@@ -473,7 +612,8 @@ extern "C" int tg_add_layernorm_fwd_res(const float* d_a, const float* d_b, int6
     if (n == 0) return TG_OK;
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)row_grid(n);
-    if (cols <= 64) add_ln_fwd_kernel<1><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, drop_p, drop_seed, d_sum);
+    if (ln4_ok(cols, {d_a, d_b, d_y, d_sum})) add_ln_fwd4_kernel<<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, drop_p, drop_seed, d_sum);
+    else if (cols <= 64) add_ln_fwd_kernel<1><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, drop_p, drop_seed, d_sum);
     else if (cols <= 320) add_ln_fwd_kernel<5><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, drop_p, drop_seed, d_sum);
     else add_ln_fwd_kernel<16><<<g, 256, 0, s>>>(d_a, d_b, n, cols, d_gamma, d_beta, d_y, d_mean, d_rstd, drop_p, drop_seed, d_sum);
     return tg::launch_status("add_ln_fwd_kernel");
@@ -487,7 +627,8 @@ extern "C" int tg_add_layernorm_bwd(const float* d_a, const float* d_b, const fl
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)row_grid(n);
     const size_t lds = sizeof(float) * ROW_WAVES * 2 * cols;
-    if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
+    if (ln4_ok(cols, {d_a, d_b, d_dy, d_dx})) add_ln_bwd4_kernel<<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, nullptr, 0.f, 0, nullptr, 0);
+    else if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
     else if (cols <= 320) add_ln_bwd_kernel<5><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
     else add_ln_bwd_kernel<16><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part);
     return tg::launch_status("add_ln_bwd_kernel");
@@ -502,7 +643,8 @@ extern "C" int tg_add_layernorm_bwd_res(const float* d_a, const float* d_b, cons
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = (unsigned)row_grid(n);
     const size_t lds = sizeof(float) * ROW_WAVES * 2 * cols;
-    if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped, part_ld);
+    if (ln4_ok(cols, {d_a, d_b, d_dy, d_dx, d_dres, d_dx_dropped})) add_ln_bwd4_kernel<<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped, part_ld);
+    else if (cols <= 64) add_ln_bwd_kernel<1><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped, part_ld);
     else if (cols <= 320) add_ln_bwd_kernel<5><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped, part_ld);
     else add_ln_bwd_kernel<16><<<g, 256, lds, s>>>(d_a, d_b, d_dy, n, cols, d_gamma, d_mean, d_rstd, d_dx, d_dgb_part, d_dres, drop_p, drop_seed, d_dx_dropped, part_ld);
     return tg::launch_status("add_ln_bwd_kernel");

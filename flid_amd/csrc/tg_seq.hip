@@ -6,6 +6,7 @@
 //   tg_dropout           <- nn.Dropout (models/DyGFormer.py:456-460), mask regenerated from (seed, index) in backward
 //   tg_segment_mean_*    <- torch.mean over each side's patches (models/DyGFormer.py:185-187)
 #include <math.h>
+#include <initializer_list>
 
 #include "tg_common.h"
 
@@ -101,44 +102,77 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed,
-                                                      float* __restrict__ y) {
-    const float scale = 1.f / (1.f - p);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float u = (float)(tg::mix32(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
-        y[i] = u >= p ? x[i] * scale : 0.f;
+// Element-wise passes over long tensors (38 400 x 800 in a DyGFormer block): four elements per lane and trip as 16-byte accesses, two
+// trips in flight, ONE 64-bit hash for the four dropout decisions (tg::res_keep_scale4: the mask of every dropout of the sequence
+// models -- tg_dropout, the fused passes below, the LayerNorm passes of tg_rowops.hip, the attention core of tg_seqattn.hip -- is that
+// function of (seed, flat index)).  One element per lane and trip with a hash each ran gelu + dropout over 30.7 M elements in 62 us
+// (4 TB/s, VALU- and latency-bound).  n % 4 != 0 or unaligned pointers: the element form.
+template <class F4, class F1>
+__device__ __forceinline__ void ew_loop(int64_t n, bool vec, F4 f4, F1 f1) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        int64_t i = tid;
+        for (; i + nth < n4; i += 2 * nth) f4(i, i + nth);
+        if (i < n4) f4(i, i);
+    } else {
+        for (int64_t i = tid; i < n; i += nth) f1(i);
     }
+}
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float v) {
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+__device__ __forceinline__ void st4(float* p, int64_t i4, const float4& v) { reinterpret_cast<float4*>(p)[i4] = v; }
+
+__global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed, float* __restrict__ y, bool vec) {
+    auto one = [&](int64_t i4) {
+        const float4 v = ld4(x, i4);
+        float k[4];
+        tg::res_keep_scale4(seed, 4 * i4, p, k);
+        return make_float4(v.x * k[0], v.y * k[1], v.z * k[2], v.w * k[3]);
+    };
+    ew_loop(n, vec, [&](int64_t a, int64_t b) { const float4 ra = one(a), rb = one(b); st4(y, a, ra); st4(y, b, rb); },
+            [&](int64_t i) { y[i] = x[i] * tg::res_keep_scale(seed, i, p); });
 }
 
 // Fused element-wise passes of a transformer block (models/DyGFormer.py:448-461): each replaces two launches over the same elements.
 //   gelu_dropout_fwd:  y = dropout(gelu(x))          gelu_dropout_bwd:  dx = gelu'(x) * dropout(dy)       (same mask: hash of seed, index)
 //   dropout_add:       y = res + dropout(x)
-__device__ __forceinline__ float drop_scale(uint64_t seed, int64_t i, float p, float scale) {
-    const float u = (float)(tg::mix32(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
-    return u >= p ? scale : 0.f;
-}
-__global__ void __launch_bounds__(256) gelu_dropout_fwd_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed, float* __restrict__ y) {
-    const float scale = 1.f / (1.f - p);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = x[i];
-        y[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f)) * drop_scale(seed, i, p, scale);
-    }
+__global__ void __launch_bounds__(256) gelu_dropout_fwd_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed, float* __restrict__ y, bool vec) {
+    auto one = [&](int64_t i4) {
+        const float4 v = ld4(x, i4);
+        float k[4];
+        tg::res_keep_scale4(seed, 4 * i4, p, k);
+        return make_float4(gelu_f(v.x) * k[0], gelu_f(v.y) * k[1], gelu_f(v.z) * k[2], gelu_f(v.w) * k[3]);
+    };
+    ew_loop(n, vec, [&](int64_t a, int64_t b) { const float4 ra = one(a), rb = one(b); st4(y, a, ra); st4(y, b, rb); },
+            [&](int64_t i) { y[i] = gelu_f(x[i]) * tg::res_keep_scale(seed, i, p); });
 }
 __global__ void __launch_bounds__(256) gelu_dropout_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n, float p,
-                                                               uint64_t seed, float* __restrict__ dx) {
-    const float scale = 1.f / (1.f - p);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = x[i];
-        const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-        const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
-        dx[i] = dy[i] * drop_scale(seed, i, p, scale) * (cdf + v * pdf);
-    }
+                                                               uint64_t seed, float* __restrict__ dx, bool vec) {
+    auto one = [&](int64_t i4) {
+        const float4 v = ld4(x, i4), d = ld4(dy, i4);
+        float k[4];
+        tg::res_keep_scale4(seed, 4 * i4, p, k);
+        return make_float4(d.x * k[0] * dgelu_f(v.x), d.y * k[1] * dgelu_f(v.y), d.z * k[2] * dgelu_f(v.z), d.w * k[3] * dgelu_f(v.w));
+    };
+    ew_loop(n, vec, [&](int64_t a, int64_t b) { const float4 ra = one(a), rb = one(b); st4(dx, a, ra); st4(dx, b, rb); },
+            [&](int64_t i) { dx[i] = dy[i] * tg::res_keep_scale(seed, i, p) * dgelu_f(x[i]); });
 }
 __global__ void __launch_bounds__(256) dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, int64_t n, float p,
-                                                          uint64_t seed, float* __restrict__ y) {
-    const float scale = 1.f / (1.f - p);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        y[i] = res[i] + x[i] * drop_scale(seed, i, p, scale);
+                                                          uint64_t seed, float* __restrict__ y, bool vec) {
+    auto one = [&](int64_t i4) {
+        const float4 v = ld4(x, i4), r = ld4(res, i4);
+        float k[4];
+        tg::res_keep_scale4(seed, 4 * i4, p, k);
+        return make_float4(r.x + v.x * k[0], r.y + v.y * k[1], r.z + v.z * k[2], r.w + v.w * k[3]);
+    };
+    ew_loop(n, vec, [&](int64_t a, int64_t b) { const float4 ra = one(a), rb = one(b); st4(y, a, ra); st4(y, b, rb); },
+            [&](int64_t i) { y[i] = res[i] + x[i] * tg::res_keep_scale(seed, i, p); });
 }
 
 // x: (n, s, d); out[i, :] = mean_{j in [lo, hi)} x[i, j, :]
@@ -168,6 +202,11 @@ __global__ void __launch_bounds__(256) segment_mean_bwd_kernel(const float* __re
     }
 }
 
+inline bool vec_ok(int64_t n, std::initializer_list<const void*> ps) {
+    if (n & 3) return false;
+    for (const void* q : ps) if (reinterpret_cast<uintptr_t>(q) & 15) return false;
+    return true;
+}
 inline unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, tg::kMaxGridBlocks)); }
 
 }  // namespace
@@ -227,26 +266,26 @@ extern "C" int tg_softmax_bwd(const float* d_y, const float* d_dy, int64_t n, in
 extern "C" int tg_dropout(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream) {
     TG_REQUIRE(d_x && d_y && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout: arguments");
     if (n == 0) return TG_OK;
-    dropout_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, n, p, seed, d_y);
+    dropout_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, n, p, seed, d_y, vec_ok(n, {d_x, d_y}));
     return tg::launch_status("dropout_kernel");
 }
 
 extern "C" int tg_gelu_dropout_fwd(const float* d_x, int64_t n, float p, uint64_t seed, float* d_y, void* stream) {
     TG_REQUIRE(d_x && d_y && n >= 0 && p >= 0.f && p < 1.f, "tg_gelu_dropout_fwd: arguments");
     if (n == 0) return TG_OK;
-    gelu_dropout_fwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, n, p, seed, d_y);
+    gelu_dropout_fwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, n, p, seed, d_y, vec_ok(n, {d_x, d_y}));
     return tg::launch_status("gelu_dropout_fwd_kernel");
 }
 extern "C" int tg_gelu_dropout_bwd(const float* d_x, const float* d_dy, int64_t n, float p, uint64_t seed, float* d_dx, void* stream) {
     TG_REQUIRE(d_x && d_dy && d_dx && n >= 0 && p >= 0.f && p < 1.f, "tg_gelu_dropout_bwd: arguments");
     if (n == 0) return TG_OK;
-    gelu_dropout_bwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, d_dy, n, p, seed, d_dx);
+    gelu_dropout_bwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, d_dy, n, p, seed, d_dx, vec_ok(n, {d_x, d_dy, d_dx}));
     return tg::launch_status("gelu_dropout_bwd_kernel");
 }
 extern "C" int tg_dropout_add(const float* d_x, const float* d_res, int64_t n, float p, uint64_t seed, float* d_y, void* stream) {
     TG_REQUIRE(d_x && d_res && d_y && n >= 0 && p >= 0.f && p < 1.f, "tg_dropout_add: arguments");
     if (n == 0) return TG_OK;
-    dropout_add_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, d_res, n, p, seed, d_y);
+    dropout_add_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d_x, d_res, n, p, seed, d_y, vec_ok(n, {d_x, d_res, d_y}));
     return tg::launch_status("dropout_add_kernel");
 }
 

@@ -27,9 +27,8 @@ constexpr int LDQ = 104;            // row stride of the Q / K / V / dO images (
 constexpr int LDP = 65;             // row stride of the probability images: odd, they are read along rows AND along columns
 
 __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t i, float p, float scale) {      // = tg_dropout's mask (tg_seq.hip)
-    if (p <= 0.f) return 1.f;
-    const float u = (float)(tg::mix32(seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ULL)) & 0xFFFFFF) * (1.0f / 16777216.0f);
-    return u >= p ? scale : 0.f;
+    (void)scale;
+    return tg::res_keep_scale(seed, i, p);
 }
 
 // rows [0, S) x [0, hd) of a (S, ld) global block -> image (SMAX x LDQ), zeros elsewhere (columns up to HDP, rows up to SMAX).  Two
