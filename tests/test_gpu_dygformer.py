@@ -190,7 +190,8 @@ def test_block_diagonal_patch_projection_equals_per_channel_products():
         assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max())), k_
 
 
-@pytest.mark.parametrize("B,S,d,heads,p", [(7, 64, 200, 2, 0.0), (5, 37, 200, 2, 0.3), (3, 5, 16, 2, 0.0), (4, 64, 100, 1, 0.2), (9, 33, 48, 4, 0.1)])
+@pytest.mark.parametrize("B,S,d,heads,p", [(7, 64, 200, 2, 0.0), (5, 37, 200, 2, 0.3), (3, 5, 16, 2, 0.0), (4, 64, 100, 1, 0.2), (9, 33, 48, 4, 0.1),
+                                            (11, 32, 200, 2, 0.0), (6, 32, 200, 2, 0.25), (5, 17, 100, 1, 0.0), (4, 31, 48, 4, 0.1)])
 def test_fused_self_attention_equals_batched_products(B, S, d, heads, p):
     """tg_seq_attn_fwd / _bwd (the attention core of a (sequence, head) as one launch per direction, tg_seqattn.hip) against the batched
     exact-fp32 products + softmax + dropout passes they replace (same seed, same mask), and against float64"""
