@@ -550,6 +550,15 @@ extern "C" int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg
     return launch_fwd<1, 8>(*a, d_u, d_agg, d_prob, s);
 }
 
+namespace {
+thread_local float* t_slot_rows_next = nullptr;
+thread_local bool t_slot_rows_taken = false;
+}  // namespace
+namespace tg {
+void attn_bwd_slot_rows_next(float* rows) { t_slot_rows_next = rows; }
+bool attn_bwd_slot_rows_taken() { return t_slot_rows_taken; }
+}  // namespace tg
+
 extern "C" int tg_attn_bwd_parts(int64_t m) { return (int)attn_grid(m); }
 
 extern "C" void tg_set_attn_fast(int mask) { g_fast = mask; }
@@ -577,6 +586,9 @@ extern "C" int tg_attn_dropped_scores(const float* d_prob, int64_t m, int heads,
 extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float* d_agg, const float* d_prob,
                            const float* d_dagg, float* d_du, float* d_dfeat, int64_t dfeat_ld, int64_t pad_feat_row,
                            float* d_dedge, int64_t dedge_ld, float* d_dte_part, void* stream) {
+    float* slot_rows = t_slot_rows_next;        // (a request is good for ONE call, whoever serves it)
+    t_slot_rows_next = nullptr;
+    t_slot_rows_taken = false;
     if (int rc = check_desc(a)) return rc;
     TG_REQUIRE(d_u && d_agg && d_prob && d_dagg && d_du && d_dte_part, "tg_attn_bwd: null pointer");
     if (a->m == 0) return TG_OK;
@@ -587,6 +599,10 @@ extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float*
     if ((g_fast & 16) && !d_dedge) {
         const int rc = tg::attn_bwd_ring(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, pad_feat_row, d_dte_part, (int)attn_grid(a->m), s);
         if (rc != 1) return rc;
+    }
+    if ((g_fast & 2) && slot_rows && d_dfeat && !d_dedge) {
+        const int rc = tg::attn_bwd_fast(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, pad_feat_row, d_dedge, dedge_ld, d_dte_part, s, slot_rows);
+        if (rc != 1) { t_slot_rows_taken = rc == TG_OK; return rc; }
     }
     if (g_fast & 2) {
         const int rc = tg::attn_bwd_fast(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, pad_feat_row, d_dedge, dedge_ld, d_dte_part, s);

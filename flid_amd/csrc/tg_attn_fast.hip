@@ -222,10 +222,13 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_fwd_fast_kerne
 // masked slots get no score gradient (masked_fill), but still pass d z through a'.
 // DF: a gradient w.r.t. the gathered node rows is wanted (dfeat); DE: w.r.t. the gathered edge rows (dedge; stand-alone
 // MultiHeadAttention.forward only -- the backbones' edge table carries no gradient, models/TGAT.py:26-29).
-template <int H, int RB, bool DF, bool DE>
+template <int H, int RB, int DFM, bool DE>
 __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kernel(tg_attn_desc a, const float* __restrict__ u, const float* __restrict__ agg,
         const float* __restrict__ prob, const float* __restrict__ dagg, float* __restrict__ du, float* __restrict__ dfeat, int64_t dfeat_ld,
         int64_t pad_row, float* __restrict__ dedge, int64_t dedge_ld, float* __restrict__ dte_part) {
+    // DFM: 0 no feature gradient; 1 added into dfeat (float atomics); 2 written as one row per slot: dfeat is then the (m k, dn) slot-row
+    // buffer and padded slots are skipped (tg::attn_bwd_slot_rows_next)
+    constexpr bool DF = DFM == 1;
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // (uniform: row arithmetic on the scalar unit)
     const int nfe = a.dn + a.de, dk = nfe + a.dt_dim, k = a.k, T = a.dt_dim;
     const LaneMap m = lane_map(a, lane);
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
             for (int i = 0; i < 2; ++i) {
                 float ag[4];
                 if (m.has[i]) {
-                    if (DF || DE) ld4(u + o + m.ucol[i], uh[h][i]);
+                    if (DFM != 0 || DE) ld4(u + o + m.ucol[i], uh[h][i]);
                     ld4(dagg + o + m.ucol[i], dg[h][i]);
                     ld4(agg + o + m.ucol[i], ag);
                 } else {
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
                     gw[j] = fmaf(dts[r], dph, gw[j]);
                     gb[j] += dph;
                 }
-                if constexpr (DF || DE) {
+                if constexpr (DFM != 0 || DE) {
                     float dz[2][4];
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -353,7 +356,9 @@ __global__ void __launch_bounds__(WPB* kWave, FLID_ATTN_OCC) attn_bwd_fast_kerne
                             for (int h = 0; h < H; ++h) v = fmaf(pd[h], dg[h][i][e], fmaf(dsc[h], uh[h][i][e], v));
                             dz[i][e] = v;
                         }
-                    if (DF && nb[r] == 0 && pad_row >= 0) {         // wave-uniform: every padded slot gathers the same row
+                    if (DFM == 2) {
+                        if (nb[r] != 0 && m.has[0]) st4(dfeat + (row * k + s) * (int64_t)a.dn + m.col[0], dz[0]);       // (nb: wave-uniform)
+                    } else if (DF && nb[r] == 0 && pad_row >= 0) {         // wave-uniform: every padded slot gathers the same row
                         if (m.has[0])
 #pragma unroll
                             for (int e = 0; e < 4; ++e) dpad[e] += dz[0][e];
@@ -451,17 +456,21 @@ int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob
 }
 
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
-                  float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s) {
+                  float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s, float* slot_rows) {
     if (!shape_ok(a) || !aligned16(u) || !aligned16(agg) || !aligned16(dagg) || !aligned16(du)) return 1;
     if (dedge && !dfeat) return 1;
+    if (slot_rows && (dedge || !dfeat || !aligned16(slot_rows))) return 1;
     const dim3 grid((unsigned)fast_grid(a.m)), block(WPB * kWave);
     const int wmax = a.dn > a.de ? a.dn : a.de;
     const size_t lds = sizeof(float) * WPB * (2 * a.dt_dim + a.dn + wmax);
 #define FLID_LAUNCH(HH, RBB, DFF, DEE) attn_bwd_fast_kernel<HH, RBB, DFF, DEE><<<grid, block, lds, s>>>(a, u, agg, prob, dagg, du, dfeat, dfeat_ld, pad_row, dedge, dedge_ld, dte)
-    if (a.heads == 1) {
-        if (dedge) FLID_LAUNCH(1, kRBB, true, true); else if (dfeat) FLID_LAUNCH(1, kRBB, true, false); else FLID_LAUNCH(1, kRBB, false, false);
+    if (slot_rows) {
+        dfeat = slot_rows;
+        if (a.heads == 1) FLID_LAUNCH(1, kRBB, 2, false); else FLID_LAUNCH(2, kRBB, 2, false);
+    } else if (a.heads == 1) {
+        if (dedge) FLID_LAUNCH(1, kRBB, 1, true); else if (dfeat) FLID_LAUNCH(1, kRBB, 1, false); else FLID_LAUNCH(1, kRBB, 0, false);
     } else {
-        if (dedge) FLID_LAUNCH(2, kRBB, true, true); else if (dfeat) FLID_LAUNCH(2, kRBB, true, false); else FLID_LAUNCH(2, kRBB, false, false);
+        if (dedge) FLID_LAUNCH(2, kRBB, 1, true); else if (dfeat) FLID_LAUNCH(2, kRBB, 1, false); else FLID_LAUNCH(2, kRBB, 0, false);
     }
 #undef FLID_LAUNCH
     return launch_status("attn_bwd_fast_kernel");

@@ -121,9 +121,24 @@ bool wgrad_group2(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t
 void wgrad_defer_next(bool on);
 int wgrad_flush_deferred(hipStream_t s);
 bool wgrad_group(int njobs, const tg_wgrad_job* jobs, int64_t rows, hipStream_t s);   // tg_gemm_bf16x3.hip; false = shapes not covered
+// The NEXT tg_attn_bwd of this thread that wants a feature gradient writes it as one row per neighbor slot (slot s of instance r at
+// rows + (r k + s) dn, padded slots skipped) instead of adding it into dfeat with float atomics -- for a gradient table whose popular
+// rows would serialise the atomics (TGN's compact `memory' + raw` table: tg_step.hip sums the rows with slot_rows_sum).  Only the fast
+// backward kernel takes the request; attn_bwd_slot_rows_taken() says whether the last tg_attn_bwd did.
+void attn_bwd_slot_rows_next(float* rows);
+bool attn_bwd_slot_rows_taken();
+// slots grouped by the table row they gather (any order inside a row): order[i] = slot, srow[i] = its row, i < *n_valid (slots with
+// nbr == 0 left out); *d_rows (device) = table rows in use, the padding row is *d_rows; cnt: nrows_cap + 1 ints of scratch, rank: n ints
+constexpr int64_t kSlotOrderMaxRows = 38000;        // LDS counters of build_slot_order: nrows_cap + 1 + 1 024 <= this
+int build_slot_order(const int32_t* slot_row, const int32_t* nbr, int64_t n, int64_t nrows_cap, const int32_t* d_rows, int32_t* cnt, int32_t* rank,
+                     int32_t* order, int32_t* srow, int32_t* n_valid, hipStream_t s);
+// table[srow[i]] += rows[order[i]] over i < *n_valid: one wave per 16 entries, runs of equal rows summed in registers, one float-atomic
+// row add per run
+int slot_rows_sum(const float* rows, int dn, const int32_t* order, const int32_t* srow, const int32_t* n_valid, int64_t n, float* table,
+                  int64_t ld, hipStream_t s);
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
-                  float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s);
+                  float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s, float* slot_rows = nullptr);
 // tg_memory.hip: a positive TGN batch's new raw messages, only each node's last one, built straight into the pending-message table
 int build_scatter_last(const float* d_mem, int64_t mem_ld, const float* d_last_update, const int32_t* d_a_ids, const int32_t* d_b_ids, const float* d_t32,
                        const float* d_edge, int64_t edge_ld, const int32_t* d_eids, const float* d_te_w, const float* d_te_b, int64_t n, int d, int de, int T,

@@ -48,6 +48,7 @@ struct Slot {
     int64_t nb = 0, lo = 0, hi = 0, uniq_count = 0;      // batch edges, embedded shard [lo, hi), distinct touched nodes
     int64_t off[8] = {};
     int32_t *blob = nullptr, *uniq = nullptr, *rowmap = nullptr;      // (uniq_t above: the distinct nodes' all-zero times)
+    int32_t *slot_order = nullptr, *slot_srow = nullptr, *slot_nvalid = nullptr;   // neighbor slots grouped by compact row (tg::build_slot_order)
     void* h_stage = nullptr;              // pinned: the staged blob + the (count, pad) words
     std::vector<int64_t> h_u; std::vector<double> h_newt; int64_t h_nu = 0;     // host mirror of the state advance
     bool has_eid = false;
@@ -55,6 +56,8 @@ struct Slot {
 
 struct TgnBuf {                           // arena regions of the memory stage (floats); U = touched nodes at most
     float *h_rows, *msg_rows, *gi, *gh, *rows, *base, *d_own, *d_raw, *dgi, *dgh, *msgs, *zero_t;
+    float* slot_rows;                     // (max_roots k, dn): the attention backward's per-slot feature gradients
+    int32_t *slot_cnt, *slot_rank;        // (max_u + 2), (max_roots k): scratch of build_slot_order
     int64_t max_u;
 };
 
@@ -98,12 +101,20 @@ int64_t rows_of_layer(const tg_stepper* st, int l /* 1-based */, int64_t n, int6
     return (L - l) == 0 ? n : n + count1;          // layers <= 2: the lower layer computes roots + level-1 rows
 }
 
+// TGN: the attention layer's gradient w.r.t. the compact table as per-slot rows + segmented sum (tg_memory.hip) instead of float atomics
+// from the attention backward.  FLID_TGN_SLOT_ROWS=0 (with FLID_GEMM_TUNE): the atomics, for A/B runs.
+const bool g_slot_rows = !(getenv("FLID_GEMM_TUNE") && getenv("FLID_TGN_SLOT_ROWS") && atoi(getenv("FLID_TGN_SLOT_ROWS")) == 0);
+
 // arena layout: sizes only (base == nullptr) or pointers
 struct Arena {
     float* base; int64_t off = 0;
     explicit Arena(float* b) : base(b) {}
     float* take(int64_t floats) { float* p = base ? base + off : nullptr; off += r64(floats); return p; }
 };
+
+// (the order build keeps one counter per table row in LDS: steppers sized for more rows than that -- a data-parallel rank's global batch
+// of several thousand edges -- keep the attention backward's atomics)
+inline bool slot_rows_on(const tg_stepper* st) { return g_slot_rows && st->c.tgn && st->tb.max_u + 2 + 1024 <= tg::kSlotOrderMaxRows; }
 
 int layout(tg_stepper* st, float* base, int64_t* total) {
     const tg_stepper_cfg& c = st->c;
@@ -123,6 +134,8 @@ int layout(tg_stepper* st, float* base, int64_t* total) {
             s.S_eid = reinterpret_cast<int32_t*>(A.take(mk)); s.S_t = A.take(mk); s.S_dt = A.take(mk);
             s.uniq = reinterpret_cast<int32_t*>(A.take(total)); s.uniq_t = A.take(total); s.rowmap = reinterpret_cast<int32_t*>(A.take(total));
             s.count_pad = reinterpret_cast<int32_t*>(A.take(4));
+            s.slot_order = reinterpret_cast<int32_t*>(A.take(mk)); s.slot_srow = reinterpret_cast<int32_t*>(A.take(mk));
+            s.slot_nvalid = reinterpret_cast<int32_t*>(A.take(4));
         }
         st->ded_cap = tg_dedupe_capacity(total);
         st->ded_keys = A.take(2 * st->ded_cap);
@@ -134,6 +147,7 @@ int layout(tg_stepper* st, float* base, int64_t* total) {
         t.h_rows = A.take(U * D); t.msg_rows = A.take(U * MD); t.gi = A.take(U * 3 * D); t.gh = A.take(U * 3 * D); t.rows = A.take(U * D);
         t.base = A.take(U * D); t.d_own = A.take(c.max_roots * D); t.d_raw = A.take(c.max_roots * D); t.dgi = A.take(U * 3 * D);
         t.dgh = A.take(U * 3 * D); t.msgs = A.take(c.max_roots * MD); t.zero_t = A.take(U);
+        t.slot_rows = A.take(mk * D); t.slot_cnt = reinterpret_cast<int32_t*>(A.take(U + 2)); t.slot_rank = reinterpret_cast<int32_t*>(A.take(mk));
     } else
     for (Slot& s : st->slots) {
         s.ids_all = reinterpret_cast<int32_t*>(A.take(st->cap));
@@ -506,7 +520,11 @@ int run_forward(tg_stepper* st, Slot& s, int slot, const Base& base, int trainin
 // (the caller reduces first and applies the update itself).
 namespace {
 // gradient w.r.t. the lowest layer's table (TGN: the compact `memory' + raw` table) -- null for TGAT, whose node table carries none
-struct BaseGrad { float* d_table; int64_t pad_row; float* d_own; float* d_raw; };
+struct BaseGrad {
+    float* d_table; int64_t pad_row; float* d_own; float* d_raw;
+    // optional: the layer's feature gradient as per-slot rows + a segmented sum over the slot order (tg::attn_bwd_slot_rows_next)
+    float* slot_rows = nullptr; const int32_t *order = nullptr, *srow = nullptr, *nvalid = nullptr; int64_t nslots = 0;
+};
 
 // the layers' backward calls; `fill_extra` floats behind the lower layers' gradient rows are zeroed with the gradient block
 // defer_last: the LAST layer's weight gradients are kept back too (the caller has another grouped launch coming on this stream that carries
@@ -559,8 +577,16 @@ int run_backward(tg_stepper* st, Slot& s, const float* d_demb, void* stream, tg_
         // An upper layer's weight gradients (1 200 rows: a ~19 + 12 us latency chain on a fraction of the chip) ride in the grouped launch
         // of the layer below -- unless a data-parallel caller wants this layer's block now (grad_ready).
         tg::wgrad_defer_next(!grad_ready && (l > 1 || defer_last));
+        const bool slot_mode = l == 1 && bg.d_table && bg.slot_rows;
+        if (slot_mode) tg::attn_bwd_slot_rows_next(bg.slot_rows);
         rc = tg_tgat_layer_bwd(&st->desc[(size_t)l - 1], &bw, stream);
         tg::wgrad_defer_next(false);
+        if (slot_mode) {
+            tg::attn_bwd_slot_rows_next(nullptr);
+            // (behind the layer's other launches: nothing of the layer reads the table's gradient)
+            if (rc == TG_OK && tg::attn_bwd_slot_rows_taken())
+                rc = tg::slot_rows_sum(bg.slot_rows, dn, bg.order, bg.srow, bg.nvalid, bg.nslots, bg.d_table, dn, (hipStream_t)stream);
+        }
         if (rc == TG_OK && grad_ready && l >= 2) {
             const int64_t lo = st->poff[2 + (size_t)(l - 1) * 11], hi = l < L ? st->poff[2 + (size_t)l * 11] : st->poff.back();
             grad_ready(user, g + lo, hi - lo);
@@ -626,6 +652,9 @@ extern "C" int tg_stepper_tgn_prepare_begin(tg_stepper* st, int slot, const int6
     TG_HIP_CHECK(hipEventRecord(s.counted, sd));
     s.h_nu = nu; s.nb = n; s.lo = lo; s.hi = hi; s.n = 2 * (hi - lo); s.has_eid = h_eid != nullptr;
     s.S_nbr = s.blob + s.off[6];
+    // the neighbor slots grouped by the compact row they gather: what the backward's feature-gradient sum walks (tg::slot_rows_sum)
+    if (slot_rows_on(st)) TG_TRY(tg::build_slot_order(s.rowmap + s.n + 2 * n, s.S_nbr, s.n * k, st->tb.max_u + 1, s.count_pad, st->tb.slot_cnt, st->tb.slot_rank,
+                                                s.slot_order, s.slot_srow, s.slot_nvalid, sd));
     s.ids_all = s.rowmap;                 // the roots' rows of the compact table
     s.state = Slot::BEGUN;
     return TG_OK;
@@ -693,7 +722,9 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
     // (fuse_tb argument: true also when more backward calls follow -- d b is finished once, on the summed d cos b, by the last call)
     // (with pending messages the GRU's grouped weight-gradient launch follows and carries the layer's along)
     int rc = run_backward(st, s, d_demb, stream, nullptr, nullptr, adam != nullptr || more,
-                          pending ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw} : BaseGrad{nullptr, 0, nullptr, nullptr}, pending ? r4(U * D) : 0,
+                          pending ? (slot_rows_on(st) ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw, t.slot_rows, s.slot_order, s.slot_srow, s.slot_nvalid, roots * st->c.k}
+                                                 : BaseGrad{d_table, s.pad, t.d_own, t.d_raw})
+                                  : BaseGrad{nullptr, 0, nullptr, nullptr}, pending ? r4(U * D) : 0,
                           accumulate, pending && !grad_ready);
     // the attention + merge layer's block is final (the time encoder's two tensors in front of it are not: d b is finished below / by the
     // caller's update): a data-parallel caller starts reducing it under the GRU's backward and the state advance
