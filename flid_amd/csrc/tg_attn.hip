@@ -500,8 +500,8 @@ int launch_bwd(const tg_attn_desc& a, const float* u, const float* agg, const fl
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // bit 0: forward on tg_attn_fast.hip, bit 1: backward, bit 2: the fast forward also where the one-instance-per-workgroup (SPLIT)
-// form of the generic kernel would run (launches of <= 4096 instances); bit 3 / 4: forward / backward on the LDS-ring kernels
-// (tg_attn_ring.hip) wherever they cover the shape.  tg_set_attn_fast() is for A/B tests and timing.
+// form of the generic kernel would run (launches of <= 4096 instances).  tg_set_attn_fast() is for A/B tests and timing.  (An LDS-ring
+// form of both kernels -- global_load_lds gathers, 3-4 x the bytes in flight -- ran 161 / 180 us against 94 / 106: commit 8606c5b.)
 int g_fast = 7;
 
 int check_desc(const tg_attn_desc* a) {
@@ -530,10 +530,6 @@ extern "C" int tg_attn_fwd(const tg_attn_desc* a, const float* d_u, float* d_agg
     const int dk = a->dn + a->de + a->dt_dim;
     // algorithmic bytes: k neighbor rows (node + edge) + 16 B slot metadata each, u in, agg out, prob out
     tg::ProfScope prof("attn_fwd", (double)a->m * (a->k * 4.0 * (a->dn + a->de) + a->k * 16.0 + 2.0 * a->heads * dk * 4 + a->heads * a->k * 4.0), s);
-    if (g_fast & 8) {
-        const int rc = tg::attn_fwd_ring(*a, d_u, d_agg, d_prob, s);
-        if (rc != 1) return rc;
-    }
     if ((g_fast & 1) && ((g_fast & 4) || !use_split(*a, 4, 2))) {
         const int rc = tg::attn_fwd_fast(*a, d_u, d_agg, d_prob, s);
         if (rc != 1) return rc;
@@ -596,10 +592,6 @@ extern "C" int tg_attn_bwd(const tg_attn_desc* a, const float* d_u, const float*
     const int dk = a->dn + a->de + a->dt_dim;
     // as forward, plus dagg and agg in, du out
     tg::ProfScope prof("attn_bwd", (double)a->m * (a->k * 4.0 * (a->dn + a->de) + a->k * 16.0 + 4.0 * a->heads * dk * 4 + a->heads * a->k * 4.0), s);
-    if ((g_fast & 16) && !d_dedge) {
-        const int rc = tg::attn_bwd_ring(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, pad_feat_row, d_dte_part, (int)attn_grid(a->m), s);
-        if (rc != 1) return rc;
-    }
     if ((g_fast & 2) && slot_rows && d_dfeat && !d_dedge) {
         const int rc = tg::attn_bwd_fast(*a, d_u, d_agg, d_prob, d_dagg, d_du, d_dfeat, dfeat_ld, pad_feat_row, d_dedge, dedge_ld, d_dte_part, s, slot_rows);
         if (rc != 1) { t_slot_rows_taken = rc == TG_OK; return rc; }

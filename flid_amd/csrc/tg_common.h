@@ -146,11 +146,6 @@ int build_scatter_last(const float* d_mem, int64_t mem_ld, const float* d_last_u
 // tg_gemm.hip: two X W^T + b products of the same M x N as one launch (TGN's two GRU gate products); false = issue them one by one
 bool gemm_pair_nt(int64_t M, int64_t N, int64_t K1, const float* A1, int64_t lda1, const float* B1, int64_t ldb1, float* C1, const float* bias1,
                   int64_t K2, const float* A2, int64_t lda2, const float* B2, int64_t ldb2, float* C2, const float* bias2, int64_t ldc, hipStream_t s);
-// tg_attn_ring.hip: the LDS-ring kernels; nparts = slab rows of dte the caller allocated (tg_attn_bwd_parts)
-int attn_fwd_ring(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);
-int attn_bwd_ring(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du, float* dfeat,
-                  int64_t dfeat_ld, int64_t pad_row, float* dte, int nparts, hipStream_t s);
-
 // ---- wave64 helpers -------------------------------------------------------------------------------
 // DPP lane exchange inside the VALU (no LDS crossbar): quad swaps, 8- and 16-lane mirrors, then the two row broadcasts
 // of the GFX9 wave64 reduction; the total lands in lane 63 and is read back as a wave-uniform scalar.
