@@ -138,52 +138,38 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ stage, int la
         // (one accumulation chain: three chains -- one per split term, summed at the end -- issue faster in isolation, 33 against 52 cycles
         // per MFMA in tools/micro/mfma_rate.hip, but their 32 extra registers cost the kernel its second workgroup per CU: 68 -> 113 us;
         // two chains, which fit: 72 -> 74 us -- the chain is not what this kernel waits for)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[s], acc, 0, 0, 0);
+        // (the weight fragment as operand A: the tile comes out TRANSPOSED in the accumulators -- lane = row, four consecutive registers
+        // = four consecutive output columns -- so it leaves as 16-byte stores with no shuffle at all: store_tile_t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s], al[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s], ah[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s], ah[s], acc, 0, 0, 0);
     }
 }
 
-template <int K_>
-__device__ __forceinline__ float quad_bcast(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K_ * 0x55, 0xf, 0xf, false));
-}
-
-// The same tile as 16-byte stores: the four lanes of a quad hold a 4 (rows) x 4 (columns) block of every register group g = r >> 2;
-// transposed inside the quad (DPP broadcasts + selects), lane j of the quad owns row 8 g + 4 h + j, columns 4 (c >> 2) .. + 3: one store
-// instruction then covers 8 rows x 128 bytes instead of 2 rows.  Needs N % 4 == 0 and 16-byte aligned rows of C.
-__device__ __forceinline__ void store_tile4(const f32x16& acc, float* __restrict__ C, int64_t ldc, int64_t row0, int64_t M, int col_lane, int N,
-                                            const float* __restrict__ bias, int h) {
-    const int j = col_lane & 3, col4 = col_lane & ~3;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && col4 < N) b4 = *reinterpret_cast<const float4*>(bias + col4);
+// A tile as the MFMA leaves it with the weight fragment as operand A: lane (i = l & 31, h = l >> 5) holds row row0 + i, register r the
+// column col0 + (r & 3) + 8 (r >> 2) + 4 h -- four consecutive registers are four consecutive columns.  vec: N % 4 == 0 and 16-byte
+// aligned rows of C: one 16-byte store per register group.  (Round 4 computed the tile the other way round and transposed it inside
+// each lane quad with DPP broadcasts + selects: ~120 vector instructions per tile, 10 per MFMA of the short form -- PMC, round 5.)
+__device__ __forceinline__ void store_tile_t(const f32x16& acc, float* __restrict__ C, int64_t ldc, int64_t row0, int64_t M, int col0, int N,
+                                             const float* __restrict__ bias, int lane, int vec) {
+    const int64_t row = row0 + (lane & 31);
+    if (row >= M) return;
+    float* crow = C + row * ldc;
+    const int h = lane >> 5;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float w[4];
+        const int col = col0 + 8 * g + 4 * h;
+        if (vec) {
+            if (col < N) {
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias) b4 = *reinterpret_cast<const float4*>(bias + col);
+                *reinterpret_cast<float4*>(crow + col) = make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w);
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // every lane of the quad sees lane k's four rows; it keeps the one of ITS row j: element (row j, column k of the quad)
-            const float t0 = k == 0 ? quad_bcast<0>(acc[4 * g + 0]) : k == 1 ? quad_bcast<1>(acc[4 * g + 0]) : k == 2 ? quad_bcast<2>(acc[4 * g + 0]) : quad_bcast<3>(acc[4 * g + 0]);
-            const float t1 = k == 0 ? quad_bcast<0>(acc[4 * g + 1]) : k == 1 ? quad_bcast<1>(acc[4 * g + 1]) : k == 2 ? quad_bcast<2>(acc[4 * g + 1]) : quad_bcast<3>(acc[4 * g + 1]);
-            const float t2 = k == 0 ? quad_bcast<0>(acc[4 * g + 2]) : k == 1 ? quad_bcast<1>(acc[4 * g + 2]) : k == 2 ? quad_bcast<2>(acc[4 * g + 2]) : quad_bcast<3>(acc[4 * g + 2]);
-            const float t3 = k == 0 ? quad_bcast<0>(acc[4 * g + 3]) : k == 1 ? quad_bcast<1>(acc[4 * g + 3]) : k == 2 ? quad_bcast<2>(acc[4 * g + 3]) : quad_bcast<3>(acc[4 * g + 3]);
-            w[k] = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
+            for (int q = 0; q < 4; ++q)
+                if (col + q < N) crow[col + q] = acc[4 * g + q] + (bias ? bias[col + q] : 0.f);
         }
-        const int64_t row = row0 + 8 * g + 4 * h + j;
-        if (row < M && col4 < N)
-            *reinterpret_cast<float4*>(C + row * ldc + col4) = make_float4(w[0] + b4.x, w[1] + b4.y, w[2] + b4.z, w[3] + b4.w);
-    }
-}
-
-// accumulator layout of the 32x32 MFMA: lane (c = l & 31, h = l >> 5), register r -> row (r & 3) + 8 (r >> 2) + 4 h, column c
-__device__ __forceinline__ void store_tile(const f32x16& acc, float* __restrict__ C, int64_t ldc, int64_t row0, int64_t M, int col, int N,
-                                           const float* __restrict__ bias, int h) {
-    if (col >= N) return;
-    const float b = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < M) C[row * ldc + col] = acc[r] + b;
     }
 }
 
@@ -212,8 +198,7 @@ __global__ void __launch_bounds__(256) gemm_pk_s_kernel(const float* __restrict_
         __builtin_amdgcn_s_barrier();                     // tile t has landed for every wave; every wave is done reading tile t - 1
         asm volatile("" ::: "memory");
         if (t > t0) {
-            if (vec) store_tile4(prev, C, ldc, row0, M, 32 * (t - 1) + (lane & 31), N, bias, h);
-            else store_tile(prev, C, ldc, row0, M, 32 * (t - 1) + (lane & 31), N, bias, h);
+            store_tile_t(prev, C, ldc, row0, M, 32 * (t - 1), N, bias, lane, vec);
         }
         if (t + 2 < t1) issue_stage(Bp, t + 2, lds, (t + 2 - t0) % NBUF, wave, lane);
         f32x16 acc;
@@ -222,8 +207,7 @@ __global__ void __launch_bounds__(256) gemm_pk_s_kernel(const float* __restrict_
         mma_stage(lds + ((t - t0) % NBUF) * STAGE, lane, ah, al, acc);
         prev = acc;
     }
-    if (vec) store_tile4(prev, C, ldc, row0, M, 32 * (t1 - 1) + (lane & 31), N, bias, h);
-    else store_tile(prev, C, ldc, row0, M, 32 * (t1 - 1) + (lane & 31), N, bias, h);
+    store_tile_t(prev, C, ldc, row0, M, 32 * (t1 - 1), N, bias, lane, vec);
 }
 
 // ---- deep contraction (K > 208), narrow output (N <= 224): the accumulators of all (up to 7) column tiles stay in registers while the
@@ -286,7 +270,7 @@ __global__ void __launch_bounds__(64 * NWV, 1) gemm_pk_l_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 3 x NT x 4 KiB of B, then NWV x 3 x 4 KiB of A
     constexpr int PER = (NT * 4 + NWV - 1) / NWV;
     constexpr int OPS = PER + 4;                                    // vector-memory operations a wave issues per stage
-    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // (scalar: LDS destinations and block numbers stay on the scalar ALU)
     const int64_t row0 = (int64_t)blockIdx.x * (32 * NWV) + wave * 32;
     char* aring = lds + 3 * NT * LSTEP + wave * (3 * 4 * BLK);
@@ -359,11 +343,11 @@ __global__ void __launch_bounds__(64 * NWV, 1) gemm_pk_l_kernel(const float* __r
             }
             // term-major: consecutive MFMAs go to different accumulators
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], bh[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[t], al[st], acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bl[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[t], ah[st], acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], bh[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[t], ah[st], acc[t], 0, 0, 0);
         }
 #if FLID_PK_STAMPS
         asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[NT - 1][15]) : "memory");      // (the MFMAs' results are needed here)
@@ -372,8 +356,7 @@ __global__ void __launch_bounds__(64 * NWV, 1) gemm_pk_l_kernel(const float* __r
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (vec) store_tile4(acc[t], C, ldc, row0, M, 32 * t + (lane & 31), N, bias, h);
-        else store_tile(acc[t], C, ldc, row0, M, 32 * t + (lane & 31), N, bias, h);
+        store_tile_t(acc[t], C, ldc, row0, M, 32 * t, N, bias, lane, vec);
     }
 }
 
