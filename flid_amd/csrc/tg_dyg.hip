@@ -157,9 +157,28 @@ __global__ void __launch_bounds__(256) dyg_cooc_bwd_kernel(const float* __restri
 
 // gradient of the two per-side means (DyGFormer.py:185-187) at every position, and its dropped copy under the top block's last seed
 __global__ void __launch_bounds__(256) dyg_segmean_bwd_kernel(const float* __restrict__ d_means, int64_t B, int S, int d, int ws, float p, uint64_t seed,
-                                                              float* __restrict__ dx, float* __restrict__ dx_dropped) {
-    const int64_t total = B * S * d;
+                                                              float* __restrict__ dx, float* __restrict__ dx_dropped, int vec) {
     const float is = 1.f / (float)ws, id = 1.f / (float)(S - ws);
+    if (vec) {          // d % 4 == 0, 16-byte aligned operands: four columns per lane, one hash for their four dropout decisions
+        const int d4 = d >> 2;
+        const int64_t total4 = B * S * d4;
+        for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * blockDim.x) {
+            const int c4 = (int)(i4 % d4);
+            const int64_t pos = i4 / d4, b = pos / S;
+            const int j = (int)(pos - b * S);
+            const float sc = j < ws ? is : id;
+            const float4 m = *reinterpret_cast<const float4*>(d_means + (j < ws ? b : B + b) * d + 4 * c4);
+            const float4 v = make_float4(m.x * sc, m.y * sc, m.z * sc, m.w * sc);
+            reinterpret_cast<float4*>(dx)[i4] = v;
+            if (dx_dropped) {
+                float k[4];
+                tg::res_keep_scale4(seed, 4 * i4, p, k);
+                reinterpret_cast<float4*>(dx_dropped)[i4] = make_float4(v.x * k[0], v.y * k[1], v.z * k[2], v.w * k[3]);
+            }
+        }
+        return;
+    }
+    const int64_t total = B * S * d;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % d);
         const int64_t pos = i / d, b = pos / S;
@@ -505,7 +524,8 @@ extern "C" int tg_dyg_backward(tg_dyg* st, const float* d_demb, void* stream, co
     {
         const int64_t tot = n * d;
         dyg_segmean_bwd_kernel<<<(unsigned)std::min<int64_t>((tot + 255) / 256, tg::kMaxGridBlocks), 256, 0, s>>>(
-            st->d_means, B, S, d, ws, p, p > 0.f ? st->seeds[4 * (c.layers - 1) + 3] : 0, dcur, p > 0.f ? st->d_f : nullptr);
+            st->d_means, B, S, d, ws, p, p > 0.f ? st->seeds[4 * (c.layers - 1) + 3] : 0, dcur, p > 0.f ? st->d_f : nullptr,
+            (d % 4 == 0 && ((reinterpret_cast<uintptr_t>(st->d_means) | reinterpret_cast<uintptr_t>(dcur) | reinterpret_cast<uintptr_t>(st->d_f)) & 15) == 0) ? 1 : 0);
         TG_TRY(tg::launch_status("dyg_segmean_bwd_kernel"));
     }
     // ---- transformer blocks, last to first -------------------------------------------------------------------------------------------
