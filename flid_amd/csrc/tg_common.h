@@ -134,8 +134,10 @@ int build_slot_order(const int32_t* slot_row, const int32_t* nbr, int64_t n, int
                      int32_t* order, int32_t* srow, int32_t* n_valid, hipStream_t s);
 // table[srow[i]] += rows[order[i]] over i < *n_valid: one wave per 16 entries, runs of equal rows summed in registers, one float-atomic
 // row add per run
+// (own_*: n_own further rows added by extra workgroups of the same launch: table[own_idx[r]] += own_a[r] + own_b[r], rows of dn floats)
 int slot_rows_sum(const float* rows, int dn, const int32_t* order, const int32_t* srow, const int32_t* n_valid, int64_t n, float* table,
-                  int64_t ld, hipStream_t s);
+                  int64_t ld, hipStream_t s, const float* own_a = nullptr, const float* own_b = nullptr, const int32_t* own_idx = nullptr,
+                  int64_t n_own = 0);
 int attn_fwd_fast(const tg_attn_desc& a, const float* u, float* agg, float* prob, hipStream_t s);          // 1 = shape not covered
 int attn_bwd_fast(const tg_attn_desc& a, const float* u, const float* agg, const float* prob, const float* dagg, float* du,
                   float* dfeat, int64_t dfeat_ld, int64_t pad_row, float* dedge, int64_t dedge_ld, float* dte, hipStream_t s, float* slot_rows = nullptr);

@@ -209,9 +209,20 @@ __global__ void __launch_bounds__(256) slot_fill_kernel(const int32_t* __restric
 // one wave per 16 grouped slots; lane l owns columns l, l + 64, ... (dn <= 256): a row is three or four coalesced loads, a run's sum
 // as many contiguous float-atomic instructions
 constexpr int SEG = 16;
+// Workgroups past the segments' (blockIdx.x >= seg_blocks) add n_own further rows, one wave each: table[own_idx[r]] += own_a[r] + own_b[r]
+// (the gradient w.r.t. the roots' own rows: the merge layer's and the query's share) -- a launch of its own before.
 __global__ void __launch_bounds__(256) slot_rows_sum_kernel(const float* __restrict__ rows, int dn, const int32_t* __restrict__ order, const int32_t* __restrict__ srow,
-                                                            const int32_t* __restrict__ n_valid, float* __restrict__ table, int64_t ld) {
+                                                            const int32_t* __restrict__ n_valid, float* __restrict__ table, int64_t ld, int seg_blocks,
+                                                            const float* __restrict__ own_a, const float* __restrict__ own_b, const int32_t* __restrict__ own_idx,
+                                                            int64_t n_own) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= seg_blocks) {
+        const int64_t r = ((int64_t)blockIdx.x - seg_blocks) * 4 + wave;
+        if (r >= n_own) return;
+        float* dst = table + (int64_t)own_idx[r] * ld;
+        for (int c = lane; c < dn; c += 64) atomicAdd(dst + c, own_a[r * dn + c] + own_b[r * dn + c]);
+        return;
+    }
     const int64_t nv = *n_valid, first = ((int64_t)blockIdx.x * 4 + wave) * SEG;
     if (first >= nv) return;
     const int cnt = nv - first < SEG ? (int)(nv - first) : SEG;
@@ -286,10 +297,12 @@ int build_slot_order(const int32_t* slot_row, const int32_t* nbr, int64_t n, int
     return launch_status("slot_fill_kernel");
 }
 int slot_rows_sum(const float* rows, int dn, const int32_t* order, const int32_t* srow, const int32_t* n_valid, int64_t n, float* table,
-                  int64_t ld, hipStream_t s) {
+                  int64_t ld, hipStream_t s, const float* own_a, const float* own_b, const int32_t* own_idx, int64_t n_own) {
     TG_REQUIRE(rows && order && srow && n_valid && table && dn > 0 && dn <= 256 && n >= 0, "slot_rows_sum: arguments");
-    if (n == 0) return TG_OK;
-    slot_rows_sum_kernel<<<(unsigned)((n + 4 * SEG - 1) / (4 * SEG)), 256, 0, s>>>(rows, dn, order, srow, n_valid, table, ld);
+    TG_REQUIRE(n_own == 0 || (own_a && own_b && own_idx), "slot_rows_sum: the own rows' operands");
+    if (n == 0 && n_own == 0) return TG_OK;
+    const int seg_blocks = (int)((n + 4 * SEG - 1) / (4 * SEG));
+    slot_rows_sum_kernel<<<(unsigned)(seg_blocks + (n_own + 3) / 4), 256, 0, s>>>(rows, dn, order, srow, n_valid, table, ld, seg_blocks, own_a, own_b, own_idx, n_own);
     return launch_status("slot_rows_sum_kernel");
 }
 // tg_msg_scatter_last behind tgn_persist_index: the winner index is in the workspace already

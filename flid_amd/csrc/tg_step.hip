@@ -524,6 +524,8 @@ struct BaseGrad {
     float* d_table; int64_t pad_row; float* d_own; float* d_raw;
     // optional: the layer's feature gradient as per-slot rows + a segmented sum over the slot order (tg::attn_bwd_slot_rows_next)
     float* slot_rows = nullptr; const int32_t *order = nullptr, *srow = nullptr, *nvalid = nullptr; int64_t nslots = 0;
+    // ... whose launch then also adds d_own + d_raw into the roots' rows own_idx[0, n_own) of the table; *own_done says that it did
+    const int32_t* own_idx = nullptr; int64_t n_own = 0; bool* own_done = nullptr;
 };
 
 // the layers' backward calls; `fill_extra` floats behind the lower layers' gradient rows are zeroed with the gradient block
@@ -584,8 +586,12 @@ int run_backward(tg_stepper* st, Slot& s, const float* d_demb, void* stream, tg_
         if (slot_mode) {
             tg::attn_bwd_slot_rows_next(nullptr);
             // (behind the layer's other launches: nothing of the layer reads the table's gradient)
-            if (rc == TG_OK && tg::attn_bwd_slot_rows_taken())
-                rc = tg::slot_rows_sum(bg.slot_rows, dn, bg.order, bg.srow, bg.nvalid, bg.nslots, bg.d_table, dn, (hipStream_t)stream);
+            if (rc == TG_OK && tg::attn_bwd_slot_rows_taken()) {
+                const bool own = bg.own_idx && bg.d_own && bg.d_raw && bg.n_own > 0;
+                rc = tg::slot_rows_sum(bg.slot_rows, dn, bg.order, bg.srow, bg.nvalid, bg.nslots, bg.d_table, dn, (hipStream_t)stream,
+                                       own ? bg.d_own : nullptr, own ? bg.d_raw : nullptr, own ? bg.own_idx : nullptr, own ? bg.n_own : 0);
+                if (rc == TG_OK && own && bg.own_done) *bg.own_done = true;
+            }
         }
         if (rc == TG_OK && grad_ready && l >= 2) {
             const int64_t lo = st->poff[2 + (size_t)(l - 1) * 11], hi = l < L ? st->poff[2 + (size_t)l * 11] : st->poff.back();
@@ -721,8 +727,10 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
     TG_REQUIRE(!(grad_ready && (adam || more)), "tg_stepper_tgn_backward: grad_ready is for the last backward of a step, before a reduction (no update here)");
     // (fuse_tb argument: true also when more backward calls follow -- d b is finished once, on the summed d cos b, by the last call)
     // (with pending messages the GRU's grouped weight-gradient launch follows and carries the layer's along)
+    bool own_done = false;                                 // (the roots' own-row gradient went into the table inside run_backward's launches)
     int rc = run_backward(st, s, d_demb, stream, nullptr, nullptr, adam != nullptr || more,
-                          pending ? (slot_rows_on(st) ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw, t.slot_rows, s.slot_order, s.slot_srow, s.slot_nvalid, roots * st->c.k}
+                          pending ? (slot_rows_on(st) ? BaseGrad{d_table, s.pad, t.d_own, t.d_raw, t.slot_rows, s.slot_order, s.slot_srow, s.slot_nvalid, roots * st->c.k,
+                                                                 s.rowmap, roots, &own_done}
                                                  : BaseGrad{d_table, s.pad, t.d_own, t.d_raw})
                                   : BaseGrad{nullptr, 0, nullptr, nullptr}, pending ? r4(U * D) : 0,
                           accumulate, pending && !grad_ready);
@@ -731,7 +739,7 @@ extern "C" int tg_stepper_tgn_backward(tg_stepper* st, int slot, tg_tgn_bank* ba
     if (rc == TG_OK && grad_ready) grad_ready(user, g + st->poff[2], st->poff.back() - st->poff[2]);
     if (rc == TG_OK && pending) {
         // the merge layer's and the query's share of the gradient w.r.t. the roots' own rows, then the GRU
-        rc = tg::scatter_add_rows2(t.d_own, t.d_raw, D, s.rowmap, roots, D, d_table, D, (hipStream_t)stream);
+        if (!own_done) rc = tg::scatter_add_rows2(t.d_own, t.d_raw, D, s.rowmap, roots, D, d_table, D, (hipStream_t)stream);
         if (rc == TG_OK) rc = tg_gru_gates_bwd_masked(t.gi, t.gh, t.h_rows, d_table, s.uniq, bank->d_has, U, D, t.dgi, t.dgh, stream);
         if (rc == TG_OK) {
             const tg_wgrad_job jobs[2] = {{t.dgi, 3 * (int64_t)D, 3 * D, t.msg_rows, MD, MD, g + st->gru_off[0], MD, g + st->gru_off[2]},
