@@ -657,6 +657,8 @@ struct ChainBwdArgs {
     const float* dout;                // (R, dn)
     const float* f1;                  // (R, dn) forward activations (ReLU mask)
     const void *pW2T, *pW1aT, *pWrT, *pWvT;   // packed transposed weights; pWvT: heads back to back (tg_packed_floats(dk, hd) apart)
+    const void* pW1bT;                // optional (with d_raw): W1[:, dq:]^T packed
+    float* d_raw;                     // optional: (R, dn) gradient w.r.t. the merge layer's raw rows = df1 W1[:, dq:]
     const float *ln_g, *cosb;
     const float* own; int64_t own_ld;
     const float* res;                 // (R, dq)
@@ -765,6 +767,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) chain_bwd_kernel(ChainBwdArgs
     }
     __syncthreads();
     STAMP();
+
+    // ---- d raw = df1 W1[:, dq:] (layers whose raw rows carry a gradient): the panel holds df1, nothing else is needed
+    if (a.d_raw) {                                             // (uniform)
+        w.begin(a.pW1bT, (a.dn + 15) >> 4, nchunks_dn);
+        w.template run_panel<NTF>(0);
+#pragma unroll
+        for (int j = 0; j < NTF; ++j) {
+            if (j >= w.tcnt) break;
+            const int col = w.out_col(j);
+            if (col >= a.dn) continue;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                if (rok[rb]) st4(a.d_raw + rgc[rb] * a.dn + col, f4(w.acc[rb][j]));
+        }
+    }
 
     // ---- dy = df1 W1[:, :dq] ;  LayerNorm backward: dsum, dres = dsum * dropout mask, the workgroup's column sums
     {
@@ -1184,13 +1201,14 @@ int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk,
 int64_t chain_blocks(int64_t rows) { return rows >= 64 * 128 ? (rows + 63) / 64 : (rows + 15) / 16; }
 
 int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, float* part, const void* pW2T, const void* pW1aT,
-              const void* pWrT, const void* pWvT, hipStream_t s) {
+              const void* pWrT, const void* pWvT, hipStream_t s, const void* pW1bT) {
     const tg_attn_desc& at = L->attn;
     ChainBwdArgs a;
     a.R = at.m; a.H = at.heads; a.dn = at.dn; a.T = at.dt_dim; a.de = at.de;
     a.hpb = chain_hpb(at.heads, at.dn, at.dt_dim);
     a.dout = Bw->dout; a.f1 = L->f1;
     a.pW2T = pW2T; a.pW1aT = pW1aT; a.pWrT = pWrT; a.pWvT = pWvT;
+    a.pW1bT = pW1bT; a.d_raw = pW1bT ? Bw->d_raw : nullptr;
     a.ln_g = L->params.ln_g; a.cosb = L->cosb;
     a.own = L->own; a.own_ld = L->own_ld;
     a.res = L->res; a.mean = L->mean; a.rstd = L->rstd;

@@ -100,7 +100,7 @@ int qu_fwd(const tg_layer_desc* L, const void* pWq, const void* pWkT, hipStream_
 int dq_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, const void* pWk, const void* pWqT, float* dq_slab, hipStream_t s);
 int64_t chain_blocks(int64_t rows);
 int chain_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc* Bw, float* dres, float* part, const void* pW2T, const void* pW1aT,
-              const void* pWrT, const void* pWvT, hipStream_t s);
+              const void* pWrT, const void* pWvT, hipStream_t s, const void* pW1bT = nullptr);
 // Column sums of tall slab matrices added (float atomics) into up to 6 destination vectors: column c belongs to the first segment with
 // c < end[i] and lands at p[i][c - begin_i]; a null p[i] drops the segment (device body: tg_colsum.h)
 struct SegDst { float* p[6]; int end[6]; int n; };

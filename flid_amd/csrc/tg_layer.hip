@@ -531,7 +531,7 @@ inline WT wt_layout(float* base, int H, int dn, int dq, int dk) {
 }
 
 // Packed weights of the chain kernels (tg_chain.hip), behind the transposed copies in the layer's wT block
-struct PK { float *Wv, *Wr, *W1, *W2, *W2T, *W1aT, *WrT, *WvT, *Wq, *WkT, *Wk, *WqT; int64_t total; };
+struct PK { float *Wv, *Wr, *W1, *W2, *W2T, *W1aT, *W1bT, *WrT, *WvT, *Wq, *WkT, *Wk, *WqT; int64_t total; };
 inline int64_t r4(int64_t n) { return (n + 3) / 4 * 4; }
 inline PK pk_layout(float* base, int H, int dn, int dq, int dk) {
     PK k;
@@ -545,6 +545,7 @@ inline PK pk_layout(float* base, int H, int dn, int dq, int dk) {
     const int hpb = (hd + 31) / 32 * 32;                 // backward: dctx in per-head blocks that start on a 32-k chunk
     k.W2T = p; p += tg::packed_floats(dn, dn);
     k.W1aT = p; p += tg::packed_floats(dq, dn);
+    k.W1bT = p; p += tg::packed_floats(dn, dn);         // d raw = df1 W1[:, dq:] (layers whose raw rows carry a gradient: TGN)
     k.WrT = p; p += tg::packed_floats(H * hpb, dq);
     k.WvT = p; p += H * tg::packed_floats(dk, hpb);
     // query side of a short (not merged) layer (qu_fwd_kernel / dq_bwd_kernel): Wq[:, :dn]; per head Wk_h^T (K = hd padded to hpb) and
@@ -759,6 +760,7 @@ static int layer_fwd_impl(const tg_layer_desc* L, void* stream, int mode, Prelud
         const int hpb = tg::chain_hpb(H, dn, T);
         jobs[n++] = tg_pack_job{P.W2, dn, dn, dn, 1, pk.W2T, 0, 0, 0, 0, 0, 0};                                      // df1 = dout W2
         jobs[n++] = tg_pack_job{P.W1, (int64_t)dq + dn, dq, dn, 1, pk.W1aT, 0, 0, 0, 0, 0, 0};                      // dy = df1 W1[:, :dq]
+        if (L->raw) jobs[n++] = tg_pack_job{P.W1 + dq, (int64_t)dq + dn, dn, dn, 1, pk.W1bT, 0, 0, 0, 0, 0, 0};       // d raw = df1 W1[:, dq:]
         jobs[n++] = tg_pack_job{P.Wr, dq, H * hpb, dq, 1, pk.WrT, dq, 0, hd, hpb, 0, 0};                             // dctx = dres Wr, columns in head blocks
         for (int h = 0; h < H; ++h)                                                                                  // dagg_h = dctx_h Wv_h
             jobs[n++] = tg_pack_job{P.Wv + (int64_t)h * hd * dk, dk, dk, hd, 1, pk.WvT + h * tg::packed_floats(dk, hpb), 0, 0, 0, 0, 0, 0};
@@ -1061,7 +1063,7 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
     // df1 = (f1 > 0) ? dout W2 : 0 -- the ReLU mask rides in the product's epilogue (one launch less per layer); widths the fused form
     // does not cover take the product and the mask kernel separately.  (db1 = sum_rows df1 comes out of the weight-gradient launch.)
     if (use_chain) {
-        TG_TRY(tg::chain_bwd(L, Bw, dres_c, part_ln, pk.W2T, pk.W1aT, pk.WrT, pk.WvT, s));
+        TG_TRY(tg::chain_bwd(L, Bw, dres_c, part_ln, pk.W2T, pk.W1aT, pk.WrT, pk.WvT, s, (Bw->d_raw && L->raw) ? pk.W1bT : nullptr));
     } else if (tg_get_gemm_mode() != 0 && dn % 4 == 0 && (reinterpret_cast<uintptr_t>(Bw->dout) & 15) == 0 && (reinterpret_cast<uintptr_t>(L->f1) & 15) == 0) {   // (the fused mask lives in the split-bf16 kernel)
         TG_TRY(tg_gemm_f32_nt_masked(R, dn, dn, Bw->dout, dn, wt.W2, dn, Bw->df1, dn, L->f1, dn, stream));
     } else {
@@ -1081,7 +1083,8 @@ extern "C" int tg_tgat_layer_bwd(const tg_layer_desc* L, const tg_layer_bwd_desc
                       WJ{Bc.df1, dn, dn, Lc.y, ldy, dq, G.W1, w1ld, G.b1},
                       WJ{Bc.df1, dn, dn, Lc.raw, Lc.raw_ld, dn, G.W1 + dq, w1ld, nullptr}}));
     if (!use_chain) TG_TRY(tg_gemm_f32(0, 1, R, dq, dn, 1.f, Bw->df1, dn, wt.W1a, dn, Bw->dy, dq, nullptr, 0, 0, stream));
-    if (Bw->d_raw) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
+    // (the backward chain computes d raw = df1 W1[:, dq:] itself, beside dy: a 6 us launch of its own on TGN's 1 200 rows before)
+    if (Bw->d_raw && !(use_chain && L->raw)) TG_TRY(tg_gemm_f32(0, 1, R, dn, dn, 1.f, Bw->df1, dn, wt.W1b, dn, Bw->d_raw, dn, nullptr, 0, 0, stream));
     // ---- residual + layer norm (+ dropout mask), all column sums in one slab -------------------------------------------------
     float* dres = dres_c;
     if (!use_chain) {
