@@ -318,6 +318,7 @@ struct MergeJobs { MergeJob j[4]; int n, total_tiles; };
 // 32 x 32 output tile per workgroup, K in LDS chunks of 32; thread (ty, tx) owns rows ty, ty+8, ty+16, ty+24 of column tx.
 // Operand tiles are loaded along whichever index is contiguous in memory.  Blocks past the tiles compute ub (forward only).
 // bx: workgroup index inside the role; qb: the query bias in LDS (computed by this workgroup: the launch that writes it to memory is this one)
+constexpr int MERGE_ALL = 5;            // chunks of 32 a merge tile fetches at once (contractions up to 160 deep)
 __device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx, const float* __restrict__ Wk, const float* qb, int H, int hd,
                                                    int dk, float* __restrict__ ub, float (*As)[33], float (*Bs)[33], float (*Cs)[33]) {
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
@@ -329,8 +330,16 @@ __device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx
         float acc = 0.f;
         if (hj < (int64_t)H * dk) {
             const int h = (int)(hj / dk), jj = (int)(hj % dk);
+            if (per <= 20) {                                 // (uniform) head_dim <= 160: the group's whole share in flight at once
+                float wv[20];
+#pragma unroll
+                for (int q = 0; q < 20; ++q) wv[q] = k0 + q < k1 ? Wk[((int64_t)h * hd + k0 + q) * dk + jj] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 20; ++q) if (k0 + q < k1) acc = fmaf(wv[q], qb[h * hd + k0 + q], acc);
+            } else {
 #pragma unroll 4
-            for (int k = k0; k < k1; ++k) acc = fmaf(Wk[((int64_t)h * hd + k) * dk + jj], qb[h * hd + k], acc);
+                for (int k = k0; k < k1; ++k) acc = fmaf(Wk[((int64_t)h * hd + k) * dk + jj], qb[h * hd + k], acc);
+            }
         }
         As[ty][tx] = acc;
         __syncthreads();
@@ -360,6 +369,45 @@ __device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx
             rb[q] = (n0 + bn < J.N && k0 + bk < J.K) ? J.B[(int64_t)(k0 + bk) * J.sBk + (int64_t)(n0 + bn) * J.sBn] : 0.f;
         }
     };
+    if (J.K <= 32 * MERGE_ALL) {
+        // a short contraction (head_dim = 136: five chunks) is fetched WHOLE before the first chunk is multiplied: one global round trip
+        // instead of one per chunk (the merge tiles were the prelude launch's long pole: 20.4 us with them, 11.0 without -- ablation,
+        // round 5); same chunk order, same sums
+        float fa[MERGE_ALL][4], fb[MERGE_ALL][4];
+#pragma unroll
+        for (int c = 0; c < MERGE_ALL; ++c) {
+            const int k0 = 32 * c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = t + 256 * q;
+                const int am = J.sAm == 1 ? (e & 31) : (e >> 5), ak = J.sAm == 1 ? (e >> 5) : (e & 31);
+                fa[c][q] = (m0 + am < J.M && k0 + ak < J.K) ? J.A[(int64_t)(m0 + am) * J.sAm + (int64_t)(k0 + ak) * J.sAk] : 0.f;
+                const int bn = J.sBn == 1 ? (e & 31) : (e >> 5), bk = J.sBn == 1 ? (e >> 5) : (e & 31);
+                fb[c][q] = (n0 + bn < J.N && k0 + bk < J.K) ? J.B[(int64_t)(k0 + bk) * J.sBk + (int64_t)(n0 + bn) * J.sBn] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MERGE_ALL; ++c) {
+            if (32 * c < J.K) {                                              // (uniform)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = t + 256 * q;
+                    const int am = J.sAm == 1 ? (e & 31) : (e >> 5), ak = J.sAm == 1 ? (e >> 5) : (e & 31);
+                    As[ak][am] = fa[c][q];
+                    const int bn = J.sBn == 1 ? (e & 31) : (e >> 5), bk = J.sBn == 1 ? (e >> 5) : (e & 31);
+                    Bs[bk][bn] = fb[c][q];
+                }
+                __syncthreads();
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) {
+                    const float b = Bs[k][tx];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(As[k][ty + 8 * q], b, acc[q]);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
     fetch(0);
     for (int k0 = 0; k0 < J.K; k0 += 32) {
 #pragma unroll
@@ -379,6 +427,7 @@ __device__ __forceinline__ void merge_weights_body(const MergeJobs& jobs, int bx
             for (int q = 0; q < 4; ++q) acc[q] = fmaf(As[k][ty + 8 * q], b, acc[q]);
         }
         __syncthreads();
+    }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -412,6 +461,9 @@ inline void add_job(MergeJobs& mj, const float* A, const float* B, float* C, flo
 //   the rest (64 tr_gy)   transposed copies, cos(b), the query bias, the raw-row gather (transpose_many_body)
 // (three launches before: 6.5 + 8.4 + 12.5 us for the 13.6 k-row layer, 5 + 5.4 us for the root layer).  The ub workgroups need the
 // query bias this same launch produces, so each recomputes it into LDS with the arithmetic of the workgroups that store it.
+#ifndef FLID_PRELUDE_EXP
+#define FLID_PRELUDE_EXP 0   // timing experiments only (results wrong): 1 no packing, 2 no transposes / gathers, 3 no merge tiles, 4 no zero fill
+#endif
 struct PreludeArgs {
     tgs::PackJobs pk;
     TrJobs tr;
@@ -425,12 +477,15 @@ __device__ __forceinline__ void prelude_body(const PreludeArgs& a, int bid, floa
     // (the merge tiles are the longest dependent chains of the launch: they take the lowest workgroup numbers and start first)
     int b = bid - a.nb_merge;
     if (b >= 0) {
-        if (b < a.nb_pack) { tgs::pack_body(a.pk, b, a.nb_pack); return; }
+        if (b < a.nb_pack) { if (FLID_PRELUDE_EXP != 1) tgs::pack_body(a.pk, b, a.nb_pack); return; }
         b -= a.nb_pack;
-        transpose_many_body(a.tr, b & 63, b >> 6, 64, sm[0]);
+        if (FLID_PRELUDE_EXP != 2) transpose_many_body(a.tr, b & 63, b >> 6, 64, sm[0]);
         return;
     }
+    if (FLID_PRELUDE_EXP == 3) return;
     b = bid;
+    if (FLID_PRELUDE_EXP == 5 && b >= a.mj.total_tiles) return;
+    if (FLID_PRELUDE_EXP == 6 && b < a.mj.total_tiles) return;
     if (b >= a.mj.total_tiles) {
         // the query-bias rows of the head(s) this workgroup's 32 outputs belong to; 8 rows of a wave in flight at a time (one row at a
         // time was 68 exposed load round trips: the launch took 35 us longer than the three it replaced)
@@ -441,20 +496,32 @@ __device__ __forceinline__ void prelude_body(const PreludeArgs& a, int bid, floa
         float* cbs = &sm[0][0][0];                       // cos(b_t), T <= 1024 (host-checked: dq <= 1024)
         for (int t = threadIdx.x; t < a.tr.mv_cols; t += 256) cbs[t] = a.tr.te_b ? tg::cos_phase(a.tr.te_b[t]) : a.tr.mv_x[t];
         __syncthreads();
-        for (int i = i_lo + 8 * wave; i < i_hi; i += 32) {
-            float acc[8];
+        // 16 rows of a wave and two column steps in flight at a time: 32 independent loads per round trip (same order of every row's sum
+        // as the workgroups that store the bias)
+        // 17 rows of a wave and two column steps in flight at a time (a head's 136 rows in two round trips; same order of every row's
+        // sum as the workgroups that store the bias).  With 8 rows and one column step these 28 workgroups were ten dependent round
+        // trips long, then five more for ub: the launch's long pole (20.4 us with them, 14.6 without: ablation, round 5).
+        constexpr int QR = 17;
+        for (int i = i_lo + QR * wave; i < i_hi; i += 4 * QR) {
+            float acc[QR];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-            for (int t = lane; t < a.tr.mv_cols; t += 64) {
-                const float cb = cbs[t];
+            for (int r = 0; r < QR; ++r) acc[r] = 0.f;
+            for (int t = lane; t < a.tr.mv_cols; t += 128) {
+                const int t1 = t + 64;
+                const bool two = t1 < a.tr.mv_cols;
+                const float cb0 = cbs[t], cb1 = two ? cbs[t1] : 0.f;
+                float w0[QR], w1[QR];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                for (int r = 0; r < QR; ++r) {
                     const int ir = min(i + r, i_hi - 1);
-                    acc[r] = fmaf(a.tr.mv_W[(int64_t)ir * a.tr.mv_ld + t], cb, acc[r]);
+                    w0[r] = a.tr.mv_W[(int64_t)ir * a.tr.mv_ld + t];
+                    w1[r] = two ? a.tr.mv_W[(int64_t)ir * a.tr.mv_ld + t1] : 0.f;
                 }
+#pragma unroll
+                for (int r = 0; r < QR; ++r) acc[r] = fmaf(w1[r], cb1, fmaf(w0[r], cb0, acc[r]));
             }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < QR; ++r) {
                 const float v = tg::wave_sum(acc[r]);
                 if (lane == 0 && i + r < i_hi) qbs[i + r] = v;
             }
@@ -478,6 +545,7 @@ __global__ void __launch_bounds__(256) layer_prelude2_kernel(PreludeArgs a, Prel
     if (bid < nb_a) { prelude_body(a, bid, sm, qbs); return; }
     if (bid < nb_a + nb_b) { prelude_body(b, bid - nb_a, sm, qbs); return; }
     const int64_t nz = (int64_t)gridDim.x - nb_a - nb_b;
+    if (FLID_PRELUDE_EXP == 4) return;
     for (int64_t i = ((int64_t)bid - nb_a - nb_b) * 256 + threadIdx.x; i < z4; i += nz * 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
