@@ -462,7 +462,8 @@ inline void add_job(MergeJobs& mj, const float* A, const float* B, float* C, flo
 // (three launches before: 6.5 + 8.4 + 12.5 us for the 13.6 k-row layer, 5 + 5.4 us for the root layer).  The ub workgroups need the
 // query bias this same launch produces, so each recomputes it into LDS with the arithmetic of the workgroups that store it.
 #ifndef FLID_PRELUDE_EXP
-#define FLID_PRELUDE_EXP 0   // timing experiments only (results wrong): 1 no packing, 2 no transposes / gathers, 3 no merge tiles, 4 no zero fill
+#define FLID_PRELUDE_EXP 0   // timing experiments only (results wrong): 1 no packing, 2 no transposes / gathers, 3 no merge tiles and no ub workgroups,
+                             // 4 no zero fill, 5 no ub workgroups, 6 no merge tiles
 #endif
 struct PreludeArgs {
     tgs::PackJobs pk;
