@@ -32,5 +32,6 @@ python3 bench.py --workload scale --no-cpu-baseline > $O/${R}_scale_config5_benc
 rocprofv3 --kernel-trace -d $O/kt_scale -o scale -- python3 bench.py --workload scale --steps 20 --warmup 6 --no-cpu-baseline --no-breakdown > /dev/null 2> $O/kt_scale.err
 python3 tools/rocpd_stats.py $O/kt_scale/scale_results.db --csv $O/${R}_scale_config5_kernel_stats.csv --timeline > $O/${R}_scale_config5_timeline.txt 2>&1
 BENCH_ARGS="--workload scale" KERNELS="chain_fwd chain_bwd wgrad2_kernel attn_bwd_fast attn_fwd_fast" bash tools/pmc_step.sh > $O/${R}_scale_config5_pmc_sq.txt 2>&1
+BENCH_ARGS="--model dygformer" KERNELS="seq_attn_bwd seq_attn_fwd gemm_pk_s gemm_pk_l wgrad2_kernel" bash tools/pmc_step.sh > $O/${R}_dygformer_pmc_sq.txt 2>&1
 rm -rf $O/kt $O/kt_tgn $O/kt_dyg $O/kt_scale gpurun_out/pmcs* $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 tail -c 300 $O/${R}_headline_bench.json; tail -3 $O/traffic.log; grep -h "host issue" $O/*.err
